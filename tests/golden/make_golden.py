@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures by importing the upstream reference (read-only at /root/reference).
+
+Runs ONLY in the build container (the reference never travels to the GPU box); the produced ``*.npz`` files are
+data (inputs are rebuilt from oracle.atst_oracle.recipe_* by seed; expected outputs are stored) and are committed.
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+
+Shims applied to the reference, in this harness only:
+  * torch.distributed gloo group of world size 1 (compute_var all-reduces unconditionally, byol.py:48-50)
+  * Tensor.cuda -> identity (hard-coded .cuda() at byol.py:44)
+  * stub ``fairseq.data.data_utils`` module (random_mask.py:1 imports it at module top)
+  * torch.rand is wrapped to RECORD the DropPath draws so that the keep decisions can be injected elsewhere
+"""
+import os
+import sys
+import types
+from functools import partial
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, "/root/reference/audiossl/methods/atstframe")
+
+from oracle import atst_oracle as O  # noqa: E402
+
+torch.set_num_threads(8)
+if not torch.distributed.is_initialized():
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29512")
+    torch.distributed.init_process_group("gloo", rank=0, world_size=1)
+torch.Tensor.cuda = lambda self, *a, **k: self
+
+fs = types.ModuleType("fairseq"); fsd = types.ModuleType("fairseq.data"); fsdu = types.ModuleType("fairseq.data.data_utils")
+fsdu.compute_mask_indices = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("fairseq stub"))
+sys.modules.update({"fairseq": fs, "fairseq.data": fsd, "fairseq.data.data_utils": fsdu})
+
+from audiossl.models.atst.atst import ATST  # noqa: E402
+from audiossl.models.atst.audio_transformer import AST  # noqa: E402
+from audiossl.modules import transformer as ref_tr  # noqa: E402
+from audiossl.utils import common as ref_common  # noqa: E402
+torch.set_num_threads(8)   # `import audiossl` exports OMP/MKL=1; restore for generation speed
+
+
+class RandRecorder:
+    """Records every torch.rand draw (DropPath is the only user on this path)."""
+    def __init__(self):
+        self.draws = []
+        self._orig = torch.rand
+
+    def __enter__(self):
+        def rec(*a, **k):
+            r = self._orig(*a, **k)
+            self.draws.append(r.reshape(-1).clone())
+            return r
+        torch.rand = rec
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand = self._orig
+
+
+def keep_from_draws(draws, depth, rates):
+    """draws: 2*(depth-1) tensors [S] in call order (block 0 is nn.Identity).  -> [depth,2,S] float {0,1}."""
+    S = draws[0].numel()
+    keep = torch.ones(depth, 2, S)
+    it = iter(draws)
+    for i in range(1, depth):
+        for j in range(2):
+            keep[i, j] = torch.floor((1.0 - rates[i]) + next(it))
+    return keep
+
+
+def sample_idx(n, k=192):
+    return np.unique(np.linspace(0, n - 1, num=min(n, k)).astype(np.int64))
+
+
+def grad_digest(named_params):
+    out = {}
+    for name, p in named_params:
+        if p.grad is None:
+            out["gnone/" + name] = np.zeros(0, np.float32)
+            continue
+        g = p.grad.detach().reshape(-1).double()
+        out["gnorm/" + name] = np.array(float(g.norm()))
+        out["gsamp/" + name] = g[sample_idx(g.numel())].float().numpy()
+    return out
+
+
+def load_recipe(model, W):
+    sd = {k: v for k, v in W.items()}
+    missing, unexpected = model.load_state_dict(sd, strict=True), None
+    return missing
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrs.items()})
+    print(f"wrote {path}  ({os.path.getsize(path)/1024:.0f} KiB, {len(arrs)} arrays)")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def gen_clip(name, ncrops, widths, lengths, B=2, seed_w=0, seed_x=1, seed_dp=7, drop=True):
+    torch.manual_seed(123)
+    model = ATST("small", ncrops=ncrops)
+    model.train()
+    W = O.recipe_weights("small", seed=seed_w)
+    load_recipe(model, W)
+    mels = [O.recipe_mel(B, w, seed=seed_x + i) for i, w in enumerate(widths)]
+    lens = [torch.tensor(l, dtype=torch.int64) for l in lengths]
+    if not drop:
+        for net in (model.student, model.teacher):
+            for blk in net.encoder.blocks:
+                blk.drop_path = torch.nn.Identity()
+    torch.manual_seed(seed_dp)
+    with RandRecorder() as rr:
+        t_out = model.teacher(mels[:2], lens[:2])
+        n_t = len(rr.draws)
+        s_out = model.student(mels, lens)
+        loss, std_s, std_t = model.loss_fn(s_out, t_out)
+    loss.backward()
+    rates = O.drop_path_rates(12)
+    arrs = dict(B=B, ncrops=ncrops, widths=np.array(widths), lengths=np.array(lengths), seed_w=seed_w, seed_x=seed_x,
+                loss=loss.item(), std_s=std_s.item(), std_t=std_t.item(),
+                teacher_out=t_out.detach().numpy(), student_out=s_out.detach().numpy())
+    if drop:
+        groups = O.group_views(widths)
+        # teacher: groups over first 2 views ; student: over all views.  11*2 draws per group pass.
+        per = 22
+        tg = O.group_views(widths[:2])
+        for gi in range(len(tg)):
+            arrs[f"keep_t{gi}"] = keep_from_draws(rr.draws[gi * per:(gi + 1) * per], 12, rates).numpy()
+        for gi in range(len(groups)):
+            arrs[f"keep_s{gi}"] = keep_from_draws(rr.draws[n_t + gi * per:n_t + (gi + 1) * per], 12, rates).numpy()
+        assert len(rr.draws) == per * (len(tg) + len(groups)), len(rr.draws)
+    arrs.update(grad_digest(model.student.named_parameters()))
+    # BN running stats after one train-mode pass
+    for k in ("student.projector.1.running_mean", "student.projector.1.running_var", "student.predictor.1.running_var",
+              "teacher.projector.1.running_mean", "teacher.projector.1.running_var"):
+        arrs["bn/" + k] = model.state_dict()[k][sample_idx(4096)].numpy()
+    # EMA (ref: atst.py:29-34) on the un-stepped student
+    model.update_teacher(0.99)
+    sd = model.state_dict()
+    for k in ("teacher.encoder.pos_embed", "teacher.encoder.blocks.3.mlp.fc1.weight", "teacher.projector.0.weight",
+              "teacher.projector.1.running_var"):
+        v = sd[k].reshape(-1)
+        arrs["ema/" + k] = v[sample_idx(v.numel())].numpy()
+    save(name, **arrs)
+
+
+def gen_blocks(name="clip_depth2_blocks"):
+    """depth-2 encoder: bit-exact patch indexing + per-block activations (drop_path 0)."""
+    enc = AST(depth=2, embed_dim=384, num_heads=6, patch_h=64, patch_w=4, qkv_bias=False,
+              norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), drop_path_rate=0.0)
+    W = O.recipe_weights("small", depth=2, seed=3)
+    enc.load_state_dict({k[len("student.encoder."):]: v for k, v in W.items() if k.startswith("student.encoder.")})
+    enc.train()
+    S = 3
+    mel = O.recipe_mel(S, 1001, seed=5)
+    length = torch.tensor([1001, 640, 403])
+    # integer-valued probe for the patch gather: value encodes (s, f, t)
+    probe = (torch.arange(S)[:, None, None, None] * 100000 + torch.arange(64)[None, None, :, None] * 1001
+             + torch.arange(1001)[None, None, None, :]).float()
+    patches_probe, _, plen = enc.patch_embed(probe, length)
+    x, pos, mel_patches, h, w, plen2 = enc.prepare_tokens(mel, None, length)
+    mask = ref_tr.get_attention_mask(x, plen2 + 1)
+    b0 = enc.blocks[0](x, plen2 + 1)
+    b1 = enc.blocks[1](b0, plen2 + 1)
+    cls = enc(mel, length=length)
+    save(name, S=S, length=length.numpy(), patch_length=plen.numpy(),
+         patches_probe=patches_probe.numpy().astype(np.int32)[:, ::25],      # every 25th patch, all 256 entries
+         tokens=x.detach().numpy()[:, ::10, ::4], attn_mask_row=mask[:, 0, 0, :].numpy(),
+         block0=b0.detach().numpy()[:, ::10, ::4], block1=b1.detach().numpy()[:, ::10, ::4], cls=cls.detach().numpy())
+
+
+def gen_frame(name="frame_small"):
+    """FrameATST needs pytorch_lightning at import (methods/atstframe/model.py:1) -> assemble it from its parts:
+    FrameAST_small + frame MultiCropWrapper + frame ByolLoss, exactly as model.py:24-76 does."""
+    import audio_transformer as fat      # methods/atstframe/audio_transformer.py
+    import byol as fbyol                 # methods/atstframe/byol.py
+    torch.manual_seed(5)
+    student = fbyol.MultiCropWrapper(fat.FrameAST_small(pos_type="cut", patch_embed="Linear"), 384, predictor=True)
+    teacher = fbyol.MultiCropWrapper(fat.FrameAST_small(pos_type="cut", patch_embed="Linear"), 384, predictor=False)
+    loss_fn = fbyol.ByolLoss(symmetric=True)
+    W = O.recipe_weights("small", frame=True, seed=11)
+    student.load_state_dict({k[len("student."):]: v for k, v in W.items() if k.startswith("student.")})
+    teacher.load_state_dict({k[len("teacher."):]: v for k, v in W.items() if k.startswith("teacher.")})
+    for p in teacher.parameters():
+        p.requires_grad = False
+    student.train(); teacher.train()
+    B = 2
+    mels = [O.recipe_mel(B, 1001, seed=21), O.recipe_mel(B, 1001, seed=22)]
+    lens = [torch.tensor([1001, 702]), torch.tensor([1001, 702])]
+    rs = np.random.RandomState(99)
+    m = torch.from_numpy(np.stack([O.block_mask(250, 0.65, 5, rng=rs) for _ in range(B)]))
+    masks = [m, m]
+    torch.manual_seed(17)
+    with RandRecorder() as rr:
+        tea = teacher(mels, lens, masks, False)
+        n_t = len(rr.draws)
+        stu = student(mels, lens, masks, True)
+        loss, std_s, std_t = loss_fn(stu, tea)
+    loss.backward()
+    rates = O.drop_path_rates(12)
+    arrs = dict(B=B, lengths=np.stack([l.numpy() for l in lens]), mask=m.numpy(), M=stu.shape[0],
+                loss=loss.item(), std_s=std_s.item(), std_t=std_t.item(),
+                teacher_out=tea.detach().numpy()[::7], student_out=stu.detach().numpy()[::7],
+                keep_t0=keep_from_draws(rr.draws[:n_t], 12, rates).numpy(),
+                keep_s0=keep_from_draws(rr.draws[n_t:], 12, rates).numpy())
+    arrs.update(grad_digest(student.named_parameters()))
+    save(name, **arrs)
+
+
+def gen_sched(name="schedules"):
+    lr = ref_common.cosine_scheduler_step(5e-4 * 4 * 384 / 256, 1e-6, 39100, 1300)
+    wd = ref_common.cosine_scheduler_step(0.04, 0.4, 39100, 0)
+    ema = ref_common.cosine_scheduler_step(0.99, 1, 39100, 0)
+    idx = np.array([0, 1, 2, 649, 1299, 1300, 1301, 5000, 20000, 39098, 39099])
+    model = ATST("small")
+    reg, noreg = ref_common.get_params_groups(model.student, debug=True)
+    names = [n for n, _ in model.student.named_parameters()]
+    sd_keys = list(model.state_dict().keys())
+    save(name, idx=idx, lr=lr[idx], wd=wd[idx], ema=ema[idx], lr_len=len(lr),
+         reg=np.array(reg), noreg=np.array(noreg), param_names=np.array(names), state_dict_keys=np.array(sd_keys),
+         n_student=sum(p.numel() for p in model.student.parameters()),
+         n_teacher=sum(p.numel() for p in model.teacher.parameters()))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["blocks", "clip2", "clip2_nodrop", "clip6", "frame", "sched"]
+    if "blocks" in which:
+        gen_blocks()
+    if "clip2" in which:
+        gen_clip("clip_small_2views", 2, [1001, 1001], [[1001, 801], [901, 1001]])
+    if "clip2_nodrop" in which:
+        gen_clip("clip_small_2views_nodrop", 2, [1001, 1001], [[1001, 1001], [1001, 1001]], drop=False, seed_x=31)
+    if "clip6" in which:
+        gen_clip("clip_small_6crops", 6, [1001, 1001, 101, 101, 101, 101],
+                 [[1001, 1001], [1001, 1001], [101, 101], [101, 77], [101, 101], [101, 101]], seed_x=41)
+    if "frame" in which:
+        gen_frame()
+    if "sched" in which:
+        gen_sched()

@@ -1,0 +1,143 @@
+"""Pin the CPU oracle (oracle/atst_oracle.py) against goldens produced by importing the upstream reference
+(tests/golden/make_golden.py).  fp32 tolerances: <=1e-4 rel for outputs/loss, <=1e-3 rel for gradients
+(SURVEY.md section 7 step 2); integer work (patch gather, patch_length, mask) is bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import atst_oracle as O
+
+torch.set_num_threads(8)
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"), allow_pickle=False)
+
+
+def sample_idx(n, k=192):
+    return np.unique(np.linspace(0, n - 1, num=min(n, k)).astype(np.int64))
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def grad_check(G, named, tol_norm=1e-3, tol_samp=2e-3):
+    worst = 0.0
+    for name, p in named:
+        if "gnone/" + name in G:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            continue
+        g = p.grad.reshape(-1).double()
+        gn = float(G["gnorm/" + name])
+        assert abs(float(g.norm()) - gn) <= tol_norm * gn + 1e-12, (name, float(g.norm()), gn)
+        r = rel(g[sample_idx(g.numel())].numpy(), G["gsamp/" + name])
+        worst = max(worst, r)
+        assert r <= tol_samp, (name, r)
+    return worst
+
+
+def student_leaves(W):
+    leaves = []
+    for k, v in W.items():
+        if k.startswith("student.") and v.dtype == torch.float32 and not k.endswith(("running_mean", "running_var")):
+            v.requires_grad_(True)
+            leaves.append((k[len("student."):], v))
+    return leaves
+
+
+def test_patch_gather_bit_exact(golden_dir):
+    G = load(golden_dir, "clip_depth2_blocks")
+    S = int(G["S"])
+    probe = (torch.arange(S)[:, None, None, None] * 100000 + torch.arange(64)[None, None, :, None] * 1001
+             + torch.arange(1001)[None, None, None, :]).float()
+    p = O.patchify(probe).numpy().astype(np.int32)[:, ::25]
+    assert np.array_equal(p, G["patches_probe"])
+    assert np.array_equal(O.patch_length(torch.from_numpy(G["length"])).numpy(), G["patch_length"])
+
+
+def test_depth2_blocks(golden_dir):
+    G = load(golden_dir, "clip_depth2_blocks")
+    W = O.recipe_weights("small", depth=2, seed=3)
+    mel = O.recipe_mel(int(G["S"]), 1001, seed=5)
+    length = torch.from_numpy(G["length"])
+    x, plen = O.encoder_tokens(W, "student.encoder.", mel, length, True)
+    assert rel(x.numpy()[:, ::10, ::4], G["tokens"]) < 1e-6
+    bias = O.key_padding_bias(251, plen + 1)
+    assert np.array_equal(bias[:, 0, 0, :].numpy(), G["attn_mask_row"])
+    cls, blocks = O.encoder_forward(W, "student.encoder.", mel, length, depth=2, drop_path_rate=0.0, return_blocks=True)
+    assert rel(blocks[0].numpy()[:, ::10, ::4], G["block0"]) < 1e-5
+    assert rel(blocks[1].numpy()[:, ::10, ::4], G["block1"]) < 1e-5
+    assert rel(cls.numpy(), G["cls"]) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["clip_small_2views", "clip_small_2views_nodrop", "clip_small_6crops"])
+def test_clip_step(golden_dir, name):
+    G = load(golden_dir, name)
+    B, ncrops = int(G["B"]), int(G["ncrops"])
+    widths = [int(w) for w in G["widths"]]
+    W = O.recipe_weights("small", seed=int(G["seed_w"]))
+    leaves = student_leaves(W)
+    mels = [O.recipe_mel(B, w, seed=int(G["seed_x"]) + i) for i, w in enumerate(widths)]
+    lens = [torch.from_numpy(l) for l in G["lengths"]]
+    kt = ks = None
+    if "keep_t0" in G:
+        kt = [torch.from_numpy(G[f"keep_t{i}"]) for i in range(len(O.group_views(widths[:2])))]
+        ks = [torch.from_numpy(G[f"keep_s{i}"]) for i in range(len(O.group_views(widths)))]
+    loss, std_s, std_t = O.atst_forward(W, mels, lens, "small", ncrops, kt, ks)
+    loss.backward()
+    assert abs(loss.item() - float(G["loss"])) < 1e-5 * max(1.0, abs(float(G["loss"])))
+    assert abs(std_s.item() - float(G["std_s"])) < 1e-5
+    assert abs(std_t.item() - float(G["std_t"])) < 1e-5
+    grad_check(G, [(n, p) for n, p in leaves])
+    for k in ("student.projector.1.running_mean", "student.projector.1.running_var", "teacher.projector.1.running_var"):
+        assert rel(W[k].detach()[sample_idx(4096)].numpy(), G["bn/" + k]) < 1e-4, k
+    for k, v in W.items():
+        v.requires_grad_(False) if v.dtype == torch.float32 else None
+    O.ema_update(W, 0.99)
+    for k in ("teacher.encoder.pos_embed", "teacher.encoder.blocks.3.mlp.fc1.weight", "teacher.projector.0.weight",
+              "teacher.projector.1.running_var"):
+        v = W[k].reshape(-1)
+        assert rel(v[sample_idx(v.numel())].numpy(), G["ema/" + k]) < 1e-6, k
+
+
+def test_frame_step(golden_dir):
+    G = load(golden_dir, "frame_small")
+    B = int(G["B"])
+    W = O.recipe_weights("small", frame=True, seed=11)
+    leaves = student_leaves(W)
+    mels = [O.recipe_mel(B, 1001, seed=21), O.recipe_mel(B, 1001, seed=22)]
+    lens = [torch.from_numpy(l) for l in G["lengths"]]
+    # restated block-mask sampler reproduces the committed mask from the same numpy stream
+    rs = np.random.RandomState(99)
+    m = np.stack([O.block_mask(250, 0.65, 5, rng=rs) for _ in range(B)])
+    assert np.array_equal(m, G["mask"])
+    masks = [torch.from_numpy(m)] * 2
+    loss, std_s, std_t = O.frame_atst_forward(W, mels, lens, masks, "small",
+                                              [torch.from_numpy(G["keep_t0"])], [torch.from_numpy(G["keep_s0"])])
+    loss.backward()
+    assert abs(loss.item() - float(G["loss"])) < 1e-5
+    assert abs(std_s.item() - float(G["std_s"])) < 1e-5 and abs(std_t.item() - float(G["std_t"])) < 1e-5
+    grad_check(G, [(n, p) for n, p in leaves])
+
+
+def test_schedules_and_groups(golden_dir):
+    G = load(golden_dir, "schedules")
+    idx = G["idx"]
+    lr = O.cosine_scheduler_step(5e-4 * 4 * 384 / 256, 1e-6, 39100, 1300)
+    wd = O.cosine_scheduler_step(0.04, 0.4, 39100, 0)
+    ema = O.cosine_scheduler_step(0.99, 1, 39100, 0)
+    assert len(lr) == int(G["lr_len"])
+    assert np.array_equal(lr[idx], G["lr"]) and np.array_equal(wd[idx], G["wd"]) and np.array_equal(ema[idx], G["ema"])
+    shapes = [(k, s) for k, s in O.student_shapes("small")
+              if not k.endswith(("running_mean", "running_var", "num_batches_tracked"))]
+    assert [k for k, _ in shapes] == list(G["param_names"])
+    reg, noreg = O.param_groups(shapes)
+    assert reg == list(G["reg"]) and noreg == list(G["noreg"])
+    W = O.recipe_weights("small")
+    assert list(W.keys()) == list(G["state_dict_keys"])
+    n_student = sum(int(np.prod(s)) for _, s in shapes)
+    assert n_student == int(G["n_student"]) == 26211328
