@@ -1,0 +1,124 @@
+// extern "C" surface of libatst_hip.so (declared in include/atst_hip.h): thin, allocation-free wrappers that turn raw
+// pointers + sizes + a stream into kernel launches.
+#include "common.h"
+#include "kernels.h"
+#include "../../include/atst_hip.h"
+
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+#define BF(p) reinterpret_cast<bf16*>(p)
+#define CBF(p) reinterpret_cast<const bf16*>(p)
+
+extern "C" {
+
+int atst_version(void) { return 100; }
+
+int atst_mel_frontend_f32(const float* wave, int n_clips, int n_samples, int win_length, const float* window,
+                          const float* fb_weights, const int* fb_start, const int* fb_len, int fb_maxlen,
+                          float* out, uint32_t* clipmax, void* stream) {
+  return atst_mel_frontend(wave, n_clips, n_samples, win_length, window, fb_weights, fb_start, fb_len, fb_maxlen, out,
+                           clipmax, ST(stream));
+}
+
+int atst_gemm_nt_bf16(const uint16_t* A, const uint16_t* B, int M, int N, int K, int lda, int ldb, int epi,
+                      void* C, int ldc, void* C2, const float* bias, const float* resid, const float* row_scale,
+                      int rows_per_seq, const uint16_t* U, const float* table, const uint8_t* rowflag, const float* alt,
+                      void* stream) {
+  GemmArgs a{};
+  a.A = CBF(A); a.B = CBF(B); a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.epi = epi; a.C = C; a.ldc = ldc;
+  a.C2 = C2; a.bias = bias; a.resid = resid; a.row_scale = row_scale; a.rows_per_seq = rows_per_seq > 0 ? rows_per_seq : 1;
+  a.U = CBF(U); a.table = table; a.rowflag = rowflag; a.alt = alt;
+  if ((epi == EPI_BIAS_GELU && (!bias || !C2)) || (epi == EPI_RESID && (!bias || !resid)) || (epi == EPI_DGELU && !U) ||
+      (epi == EPI_PATCH && (!table || !bias)))
+    return ATST_EINVAL;
+  return atst_gemm_nt(a, ST(stream));
+}
+
+int atst_gemm_tn_bf16(const uint16_t* dY, const uint16_t* X, int M, int N, int K, int ldy, int ldx, float* dW, int ldw,
+                      int m_per_split, void* stream) {
+  WgradArgs a{};
+  a.dY = CBF(dY); a.X = CBF(X); a.M = M; a.N = N; a.K = K; a.ldy = ldy; a.ldx = ldx; a.dW = dW; a.ldw = ldw;
+  a.m_per_split = m_per_split;
+  return atst_gemm_tn(a, ST(stream));
+}
+
+int atst_layernorm_fwd(const float* x, const float* gamma, const float* beta, uint16_t* y, float* mean, float* rstd,
+                       int M, int C, void* stream) {
+  return atst_ln_fwd(x, gamma, beta, BF(y), mean, rstd, M, C, ST(stream));
+}
+
+int atst_layernorm_bwd(const uint16_t* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                       const float* dres, float* dx, uint16_t* g, const float* row_scale, int rows_per_seq,
+                       float* dgamma, float* dbeta, float* dbias_up, int M, int C, void* stream) {
+  LnBwdArgs a{};
+  a.dy = CBF(dy); a.x = x; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.dres = dres; a.dx = dx; a.g = BF(g);
+  a.row_scale = row_scale; a.rows_per_seq = rows_per_seq > 0 ? rows_per_seq : 1; a.dgamma = dgamma; a.dbeta = dbeta;
+  a.dbias_up = dbias_up; a.M = M; a.C = C;
+  return atst_ln_bwd(a, ST(stream));
+}
+
+int atst_attention_fwd(const uint16_t* qkv, const int* valid, uint16_t* o, float* lse, int S, int H, int NP, void* stream) {
+  AttnArgs a{};
+  a.qkv = CBF(qkv); a.valid = valid; a.o = BF(o); a.lse = lse; a.S = S; a.H = H; a.NP = NP;
+  return atst_attn_fwd(a, ST(stream));
+}
+
+int atst_attention_bwd(const uint16_t* qkv, const int* valid, const uint16_t* o, const float* lse, const uint16_t* d_o,
+                       uint16_t* dqkv, int S, int H, int NP, void* stream) {
+  AttnArgs a{};
+  a.qkv = CBF(qkv); a.valid = valid; a.o = BF(const_cast<uint16_t*>(o)); a.lse = const_cast<float*>(lse);
+  a.d_o = CBF(d_o); a.dqkv = BF(dqkv); a.S = S; a.H = H; a.NP = NP;
+  return atst_attn_bwd(a, ST(stream));
+}
+
+int atst_patchify_bf16(const float* mel, int S, int width, int NP, int use_cls, uint16_t* out, void* stream) {
+  return atst_patchify(mel, S, width, NP, use_cls, BF(out), ST(stream));
+}
+int atst_gather_rows_bf16(const uint16_t* src, const int* rows, int R, int C, float* dst, void* stream) {
+  return atst_gather_rows(CBF(src), rows, R, C, dst, ST(stream));
+}
+int atst_scatter_rows_bf16(const float* src, const int* rows, int R, int C, uint16_t* dst, void* stream) {
+  return atst_scatter_rows(src, rows, R, C, BF(dst), ST(stream));
+}
+int atst_colsum_bf16_f32(const uint16_t* x, int M, int N, int ld, float* out, void* stream) {
+  return atst_colsum_bf16(CBF(x), M, N, ld, out, ST(stream));
+}
+int atst_cast_bf16(const float* x, size_t n, uint16_t* y, void* stream) { return atst_cast_f32_bf16(x, n, BF(y), ST(stream)); }
+int atst_transpose_bf16_2d(const uint16_t* src, int rows, int cols, uint16_t* dst, void* stream) {
+  return atst_transpose_bf16(CBF(src), rows, cols, BF(dst), ST(stream));
+}
+
+int atst_bn_stats_f32(const float* h, int R, int N, float* mean, float* m2, void* stream) {
+  return atst_bn_stats(h, R, N, mean, m2, ST(stream));
+}
+int atst_bn_apply_relu_bf16(const float* h, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                            int R, int N, uint16_t* y, void* stream) {
+  return atst_bn_apply_relu(h, mean, rstd, gamma, beta, R, N, BF(y), ST(stream));
+}
+int atst_bn_relu_bwd_sums(const float* dy, const float* h, const float* mean, const float* rstd, const float* gamma,
+                          const float* beta, int R, int N, float* sum_dy, float* sum_dy_xhat, void* stream) {
+  return atst_bn_relu_bwd(dy, h, mean, rstd, gamma, beta, R, N, sum_dy, sum_dy_xhat, ST(stream));
+}
+int atst_bn_bwd_dx_bf16(const float* dy, const float* h, const float* mean, const float* rstd, const float* gamma,
+                        const float* beta, const float* sum_dy, const float* sum_dy_xhat, float inv_count, int R, int N,
+                        uint16_t* dh, void* stream) {
+  return atst_bn_bwd_dx(dy, h, mean, rstd, gamma, beta, sum_dy, sum_dy_xhat, inv_count, R, N, BF(dh), ST(stream));
+}
+int atst_byol_loss_f32(const float* student, const float* teacher, int B, int ncrops, int D, float* acc, float* dstudent,
+                       float* stats, void* stream) {
+  return atst_byol_loss(student, teacher, B, ncrops, D, acc, dstudent, stats, ST(stream));
+}
+
+int atst_adamw_ema_step(float* p, const float* g, float* m, float* v, float* t, uint16_t* p_bf16, uint16_t* t_bf16,
+                        const uint8_t* chunk_flags, size_t n, size_t n_teacher, double lr, double wd, double beta1,
+                        double beta2, double eps, double step_size, double ema_m, double grad_scale, void* stream) {
+  OptimArgs a{};
+  a.p = p; a.g = g; a.m = m; a.v = v; a.t = t; a.p_bf16 = BF(p_bf16); a.t_bf16 = BF(t_bf16); a.chunk_flags = chunk_flags;
+  a.n = n; a.n_teacher = n_teacher;
+  // scalars arrive as doubles and are rounded once here, exactly as torch rounds python floats for fp32 tensors
+  a.lr_wd = (float)(lr * wd); a.beta1 = (float)beta1; a.beta2 = (float)beta2; a.om_beta1 = (float)(1.0 - beta1);
+  a.om_beta2 = (float)(1.0 - beta2); a.eps = (float)eps; a.step_size = (float)step_size; a.ema_m = (float)ema_m;
+  a.om_ema = (float)(1.0 - ema_m); a.grad_scale = (float)grad_scale;
+  return atst_adamw_ema(a, ST(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,364 @@
+// Fused multi-head self-attention (head_dim 64, <= 256 tokens / sequence) forward + backward for gfx950.
+//
+// Reference math (audiossl/modules/transformer.py:107-121, 152-159):
+//     attn = softmax(q k^T * hd^-0.5 + mask) ; mask[b,.,.,j] = -10000 * (j >= length[b]) ; y = attn v
+// The [S,H,N,N] probability tensor and the [S,1,N,N] mask of the reference are never materialised: K and V of one
+// (sequence, head) live in LDS (2 x 36 KB at N=256), scores stay in MFMA accumulators, the key-padding bias is computed
+// from `valid[s]` in registers.  Key tiles that lie completely beyond valid[s] are skipped: their reference weight is
+// exp(-10000 + ...) == 0 exactly in fp32.
+//
+// All three kernels use the "swapped" orientation S^T = K Q^T so that one lane owns one query column: row max / sum are
+// in-lane over 16 registers + one cross-half shuffle, and the probability registers are re-used directly as the B
+// operand of the second MFMA (no LDS round trip).  Transposed operands (V^T, K^T, Q^T, dO^T) are produced by
+// ds_read_b64_tr_b16 from the row-major LDS images.
+//
+//   forward            : wave = 32 queries ; loop over key tiles of 32 ; online softmax ; O^T += V^T P^T
+//   backward, dK/dV    : wave = 32 keys    ; loop over query tiles  ; dV^T += dO^T P ; dK^T += Q^T dS
+//   backward, dQ       : wave = 32 queries ; loop over key tiles    ; dQ^T += K^T dS^T
+// (S and dP are recomputed in both backward kernels instead of exchanging dS through LDS or atomics.)
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int HD = 64;
+constexpr int A_LD = HD + 8;          // 72 bf16 = 144 B LDS row stride
+constexpr float MASK_NEG = -10000.0f;
+constexpr float LOG2E = 1.4426950408889634f;
+
+template <int NP> struct Geo {
+  static constexpr int CHUNKS = NP / 32;                          // 32-row tiles per sequence
+  static constexpr int G = CHUNKS >= 4 ? 1 : 4 / CHUNKS;          // (sequence, head) pairs per 4-wave block
+  static constexpr int WPP = 4 / G;                               // waves per pair
+  static constexpr int CPW = CHUNKS / WPP;                        // tiles per wave
+  static constexpr int LDS_MAT = NP * A_LD;                       // elements of one staged [NP][72] matrix
+};
+
+// stage rows [0,NP) x 64 columns (col0..) of a [*, ld] bf16 matrix into sm[NP][A_LD] with `nthr` threads
+template <int NP>
+DEVFN void stage_rows(bf16* sm, const bf16* g, size_t ld, int t, int nthr) {
+  for (int c = t; c < NP * 8; c += nthr) {
+    const int r = c >> 3, k = (c & 7) * 8;
+    *reinterpret_cast<bf16x8*>(sm + r * A_LD + k) = ld_frag(g + (size_t)r * ld + k);
+  }
+}
+
+DEVFN void zero16(f32x16& a) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a[r] = 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NP>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
+  using GE = Geo<NP>;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+  const int C = p.H * HD;
+  const size_t ld = 3 * (size_t)C;
+  const int pair_in_blk = wid / GE::WPP, wave_in_pair = wid % GE::WPP;
+  const int pair = blockIdx.x * GE::G + pair_in_blk;
+  const int npairs = p.S * p.H;
+  const bool active = pair < npairs;
+  const int s = active ? pair / p.H : 0, h = active ? pair % p.H : 0;
+  bf16* sK = reinterpret_cast<bf16*>(smem_raw) + pair_in_blk * 2 * GE::LDS_MAT;
+  bf16* sV = sK + GE::LDS_MAT;
+  const bf16* base = p.qkv + (size_t)s * NP * ld + h * HD;
+  if (active) {
+    const int t = wave_in_pair * 64 + lane, nthr = GE::WPP * 64;
+    stage_rows<NP>(sK, base + C, ld, t, nthr);
+    stage_rows<NP>(sV, base + 2 * C, ld, t, nthr);
+  }
+  __syncthreads();
+  if (!active) return;
+  const int valid = p.valid[s];
+  const int ntile = (valid + 31) / 32 < GE::CHUNKS ? (valid + 31) / 32 : GE::CHUNKS;
+  const float scale = 0.125f;
+
+  for (int cw = 0; cw < GE::CPW; ++cw) {
+    const int q0 = (wave_in_pair * GE::CPW + cw) * 32;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = ld_frag(base + (size_t)(q0 + l31) * ld + ks * 16 + hi * 8);
+    float m_run = -1e30f, l_run = 0.f;
+    f32x16 o0, o1; zero16(o0); zero16(o1);
+    for (int j = 0; j < ntile; ++j) {
+      f32x16 sc; zero16(sc);
+      const bf16* kr = sK + (j * 32 + l31) * A_LD + hi * 8;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) sc = mfma32(ld_frag(kr + ks * 16), qf[ks], sc);
+      float pv[16];
+      float mx = -1e30f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kv = j * 32 + crow32(r, hi);
+        pv[r] = sc[r] * scale + (kv >= valid ? MASK_NEG : 0.f);
+        mx = fmaxf(mx, pv[r]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = exp2f((m_run - m_new) * LOG2E);
+      float rs = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { pv[r] = exp2f((pv[r] - m_new) * LOG2E); rs += pv[r]; }
+      rs += __shfl_xor(rs, 32, 64);
+      l_run = l_run * alpha + rs;
+      m_run = m_new;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const bf16x8 pf = pack8(pv + 8 * t);
+        o0 = mfma32(ld_frag_tr(sV, A_LD, j * 32 + 16 * t, 0, lane), pf, o0);
+        o1 = mfma32(ld_frag_tr(sV, A_LD, j * 32 + 16 * t, 32, lane), pf, o1);
+      }
+    }
+    const float inv = 1.0f / l_run;
+    bf16* orow = p.o + ((size_t)s * NP + q0 + l31) * C + h * HD;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 a, b;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { a[e] = f2bf(o0[4 * g + e] * inv); b[e] = f2bf(o1[4 * g + e] * inv); }
+      *reinterpret_cast<bf16x4*>(orow + 8 * g + 4 * hi) = a;
+      *reinterpret_cast<bf16x4*>(orow + 32 + 8 * g + 4 * hi) = b;
+    }
+    if (hi == 0) p.lse[((size_t)s * p.H + h) * NP + q0 + l31] = m_run + __logf(l_run);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward part 1: dK, dV.  LDS: Q [NP][72], dO [NP][72], lse[NP], D[NP] per pair.
+template <int NP>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
+  using GE = Geo<NP>;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+  const int C = p.H * HD;
+  const size_t ld = 3 * (size_t)C;
+  const int pair_in_blk = wid / GE::WPP, wave_in_pair = wid % GE::WPP;
+  const int pair = blockIdx.x * GE::G + pair_in_blk;
+  const bool active = pair < p.S * p.H;
+  const int s = active ? pair / p.H : 0, h = active ? pair % p.H : 0;
+  constexpr int PAIR_BYTES = 2 * GE::LDS_MAT * 2 + 2 * NP * 4;
+  char* pb = smem_raw + pair_in_blk * PAIR_BYTES;
+  bf16* sQ = reinterpret_cast<bf16*>(pb);
+  bf16* sDO = sQ + GE::LDS_MAT;
+  float* sLse = reinterpret_cast<float*>(sDO + GE::LDS_MAT);
+  float* sD = sLse + NP;
+  const bf16* base = p.qkv + (size_t)s * NP * ld + h * HD;
+  const bf16* dobase = p.d_o + (size_t)s * NP * C + h * HD;
+  const bf16* obase = p.o + (size_t)s * NP * C + h * HD;
+  if (active) {
+    const int t = wave_in_pair * 64 + lane, nthr = GE::WPP * 64;
+    stage_rows<NP>(sQ, base, ld, t, nthr);
+    stage_rows<NP>(sDO, dobase, (size_t)C, t, nthr);
+    for (int q = t; q < NP; q += nthr) {
+      float d = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const bf16x8 a = ld_frag(dobase + (size_t)q * C + k * 8), b = ld_frag(obase + (size_t)q * C + k * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d += bf2f(a[e]) * bf2f(b[e]);
+      }
+      sD[q] = d;
+      sLse[q] = p.lse[((size_t)s * p.H + h) * NP + q];
+    }
+  }
+  __syncthreads();
+  if (!active) return;
+  const int valid = p.valid[s];
+  const float scale = 0.125f;
+  // queries beyond the valid range still exist in the reference (their dO is exactly zero), so all query tiles run
+  for (int cw = 0; cw < GE::CPW; ++cw) {
+    const int k0 = (wave_in_pair * GE::CPW + cw) * 32;
+    bf16* dkrow = p.dqkv + ((size_t)s * NP + k0 + l31) * ld + C + h * HD;
+    bf16* dvrow = dkrow + C;
+    f32x16 dk0, dk1, dv0, dv1; zero16(dk0); zero16(dk1); zero16(dv0); zero16(dv1);
+    if (k0 < valid) {
+      bf16x8 kf[4], vf[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        kf[ks] = ld_frag(base + C + (size_t)(k0 + l31) * ld + ks * 16 + hi * 8);
+        vf[ks] = ld_frag(base + 2 * C + (size_t)(k0 + l31) * ld + ks * 16 + hi * 8);
+      }
+      const float kbias = (k0 + l31 >= valid) ? MASK_NEG : 0.f;
+      for (int i = 0; i < GE::CHUNKS; ++i) {
+        f32x16 sc, dp; zero16(sc); zero16(dp);
+        const bf16* qr = sQ + (i * 32 + l31) * A_LD + hi * 8;
+        const bf16* dr = sDO + (i * 32 + l31) * A_LD + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          sc = mfma32(ld_frag(qr + ks * 16), kf[ks], sc);       // S[q, kv]
+          dp = mfma32(ld_frag(dr + ks * 16), vf[ks], dp);       // dP[q, kv]
+        }
+        float pv[16], ds[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 l4 = *reinterpret_cast<const f32x4*>(sLse + i * 32 + 8 * g + 4 * hi);
+          const f32x4 d4 = *reinterpret_cast<const f32x4*>(sD + i * 32 + 8 * g + 4 * hi);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * g + e;
+            const float pr = exp2f((sc[r] * scale + kbias - l4[e]) * LOG2E);
+            pv[r] = pr;
+            ds[r] = pr * (dp[r] - d4[e]) * scale;
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const bf16x8 pf = pack8(pv + 8 * t), dsf = pack8(ds + 8 * t);
+          dv0 = mfma32(ld_frag_tr(sDO, A_LD, i * 32 + 16 * t, 0, lane), pf, dv0);
+          dv1 = mfma32(ld_frag_tr(sDO, A_LD, i * 32 + 16 * t, 32, lane), pf, dv1);
+          dk0 = mfma32(ld_frag_tr(sQ, A_LD, i * 32 + 16 * t, 0, lane), dsf, dk0);
+          dk1 = mfma32(ld_frag_tr(sQ, A_LD, i * 32 + 16 * t, 32, lane), dsf, dk1);
+        }
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 a, b, c, d;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a[e] = f2bf(dk0[4 * g + e]); b[e] = f2bf(dk1[4 * g + e]);
+        c[e] = f2bf(dv0[4 * g + e]); d[e] = f2bf(dv1[4 * g + e]);
+      }
+      *reinterpret_cast<bf16x4*>(dkrow + 8 * g + 4 * hi) = a;
+      *reinterpret_cast<bf16x4*>(dkrow + 32 + 8 * g + 4 * hi) = b;
+      *reinterpret_cast<bf16x4*>(dvrow + 8 * g + 4 * hi) = c;
+      *reinterpret_cast<bf16x4*>(dvrow + 32 + 8 * g + 4 * hi) = d;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward part 2: dQ.  LDS: K [NP][72], V [NP][72] per pair.
+template <int NP>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
+  using GE = Geo<NP>;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+  const int C = p.H * HD;
+  const size_t ld = 3 * (size_t)C;
+  const int pair_in_blk = wid / GE::WPP, wave_in_pair = wid % GE::WPP;
+  const int pair = blockIdx.x * GE::G + pair_in_blk;
+  const bool active = pair < p.S * p.H;
+  const int s = active ? pair / p.H : 0, h = active ? pair % p.H : 0;
+  bf16* sK = reinterpret_cast<bf16*>(smem_raw) + pair_in_blk * 2 * GE::LDS_MAT;
+  bf16* sV = sK + GE::LDS_MAT;
+  const bf16* base = p.qkv + (size_t)s * NP * ld + h * HD;
+  if (active) {
+    const int t = wave_in_pair * 64 + lane, nthr = GE::WPP * 64;
+    stage_rows<NP>(sK, base + C, ld, t, nthr);
+    stage_rows<NP>(sV, base + 2 * C, ld, t, nthr);
+  }
+  __syncthreads();
+  if (!active) return;
+  const int valid = p.valid[s];
+  const int ntile = (valid + 31) / 32 < GE::CHUNKS ? (valid + 31) / 32 : GE::CHUNKS;
+  const float scale = 0.125f;
+  for (int cw = 0; cw < GE::CPW; ++cw) {
+    const int q0 = (wave_in_pair * GE::CPW + cw) * 32;
+    const size_t qrow = (size_t)s * NP + q0 + l31;
+    bf16x8 qf[4], dof[4];
+    float dpart = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      qf[ks] = ld_frag(base + (size_t)(q0 + l31) * ld + ks * 16 + hi * 8);
+      dof[ks] = ld_frag(p.d_o + qrow * C + h * HD + ks * 16 + hi * 8);
+      const bf16x8 of = ld_frag(p.o + qrow * C + h * HD + ks * 16 + hi * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dpart += bf2f(dof[ks][e]) * bf2f(of[e]);
+    }
+    const float D = dpart + __shfl_xor(dpart, 32, 64);
+    const float lse = p.lse[((size_t)s * p.H + h) * NP + q0 + l31];
+    f32x16 dq0, dq1; zero16(dq0); zero16(dq1);
+    for (int j = 0; j < ntile; ++j) {
+      f32x16 sc, dp; zero16(sc); zero16(dp);
+      const bf16* kr = sK + (j * 32 + l31) * A_LD + hi * 8;
+      const bf16* vr = sV + (j * 32 + l31) * A_LD + hi * 8;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        sc = mfma32(ld_frag(kr + ks * 16), qf[ks], sc);        // S^T[kv, q]
+        dp = mfma32(ld_frag(vr + ks * 16), dof[ks], dp);       // dP^T[kv, q]
+      }
+      float ds[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kv = j * 32 + crow32(r, hi);
+        const float pr = exp2f((sc[r] * scale + (kv >= valid ? MASK_NEG : 0.f) - lse) * LOG2E);
+        ds[r] = pr * (dp[r] - D) * scale;
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const bf16x8 dsf = pack8(ds + 8 * t);
+        dq0 = mfma32(ld_frag_tr(sK, A_LD, j * 32 + 16 * t, 0, lane), dsf, dq0);
+        dq1 = mfma32(ld_frag_tr(sK, A_LD, j * 32 + 16 * t, 32, lane), dsf, dq1);
+      }
+    }
+    bf16* dqrow = p.dqkv + qrow * ld + h * HD;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 a, b;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { a[e] = f2bf(dq0[4 * g + e]); b[e] = f2bf(dq1[4 * g + e]); }
+      *reinterpret_cast<bf16x4*>(dqrow + 8 * g + 4 * hi) = a;
+      *reinterpret_cast<bf16x4*>(dqrow + 32 + 8 * g + 4 * hi) = b;
+    }
+  }
+}
+
+template <int NP> int fwd_lds() { return Geo<NP>::G * 2 * Geo<NP>::LDS_MAT * 2; }
+template <int NP> int dkv_lds() { return Geo<NP>::G * (2 * Geo<NP>::LDS_MAT * 2 + 2 * NP * 4); }
+
+template <int NP>
+int launch_fwd(const AttnArgs& a, hipStream_t st) {
+  static bool done = false;
+  const int lds = fwd_lds<NP>();
+  if (!done) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    done = true;
+  }
+  const int nblk = (a.S * a.H + Geo<NP>::G - 1) / Geo<NP>::G;
+  hipLaunchKernelGGL(attn_fwd_kernel<NP>, dim3(nblk), dim3(256), lds, st, a);
+  return (int)hipGetLastError();
+}
+template <int NP>
+int launch_bwd(const AttnArgs& a, hipStream_t st) {
+  static bool done = false;
+  const int lds1 = dkv_lds<NP>(), lds2 = fwd_lds<NP>();
+  if (!done) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+    if (e != hipSuccess) return (int)e;
+    done = true;
+  }
+  const int nblk = (a.S * a.H + Geo<NP>::G - 1) / Geo<NP>::G;
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel<NP>, dim3(nblk), dim3(256), lds1, st, a);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel<NP>, dim3(nblk), dim3(256), lds2, st, a);
+  return (int)hipGetLastError();
+}
+}  // namespace
+
+int atst_attn_fwd(const AttnArgs& a, hipStream_t st) {
+  if (a.S <= 0) return ATST_OK;
+  switch (a.NP) {
+    case 256: return launch_fwd<256>(a, st);
+    case 128: return launch_fwd<128>(a, st);
+    case 64: return launch_fwd<64>(a, st);
+    case 32: return launch_fwd<32>(a, st);
+  }
+  return ATST_EINVAL;
+}
+int atst_attn_bwd(const AttnArgs& a, hipStream_t st) {
+  if (a.S <= 0) return ATST_OK;
+  switch (a.NP) {
+    case 256: return launch_bwd<256>(a, st);
+    case 128: return launch_bwd<128>(a, st);
+    case 64: return launch_bwd<64>(a, st);
+    case 32: return launch_bwd<32>(a, st);
+  }
+  return ATST_EINVAL;
+}

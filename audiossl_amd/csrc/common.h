@@ -1,0 +1,83 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) ATST kernels.  wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32;
+
+#define ATST_OK 0
+#define ATST_EINVAL 1001        // bad argument (shape not supported by the compiled kernels)
+
+#define DEVFN __device__ __forceinline__
+
+DEVFN float bf2f(bf16 v) { return (float)v; }
+DEVFN bf16 f2bf(float v) { return (bf16)v; }
+
+DEVFN float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+DEVFN float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// exact-erf GELU and its derivative (nn.GELU default, ref: audiossl/modules/transformer.py:70-92)
+DEVFN float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+DEVFN float gelu_grad_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// XCD-aware, bijective remap of a 1-D grid: block b runs on XCD b%8 (observed, speed only); give every XCD a
+// contiguous chunk of logical ids so that neighbouring tiles share one L2.
+DEVFN int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, loc = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + loc;
+}
+
+// ---- MFMA fragment helpers (layouts verified on hardware by tools/probes/probe_isa.hip) ------------------------------
+// v_mfma_f32_32x32x16_bf16: A lane l holds row (l&31), k = (l>>5)*8 + 0..7 ; B lane l holds col (l&31), same k ;
+// C/D lane l, reg r: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5).
+DEVFN f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+DEVFN int crow32(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// 16-byte row-major fragment from LDS / global: 8 consecutive k of one row.
+DEVFN bf16x8 ld_frag(const bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
+
+// ds_read_b64_tr_b16: per 16-lane group, lane a supplies the address of 4 contiguous bf16; lane i receives
+// element (i&3) of lanes 4j+(i>>2), j=0..3  ==  column i of the group's row-major [4][16] block.
+DEVFN s16x4 lds_tr4(const bf16* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
+}
+// A-operand fragment of X^T taken from a row-major LDS image X[row][col] (ld elements per row):
+// lane (c = l&31, hi = l>>5) receives X[r0 + 8*(e>>2) + 4*hi + (e&3)][c0 + c], e = 0..7  -- the k-order that a
+// C-layout register block (regs 8t..8t+7) has when it is re-used as the B operand.
+DEVFN bf16x8 ld_frag_tr(const bf16* X, int ld, int r0, int c0, int lane) {
+  const int a = lane & 15, g = lane >> 4;
+  const bf16* p = X + (r0 + 4 * (g >> 1) + (a >> 2)) * ld + c0 + (g & 1) * 16 + 4 * (a & 3);
+  s16x4 lo = lds_tr4(p);
+  s16x4 hi = lds_tr4(p + 8 * ld);
+  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+  u.s.a = lo; u.s.b = hi;
+  return u.v;
+}
+// pack 8 floats (C-layout regs 8t..8t+7) into a bf16 operand fragment
+DEVFN bf16x8 pack8(const float* v) {
+  bf16x8 o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = f2bf(v[i]);
+  return o;
+}

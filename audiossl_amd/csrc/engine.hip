@@ -1,0 +1,206 @@
+// Whole-encoder forward / backward driver: one host call enqueues every kernel of AST.forward / FrameAST.forward
+// (audiossl/models/atst/audio_transformer.py:188-221, audiossl/methods/atstframe/audio_transformer.py:183-207,
+// 12 x Block.forward audiossl/modules/transformer.py:136-150) or of its backward on a HIP stream.  No Python, no
+// autograd graph, no per-op dispatch: the activation tape is a fixed carve of one caller-owned workspace.
+#include "common.h"
+#include "kernels.h"
+#include "../../include/atst_hip.h"
+
+namespace {
+
+struct LayerWs {
+  bf16 *h1, *qkv, *o, *h2, *u, *a;
+  float *mean1, *rstd1, *mean2, *rstd2, *lse;
+};
+struct Ws {
+  bf16* patches; float* table;
+  float* x[2 * ATST_MAX_DEPTH + 1];
+  LayerWs L[ATST_MAX_DEPTH];
+  bf16* hN; float *meanN, *rstdN;
+  // backward scratch
+  float *dxA, *dxB;
+  bf16 *g, *dh, *du, *dqkv, *d_o, *dout;
+  size_t bytes;
+};
+
+struct Carver {
+  char* base; size_t off;
+  template <typename T> T* take(size_t n) {
+    off = (off + 255) & ~(size_t)255;
+    T* p = reinterpret_cast<T*>(base + off);
+    off += n * sizeof(T);
+    return p;
+  }
+};
+
+Ws carve(void* ws, int S, int NP, int C, int H, int depth, int train) {
+  Ws w{};
+  Carver c{reinterpret_cast<char*>(ws), 0};
+  const size_t M = (size_t)S * NP;
+  w.patches = c.take<bf16>(M * 256);
+  w.table = c.take<float>((size_t)NP * C);
+  const int nx = train ? 2 * depth + 1 : 1;
+  for (int i = 0; i < nx; ++i) w.x[i] = c.take<float>(M * C);
+  for (int i = nx; i < 2 * depth + 1; ++i) w.x[i] = w.x[0];
+  const int nl = train ? depth : 1;
+  for (int i = 0; i < nl; ++i) {
+    LayerWs& l = w.L[i];
+    l.h1 = c.take<bf16>(M * C); l.qkv = c.take<bf16>(M * 3 * C); l.o = c.take<bf16>(M * C);
+    l.h2 = c.take<bf16>(M * C); l.u = c.take<bf16>(M * 4 * C); l.a = c.take<bf16>(M * 4 * C);
+    l.mean1 = c.take<float>(M); l.rstd1 = c.take<float>(M); l.mean2 = c.take<float>(M); l.rstd2 = c.take<float>(M);
+    l.lse = c.take<float>((size_t)S * H * NP);
+  }
+  for (int i = nl; i < depth; ++i) w.L[i] = w.L[0];
+  w.hN = c.take<bf16>(M * C); w.meanN = c.take<float>(M); w.rstdN = c.take<float>(M);
+  if (train) {
+    w.dxA = c.take<float>(M * C); w.dxB = c.take<float>(M * C);
+    w.g = c.take<bf16>(M * C); w.dh = c.take<bf16>(M * C); w.du = c.take<bf16>(M * 4 * C);
+    w.dqkv = c.take<bf16>(M * 3 * C); w.d_o = c.take<bf16>(M * C); w.dout = c.take<bf16>(M * C);
+  }
+  w.bytes = (c.off + 255) & ~(size_t)255;
+  return w;
+}
+
+inline const bf16* B16(const uint16_t* p) { return reinterpret_cast<const bf16*>(p); }
+
+#define RUN(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
+
+int gemm(const bf16* A, const bf16* B, int M, int N, int K, int epi, void* C, hipStream_t st, const float* bias = nullptr,
+         const float* resid = nullptr, const float* row_scale = nullptr, int rps = 1, void* C2 = nullptr,
+         const bf16* U = nullptr) {
+  GemmArgs a{};
+  a.A = A; a.B = B; a.M = M; a.N = N; a.K = K; a.lda = K; a.ldb = K; a.epi = epi; a.C = C; a.ldc = N; a.C2 = C2;
+  a.bias = bias; a.resid = resid; a.row_scale = row_scale; a.rows_per_seq = rps; a.U = U;
+  return atst_gemm_nt(a, st);
+}
+int wgrad(const bf16* dY, const bf16* X, int M, int N, int K, float* dW, hipStream_t st) {
+  WgradArgs a{};
+  a.dY = dY; a.X = X; a.M = M; a.N = N; a.K = K; a.ldy = N; a.ldx = K; a.dW = dW; a.ldw = K; a.m_per_split = 0;
+  return atst_gemm_tn(a, st);
+}
+}  // namespace
+
+extern "C" size_t atst_encoder_ws_bytes(int S, int NP, int C, int H, int depth, int train) {
+  return carve(nullptr, S, NP, C, H, depth, train).bytes;
+}
+
+static bool check(const atst_encoder_t* e) {
+  if (!e || e->depth < 1 || e->depth > ATST_MAX_DEPTH) return false;
+  if (e->C != e->H * 64 || (e->C != 384 && e->C != 768)) return false;
+  if (e->NP != 32 && e->NP != 64 && e->NP != 128 && e->NP != 256) return false;
+  if (e->n_tok + e->use_cls > e->NP) return false;
+  if (e->ws_bytes < atst_encoder_ws_bytes(e->S, e->NP, e->C, e->H, e->depth, e->train)) return false;
+  return true;
+}
+
+extern "C" const uint16_t* atst_encoder_out(const atst_encoder_t* e) {
+  return reinterpret_cast<const uint16_t*>(carve(e->ws, e->S, e->NP, e->C, e->H, e->depth, e->train).hN);
+}
+extern "C" uint16_t* atst_encoder_dout(const atst_encoder_t* e) {
+  return reinterpret_cast<uint16_t*>(carve(e->ws, e->S, e->NP, e->C, e->H, e->depth, e->train).dout);
+}
+extern "C" const float* atst_encoder_block_out(const atst_encoder_t* e, int i) {
+  return carve(e->ws, e->S, e->NP, e->C, e->H, e->depth, e->train).x[2 * i + 2];
+}
+extern "C" const float* atst_encoder_tokens(const atst_encoder_t* e) {
+  return carve(e->ws, e->S, e->NP, e->C, e->H, e->depth, e->train).x[0];
+}
+
+extern "C" int atst_encoder_fwd(const atst_encoder_t* e, void* stream) {
+  if (!check(e)) return ATST_EINVAL;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const Ws w = carve(e->ws, e->S, e->NP, e->C, e->H, e->depth, e->train);
+  const int S = e->S, NP = e->NP, C = e->C, M = S * NP;
+  const float* p = e->p32; const bf16* q = B16(e->p16);
+  const atst_enc_off_t& o = e->off;
+
+  RUN(atst_patchify(e->mel, S, e->width, NP, e->use_cls, w.patches, st));
+  RUN(atst_token_table(e->use_cls ? p + o.cls_token : nullptr, p + o.pos_embed, p + o.patch_b, NP, e->n_tok, C, e->use_cls, w.table, st));
+  {
+    GemmArgs a{};
+    a.A = w.patches; a.B = q + o.patch_w; a.M = M; a.N = C; a.K = 256; a.lda = 256; a.ldb = 256; a.epi = EPI_PATCH;
+    a.C = w.x[0]; a.ldc = C; a.bias = p + o.patch_b; a.rows_per_seq = NP; a.table = w.table; a.rowflag = e->rowflag;
+    a.alt = p + o.mask_embed;
+    RUN(atst_gemm_nt(a, st));
+  }
+  for (int i = 0; i < e->depth; ++i) {
+    const atst_layer_off_t& lo = o.layer[i];
+    const LayerWs& l = w.L[i];
+    const float* s1 = e->dp_scale ? e->dp_scale + (size_t)(2 * i) * S : nullptr;
+    const float* s2 = e->dp_scale ? e->dp_scale + (size_t)(2 * i + 1) * S : nullptr;
+    RUN(atst_ln_fwd(w.x[2 * i], p + lo.ln1_w, p + lo.ln1_b, l.h1, l.mean1, l.rstd1, M, C, st));
+    RUN(gemm(l.h1, q + lo.qkv_w, M, 3 * C, C, EPI_BF16, l.qkv, st));
+    AttnArgs at{};
+    at.qkv = l.qkv; at.valid = e->valid; at.o = l.o; at.lse = l.lse; at.S = S; at.H = e->H; at.NP = NP;
+    RUN(atst_attn_fwd(at, st));
+    RUN(gemm(l.o, q + lo.proj_w, M, C, C, EPI_RESID, w.x[2 * i + 1], st, p + lo.proj_b, w.x[2 * i], s1, NP));
+    RUN(atst_ln_fwd(w.x[2 * i + 1], p + lo.ln2_w, p + lo.ln2_b, l.h2, l.mean2, l.rstd2, M, C, st));
+    RUN(gemm(l.h2, q + lo.fc1_w, M, 4 * C, C, EPI_BIAS_GELU, l.u, st, p + lo.fc1_b, nullptr, nullptr, 1, l.a));
+    RUN(gemm(l.a, q + lo.fc2_w, M, C, 4 * C, EPI_RESID, w.x[2 * i + 2], st, p + lo.fc2_b, w.x[2 * i + 1], s2, NP));
+  }
+  RUN(atst_ln_fwd(w.x[2 * e->depth], p + o.norm_w, p + o.norm_b, w.hN, w.meanN, w.rstdN, M, C, st));
+  return ATST_OK;
+}
+
+extern "C" int atst_encoder_bwd(const atst_encoder_t* e, void* stream) {
+  if (!check(e) || !e->train || !e->p16t || !e->g32) return ATST_EINVAL;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const Ws w = carve(e->ws, e->S, e->NP, e->C, e->H, e->depth, e->train);
+  const int S = e->S, NP = e->NP, C = e->C, M = S * NP, D = e->depth;
+  const float* p = e->p32; const bf16* qt = B16(e->p16t);
+  float* G = e->g32;
+  const atst_enc_off_t& o = e->off;
+  auto dps = [&](int layer, int which) -> const float* {
+    return e->dp_scale ? e->dp_scale + (size_t)(2 * layer + which) * S : nullptr;
+  };
+
+  float* cur = w.dxA; float* oth = w.dxB;
+  {
+    LnBwdArgs a{};
+    a.dy = w.dout; a.x = w.x[2 * D]; a.mean = w.meanN; a.rstd = w.rstdN; a.gamma = p + o.norm_w; a.dres = nullptr;
+    a.dx = cur; a.g = w.g; a.row_scale = dps(D - 1, 1); a.rows_per_seq = NP;
+    a.dgamma = G + o.norm_w; a.dbeta = G + o.norm_b; a.dbias_up = G + o.layer[D - 1].fc2_b; a.M = M; a.C = C;
+    RUN(atst_ln_bwd(a, st));
+  }
+  for (int i = D - 1; i >= 0; --i) {
+    const atst_layer_off_t& lo = o.layer[i];
+    const LayerWs& l = w.L[i];
+    // ---- MLP branch: x_out = x_mid + s2 * (fc2(gelu(fc1(LN2(x_mid)))) + b2) ; w.g = s2 * d(x_out)
+    RUN(wgrad(w.g, l.a, M, C, 4 * C, G + lo.fc2_w, st));
+    RUN(gemm(w.g, qt + lo.fc2_w, M, 4 * C, C, EPI_DGELU, w.du, st, nullptr, nullptr, nullptr, 1, nullptr, l.u));
+    RUN(atst_colsum_bf16(w.du, M, 4 * C, 4 * C, G + lo.fc1_b, st));
+    RUN(wgrad(w.du, l.h2, M, 4 * C, C, G + lo.fc1_w, st));
+    RUN(gemm(w.du, qt + lo.fc1_w, M, C, 4 * C, EPI_BF16, w.dh, st));
+    {
+      LnBwdArgs a{};
+      a.dy = w.dh; a.x = w.x[2 * i + 1]; a.mean = l.mean2; a.rstd = l.rstd2; a.gamma = p + lo.ln2_w; a.dres = cur;
+      a.dx = oth; a.g = w.g; a.row_scale = dps(i, 0); a.rows_per_seq = NP;
+      a.dgamma = G + lo.ln2_w; a.dbeta = G + lo.ln2_b; a.dbias_up = G + lo.proj_b; a.M = M; a.C = C;
+      RUN(atst_ln_bwd(a, st));
+      float* t = cur; cur = oth; oth = t;
+    }
+    // ---- attention branch: x_mid = x_in + s1 * (proj(attn(LN1(x_in))) + bp) ; w.g = s1 * d(x_mid)
+    RUN(wgrad(w.g, l.o, M, C, C, G + lo.proj_w, st));
+    RUN(gemm(w.g, qt + lo.proj_w, M, C, C, EPI_BF16, w.d_o, st));
+    AttnArgs at{};
+    at.qkv = l.qkv; at.valid = e->valid; at.o = l.o; at.lse = l.lse; at.d_o = w.d_o; at.dqkv = w.dqkv;
+    at.S = S; at.H = e->H; at.NP = NP;
+    RUN(atst_attn_bwd(at, st));
+    RUN(wgrad(w.dqkv, l.h1, M, 3 * C, C, G + lo.qkv_w, st));
+    RUN(gemm(w.dqkv, qt + lo.qkv_w, M, C, 3 * C, EPI_BF16, w.dh, st));
+    {
+      LnBwdArgs a{};
+      a.dy = w.dh; a.x = w.x[2 * i]; a.mean = l.mean1; a.rstd = l.rstd1; a.gamma = p + lo.ln1_w; a.dres = cur;
+      a.dx = oth; a.g = i > 0 ? w.g : nullptr; a.row_scale = i > 0 ? dps(i - 1, 1) : nullptr; a.rows_per_seq = NP;
+      a.dgamma = G + lo.ln1_w; a.dbeta = G + lo.ln1_b; a.dbias_up = i > 0 ? G + o.layer[i - 1].fc2_b : nullptr;
+      a.M = M; a.C = C;
+      RUN(atst_ln_bwd(a, st));
+      float* t = cur; cur = oth; oth = t;
+    }
+  }
+  // ---- token stage: x0 = (1-m) (patch W^T + b) + m mask_embed + pos  (+ CLS)
+  RUN(atst_token_grad(cur, e->rowflag, S, NP, e->n_tok, C, e->use_cls, e->use_cls ? G + o.cls_token : nullptr,
+                      G + o.pos_embed, G + o.patch_b, e->rowflag ? G + o.mask_embed : nullptr, w.g, st));
+  RUN(wgrad(w.g, w.patches, M, C, 256, G + o.patch_w, st));
+  return ATST_OK;
+}

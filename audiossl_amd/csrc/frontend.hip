@@ -1,0 +1,169 @@
+// Log-mel front end on gfx950:  waveform -> reflect-pad/frame/Hann -> 1024-point real FFT -> |.|^2 -> 64-band HTK mel
+// -> 10 log10 -> (per clip) clamp at max-80 dB -> min-max to [-1,1].
+// Restates torchaudio MelSpectrogram(16000, n_fft=1024, win_length=W, hop=160, f_min=60, f_max=7800, n_mels=64) ->
+// AmplitudeToDB("power", top_db=80) -> MinMax(-79.6482, 50.6842) as called from audiossl/methods/atst/transform.py:14-18
+// and audiossl/methods/atstframe/transform.py:16-22  (the reference runs this on CPU dataloader workers, 1 thread each).
+//
+// HBM-bound by design (0.64 MB read + 0.26 MB written per clip-view), so no GEMM reshaping: one wave computes one frame
+// as a 512-point complex Stockham radix-8 FFT (3 passes through LDS) of the even/odd-packed real signal, un-packs the
+// 513 bins, and reduces the triangular filters from LDS.  A block buffers 32 frames x 64 bands in LDS so that the
+// [64, T] output rows are written in 128-B segments.  The per-clip maximum is an atomicMax on an order-preserving key.
+#include <cmath>
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int NFFT = 1024, HOPS = 160, NBIN = 513, NMEL = 64;
+constexpr int FPB = 32;                       // frames per block (8 per wave)
+constexpr float DB_MIN = -79.6482f, DB_MAX = 50.6842f, TOP_DB = 80.0f, DB_BIAS = 200.0f;
+
+__device__ float2 g_tw512[512];               // exp(-2 pi i j / 512)
+__device__ float2 g_tw1024[NBIN];             // exp(-2 pi i k / 1024), k <= 512
+
+DEVFN float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+DEVFN float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+DEVFN float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+DEVFN float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }          // a * (-i)
+
+// 8-point DFT, natural-order in / natural-order out (three radix-2 layers)
+DEVFN void dft8(float2* u) {
+  const float s = 0.70710678118654752f;
+  float2 a[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { a[i] = cadd(u[i], u[i + 4]); a[i + 4] = csub(u[i], u[i + 4]); }
+  a[5] = cmul(a[5], make_float2(s, -s));
+  a[6] = mul_mi(a[6]);
+  a[7] = cmul(a[7], make_float2(-s, -s));
+  float2 b[8];
+#pragma unroll
+  for (int h = 0; h < 8; h += 4) {
+    b[h] = cadd(a[h], a[h + 2]); b[h + 2] = csub(a[h], a[h + 2]);
+    b[h + 1] = cadd(a[h + 1], a[h + 3]); b[h + 3] = mul_mi(csub(a[h + 1], a[h + 3]));
+  }
+  float2 c[8];
+#pragma unroll
+  for (int h = 0; h < 8; h += 4) {
+    c[h] = cadd(b[h], b[h + 1]); c[h + 1] = csub(b[h], b[h + 1]);
+    c[h + 2] = cadd(b[h + 2], b[h + 3]); c[h + 3] = csub(b[h + 2], b[h + 3]);
+  }
+  u[0] = c[0]; u[1] = c[4]; u[2] = c[2]; u[3] = c[6]; u[4] = c[1]; u[5] = c[5]; u[6] = c[3]; u[7] = c[7];
+}
+
+DEVFN int reflect(int i, int n) { i = i < 0 ? -i : i; return i >= n ? 2 * (n - 1) - i : i; }
+
+__global__ __launch_bounds__(256) void stft_mel_db_kernel(const float* __restrict__ wave, int n_samples, int T,
+                                                          const float* __restrict__ window, const float* __restrict__ fbw,
+                                                          const int* __restrict__ fb_start, const int* __restrict__ fb_len,
+                                                          int fb_maxlen, float* __restrict__ out, unsigned int* __restrict__ clipmax) {
+  __shared__ float2 fa[4][512];
+  __shared__ float2 fb[4][512];
+  __shared__ float pw[4][NBIN + 7];
+  __shared__ float dbb[NMEL][FPB + 1];
+  __shared__ float wmax[4];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int clip = blockIdx.y, t0 = blockIdx.x * FPB;
+  const float* w = wave + (size_t)clip * n_samples;
+  const int m_start = fb_start[lane], m_len = fb_len[lane];
+  float vmax = -1e30f;
+  for (int fi = 0; fi < FPB / 4; ++fi) {
+    const int fl = fi * 4 + wid;                       // frame within block
+    int t = t0 + fl; if (t >= T) t = T - 1;             // duplicates are computed but never stored
+    const int base = t * HOPS - NFFT / 2;
+    float2 u[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int j0 = 2 * (lane + 64 * r);
+      const f32x2 wn = *reinterpret_cast<const f32x2*>(window + j0);
+      u[r] = make_float2(w[reflect(base + j0, n_samples)] * wn[0], w[reflect(base + j0 + 1, n_samples)] * wn[1]);
+    }
+    dft8(u);                                            // pass p = 1 : no twiddles, out index lane*8 + r
+#pragma unroll
+    for (int r = 0; r < 8; ++r) fa[wid][lane * 8 + r] = u[r];
+    __syncthreads();
+    {                                                   // pass p = 8
+      const int k = lane & 7, j = (lane - k) * 8 + k;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) u[r] = cmul(fa[wid][lane + 64 * r], g_tw512[k * r * 8]);
+      dft8(u);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) fb[wid][j + r * 8] = u[r];
+    }
+    __syncthreads();
+    {                                                   // pass p = 64
+#pragma unroll
+      for (int r = 0; r < 8; ++r) u[r] = cmul(fb[wid][lane + 64 * r], g_tw512[lane * r]);
+      dft8(u);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) fa[wid][lane + 64 * r] = u[r];
+    }
+    __syncthreads();
+    for (int k = lane; k <= 512; k += 64) {             // un-pack the real transform, power spectrum
+      const float2 zk = fa[wid][k & 511];
+      float2 zc = fa[wid][(512 - k) & 511]; zc.y = -zc.y;
+      const float2 e = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y + zc.y));
+      const float2 d = csub(zk, zc);
+      const float2 o = make_float2(0.5f * d.y, -0.5f * d.x);      // d / (2i)
+      const float2 x = cadd(e, cmul(g_tw1024[k], o));
+      pw[wid][k] = x.x * x.x + x.y * x.y;
+    }
+    __syncthreads();
+    float mel = 0.f;
+    for (int q = 0; q < m_len; ++q) mel += fbw[lane * fb_maxlen + q] * pw[wid][m_start + q];
+    const float db = 10.0f * log10f(fmaxf(mel, 1e-10f));
+    dbb[lane][fl] = db;
+    if (t0 + fl < T) vmax = fmaxf(vmax, db);
+  }
+  vmax = wave_max(vmax);
+  if (lane == 0) wmax[wid] = vmax;
+  __syncthreads();
+  if (tid == 0) {
+    const float m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])) + DB_BIAS;   // > 0 : uint order == float order
+    atomicMax(clipmax + clip, __float_as_uint(m));
+  }
+  float* o = out + (size_t)clip * NMEL * T;
+  for (int i = tid; i < NMEL * FPB; i += 256) {
+    const int m = i / FPB, f = i % FPB;
+    if (t0 + f < T) o[(size_t)m * T + t0 + f] = dbb[m][f];
+  }
+}
+
+__global__ void db_finalize_kernel(float* __restrict__ x, const unsigned int* __restrict__ clipmax, int per_clip) {
+  const int clip = blockIdx.y;
+  const float floor_db = __uint_as_float(clipmax[clip]) - DB_BIAS - TOP_DB;
+  float* p = x + (size_t)clip * per_clip;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < per_clip; i += gridDim.x * blockDim.x) {
+    const float db = fmaxf(p[i], floor_db);
+    p[i] = (db - DB_MIN) / (DB_MAX - DB_MIN) * 2.0f - 1.0f;
+  }
+}
+
+int init_twiddles() {
+  static bool done = false;
+  if (done) return 0;
+  static float2 h512[512], h1024[NBIN];
+  for (int j = 0; j < 512; ++j) { const double a = -2.0 * M_PI * j / 512.0; h512[j] = make_float2((float)std::cos(a), (float)std::sin(a)); }
+  for (int k = 0; k < NBIN; ++k) { const double a = -2.0 * M_PI * k / 1024.0; h1024[k] = make_float2((float)std::cos(a), (float)std::sin(a)); }
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_tw512), h512, sizeof(h512));
+  if (e != hipSuccess) return (int)e;
+  e = hipMemcpyToSymbol(HIP_SYMBOL(g_tw1024), h1024, sizeof(h1024));
+  if (e != hipSuccess) return (int)e;
+  done = true;
+  return 0;
+}
+}  // namespace
+
+int atst_mel_frontend(const float* wave, int n_clips, int n_samples, int win_length, const float* window,
+                      const float* fb_weights, const int* fb_start, const int* fb_len, int fb_maxlen,
+                      float* out, unsigned int* clipmax, hipStream_t st) {
+  (void)win_length;                                   // the zero-padded 1024-tap window is supplied by the caller
+  if (n_clips <= 0 || n_samples < NFFT / 2 + 1) return ATST_EINVAL;
+  int rc = init_twiddles();
+  if (rc) return rc;
+  const int T = 1 + n_samples / HOPS;
+  hipMemsetAsync(clipmax, 0, n_clips * sizeof(unsigned int), st);
+  hipLaunchKernelGGL(stft_mel_db_kernel, dim3((T + FPB - 1) / FPB, n_clips), dim3(256), 0, st, wave, n_samples, T, window,
+                     fb_weights, fb_start, fb_len, fb_maxlen, out, clipmax);
+  hipLaunchKernelGGL(db_finalize_kernel, dim3(16, n_clips), dim3(256), 0, st, out, clipmax, NMEL * T);
+  return (int)hipGetLastError();
+}

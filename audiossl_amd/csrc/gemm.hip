@@ -1,0 +1,263 @@
+// bf16 MFMA GEMMs for the ATST encoder / heads on gfx950.
+//
+//   gemm_nt  : C[M,N] = A[M,K] * B[N,K]^T  (+ fused epilogue)      forward GEMMs (weights are [out,in] row-major, torch
+//              convention) and dgrad GEMMs (B = pre-transposed bf16 weight copy)
+//   gemm_tn  : dW[N,K] += dY[M,N]^T * X[M,K]  (fp32 atomic accumulate, split over M)   wgrad GEMMs; both operands are
+//              m-major in HBM, so fragments come from row-major LDS tiles through ds_read_b64_tr_b16.
+//
+// Tile 128x128x64, 4 waves (2x2), each wave 64x64 = 2x2 v_mfma_f32_32x32x16_bf16 accumulators; register-staged
+// global->LDS double buffering (one barrier per K-tile); XCD-aware block->tile map so blocks that share an A row panel
+// share an L2.  Reference math being accelerated: nn.Linear in audiossl/modules/transformer.py:109,119,87-90 and
+// audiossl/models/atst/audio_transformer.py:63,69 ; audiossl/models/atst/byol.py:13.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int LDS_LD = BK + 8;                 // 72 bf16 = 144 B row stride: 16-B aligned, conflict-free b128 reads
+constexpr int TILE_ELEMS = BM * LDS_LD;        // per operand per buffer
+constexpr int GEMM_LDS_BYTES = 2 * 2 * TILE_ELEMS * 2;   // 73,728 B -> 2 blocks / CU
+
+template <int EPI>
+DEVFN void epilogue(const GemmArgs& p, int row, int col, float v) {
+  const size_t idx = (size_t)row * p.ldc + col;
+  if constexpr (EPI == EPI_BF16) {
+    if (p.bias) v += p.bias[col];
+    reinterpret_cast<bf16*>(p.C)[idx] = f2bf(v);
+  } else if constexpr (EPI == EPI_F32) {
+    if (p.bias) v += p.bias[col];
+    reinterpret_cast<float*>(p.C)[idx] = v;
+  } else if constexpr (EPI == EPI_BIAS_GELU) {
+    v += p.bias[col];
+    reinterpret_cast<bf16*>(p.C)[idx] = f2bf(v);                 // pre-activation u (saved for backward)
+    reinterpret_cast<bf16*>(p.C2)[idx] = f2bf(gelu_f(v));        // activation a
+  } else if constexpr (EPI == EPI_RESID) {
+    const float s = p.row_scale ? p.row_scale[row / p.rows_per_seq] : 1.0f;
+    reinterpret_cast<float*>(p.C)[idx] = p.resid[idx] + s * (v + p.bias[col]);
+  } else if constexpr (EPI == EPI_DGELU) {
+    const float u = bf2f(p.U[idx]);
+    reinterpret_cast<bf16*>(p.C)[idx] = f2bf(v * gelu_grad_f(u));
+  } else if constexpr (EPI == EPI_PATCH) {
+    const int tok = row % p.rows_per_seq;
+    const float t = p.table[(size_t)tok * p.N + col];
+    float o = v + t;
+    if (p.rowflag && p.rowflag[row]) o = t - p.bias[col] + p.alt[col];   // mask-token substitution (ATST-Frame)
+    reinterpret_cast<float*>(p.C)[idx] = o;
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  bf16* smem = reinterpret_cast<bf16*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1, hi = lane >> 5, l31 = lane & 31;
+
+  const int ntn = p.N / BN;
+  const int ntm = (p.M + BM - 1) / BM;
+  const int id = xcd_remap(blockIdx.x, ntm * ntn);
+  const int m0 = (id / ntn) * BM, n0 = (id % ntn) * BN;
+
+  // staging map: 1024 16-B chunks per operand tile, 4 per thread
+  int s_row[4], s_col[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const int c = tid + 256 * i; s_row[i] = c >> 3; s_col[i] = (c & 7) * 8; }
+  const bf16* gA[4]; const bf16* gB[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int ra = m0 + s_row[i]; ra = ra < p.M ? ra : p.M - 1;          // clamp: rows >= M are never stored
+    gA[i] = p.A + (size_t)ra * p.lda + s_col[i];
+    gB[i] = p.B + (size_t)(n0 + s_row[i]) * p.ldb + s_col[i];
+  }
+  bf16x8 ra[4], rb[4];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { ra[i] = ld_frag(gA[i] + kt * BK); rb[i] = ld_frag(gB[i] + kt * BK); }
+  };
+  auto swrite = [&](int buf) {
+    bf16* sA = smem + buf * 2 * TILE_ELEMS; bf16* sB = sA + TILE_ELEMS;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<bf16x8*>(sA + s_row[i] * LDS_LD + s_col[i]) = ra[i];
+      *reinterpret_cast<bf16x8*>(sB + s_row[i] * LDS_LD + s_col[i]) = rb[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = p.K / BK;
+  gload(0);
+  swrite(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);                       // HBM latency hides under this tile's MFMAs
+    const bf16* sA = smem + buf * 2 * TILE_ELEMS + (wm * 64 + l31) * LDS_LD + hi * 8;
+    const bf16* sB = smem + buf * 2 * TILE_ELEMS + TILE_ELEMS + (wn * 64 + l31) * LDS_LD + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      bf16x8 a0 = ld_frag(sA + ks * 16), a1 = ld_frag(sA + 32 * LDS_LD + ks * 16);
+      bf16x8 b0 = ld_frag(sB + ks * 16), b1 = ld_frag(sB + 32 * LDS_LD + ks * 16);
+      acc[0][0] = mfma32(a0, b0, acc[0][0]);
+      acc[0][1] = mfma32(a0, b1, acc[0][1]);
+      acc[1][0] = mfma32(a1, b0, acc[1][0]);
+      acc[1][1] = mfma32(a1, b1, acc[1][1]);
+    }
+    if (kt + 1 < nk) swrite(buf ^ 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm * 64 + mi * 32 + crow32(r, hi);
+      if (row < p.M) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) epilogue<EPI>(p, row, n0 + wn * 64 + ni * 32 + l31, acc[mi][ni][r]);
+      }
+    }
+}
+
+// ---- wgrad: dW[n,k] += sum_m dY[m,n] X[m,k] -------------------------------------------------------------------------
+constexpr int WM = 64;                          // contraction rows per stage
+constexpr int W_LD = 128 + 16;                  // 144 bf16 = 288 B row stride
+constexpr int W_TILE = WM * W_LD;
+constexpr int WGRAD_LDS_BYTES = 2 * 2 * W_TILE * 2;   // 73,728 B
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(WgradArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  bf16* smem = reinterpret_cast<bf16*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wn = wid >> 1, wk = wid & 1, hi = lane >> 5, l31 = lane & 31;
+  const int ntn = p.N / 128, ntk = p.K / 128;
+  int id = blockIdx.x;
+  const int tile = id % (ntn * ntk), split = id / (ntn * ntk);
+  const int n0 = (tile / ntk) * 128, k0 = (tile % ntk) * 128;
+  const int m_begin = split * p.m_per_split;
+  int m_end = m_begin + p.m_per_split; if (m_end > p.M) m_end = p.M;
+  if (m_begin >= m_end) return;
+  const int nst = (m_end - m_begin + WM - 1) / WM;
+
+  int s_row[4], s_col[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const int c = tid + 256 * i; s_row[i] = c >> 4; s_col[i] = (c & 15) * 8; }
+  bf16x8 ry[4], rx[4];
+  auto gload = [&](int st) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m_begin + st * WM + s_row[i];
+      if (m < m_end) {
+        ry[i] = ld_frag(p.dY + (size_t)m * p.ldy + n0 + s_col[i]);
+        rx[i] = ld_frag(p.X + (size_t)m * p.ldx + k0 + s_col[i]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { ry[i][e] = f2bf(0.f); rx[i][e] = f2bf(0.f); }
+      }
+    }
+  };
+  auto swrite = [&](int buf) {
+    bf16* sY = smem + buf * 2 * W_TILE; bf16* sX = sY + W_TILE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<bf16x8*>(sY + s_row[i] * W_LD + s_col[i]) = ry[i];
+      *reinterpret_cast<bf16x8*>(sX + s_row[i] * W_LD + s_col[i]) = rx[i];
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  gload(0);
+  swrite(0);
+  __syncthreads();
+  for (int st = 0; st < nst; ++st) {
+    const int buf = st & 1;
+    if (st + 1 < nst) gload(st + 1);
+    const bf16* sY = smem + buf * 2 * W_TILE; const bf16* sX = sY + W_TILE;
+#pragma unroll
+    for (int ms = 0; ms < WM / 16; ++ms) {
+      // both operands use the same (transposed-read) k order, so the contraction is consistent
+      bf16x8 a0 = ld_frag_tr(sY, W_LD, ms * 16, wn * 64, lane), a1 = ld_frag_tr(sY, W_LD, ms * 16, wn * 64 + 32, lane);
+      bf16x8 b0 = ld_frag_tr(sX, W_LD, ms * 16, wk * 64, lane), b1 = ld_frag_tr(sX, W_LD, ms * 16, wk * 64 + 32, lane);
+      acc[0][0] = mfma32(a0, b0, acc[0][0]);
+      acc[0][1] = mfma32(a0, b1, acc[0][1]);
+      acc[1][0] = mfma32(a1, b0, acc[1][0]);
+      acc[1][1] = mfma32(a1, b1, acc[1][1]);
+    }
+    if (st + 1 < nst) swrite(buf ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + wn * 64 + ni * 32 + crow32(r, hi);
+#pragma unroll
+      for (int ki = 0; ki < 2; ++ki)
+        atomicAdd(p.dW + (size_t)n * p.ldw + k0 + wk * 64 + ki * 32 + l31, acc[ni][ki][r]);
+    }
+}
+
+template <int EPI>
+int launch_nt(const GemmArgs& a, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  const int nblk = ((a.M + BM - 1) / BM) * (a.N / BN);
+  hipLaunchKernelGGL(gemm_nt_kernel<EPI>, dim3(nblk), dim3(256), GEMM_LDS_BYTES, st, a);
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+int atst_gemm_nt(const GemmArgs& a, hipStream_t st) {
+  if (a.M <= 0 || a.N % BN || a.K % BK || a.lda % 8 || a.ldb % 8) return ATST_EINVAL;
+  switch (a.epi) {
+    case EPI_BF16: return launch_nt<EPI_BF16>(a, st);
+    case EPI_F32: return launch_nt<EPI_F32>(a, st);
+    case EPI_BIAS_GELU: return launch_nt<EPI_BIAS_GELU>(a, st);
+    case EPI_RESID: return launch_nt<EPI_RESID>(a, st);
+    case EPI_DGELU: return launch_nt<EPI_DGELU>(a, st);
+    case EPI_PATCH: return launch_nt<EPI_PATCH>(a, st);
+  }
+  return ATST_EINVAL;
+}
+
+int atst_gemm_tn(const WgradArgs& a, hipStream_t st) {
+  if (a.M <= 0 || a.N % 128 || a.K % 128 || a.ldy % 8 || a.ldx % 8) return ATST_EINVAL;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WGRAD_LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  WgradArgs p = a;
+  if (p.m_per_split <= 0) {
+    // aim for ~4 blocks per CU; keep splits a multiple of the stage depth
+    const int tiles = (a.N / 128) * (a.K / 128);
+    int splits = (1024 + tiles - 1) / tiles;
+    int mps = (a.M + splits - 1) / splits;
+    mps = ((mps + WM - 1) / WM) * WM;
+    if (mps < 4 * WM) mps = 4 * WM;
+    p.m_per_split = mps;
+  }
+  const int splits = (p.M + p.m_per_split - 1) / p.m_per_split;
+  const int nblk = (p.N / 128) * (p.K / 128) * splits;
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(nblk), dim3(256), WGRAD_LDS_BYTES, st, p);
+  return (int)hipGetLastError();
+}

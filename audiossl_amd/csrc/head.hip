@@ -1,0 +1,178 @@
+// BYOL projector / predictor support kernels and the cosine loss (the GEMMs themselves are gemm.hip).
+// Reference: audiossl/models/atst/byol.py:6-22 (Linear -> BatchNorm1d(train) -> ReLU -> Linear), :24-78 (loss, monitors).
+// Statistics are fp32; the cross-rank (SyncBatchNorm) combination of [mean, M2, count] and of [sum_dy, sum_dy_xhat] is
+// done by the host between these kernels (tiny vectors), see audiossl_amd/engine.py.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+// out[n] += sum_r f(h[r,n])   block = 64 columns x 4 row groups
+template <int MODE>  // 0: sum h ; 1: sum (h-mean)^2
+__global__ __launch_bounds__(256) void bn_col_kernel(const float* __restrict__ h, int R, int N, const float* __restrict__ mean,
+                                                     float* __restrict__ out) {
+  __shared__ float red[4][64];
+  const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + c;
+  const float mu = MODE == 1 ? mean[col] : 0.f;
+  float a = 0.f;
+  for (int r = blockIdx.y * 4 + rg; r < R; r += gridDim.y * 4) {
+    const float v = h[(size_t)r * N + col] - mu;
+    a += MODE == 1 ? v * v : v;
+  }
+  red[rg][c] = a;
+  __syncthreads();
+  if (threadIdx.x < 64) atomicAdd(out + col, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+}
+__global__ void scale_kernel(float* x, int n, float s) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] *= s;
+}
+
+__global__ void bn_apply_relu_kernel(const float* __restrict__ h, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                     const float* __restrict__ gamma, const float* __restrict__ beta, size_t total, int N,
+                                     bf16* __restrict__ y) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % N);
+    const float v = (h[i] - mean[c]) * rstd[c] * gamma[c] + beta[c];
+    y[i] = f2bf(v > 0.f ? v : 0.f);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ h,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          int R, int N, float* __restrict__ sum_dy, float* __restrict__ sum_dy_xhat) {
+  __shared__ float red[2][4][64];
+  const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + c;
+  const float mu = mean[col], rs = rstd[col], gm = gamma[col], bt = beta[col];
+  float a = 0.f, b = 0.f;
+  for (int r = blockIdx.y * 4 + rg; r < R; r += gridDim.y * 4) {
+    const float xh = (h[(size_t)r * N + col] - mu) * rs;
+    const float d = (xh * gm + bt > 0.f) ? dy[(size_t)r * N + col] : 0.f;
+    a += d; b += d * xh;
+  }
+  red[0][rg][c] = a; red[1][rg][c] = b;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    atomicAdd(sum_dy + col, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+    atomicAdd(sum_dy_xhat + col, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+  }
+}
+
+__global__ void bn_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ h, const float* __restrict__ mean,
+                                 const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                 const float* __restrict__ sum_dy, const float* __restrict__ sum_dy_xhat, float inv_count,
+                                 size_t total, int N, bf16* __restrict__ dh) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % N);
+    const float xh = (h[i] - mean[c]) * rstd[c];
+    const float d = (xh * gamma[c] + beta[c] > 0.f) ? dy[i] : 0.f;
+    dh[i] = f2bf(gamma[c] * rstd[c] * (d - sum_dy[c] * inv_count - xh * sum_dy_xhat[c] * inv_count));
+  }
+}
+
+__global__ void cast_kernel(const float* __restrict__ x, size_t n, bf16* __restrict__ y) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = f2bf(x[i]);
+}
+
+// One wave per row.  Rows [0, ncrops*B) are student rows (view-major), rows [ncrops*B, ncrops*B + 2B) teacher rows.
+// acc[0] += sum over pairs <t_hat, s_hat> ; stats[0..D) student col sums, [D..2D) student col sq-sums, [2D..4D) teacher.
+__global__ __launch_bounds__(256) void byol_loss_kernel(const float* __restrict__ student, const float* __restrict__ teacher,
+                                                        int B, int ncrops, float coef, float* __restrict__ acc,
+                                                        float* __restrict__ dstudent, float* __restrict__ stats) {
+  constexpr int D = 256;
+  const int lane = threadIdx.x & 63;
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int ns = ncrops * B;
+  if (row >= ns + 2 * B) return;
+  if (row >= ns) {                                        // teacher row: monitors only
+    const f32x4 t = *reinterpret_cast<const f32x4*>(teacher + (size_t)(row - ns) * D + lane * 4);
+    const float n = fmaxf(sqrtf(wave_sum(t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3])), 1e-12f);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float v = t[e] / n;
+      atomicAdd(stats + 2 * D + lane * 4 + e, v);
+      atomicAdd(stats + 3 * D + lane * 4 + e, v * v);
+    }
+    return;
+  }
+  const int iv = row / B, b = row % B;
+  const f32x4 s = *reinterpret_cast<const f32x4*>(student + (size_t)row * D + lane * 4);
+  const float ns_ = fmaxf(sqrtf(wave_sum(s[0] * s[0] + s[1] * s[1] + s[2] * s[2] + s[3] * s[3])), 1e-12f);
+  float sh[4], T[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) sh[e] = s[e] / ns_;
+  for (int iq = 0; iq < 2; ++iq) {
+    if (iq == iv) continue;
+    const f32x4 t = *reinterpret_cast<const f32x4*>(teacher + (size_t)(iq * B + b) * D + lane * 4);
+    const float n = fmaxf(sqrtf(wave_sum(t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3])), 1e-12f);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) T[e] += t[e] / n;
+  }
+  const float dot = wave_sum(T[0] * sh[0] + T[1] * sh[1] + T[2] * sh[2] + T[3] * sh[3]);
+  f32x4 g;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    g[e] = -coef * (T[e] - sh[e] * dot) / ns_;
+    atomicAdd(stats + lane * 4 + e, sh[e]);
+    atomicAdd(stats + D + lane * 4 + e, sh[e] * sh[e]);
+  }
+  *reinterpret_cast<f32x4*>(dstudent + (size_t)row * D + lane * 4) = g;
+  if (lane == 0) atomicAdd(acc, dot);
+}
+}  // namespace
+
+int atst_bn_stats(const float* h, int R, int N, float* mean, float* m2, hipStream_t st) {
+  if (N % 64 || R <= 0) return ATST_EINVAL;
+  int gy = (R + 63) / 64; if (gy > 32) gy = 32;
+  hipMemsetAsync(mean, 0, N * sizeof(float), st);
+  hipMemsetAsync(m2, 0, N * sizeof(float), st);
+  hipLaunchKernelGGL(bn_col_kernel<0>, dim3(N / 64, gy), dim3(256), 0, st, h, R, N, (const float*)nullptr, mean);
+  hipLaunchKernelGGL(scale_kernel, dim3((N + 255) / 256), dim3(256), 0, st, mean, N, 1.0f / R);
+  hipLaunchKernelGGL(bn_col_kernel<1>, dim3(N / 64, gy), dim3(256), 0, st, h, R, N, (const float*)mean, m2);
+  return (int)hipGetLastError();
+}
+int atst_bn_apply_relu(const float* h, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                       int R, int N, bf16* y, hipStream_t st) {
+  const size_t total = (size_t)R * N;
+  int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(bn_apply_relu_kernel, dim3(grid), dim3(256), 0, st, h, mean, rstd, gamma, beta, total, N, y);
+  return (int)hipGetLastError();
+}
+int atst_bn_relu_bwd(const float* dy, const float* h, const float* mean, const float* rstd, const float* gamma,
+                     const float* beta, int R, int N, float* sum_dy, float* sum_dy_xhat, hipStream_t st) {
+  if (N % 64 || R <= 0) return ATST_EINVAL;
+  int gy = (R + 63) / 64; if (gy > 32) gy = 32;
+  hipMemsetAsync(sum_dy, 0, N * sizeof(float), st);
+  hipMemsetAsync(sum_dy_xhat, 0, N * sizeof(float), st);
+  hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3(N / 64, gy), dim3(256), 0, st, dy, h, mean, rstd, gamma, beta, R, N, sum_dy, sum_dy_xhat);
+  return (int)hipGetLastError();
+}
+int atst_bn_bwd_dx(const float* dy, const float* h, const float* mean, const float* rstd, const float* gamma,
+                   const float* beta, const float* sum_dy, const float* sum_dy_xhat, float inv_count, int R, int N,
+                   bf16* dh, hipStream_t st) {
+  const size_t total = (size_t)R * N;
+  int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3(grid), dim3(256), 0, st, dy, h, mean, rstd, gamma, beta, sum_dy, sum_dy_xhat,
+                     inv_count, total, N, dh);
+  return (int)hipGetLastError();
+}
+int atst_cast_f32_bf16(const float* x, size_t n, bf16* y, hipStream_t st) {
+  if (n == 0) return ATST_OK;
+  int grid = (int)((n + 255) / 256); if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(cast_kernel, dim3(grid), dim3(256), 0, st, x, n, y);
+  return (int)hipGetLastError();
+}
+int atst_byol_loss(const float* student, const float* teacher, int B, int ncrops, int D, float* loss, float* dstudent,
+                   float* stats, hipStream_t st) {
+  if (D != 256 || B <= 0 || ncrops < 2) return ATST_EINVAL;
+  const int npairs = 2 * ncrops - 2;
+  const float coef = 2.0f / ((float)npairs * (float)B);
+  hipMemsetAsync(loss, 0, sizeof(float), st);
+  hipMemsetAsync(stats, 0, 4 * D * sizeof(float), st);
+  const int rows = (ncrops + 2) * B;
+  hipLaunchKernelGGL(byol_loss_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, student, teacher, B, ncrops, coef, loss, dstudent, stats);
+  return (int)hipGetLastError();
+}

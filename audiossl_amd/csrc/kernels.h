@@ -1,0 +1,98 @@
+// Internal launch interface between the kernel translation units and the C-ABI / engine (api.hip, engine.hip).
+#pragma once
+#include "common.h"
+
+enum GemmEpilogue { EPI_BF16 = 0, EPI_F32 = 1, EPI_BIAS_GELU = 2, EPI_RESID = 3, EPI_DGELU = 4, EPI_PATCH = 5 };
+
+struct GemmArgs {
+  const bf16* A; const bf16* B;      // A [M,K] lda ; B [N,K] ldb   (C = A * B^T)
+  int M, N, K, lda, ldb;
+  int epi;
+  void* C; int ldc;                  // primary output (dtype by epilogue)
+  void* C2;                          // EPI_BIAS_GELU: activation output (bf16)
+  const float* bias;                 // [N] or null
+  const float* resid;                // EPI_RESID: fp32 [M,ldc]
+  const float* row_scale;            // EPI_RESID: per-sequence DropPath scale [M / rows_per_seq] or null
+  int rows_per_seq;
+  const bf16* U;                     // EPI_DGELU: saved pre-activation
+  const float* table;                // EPI_PATCH: [rows_per_seq, N] per-token additive table
+  const uint8_t* rowflag;            // EPI_PATCH: [M] 1 = replace by mask token (or null)
+  const float* alt;                  // EPI_PATCH: mask_embed [N]
+};
+int atst_gemm_nt(const GemmArgs& a, hipStream_t st);
+
+struct WgradArgs {
+  const bf16* dY; const bf16* X;     // dY [M, >=N] ldy ; X [M, >=K] ldx
+  int M, N, K, ldy, ldx;
+  float* dW; int ldw;                // fp32 [N, K], accumulated with atomics
+  int m_per_split;                   // 0 = auto
+};
+int atst_gemm_tn(const WgradArgs& a, hipStream_t st);
+
+// LayerNorm (eps 1e-6), C in {384, 768}
+int atst_ln_fwd(const float* x, const float* gamma, const float* beta, bf16* y, float* mean, float* rstd, int M, int C, hipStream_t st);
+struct LnBwdArgs {
+  const bf16* dy;                    // [M,C] gradient wrt the LN output
+  const float* x; const float* mean; const float* rstd; const float* gamma;
+  const float* dres;                 // [M,C] fp32 gradient arriving through the residual (or null = 0)
+  float* dx;                         // [M,C] fp32 out: dres + LN backward
+  bf16* g;                           // [M,C] bf16 out: row_scale * dx   (operand of the upstream proj / fc2 backward), or null
+  const float* row_scale; int rows_per_seq;
+  float* dgamma; float* dbeta;       // [C] fp32 accumulated
+  float* dbias_up;                   // [C] fp32 accumulated: column sum of g (bias gradient of the upstream linear) or null
+  int M, C;
+};
+int atst_ln_bwd(const LnBwdArgs& a, hipStream_t st);
+
+// fused attention, head_dim 64, NP (padded tokens / sequence) in {32, 64, 128, 256}
+struct AttnArgs {
+  const bf16* qkv;                   // [S*NP, 3*C]
+  const int* valid;                  // [S] number of valid key tokens per sequence
+  bf16* o;                           // fwd out [S*NP, C]
+  float* lse;                        // fwd out [S, H, NP]
+  const bf16* d_o;                   // bwd in  [S*NP, C]
+  bf16* dqkv;                        // bwd out [S*NP, 3*C]
+  int S, H, NP;
+};
+int atst_attn_fwd(const AttnArgs& a, hipStream_t st);
+int atst_attn_bwd(const AttnArgs& a, hipStream_t st);
+
+// token plumbing
+int atst_patchify(const float* mel, int S, int width, int NP, int use_cls, bf16* out, hipStream_t st);
+int atst_token_table(const float* cls, const float* pos, const float* bias, int NP, int n_tok, int C, int use_cls, float* table, hipStream_t st);
+int atst_gather_rows(const bf16* src, const int* rows, int R, int C, float* dst, hipStream_t st);
+int atst_scatter_rows(const float* src, const int* rows, int R, int C, bf16* dst, hipStream_t st);
+int atst_colsum_bf16(const bf16* x, int M, int N, int ld, float* out, hipStream_t st);
+int atst_token_grad(const float* dx0, const uint8_t* rowflag, int S, int NP, int n_tok, int C, int use_cls,
+                    float* dcls, float* dpos, float* dbias, float* dmask, bf16* g0, hipStream_t st);
+
+// heads
+int atst_bn_stats(const float* h, int R, int N, float* mean, float* m2, hipStream_t st);
+int atst_bn_apply_relu(const float* h, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                       int R, int N, bf16* y, hipStream_t st);
+int atst_bn_relu_bwd(const float* dy, const float* h, const float* mean, const float* rstd, const float* gamma,
+                     const float* beta, int R, int N, float* sum_dy, float* sum_dy_xhat, hipStream_t st);
+int atst_bn_bwd_dx(const float* dy, const float* h, const float* mean, const float* rstd, const float* gamma,
+                   const float* beta, const float* sum_dy, const float* sum_dy_xhat, float inv_count, int R, int N,
+                   bf16* dh, hipStream_t st);
+int atst_cast_f32_bf16(const float* x, size_t n, bf16* y, hipStream_t st);
+int atst_byol_loss(const float* student, const float* teacher, int B, int ncrops, int D, float* loss, float* dstudent,
+                   float* stats, hipStream_t st);
+
+// optimizer
+struct OptimArgs {
+  float* p; const float* g; float* m; float* v;       // student flat buffers [n]
+  float* t;                                           // teacher flat buffer [n_teacher] (same offsets) or null
+  bf16* p_bf16; bf16* t_bf16;                         // bf16 shadow copies (or null)
+  const uint8_t* chunk_flags;                         // one byte per 256-element chunk: bit0 decay, bit1 update, bit2 ema
+  size_t n; size_t n_teacher;
+  float lr_wd, beta1, beta2, om_beta1, om_beta2, eps, step_size, ema_m, om_ema;   // host-rounded from doubles
+  float grad_scale;                                   // multiplies g before use (1/world for DDP-sum)
+};
+int atst_adamw_ema(const OptimArgs& a, hipStream_t st);
+int atst_transpose_bf16(const bf16* src, int rows, int cols, bf16* dst, hipStream_t st);
+
+// front end
+int atst_mel_frontend(const float* wave, int n_clips, int n_samples, int win_length, const float* window,
+                      const float* fb_weights, const int* fb_start, const int* fb_len, int fb_maxlen,
+                      float* out, unsigned int* clipmax, hipStream_t st);

@@ -1,0 +1,82 @@
+// Fused HF-AdamW step + EMA teacher update + bf16 shadow-copy refresh over the flat parameter buffers, and the batched
+// bf16 transpose that produces the dgrad operand (W^T) copies.
+// Reference: transformers.optimization.AdamW as called from audiossl/methods/atst/model.py:44-48 (eps 1e-6 added to the
+// un-corrected sqrt(v), bias correction folded into the step size, decoupled weight decay applied AFTER the Adam update,
+// parameters whose grad is None skipped) and ATST.update_teacher, audiossl/models/atst/atst.py:29-34.
+// The reference runs ~160 tensors x 6 elementwise kernels for AdamW plus ~150 x 2 for the EMA; here it is one HBM pass:
+// read p,g,m,v,t  write p,m,v,t + two bf16 copies  = 46 B / parameter.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+__global__ __launch_bounds__(256) void adamw_ema_kernel(OptimArgs a) {
+  const size_t nchunk = (a.n + 255) / 256;
+  const int sub = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (size_t chunk = (size_t)blockIdx.x * 4 + sub; chunk < nchunk; chunk += (size_t)gridDim.x * 4) {
+    const uint8_t fl = a.chunk_flags[chunk];
+    const size_t i = chunk * 256 + lane * 4;
+    f32x4 p = *reinterpret_cast<const f32x4*>(a.p + i);
+    if (fl & 2) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(a.g + i);
+      f32x4 m = *reinterpret_cast<const f32x4*>(a.m + i);
+      f32x4 v = *reinterpret_cast<const f32x4*>(a.v + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float ge = g[e] * a.grad_scale;
+        m[e] = a.beta1 * m[e] + a.om_beta1 * ge;
+        v[e] = a.beta2 * v[e] + a.om_beta2 * (ge * ge);
+        p[e] = p[e] - a.step_size * (m[e] / (sqrtf(v[e]) + a.eps));
+        if (fl & 1) p[e] = p[e] - a.lr_wd * p[e];
+      }
+      *reinterpret_cast<f32x4*>(a.m + i) = m;
+      *reinterpret_cast<f32x4*>(a.v + i) = v;
+      *reinterpret_cast<f32x4*>(a.p + i) = p;
+    }
+    if (a.p_bf16) {
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = f2bf(p[e]);
+      *reinterpret_cast<bf16x4*>(a.p_bf16 + i) = o;
+    }
+    if (a.t && (fl & 4) && i < a.n_teacher) {
+      f32x4 t = *reinterpret_cast<const f32x4*>(a.t + i);
+      const float om = a.om_ema;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] = t[e] * a.ema_m + om * p[e];
+      *reinterpret_cast<f32x4*>(a.t + i) = t;
+      if (a.t_bf16) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = f2bf(t[e]);
+        *reinterpret_cast<bf16x4*>(a.t_bf16 + i) = o;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16* __restrict__ src, int rows, int cols, bf16* __restrict__ dst) {
+  __shared__ bf16 tile[64][66];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    tile[r][c] = (r0 + r < rows && c0 + c < cols) ? src[(size_t)(r0 + r) * cols + c0 + c] : f2bf(0.f);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int c = i >> 6, r = i & 63;
+    if (r0 + r < rows && c0 + c < cols) dst[(size_t)(c0 + c) * rows + r0 + r] = tile[r][c];
+  }
+}
+}  // namespace
+
+int atst_adamw_ema(const OptimArgs& a, hipStream_t st) {
+  if (a.n == 0 || (a.n % 256)) return ATST_EINVAL;
+  const size_t nchunk = a.n / 256;
+  int grid = (int)((nchunk + 3) / 4); if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(adamw_ema_kernel, dim3(grid), dim3(256), 0, st, a);
+  return (int)hipGetLastError();
+}
+int atst_transpose_bf16(const bf16* src, int rows, int cols, bf16* dst, hipStream_t st) {
+  hipLaunchKernelGGL(transpose_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, st, src, rows, cols, dst);
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,155 @@
+// Token plumbing around the encoder: patch gather (bit-exact index map), per-token additive table (CLS / positional /
+// bias), ragged row gather / scatter, column sums, and the gradient reduction of the token-embedding stage.
+// Reference: audiossl/models/atst/audio_transformer.py:56-75 (PatchEmbed_v2), :153-186 (prepare_tokens);
+//            audiossl/methods/atstframe/audio_transformer.py:161-207.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+// out[(s*NP + tok), k] , k = f*4 + t  <-  mel[s, 0, f, p*4 + t] , p = tok - use_cls ; rows without a patch are zero.
+// One block = one sequence x 16 tokens: 64x64 fp32 tile through LDS so that both the mel reads (time-contiguous) and
+// the patch-row writes (k-contiguous) are coalesced.
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ mel, int width, int NP, int use_cls,
+                                                       int n_patch, bf16* __restrict__ out) {
+  __shared__ float tile[64][65];
+  const int s = blockIdx.y, tok0 = blockIdx.x * 16, tid = threadIdx.x;
+  const int p0 = tok0 - use_cls;
+  const float* m = mel + (size_t)s * 64 * width;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int idx = tid + 256 * i, f = idx >> 6, tt = idx & 63;
+    const int p = p0 + (tt >> 2);
+    float v = 0.f;
+    if (p >= 0 && p < n_patch) v = m[(size_t)f * width + p * 4 + (tt & 3)];
+    tile[f][tt] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + 256 * i, pp = c >> 6, f = c & 63;
+    const int tok = tok0 + pp;
+    if (tok < NP) {
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = f2bf(tile[f][pp * 4 + e]);
+      *reinterpret_cast<bf16x4*>(out + ((size_t)s * NP + tok) * 256 + f * 4) = o;
+    }
+  }
+}
+
+__global__ void token_table_kernel(const float* cls, const float* pos, const float* bias, int NP, int n_tok, int C,
+                                   int use_cls, float* table) {
+  const int n = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float v = 0.f;
+    if (use_cls) {
+      if (n == 0) v = cls[c] + pos[c];
+      else if (n <= n_tok) v = bias[c] + pos[(size_t)n * C + c];
+    } else if (n < n_tok) {
+      v = bias[c] + pos[(size_t)(n + 1) * C + c];
+    }
+    table[(size_t)n * C + c] = v;
+  }
+}
+
+__global__ void gather_rows_kernel(const bf16* __restrict__ src, const int* __restrict__ rows, int R, int C, float* __restrict__ dst) {
+  const int r = blockIdx.x;
+  const bf16* s = src + (size_t)rows[r] * C;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) dst[(size_t)r * C + c] = bf2f(s[c]);
+}
+__global__ void scatter_rows_kernel(const float* __restrict__ src, const int* __restrict__ rows, int R, int C, bf16* __restrict__ dst) {
+  const int r = blockIdx.x;
+  bf16* d = dst + (size_t)rows[r] * C;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) d[c] = f2bf(src[(size_t)r * C + c]);
+}
+
+// out[n] += sum_m x[m, n] ; block = 128 columns x (rows strided by gridDim.y * 4)
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x, int M, int N, int ld, float* __restrict__ out) {
+  __shared__ float red[4][128];
+  const int cp = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int col = blockIdx.x * 128 + cp * 2;
+  float a0 = 0.f, a1 = 0.f;
+  for (int m = blockIdx.y * 4 + rg; m < M; m += gridDim.y * 4) {
+    const bf16x2 v = *reinterpret_cast<const bf16x2*>(x + (size_t)m * ld + col);
+    a0 += bf2f(v[0]); a1 += bf2f(v[1]);
+  }
+  red[rg][cp * 2] = a0; red[rg][cp * 2 + 1] = a1;
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int c = threadIdx.x;
+    atomicAdd(out + blockIdx.x * 128 + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+  }
+}
+
+// gradient of the token-embedding stage.  block = token n (x) sequence slice ; thread = 2 columns.
+__global__ void token_grad_kernel(const float* __restrict__ dx0, const uint8_t* __restrict__ rowflag, int S, int NP,
+                                  int n_tok, int C, int use_cls, float* dcls, float* dpos, float* dbias, float* dmask,
+                                  bf16* __restrict__ g0) {
+  const int n = blockIdx.x, c = threadIdx.x * 2;
+  if (c >= C) return;
+  const int s_per = (S + gridDim.y - 1) / gridDim.y;
+  const int s_begin = blockIdx.y * s_per;
+  const int s_end = s_begin + s_per < S ? s_begin + s_per : S;
+  const bool is_cls = use_cls && n == 0;
+  const bool is_patch = use_cls ? (n >= 1 && n <= n_tok) : (n < n_tok);
+  float all0 = 0.f, all1 = 0.f, un0 = 0.f, un1 = 0.f, mk0 = 0.f, mk1 = 0.f;
+  for (int s = s_begin; s < s_end; ++s) {
+    const size_t row = (size_t)s * NP + n;
+    const f32x2 v = *reinterpret_cast<const f32x2*>(dx0 + row * C + c);
+    const bool masked = rowflag && rowflag[row];
+    all0 += v[0]; all1 += v[1];
+    bf16x2 o;
+    if (masked) { mk0 += v[0]; mk1 += v[1]; o[0] = f2bf(0.f); o[1] = f2bf(0.f); }
+    else { un0 += v[0]; un1 += v[1]; o[0] = f2bf(v[0]); o[1] = f2bf(v[1]); }
+    if (!is_patch) { o[0] = f2bf(0.f); o[1] = f2bf(0.f); }
+    *reinterpret_cast<bf16x2*>(g0 + row * C + c) = o;
+  }
+  if (is_cls) { atomicAdd(dcls + c, all0); atomicAdd(dcls + c + 1, all1); }
+  if (is_cls || is_patch) {
+    const int pi = use_cls ? n : n + 1;
+    atomicAdd(dpos + (size_t)pi * C + c, all0); atomicAdd(dpos + (size_t)pi * C + c + 1, all1);
+  }
+  if (is_patch) {
+    atomicAdd(dbias + c, un0); atomicAdd(dbias + c + 1, un1);
+    if (dmask && rowflag) { atomicAdd(dmask + c, mk0); atomicAdd(dmask + c + 1, mk1); }
+  }
+}
+}  // namespace
+
+int atst_patchify(const float* mel, int S, int width, int NP, int use_cls, bf16* out, hipStream_t st) {
+  if (S <= 0) return ATST_OK;
+  const int n_patch = (width - width % 4) / 4;
+  if (n_patch + use_cls > NP) return ATST_EINVAL;
+  hipLaunchKernelGGL(patchify_kernel, dim3((NP + 15) / 16, S), dim3(256), 0, st, mel, width, NP, use_cls, n_patch, out);
+  return (int)hipGetLastError();
+}
+int atst_token_table(const float* cls, const float* pos, const float* bias, int NP, int n_tok, int C, int use_cls, float* table, hipStream_t st) {
+  hipLaunchKernelGGL(token_table_kernel, dim3(NP), dim3(128), 0, st, cls, pos, bias, NP, n_tok, C, use_cls, table);
+  return (int)hipGetLastError();
+}
+int atst_gather_rows(const bf16* src, const int* rows, int R, int C, float* dst, hipStream_t st) {
+  if (R <= 0) return ATST_OK;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(R), dim3(128), 0, st, src, rows, R, C, dst);
+  return (int)hipGetLastError();
+}
+int atst_scatter_rows(const float* src, const int* rows, int R, int C, bf16* dst, hipStream_t st) {
+  if (R <= 0) return ATST_OK;
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3(R), dim3(128), 0, st, src, rows, R, C, dst);
+  return (int)hipGetLastError();
+}
+int atst_colsum_bf16(const bf16* x, int M, int N, int ld, float* out, hipStream_t st) {
+  if (M <= 0) return ATST_OK;
+  if (N % 128) return ATST_EINVAL;
+  int gy = (M + 255) / 256; if (gy > 64) gy = 64;
+  hipLaunchKernelGGL(colsum_kernel, dim3(N / 128, gy), dim3(256), 0, st, x, M, N, ld, out);
+  return (int)hipGetLastError();
+}
+int atst_token_grad(const float* dx0, const uint8_t* rowflag, int S, int NP, int n_tok, int C, int use_cls,
+                    float* dcls, float* dpos, float* dbias, float* dmask, bf16* g0, hipStream_t st) {
+  if (S <= 0) return ATST_OK;
+  int gy = S / 32; if (gy < 1) gy = 1; if (gy > 16) gy = 16;
+  hipLaunchKernelGGL(token_grad_kernel, dim3(NP, gy), dim3(C / 2), 0, st, dx0, rowflag, S, NP, n_tok, C, use_cls,
+                     dcls, dpos, dbias, dmask, g0);
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,126 @@
+/* C ABI of libatst_hip.so -- the MI355X (gfx950) kernels behind the ATST / ATST-Frame pre-training hot path.
+ *
+ * The reference (Audio-WestlakeU/audiossl) has no native code and no FFI: its hot path is eager torch.nn calls.
+ * Each entry point below therefore cites the reference *Python* call it replaces (path:line relative to the upstream
+ * repository root).  Conventions for every function:
+ *   - all pointers are DEVICE pointers owned by the caller (nothing is allocated or freed here), `stream` is a
+ *     hipStream_t passed as void*; work is enqueued asynchronously on it;
+ *   - bf16 tensors are passed as uint16_t* (raw bfloat16 bits), row-major, torch [out,in] convention for weights;
+ *   - the return value is 0 on success, a hipError_t value, or ATST_EINVAL (1001) for an unsupported shape;
+ *   - no entry point synchronises the device.
+ * Binding sketches for the reference side are in INTEGRATION.md.
+ */
+#ifndef ATST_HIP_H
+#define ATST_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ATST_MAX_DEPTH 24
+
+/* GEMM epilogues (gemm_nt) */
+enum { ATST_EPI_BF16 = 0, ATST_EPI_F32 = 1, ATST_EPI_BIAS_GELU = 2, ATST_EPI_RESID = 3, ATST_EPI_DGELU = 4, ATST_EPI_PATCH = 5 };
+
+int atst_version(void);
+
+/* ---- front end: torchaudio MelSpectrogram -> AmplitudeToDB(top_db=80) -> MinMax ---------------------------------
+ * replaces audiossl/methods/atst/transform.py:14-33 (`self.mel_feature`) / methods/atstframe/transform.py:16-41.
+ * wave [n_clips, n_samples] f32 -> out [n_clips, 64, 1 + n_samples/160] f32.  window: 1024 taps (Hann(win_length)
+ * zero-padded centred); fb_*: compact triangular filterbank (64 bands: start bin, length, weights [64, fb_maxlen]).
+ * clipmax: n_clips uint32 scratch. */
+int atst_mel_frontend_f32(const float* wave, int n_clips, int n_samples, int win_length, const float* window,
+                          const float* fb_weights, const int* fb_start, const int* fb_len, int fb_maxlen,
+                          float* out, uint32_t* clipmax, void* stream);
+
+/* ---- single operators (unit-tested against the oracle through this ABI) ------------------------------------------ */
+/* C = A[M,K] * B[N,K]^T with fused epilogue; replaces nn.Linear at audiossl/modules/transformer.py:87-90,109,119.   */
+int atst_gemm_nt_bf16(const uint16_t* A, const uint16_t* B, int M, int N, int K, int lda, int ldb, int epi,
+                      void* C, int ldc, void* C2, const float* bias, const float* resid, const float* row_scale,
+                      int rows_per_seq, const uint16_t* U, const float* table, const uint8_t* rowflag, const float* alt,
+                      void* stream);
+/* dW[N,K] += dY[M,N]^T X[M,K]  (fp32 accumulate); autograd of the same nn.Linear calls.                              */
+int atst_gemm_tn_bf16(const uint16_t* dY, const uint16_t* X, int M, int N, int K, int ldy, int ldx, float* dW, int ldw,
+                      int m_per_split, void* stream);
+/* nn.LayerNorm(eps=1e-6): audiossl/modules/transformer.py:128,132 ; audio_transformer.py:113                         */
+int atst_layernorm_fwd(const float* x, const float* gamma, const float* beta, uint16_t* y, float* mean, float* rstd,
+                       int M, int C, void* stream);
+int atst_layernorm_bwd(const uint16_t* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                       const float* dres, float* dx, uint16_t* g, const float* row_scale, int rows_per_seq,
+                       float* dgamma, float* dbeta, float* dbias_up, int M, int C, void* stream);
+/* Attention.forward + get_attention_mask: audiossl/modules/transformer.py:107-121,152-159                            */
+int atst_attention_fwd(const uint16_t* qkv, const int* valid, uint16_t* o, float* lse, int S, int H, int NP, void* stream);
+int atst_attention_bwd(const uint16_t* qkv, const int* valid, const uint16_t* o, const float* lse, const uint16_t* d_o,
+                       uint16_t* dqkv, int S, int H, int NP, void* stream);
+/* PatchEmbed_v2 gather: audiossl/models/atst/audio_transformer.py:56-75 (bit-exact index map, bf16 values)          */
+int atst_patchify_bf16(const float* mel, int S, int width, int NP, int use_cls, uint16_t* out, void* stream);
+int atst_gather_rows_bf16(const uint16_t* src, const int* rows, int R, int C, float* dst, void* stream);
+int atst_scatter_rows_bf16(const float* src, const int* rows, int R, int C, uint16_t* dst, void* stream);
+int atst_colsum_bf16_f32(const uint16_t* x, int M, int N, int ld, float* out, void* stream);
+int atst_cast_bf16(const float* x, size_t n, uint16_t* y, void* stream);
+int atst_transpose_bf16_2d(const uint16_t* src, int rows, int cols, uint16_t* dst, void* stream);
+
+/* build_mlp's BatchNorm1d(train)+ReLU: audiossl/models/atst/byol.py:13-16                                            */
+int atst_bn_stats_f32(const float* h, int R, int N, float* mean, float* m2, void* stream);
+int atst_bn_apply_relu_bf16(const float* h, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                            int R, int N, uint16_t* y, void* stream);
+int atst_bn_relu_bwd_sums(const float* dy, const float* h, const float* mean, const float* rstd, const float* gamma,
+                          const float* beta, int R, int N, float* sum_dy, float* sum_dy_xhat, void* stream);
+int atst_bn_bwd_dx_bf16(const float* dy, const float* h, const float* mean, const float* rstd, const float* gamma,
+                        const float* beta, const float* sum_dy, const float* sum_dy_xhat, float inv_count, int R, int N,
+                        uint16_t* dh, void* stream);
+/* ByolLoss.forward + its backward: audiossl/models/atst/byol.py:24-78.  acc[0] = sum of pair cosines,
+ * loss = 2 - 2*acc/((2*ncrops-2)*B); stats [4,256] = student/teacher column sums and square sums of normalised rows. */
+int atst_byol_loss_f32(const float* student, const float* teacher, int B, int ncrops, int D, float* acc, float* dstudent,
+                       float* stats, void* stream);
+
+/* HF-AdamW + EMA teacher + bf16 shadow refresh over flat buffers: audiossl/methods/atst/model.py:44-51,
+ * audiossl/models/atst/atst.py:29-34.  chunk_flags: one byte per 256 elements (bit0 weight-decay, bit1 update, bit2 EMA). */
+int atst_adamw_ema_step(float* p, const float* g, float* m, float* v, float* t, uint16_t* p_bf16, uint16_t* t_bf16,
+                        const uint8_t* chunk_flags, size_t n, size_t n_teacher, double lr, double wd, double beta1,
+                        double beta2, double eps, double step_size, double ema_m, double grad_scale, void* stream);
+
+/* ---- whole-encoder engine: AST.forward / FrameAST.forward and their autograd ---------------------------------------
+ * replaces audiossl/models/atst/audio_transformer.py:188-221 and methods/atstframe/audio_transformer.py:183-207
+ * (12 x Block.forward, audiossl/modules/transformer.py:136-150).  Offsets index the flat parameter buffers. */
+typedef struct {
+  int64_t ln1_w, ln1_b, qkv_w, proj_w, proj_b, ln2_w, ln2_b, fc1_w, fc1_b, fc2_w, fc2_b;
+} atst_layer_off_t;
+
+typedef struct {
+  int64_t mask_embed, cls_token, pos_embed, patch_w, patch_b, norm_w, norm_b;
+  atst_layer_off_t layer[ATST_MAX_DEPTH];
+} atst_enc_off_t;
+
+typedef struct {
+  /* geometry */
+  int S, NP, n_tok, width, C, H, depth, use_cls, train;
+  /* parameters: fp32 masters, bf16 shadows ([out,in]) and bf16 transposed shadows ([in,out], backward only) */
+  const float* p32; const uint16_t* p16; const uint16_t* p16t;
+  float* g32;                         /* flat fp32 gradient buffer (backward accumulates into it) */
+  atst_enc_off_t off;
+  /* per-call inputs */
+  const float* mel;                   /* [S,1,64,width] */
+  const int* valid;                   /* [S] valid key tokens (patch_length + use_cls) */
+  const uint8_t* rowflag;             /* [S*NP] 1 = substitute mask token (ATST-Frame student) or NULL */
+  const float* dp_scale;              /* [depth,2,S] DropPath keep/keep_prob factors or NULL */
+  void* ws; size_t ws_bytes;          /* activation workspace, atst_encoder_ws_bytes() */
+} atst_encoder_t;
+
+size_t atst_encoder_ws_bytes(int S, int NP, int C, int H, int depth, int train);
+/* forward: leaves LN(final) of every token as bf16 [S*NP, C] at atst_encoder_out(); */
+int atst_encoder_fwd(const atst_encoder_t* e, void* stream);
+const uint16_t* atst_encoder_out(const atst_encoder_t* e);
+/* backward: d(LN(final)) bf16 [S*NP, C] must have been written to atst_encoder_dout() (zero for unused rows) */
+uint16_t* atst_encoder_dout(const atst_encoder_t* e);
+int atst_encoder_bwd(const atst_encoder_t* e, void* stream);
+/* block-level activation taps for tests: fp32 residual stream after block i (i in [0,depth)), train=1 only */
+const float* atst_encoder_block_out(const atst_encoder_t* e, int i);
+const float* atst_encoder_tokens(const atst_encoder_t* e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ATST_HIP_H */

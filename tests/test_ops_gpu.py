@@ -1,0 +1,279 @@
+"""Per-kernel parity tests, called through the C ABI (audiossl_amd.hip -> libatst_hip.so) on a real MI355X.
+
+Each HIP kernel is compared with a plain fp32 formulation of the same op on the same (bf16-representable) inputs.
+Tolerances: products of bf16 inputs are exact in fp32, so fp32 outputs differ only by accumulation order (<=2e-5 rel);
+bf16 outputs carry one rounding (2^-9 = 2e-3 rel); integer / index work is bit-exact.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from audiossl_amd import hip  # noqa: E402
+from oracle import atst_oracle as O  # noqa: E402
+
+DEV = "cuda"
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def relerr(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _lib():
+    hip.load()
+    yield
+    torch.cuda.synchronize()
+
+
+def gemm_nt(A, B, epi, out_dtype, **kw):
+    M, K = A.shape
+    N = B.shape[0]
+    Cout = torch.empty(M, N, dtype=out_dtype, device=DEV)
+    C2 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV) if epi == hip.EPI_BIAS_GELU else None
+    hip.call("atst_gemm_nt_bf16", hip.ptr(A), hip.ptr(B), M, N, K, K, K, epi, hip.ptr(Cout), N, hip.ptr(C2),
+             hip.ptr(kw.get("bias")), hip.ptr(kw.get("resid")), hip.ptr(kw.get("row_scale")), kw.get("rps", 1),
+             hip.ptr(kw.get("U")), hip.ptr(kw.get("table")), hip.ptr(kw.get("rowflag")), hip.ptr(kw.get("alt")), hip.stream())
+    return Cout, C2
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 384, 256), (128, 128, 64), (1027, 1152, 384), (512, 256, 4096)])
+def test_gemm_nt_plain(M, N, K):
+    A, B = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2))       # asymmetric operands: catches transposed fragments
+    ref = A.float() @ B.float().t()
+    out, _ = gemm_nt(A, B, hip.EPI_F32, torch.float32)
+    assert relerr(out, ref) < 2e-5
+    bias = rnd(N, seed=3)
+    outb, _ = gemm_nt(A, B, hip.EPI_BF16, torch.bfloat16, bias=bias)
+    assert relerr(outb.float(), ref + bias) < 4e-3
+
+
+def test_gemm_nt_epilogues():
+    M, N, K, rps = 640, 384, 128, 64
+    A, B = bf(rnd(M, K, seed=1, scale=0.5)), bf(rnd(N, K, seed=2, scale=0.5))
+    bias = rnd(N, seed=3)
+    ref = A.float() @ B.float().t()
+    # bias + GELU (u, a)
+    u, a = gemm_nt(A, B, hip.EPI_BIAS_GELU, torch.bfloat16, bias=bias)
+    assert relerr(u.float(), ref + bias) < 4e-3
+    assert relerr(a.float(), torch.nn.functional.gelu(ref + bias)) < 5e-3
+    # residual with per-sequence DropPath scale
+    resid = rnd(M, N, seed=4)
+    scale = torch.tensor([1.0, 0.0, 1.25, 1.0, 1.25, 0.0, 1.0, 1.0, 1.0, 1.25], device=DEV)
+    x, _ = gemm_nt(A, B, hip.EPI_RESID, torch.float32, bias=bias, resid=resid, row_scale=scale, rps=rps)
+    want = resid + scale.repeat_interleave(rps)[:, None] * (ref + bias)
+    assert relerr(x, want) < 2e-5
+    # dgelu
+    U = bf(rnd(M, N, seed=5))
+    d, _ = gemm_nt(A, B, hip.EPI_DGELU, torch.bfloat16, U=U)
+    uf = U.float().requires_grad_(True)
+    torch.nn.functional.gelu(uf).backward(ref)
+    assert relerr(d.float(), uf.grad) < 5e-3
+    # patch epilogue: per-token table + mask-token substitution
+    table = rnd(rps, N, seed=6)
+    flag = (torch.arange(M, device=DEV) % 5 == 0).to(torch.uint8)
+    alt = rnd(N, seed=7)
+    t, _ = gemm_nt(A, B, hip.EPI_PATCH, torch.float32, bias=bias, table=table, rowflag=flag, alt=alt, rps=rps)
+    tab = table.repeat(M // rps, 1)
+    want = torch.where(flag.bool()[:, None], tab - bias + alt, ref + tab)
+    assert relerr(t, want) < 2e-5
+
+
+@pytest.mark.parametrize("M,N,K,split", [(1000, 256, 384, 0), (64, 128, 128, 0), (4099, 384, 256, 512), (777, 1152, 384, 0)])
+def test_gemm_tn(M, N, K, split):
+    dY, X = bf(rnd(M, N, seed=1)), bf(rnd(M, K, seed=2))
+    dW = torch.full((N, K), 0.5, device=DEV)
+    hip.call("atst_gemm_tn_bf16", hip.ptr(dY), hip.ptr(X), M, N, K, N, K, hip.ptr(dW), K, split, hip.stream())
+    ref = dY.float().t() @ X.float() + 0.5
+    assert relerr(dW, ref) < 2e-5
+
+
+@pytest.mark.parametrize("C", [384, 768])
+def test_layernorm(C):
+    M, rps = 517, 11
+    x = rnd(M, C, seed=1) * 2 + 0.3
+    gamma, beta = 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
+    y = torch.empty(M, C, dtype=torch.bfloat16, device=DEV)
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    hip.call("atst_layernorm_fwd", hip.ptr(x), hip.ptr(gamma), hip.ptr(beta), hip.ptr(y), hip.ptr(mean), hip.ptr(rstd), M, C, hip.stream())
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (C,), gr, br, 1e-6)
+    assert relerr(y.float(), ref) < 4e-3
+    assert relerr(mean, x.mean(1)) < 1e-5
+    dy = bf(rnd(M, C, seed=4))
+    dres = rnd(M, C, seed=5)
+    scale = (torch.arange((M + rps - 1) // rps, device=DEV) % 3).float() * 0.5
+    ref.backward(dy.float())
+    dx = torch.empty(M, C, device=DEV)
+    g = torch.empty(M, C, dtype=torch.bfloat16, device=DEV)
+    dgamma, dbeta, dbu = (torch.zeros(C, device=DEV) for _ in range(3))
+    hip.call("atst_layernorm_bwd", hip.ptr(dy), hip.ptr(x), hip.ptr(mean), hip.ptr(rstd), hip.ptr(gamma), hip.ptr(dres),
+             hip.ptr(dx), hip.ptr(g), hip.ptr(scale), rps, hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(dbu), M, C, hip.stream())
+    want_dx = dres + xr.grad
+    assert relerr(dx, want_dx) < 2e-5
+    assert relerr(dgamma, gr.grad) < 2e-5 and relerr(dbeta, br.grad) < 2e-5
+    want_g = want_dx * scale.repeat_interleave(rps)[:M, None]
+    assert relerr(g.float(), want_g) < 4e-3
+    assert relerr(dbu, want_g.sum(0)) < 2e-3
+
+
+def attn_ref(qkv, valid, S, H, NP):
+    C = H * 64
+    q, k, v = qkv.float().reshape(S, NP, 3, H, 64).permute(2, 0, 3, 1, 4)
+    att = (q @ k.transpose(-2, -1)) * 0.125
+    mask = (torch.arange(NP, device=qkv.device)[None, :] >= valid[:, None]).float() * -10000.0
+    att = (att + mask[:, None, None, :]).softmax(-1)
+    return (att @ v).transpose(1, 2).reshape(S * NP, C)
+
+
+@pytest.mark.parametrize("NP,valid", [(256, [251, 100, 33]), (32, [26, 26, 20, 1, 7]), (64, [64, 40, 3]), (128, [128, 97])])
+def test_attention(NP, valid):
+    S, H = len(valid), 6
+    C = H * 64
+    qkv = bf(rnd(S * NP, 3 * C, seed=1))
+    vt = torch.tensor(valid, dtype=torch.int32, device=DEV)
+    o = torch.empty(S * NP, C, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(S, H, NP, device=DEV)
+    hip.call("atst_attention_fwd", hip.ptr(qkv), hip.ptr(vt), hip.ptr(o), hip.ptr(lse), S, H, NP, hip.stream())
+    qr = qkv.float().requires_grad_(True)
+    ref = attn_ref(qr, vt, S, H, NP)
+    assert relerr(o.float(), ref) < 6e-3
+    # backward: upstream gradient is zero on rows that are not valid tokens (as in the encoder)
+    rowvalid = (torch.arange(NP, device=DEV)[None, :] < vt[:, None]).reshape(-1, 1).float()
+    d_o = bf(rnd(S * NP, C, seed=2) * rowvalid)
+    ref.backward(d_o.float())
+    dqkv = torch.empty_like(qkv)
+    hip.call("atst_attention_bwd", hip.ptr(qkv), hip.ptr(vt), hip.ptr(o), hip.ptr(lse), hip.ptr(d_o), hip.ptr(dqkv), S, H, NP, hip.stream())
+    got, want = dqkv.float().reshape(S * NP, 3, C), qr.grad.reshape(S * NP, 3, C)
+    for i, name in enumerate("qkv"):
+        assert relerr(got[:, i], want[:, i]) < 1.5e-2, name
+    # keys beyond `valid` receive exactly zero gradient
+    inval = (rowvalid == 0).reshape(-1)
+    assert float(got[inval][:, 1:].abs().max()) == 0.0 if inval.any() else True
+
+
+def test_patchify_bit_exact():
+    S, width, NP = 3, 1001, 256
+    mel = ((torch.arange(S)[:, None, None, None] * 7 + torch.arange(64)[None, None, :, None] * 3
+            + torch.arange(width)[None, None, None, :]) % 251).float()
+    want = O.patchify(mel)                                            # [S,250,256]
+    out = torch.empty(S * NP, 256, dtype=torch.bfloat16, device=DEV)
+    hip.call("atst_patchify_bf16", hip.ptr(mel.to(DEV)), S, width, NP, 1, hip.ptr(out), hip.stream())
+    got = out.float().cpu().reshape(S, NP, 256)
+    assert torch.equal(got[:, 1:251], want) and float(got[:, 0].abs().max()) == 0 and float(got[:, 251:].abs().max()) == 0
+    hip.call("atst_patchify_bf16", hip.ptr(mel.to(DEV)), S, width, NP, 0, hip.ptr(out), hip.stream())
+    got = out.float().cpu().reshape(S, NP, 256)
+    assert torch.equal(got[:, :250], want) and float(got[:, 250:].abs().max()) == 0
+    # short local view: 101 frames -> 25 patches, NP = 32
+    mel2 = mel[:, :, :, :101].contiguous()
+    out2 = torch.empty(S * 32, 256, dtype=torch.bfloat16, device=DEV)
+    hip.call("atst_patchify_bf16", hip.ptr(mel2.to(DEV)), S, 101, 32, 1, hip.ptr(out2), hip.stream())
+    got2 = out2.float().cpu().reshape(S, 32, 256)
+    assert torch.equal(got2[:, 1:26], O.patchify(mel2)) and float(got2[:, 26:].abs().max()) == 0
+
+
+def test_rows_colsum_transpose():
+    M, Cc = 700, 384
+    src = bf(rnd(M, Cc, seed=1))
+    rows = torch.tensor([0, 5, 699, 256, 3], dtype=torch.int32, device=DEV)
+    dst = torch.empty(5, Cc, device=DEV)
+    hip.call("atst_gather_rows_bf16", hip.ptr(src), hip.ptr(rows), 5, Cc, hip.ptr(dst), hip.stream())
+    assert torch.equal(dst, src.float()[rows.long()])
+    back = torch.zeros(M, Cc, dtype=torch.bfloat16, device=DEV)
+    hip.call("atst_scatter_rows_bf16", hip.ptr(dst), hip.ptr(rows), 5, Cc, hip.ptr(back), hip.stream())
+    want = torch.zeros(M, Cc, device=DEV); want[rows.long()] = dst
+    assert torch.equal(back.float(), want)
+    cs = torch.zeros(Cc, device=DEV)
+    hip.call("atst_colsum_bf16_f32", hip.ptr(src), M, Cc, Cc, hip.ptr(cs), hip.stream())
+    assert relerr(cs, src.float().sum(0)) < 1e-5
+    t = torch.empty(Cc, M, dtype=torch.bfloat16, device=DEV)
+    hip.call("atst_transpose_bf16_2d", hip.ptr(src), M, Cc, hip.ptr(t), hip.stream())
+    assert torch.equal(t, src.t().contiguous())
+
+
+def test_bn_relu_head():
+    R, N = 300, 4096
+    h = rnd(R, N, seed=1) * 2 + 0.5
+    gamma, beta = 1 + 0.1 * rnd(N, seed=2), 0.1 * rnd(N, seed=3)
+    mean, m2 = torch.empty(N, device=DEV), torch.empty(N, device=DEV)
+    hip.call("atst_bn_stats_f32", hip.ptr(h), R, N, hip.ptr(mean), hip.ptr(m2), hip.stream())
+    assert relerr(mean, h.mean(0)) < 1e-5 and relerr(m2 / R, h.var(0, unbiased=False)) < 1e-5
+    rstd = torch.rsqrt(m2 / R + 1e-5)
+    y = torch.empty(R, N, dtype=torch.bfloat16, device=DEV)
+    hip.call("atst_bn_apply_relu_bf16", hip.ptr(h), hip.ptr(mean), hip.ptr(rstd), hip.ptr(gamma), hip.ptr(beta), R, N, hip.ptr(y), hip.stream())
+    hr, gr, br = h.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = torch.relu(torch.nn.functional.batch_norm(hr, None, None, gr, br, True, 0.1, 1e-5))
+    assert relerr(y.float(), ref) < 4e-3
+    dy = rnd(R, N, seed=4)
+    ref.backward(dy)
+    s1, s2 = torch.empty(N, device=DEV), torch.empty(N, device=DEV)
+    hip.call("atst_bn_relu_bwd_sums", hip.ptr(dy), hip.ptr(h), hip.ptr(mean), hip.ptr(rstd), hip.ptr(gamma), hip.ptr(beta), R, N,
+             hip.ptr(s1), hip.ptr(s2), hip.stream())
+    assert relerr(s1, br.grad) < 1e-4 and relerr(s2, gr.grad) < 1e-4
+    dh = torch.empty(R, N, dtype=torch.bfloat16, device=DEV)
+    hip.call("atst_bn_bwd_dx_bf16", hip.ptr(dy), hip.ptr(h), hip.ptr(mean), hip.ptr(rstd), hip.ptr(gamma), hip.ptr(beta),
+             hip.ptr(s1), hip.ptr(s2), 1.0 / R, R, N, hip.ptr(dh), hip.stream())
+    assert relerr(dh.float(), hr.grad) < 4e-3
+
+
+@pytest.mark.parametrize("B,ncrops", [(2, 2), (7, 6), (64, 2)])
+def test_byol_loss(B, ncrops):
+    s = rnd(ncrops * B, 256, seed=1)
+    t = rnd(2 * B, 256, seed=2)
+    acc = torch.empty(1, device=DEV)
+    ds = torch.empty_like(s)
+    stats = torch.empty(4, 256, device=DEV)
+    hip.call("atst_byol_loss_f32", hip.ptr(s), hip.ptr(t), B, ncrops, 256, hip.ptr(acc), hip.ptr(ds), hip.ptr(stats), hip.stream())
+    sc = s.cpu().clone().requires_grad_(True)
+    loss, std_s, std_t = O.byol_loss(sc, t.cpu(), ncrops)
+    loss.backward()
+    got = 2.0 - 2.0 * acc.item() / ((2 * ncrops - 2) * B)
+    assert abs(got - loss.item()) < 1e-5
+    assert relerr(ds, sc.grad) < 1e-5
+
+    def std_from(sums, sq, n):
+        var = sq / (n - 1) - sums ** 2 / (n * (n - 1))
+        return torch.sqrt(var + 1e-6).mean().item()
+    assert abs(std_from(stats[0], stats[1], ncrops * B) - std_s.item()) < 1e-5
+    assert abs(std_from(stats[2], stats[3], 2 * B) - std_t.item()) < 1e-5
+
+
+def test_adamw_ema_vs_oracle():
+    n, nt = 256 * 40, 256 * 24
+    p, g = rnd(n, seed=1), rnd(n, seed=2) * 0.1
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    t = rnd(nt, seed=3)
+    flags = torch.zeros(n // 256, dtype=torch.uint8, device=DEV)
+    flags[:10] = 1 | 2 | 4        # decay + update + ema
+    flags[10:20] = 2 | 4          # no decay
+    flags[20:24] = 4              # frozen (grad None in the reference) but still EMA'd
+    flags[24:] = 1 | 2            # student-only (predictor)
+    p16 = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    t16 = torch.empty(nt, dtype=torch.bfloat16, device=DEV)
+    P, M_, V_, T = p.cpu().clone(), m.cpu().clone(), v.cpu().clone(), t.cpu().clone()
+    lr, wd, ema = 3e-4, 0.05, 0.99
+    for step in (1, 2, 3):
+        ss = lr * math.sqrt(1 - 0.999 ** step) / (1 - 0.9 ** step)
+        hip.call("atst_adamw_ema_step", hip.ptr(p), hip.ptr(g), hip.ptr(m), hip.ptr(v), hip.ptr(t), hip.ptr(p16), hip.ptr(t16),
+                 hip.ptr(flags), n, nt, lr, wd, 0.9, 0.999, 1e-6, ss, ema, 1.0, hip.stream())
+        G = g.cpu()
+        for lo, hi_, decay, upd in ((0, 2560, True, True), (2560, 5120, False, True), (5120, 6144, False, False), (6144, n, True, True)):
+            if upd:
+                O.hf_adamw_step(P[lo:hi_], G[lo:hi_], M_[lo:hi_], V_[lo:hi_], step, lr, wd if decay else 0.0)
+        T.mul_(ema).add_((1 - ema) * P[:nt])
+    assert relerr(p, P) < 1e-6 and relerr(t, T) < 1e-6 and relerr(m, M_) < 1e-6 and relerr(v, V_) < 1e-6
+    assert torch.equal(p16, p.to(torch.bfloat16)) and torch.equal(t16, t.to(torch.bfloat16))
