@@ -18,6 +18,7 @@
 // (S and dP are recomputed in both backward kernels instead of exchanging dS through LDS or atomics.)
 #include "common.h"
 #include "kernels.h"
+#include "profile.h"
 
 namespace {
 
@@ -321,6 +322,7 @@ int launch_fwd(const AttnArgs& a, hipStream_t st) {
     done = true;
   }
   const int nblk = (a.S * a.H + Geo<NP>::G - 1) / Geo<NP>::G;
+  ProfScope ps(PK_ATTN_FWD, 4.0 * a.S * a.H * (double)NP * NP * HD, st);     // QK^T + PV on the padded geometry
   hipLaunchKernelGGL(attn_fwd_kernel<NP>, dim3(nblk), dim3(256), lds, st, a);
   return (int)hipGetLastError();
 }
@@ -336,8 +338,14 @@ int launch_bwd(const AttnArgs& a, hipStream_t st) {
     done = true;
   }
   const int nblk = (a.S * a.H + Geo<NP>::G - 1) / Geo<NP>::G;
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel<NP>, dim3(nblk), dim3(256), lds1, st, a);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel<NP>, dim3(nblk), dim3(256), lds2, st, a);
+  {
+    ProfScope ps(PK_ATTN_BWD_DKV, 8.0 * a.S * a.H * (double)NP * NP * HD, st);   // S, dP, dV, dK
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<NP>, dim3(nblk), dim3(256), lds1, st, a);
+  }
+  {
+    ProfScope ps(PK_ATTN_BWD_DQ, 6.0 * a.S * a.H * (double)NP * NP * HD, st);    // S, dP (recomputed), dQ
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<NP>, dim3(nblk), dim3(256), lds2, st, a);
+  }
   return (int)hipGetLastError();
 }
 }  // namespace

@@ -11,6 +11,7 @@
 #include <cmath>
 #include "common.h"
 #include "kernels.h"
+#include "profile.h"
 
 namespace {
 
@@ -162,6 +163,7 @@ int atst_mel_frontend(const float* wave, int n_clips, int n_samples, int win_len
   if (rc) return rc;
   const int T = 1 + n_samples / HOPS;
   hipMemsetAsync(clipmax, 0, n_clips * sizeof(unsigned int), st);
+  ProfScope ps(PK_MEL, (double)n_clips * (4.0 * n_samples + 4.0 * NMEL * T), st);   // wave read once + dB written once
   hipLaunchKernelGGL(stft_mel_db_kernel, dim3((T + FPB - 1) / FPB, n_clips), dim3(256), 0, st, wave, n_samples, T, window,
                      fb_weights, fb_start, fb_len, fb_maxlen, out, clipmax);
   hipLaunchKernelGGL(db_finalize_kernel, dim3(16, n_clips), dim3(256), 0, st, out, clipmax, NMEL * T);

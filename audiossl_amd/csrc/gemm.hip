@@ -11,6 +11,7 @@
 // audiossl/models/atst/audio_transformer.py:63,69 ; audiossl/models/atst/byol.py:13.
 #include "common.h"
 #include "kernels.h"
+#include "profile.h"
 
 namespace {
 
@@ -219,6 +220,7 @@ int launch_nt(const GemmArgs& a, hipStream_t st) {
     attr_done = true;
   }
   const int nblk = ((a.M + BM - 1) / BM) * (a.N / BN);
+  ProfScope ps(PK_GEMM_NT0 + EPI, 2.0 * a.M * a.N * a.K, st);
   hipLaunchKernelGGL(gemm_nt_kernel<EPI>, dim3(nblk), dim3(256), GEMM_LDS_BYTES, st, a);
   return (int)hipGetLastError();
 }
@@ -258,6 +260,7 @@ int atst_gemm_tn(const WgradArgs& a, hipStream_t st) {
   }
   const int splits = (p.M + p.m_per_split - 1) / p.m_per_split;
   const int nblk = (p.N / 128) * (p.K / 128) * splits;
+  ProfScope ps(PK_GEMM_TN, 2.0 * p.M * p.N * p.K, st);
   hipLaunchKernelGGL(gemm_tn_kernel, dim3(nblk), dim3(256), WGRAD_LDS_BYTES, st, p);
   return (int)hipGetLastError();
 }

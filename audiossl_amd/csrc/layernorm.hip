@@ -4,6 +4,7 @@
 // gradient handed to the upstream linear layer, and that layer's bias gradient (column sum), so dx is read once.
 #include "common.h"
 #include "kernels.h"
+#include "profile.h"
 
 namespace {
 constexpr float LN_EPS = 1e-6f;
@@ -118,6 +119,7 @@ int ln_grid(int M) { int b = (M + 3) / 4; return b < 2048 ? b : 2048; }
 
 int atst_ln_fwd(const float* x, const float* gamma, const float* beta, bf16* y, float* mean, float* rstd, int M, int C, hipStream_t st) {
   if (M <= 0) return ATST_OK;
+  ProfScope ps(PK_LN_FWD, (double)M * C * 6.0, st);                  // read fp32, write bf16
   if (C == 384) hipLaunchKernelGGL(ln_fwd_kernel<6>, dim3(ln_grid(M)), dim3(256), 0, st, x, gamma, beta, y, mean, rstd, M);
   else if (C == 768) hipLaunchKernelGGL(ln_fwd_kernel<12>, dim3(ln_grid(M)), dim3(256), 0, st, x, gamma, beta, y, mean, rstd, M);
   else return ATST_EINVAL;
@@ -127,6 +129,7 @@ int atst_ln_fwd(const float* x, const float* gamma, const float* beta, bf16* y, 
 int atst_ln_bwd(const LnBwdArgs& a, hipStream_t st) {
   if (a.M <= 0) return ATST_OK;
   int grid = (a.M + 63) / 64; if (grid > 1024) grid = 1024; if (grid < 1) grid = 1;
+  ProfScope ps(PK_LN_BWD, (double)a.M * a.C * (2.0 + 4.0 + (a.dres ? 4.0 : 0.0) + 4.0 + (a.g ? 2.0 : 0.0)), st);
   if (a.C == 384) hipLaunchKernelGGL(ln_bwd_kernel<6>, dim3(grid), dim3(256), 0, st, a);
   else if (a.C == 768) hipLaunchKernelGGL(ln_bwd_kernel<12>, dim3(grid), dim3(256), 0, st, a);
   else return ATST_EINVAL;

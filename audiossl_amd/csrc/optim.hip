@@ -7,6 +7,7 @@
 // read p,g,m,v,t  write p,m,v,t + two bf16 copies  = 46 B / parameter.
 #include "common.h"
 #include "kernels.h"
+#include "profile.h"
 
 namespace {
 __global__ __launch_bounds__(256) void adamw_ema_kernel(OptimArgs a) {
@@ -73,6 +74,7 @@ int atst_adamw_ema(const OptimArgs& a, hipStream_t st) {
   if (a.n == 0 || (a.n % 256)) return ATST_EINVAL;
   const size_t nchunk = a.n / 256;
   int grid = (int)((nchunk + 3) / 4); if (grid > 4096) grid = 4096;
+  ProfScope ps(PK_OPTIM, (double)a.n * 34.0 + (double)a.n_teacher * 10.0, st);
   hipLaunchKernelGGL(adamw_ema_kernel, dim3(grid), dim3(256), 0, st, a);
   return (int)hipGetLastError();
 }

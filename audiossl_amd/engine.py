@@ -1,0 +1,516 @@
+"""Host-side driver of the HIP hot path: flat parameter buffers, encoder passes, BYOL heads, loss, fused optimizer.
+
+Mirrors what ``ATST.forward`` + autograd + ``AdamW.step`` + ``ATST.update_teacher`` do in the reference
+(audiossl/models/atst/atst.py:24-34, audiossl/models/atst/byol.py:57-121, audiossl/methods/atst/model.py:24-51 and the
+ATST-Frame twins under audiossl/methods/atstframe/), but every tensor op is a call into libatst_hip.so.
+torch is used for device memory, streams and torch.distributed only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from collections import OrderedDict
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+from . import hip
+
+ARCH = {"small": dict(embed_dim=384, depth=12, num_heads=6), "base": dict(embed_dim=768, depth=12, num_heads=12)}
+ALIGN = 256          # every tensor starts on a 256-element boundary of the flat buffers (one flag byte per chunk)
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+HEAD_HIDDEN, HEAD_OUT = 4096, 256
+
+
+def _round_up(n, a=ALIGN):
+    return (n + a - 1) // a * a
+
+
+def encoder_param_shapes(arch: str, depth: Optional[int] = None, frame: bool = False, n_pos: int = 251):
+    """Parameter names/shapes in the reference's registration order (= state_dict order).
+    ref: audiossl/models/atst/audio_transformer.py:80-120 ; audiossl/methods/atstframe/audio_transformer.py:101-149."""
+    cfg = ARCH[arch]
+    d, depth = cfg["embed_dim"], (cfg["depth"] if depth is None else depth)
+    out = [("mask_embed", (1, 1, d))]
+    if not frame:
+        out.append(("cls_token", (1, 1, d)))
+    out += [("pos_embed", (1, n_pos, d)), ("patch_embed.patch_embed.weight", (d, 256)), ("patch_embed.patch_embed.bias", (d,))]
+    for i in range(depth):
+        b = f"blocks.{i}."
+        out += [(b + "norm1.weight", (d,)), (b + "norm1.bias", (d,)), (b + "attn.qkv.weight", (3 * d, d)),
+                (b + "attn.proj.weight", (d, d)), (b + "attn.proj.bias", (d,)), (b + "norm2.weight", (d,)),
+                (b + "norm2.bias", (d,)), (b + "mlp.fc1.weight", (4 * d, d)), (b + "mlp.fc1.bias", (4 * d,)),
+                (b + "mlp.fc2.weight", (d, 4 * d)), (b + "mlp.fc2.bias", (d,))]
+    nf = "norm_frame" if frame else "norm"
+    out += [(nf + ".weight", (d,)), (nf + ".bias", (d,))]
+    return out
+
+
+def head_param_shapes(in_dim: int):
+    """ref: audiossl/models/atst/byol.py:6-22 (Linear no-bias, BatchNorm1d affine, ReLU, Linear no-bias)."""
+    return [("0.weight", (HEAD_HIDDEN, in_dim)), ("1.weight", (HEAD_HIDDEN,)), ("1.bias", (HEAD_HIDDEN,)),
+            ("3.weight", (HEAD_OUT, HEAD_HIDDEN))]
+
+
+class FlatLayout:
+    """name -> (offset, shape) for 'encoder.*', 'projector.*', 'predictor.*' in one flat buffer."""
+
+    def __init__(self, arch: str, depth: Optional[int], frame: bool):
+        d = ARCH[arch]["embed_dim"]
+        self.entries: "OrderedDict[str, Tuple[int, Tuple[int, ...]]]" = OrderedDict()
+        off = 0
+        groups = [("encoder.", encoder_param_shapes(arch, depth, frame)), ("projector.", head_param_shapes(d)),
+                  ("predictor.", head_param_shapes(HEAD_OUT))]
+        for prefix, shapes in groups:
+            for name, shape in shapes:
+                self.entries[prefix + name] = (off, shape)
+                off = _round_up(off + math.prod(shape))
+            if prefix == "projector.":
+                self.n_teacher = off
+        self.n_student = off
+
+    def numel(self, name):
+        return math.prod(self.entries[name][1])
+
+
+class Workspace:
+    """A caller-owned device byte buffer carved by the C engine; exposes typed torch views at raw pointers."""
+
+    def __init__(self, nbytes: int, device):
+        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+    def view(self, ptr: int, shape, dtype):
+        off = ptr - self.buf.data_ptr()
+        n = math.prod(shape) * torch.empty(0, dtype=dtype).element_size()
+        assert 0 <= off and off + n <= self.buf.numel()
+        return self.buf[off:off + n].view(dtype).view(*shape)
+
+
+def pad_tokens(n: int) -> int:
+    for np_ in (32, 64, 128, 256):
+        if n <= np_:
+            return np_
+    raise hip.HipError(f"{n} tokens per sequence exceed the 256-token attention kernels (10 s @ 16 kHz = 251)")
+
+
+class EncoderPass:
+    """One encoder invocation geometry (S sequences of one mel width) with its activation workspace."""
+
+    def __init__(self, eng: "AtstEngine", net: str, S: int, width: int, train: bool):
+        self.eng, self.net, self.S, self.width, self.train = eng, net, S, width, train
+        cfg = eng.cfg
+        self.n_tok = (width - width % 4) // 4
+        self.use_cls = 0 if eng.frame else 1
+        if self.n_tok + self.use_cls > eng.n_pos:
+            raise hip.HipError(f"mel width {width} needs {self.n_tok + self.use_cls} positions; pos_embed has {eng.n_pos} "
+                               "(pos_type='cut', ref: audio_transformer.py:95-102)")
+        self.NP = pad_tokens(self.n_tok + self.use_cls)
+        self.M = S * self.NP
+        lib = hip.load()
+        nbytes = lib.atst_encoder_ws_bytes(S, self.NP, cfg["embed_dim"], cfg["num_heads"], eng.depth, int(train))
+        self.ws = Workspace(nbytes, eng.device)
+        e = hip.Encoder()
+        e.S, e.NP, e.n_tok, e.width, e.C, e.H, e.depth = S, self.NP, self.n_tok, width, cfg["embed_dim"], cfg["num_heads"], eng.depth
+        e.use_cls, e.train = self.use_cls, int(train)
+        if net == "student":
+            e.p32, e.p16, e.p16t, e.g32 = eng.p32.data_ptr(), eng.p16.data_ptr(), eng.p16t.data_ptr(), eng.g32.data_ptr()
+        else:
+            e.p32, e.p16, e.p16t, e.g32 = eng.t32.data_ptr(), eng.t16.data_ptr(), None, None
+        e.off = eng.enc_off
+        e.ws, e.ws_bytes = self.ws.buf.data_ptr(), nbytes
+        self.e = e
+        self.out = self.ws.view(lib.atst_encoder_out(C.byref(e)), (self.M, e.C), torch.bfloat16)
+        self.dout = self.ws.view(lib.atst_encoder_dout(C.byref(e)), (self.M, e.C), torch.bfloat16) if train else None
+        self._keep = None
+
+    def forward(self, mel: torch.Tensor, valid: torch.Tensor, rowflag: Optional[torch.Tensor], dp_scale: Optional[torch.Tensor]):
+        assert mel.shape == (self.S, 1, 64, self.width) and mel.dtype == torch.float32
+        self._keep = (mel, valid, rowflag, dp_scale)        # keep inputs alive until backward
+        e = self.e
+        e.mel, e.valid = hip.ptr(mel), hip.ptr(valid)
+        e.rowflag, e.dp_scale = hip.ptr(rowflag), hip.ptr(dp_scale)
+        hip.check(hip.load().atst_encoder_fwd(C.byref(e), hip.stream()), "atst_encoder_fwd")
+        return self.out
+
+    def backward(self):
+        hip.check(hip.load().atst_encoder_bwd(C.byref(self.e), hip.stream()), "atst_encoder_bwd")
+
+    def tokens(self):
+        return self.ws.view(hip.load().atst_encoder_tokens(C.byref(self.e)), (self.M, self.e.C), torch.float32)
+
+    def block_out(self, i):
+        return self.ws.view(hip.load().atst_encoder_block_out(C.byref(self.e), i), (self.M, self.e.C), torch.float32)
+
+
+class HeadPass:
+    """Linear(no bias) -> BatchNorm1d(train, cross-rank statistics) -> ReLU -> Linear(no bias), forward and backward.
+    ref: audiossl/models/atst/byol.py:6-22 ; SyncBatchNorm semantics from Trainer(sync_batchnorm=True), methods/atst/train.py:22."""
+
+    def __init__(self, eng: "AtstEngine", net: str, which: str, in_dim: int):
+        self.eng, self.net, self.which, self.in_dim = eng, net, which, in_dim
+        self.saved = None
+
+    def _w(self, name, transposed=False, f32=False, grad=False):
+        eng = self.eng
+        off, shape = eng.layout.entries[f"{self.which}.{name}"]
+        n = math.prod(shape)
+        if grad:
+            return eng.g32[off:off + n]
+        if f32:
+            return (eng.p32 if self.net == "student" else eng.t32)[off:off + n]
+        if transposed:
+            return eng.p16t[off:off + n]
+        return (eng.p16 if self.net == "student" else eng.t16)[off:off + n]
+
+    def forward(self, x: torch.Tensor, train: bool) -> torch.Tensor:
+        eng, R = self.eng, x.shape[0]
+        dev, st = x.device, hip.stream()
+        x16 = torch.empty(R, self.in_dim, dtype=torch.bfloat16, device=dev)
+        hip.call("atst_cast_bf16", hip.ptr(x), R * self.in_dim, hip.ptr(x16), st)
+        h = torch.empty(R, HEAD_HIDDEN, device=dev)
+        _gemm(x16, self._w("0.weight"), R, HEAD_HIDDEN, self.in_dim, hip.EPI_F32, h)
+        mean, m2 = torch.empty(HEAD_HIDDEN, device=dev), torch.empty(HEAD_HIDDEN, device=dev)
+        hip.call("atst_bn_stats_f32", hip.ptr(h), R, HEAD_HIDDEN, hip.ptr(mean), hip.ptr(m2), st)
+        count = float(R)
+        if eng.world > 1:
+            # SyncBatchNorm: exchange [mean, M2, count], combine with the parallel-variance formula (count-weighted,
+            # so ragged per-rank row counts of ATST-Frame are handled)
+            pack = torch.cat([mean, m2, torch.tensor([count], device=dev)])
+            allp = [torch.empty_like(pack) for _ in range(eng.world)]
+            dist.all_gather(allp, pack)
+            allp = torch.stack(allp)
+            means, m2s, cnts = allp[:, :HEAD_HIDDEN], allp[:, HEAD_HIDDEN:2 * HEAD_HIDDEN], allp[:, -1:]
+            count = float(cnts.sum())
+            mean = (means * cnts).sum(0) / count
+            m2 = (m2s + cnts * (means - mean) ** 2).sum(0)
+        var = m2 / count
+        rstd = torch.rsqrt(var + BN_EPS)
+        bn = eng.bn_buffers[f"{self.net}.{self.which}"]
+        with torch.no_grad():
+            bn["running_mean"].mul_(1 - BN_MOMENTUM).add_(mean, alpha=BN_MOMENTUM)
+            bn["running_var"].mul_(1 - BN_MOMENTUM).add_(m2 / max(count - 1.0, 1.0), alpha=BN_MOMENTUM)
+            bn["num_batches_tracked"] += 1
+        y16 = torch.empty(R, HEAD_HIDDEN, dtype=torch.bfloat16, device=dev)
+        hip.call("atst_bn_apply_relu_bf16", hip.ptr(h), hip.ptr(mean), hip.ptr(rstd), hip.ptr(self._w("1.weight", f32=True)),
+                 hip.ptr(self._w("1.bias", f32=True)), R, HEAD_HIDDEN, hip.ptr(y16), st)
+        out = torch.empty(R, HEAD_OUT, device=dev)
+        _gemm(y16, self._w("3.weight"), R, HEAD_OUT, HEAD_HIDDEN, hip.EPI_F32, out)
+        if train:
+            self.saved = (x16, h, mean, rstd, y16, count)
+        return out
+
+    def backward(self, dout: torch.Tensor) -> torch.Tensor:
+        eng = self.eng
+        x16, h, mean, rstd, y16, count = self.saved
+        R, dev, st = x16.shape[0], x16.device, hip.stream()
+        d16 = torch.empty(R, HEAD_OUT, dtype=torch.bfloat16, device=dev)
+        hip.call("atst_cast_bf16", hip.ptr(dout), R * HEAD_OUT, hip.ptr(d16), st)
+        _wgrad(d16, y16, R, HEAD_OUT, HEAD_HIDDEN, self._w("3.weight", grad=True))
+        dy = torch.empty(R, HEAD_HIDDEN, device=dev)
+        _gemm(d16, self._w("3.weight", transposed=True), R, HEAD_HIDDEN, HEAD_OUT, hip.EPI_F32, dy)
+        gamma, beta = self._w("1.weight", f32=True), self._w("1.bias", f32=True)
+        s1, s2 = torch.empty(HEAD_HIDDEN, device=dev), torch.empty(HEAD_HIDDEN, device=dev)
+        hip.call("atst_bn_relu_bwd_sums", hip.ptr(dy), hip.ptr(h), hip.ptr(mean), hip.ptr(rstd), hip.ptr(gamma), hip.ptr(beta),
+                 R, HEAD_HIDDEN, hip.ptr(s1), hip.ptr(s2), st)
+        self._w("1.bias", grad=True).add_(s1)          # local sums: DDP averages parameter gradients afterwards
+        self._w("1.weight", grad=True).add_(s2)
+        if eng.world > 1:
+            pack = torch.cat([s1, s2])
+            dist.all_reduce(pack)
+            s1, s2 = pack[:HEAD_HIDDEN].contiguous(), pack[HEAD_HIDDEN:].contiguous()
+        dh16 = torch.empty(R, HEAD_HIDDEN, dtype=torch.bfloat16, device=dev)
+        hip.call("atst_bn_bwd_dx_bf16", hip.ptr(dy), hip.ptr(h), hip.ptr(mean), hip.ptr(rstd), hip.ptr(gamma), hip.ptr(beta),
+                 hip.ptr(s1), hip.ptr(s2), 1.0 / count, R, HEAD_HIDDEN, hip.ptr(dh16), st)
+        _wgrad(dh16, x16, R, HEAD_HIDDEN, self.in_dim, self._w("0.weight", grad=True))
+        dx = torch.empty(R, self.in_dim, device=dev)
+        _gemm(dh16, self._w("0.weight", transposed=True), R, self.in_dim, HEAD_HIDDEN, hip.EPI_F32, dx)
+        self.saved = None
+        return dx
+
+
+def _gemm(A, B, M, N, K, epi, out):
+    hip.call("atst_gemm_nt_bf16", hip.ptr(A), hip.ptr(B), M, N, K, K, K, epi, hip.ptr(out), N, None, None, None, None, 1,
+             None, None, None, None, hip.stream())
+
+
+def _wgrad(dY, X, M, N, K, dW):
+    hip.call("atst_gemm_tn_bf16", hip.ptr(dY), hip.ptr(X), M, N, K, N, K, hip.ptr(dW), K, 0, hip.stream())
+
+
+def group_views(widths: Sequence[int]) -> List[Tuple[int, int]]:
+    """consecutive equal-width views share one encoder pass. ref: audiossl/models/atst/byol.py:107-112."""
+    groups, start = [], 0
+    for i in range(1, len(widths) + 1):
+        if i == len(widths) or widths[i] != widths[start]:
+            groups.append((start, i))
+            start = i
+    return groups
+
+
+class AtstEngine:
+    """Owns the flat parameter / gradient / optimizer-state buffers of student and teacher and runs the training step."""
+
+    def __init__(self, arch: str = "small", frame: bool = False, depth: Optional[int] = None, ncrops: int = 2,
+                 device: Optional[torch.device] = None, drop_path_rate: float = 0.1, n_pos: int = 251):
+        if arch not in ARCH:
+            raise RuntimeError("arch {} is not implemented".format(arch))      # ref: models/atst/atst.py:17
+        hip.load()                                                               # fail loudly when the .so is missing
+        if not torch.cuda.is_available():
+            raise hip.HipError("AtstEngine needs a HIP device (MI355X); there is no CPU product path")
+        self.arch, self.frame, self.ncrops = arch, frame, ncrops
+        self.cfg = ARCH[arch]
+        self.depth = self.cfg["depth"] if depth is None else depth
+        self.n_pos = n_pos
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.layout = L = FlatLayout(arch, self.depth, frame)
+        dev = self.device
+        z = lambda n, dt=torch.float32: torch.zeros(n, dtype=dt, device=dev)
+        self.p32, self.g32, self.m32, self.v32 = z(L.n_student), z(L.n_student), z(L.n_student), z(L.n_student)
+        self.t32 = z(L.n_teacher)
+        self.p16, self.p16t, self.t16 = z(L.n_student, torch.bfloat16), z(L.n_student, torch.bfloat16), z(L.n_teacher, torch.bfloat16)
+        self.bn_buffers: Dict[str, Dict[str, torch.Tensor]] = {}
+        for key in ("student.projector", "student.predictor", "teacher.projector"):
+            self.bn_buffers[key] = dict(running_mean=z(HEAD_HIDDEN), running_var=torch.ones(HEAD_HIDDEN, device=dev),
+                                        num_batches_tracked=torch.zeros((), dtype=torch.int64, device=dev))
+        # drop-path rates: torch.linspace(0, rate, depth) evaluated in fp32 like the reference (audio_transformer.py:107)
+        self.dpr = [float(v) for v in torch.linspace(0, drop_path_rate, self.depth)]
+        self.enc_off = self._build_offsets()
+        flags = torch.zeros(L.n_student // ALIGN, dtype=torch.uint8)
+        for name, (off, shape) in L.entries.items():
+            n = math.prod(shape)
+            decay = not (name.endswith(".bias") or len(shape) == 1)                  # ref: utils/common.py:58
+            update = not (name == "encoder.mask_embed" and not frame)                 # grad is None in clip ATST
+            ema = not name.startswith("predictor.")
+            f = (1 if decay else 0) | (2 if update else 0) | (4 if ema else 0)
+            flags[off // ALIGN:(off + n + ALIGN - 1) // ALIGN] = f
+        self.flags = flags.to(dev)
+        self.flags_ema_only = (flags & 4).to(dev)
+        self.opt_step = 0
+        self._passes: Dict[Tuple, EncoderPass] = {}
+        self._synced_version = (-1, -1)
+        self.heads = {"teacher.projector": HeadPass(self, "teacher", "projector", self.cfg["embed_dim"]),
+                      "student.projector": HeadPass(self, "student", "projector", self.cfg["embed_dim"]),
+                      "student.predictor": HeadPass(self, "student", "predictor", HEAD_OUT)}
+        self._acc = torch.zeros(1, device=dev)
+        self._stats = torch.zeros(4, HEAD_OUT, device=dev)
+        self._student_groups = None
+        self._grads_summed = False
+
+    # ---------------------------------------------------------------------------------------------------------------
+    def _build_offsets(self) -> hip.EncOff:
+        E, o = self.layout.entries, hip.EncOff()
+        g = lambda n: E["encoder." + n][0]
+        o.mask_embed, o.pos_embed = g("mask_embed"), g("pos_embed")
+        o.cls_token = g("cls_token") if not self.frame else 0
+        o.patch_w, o.patch_b = g("patch_embed.patch_embed.weight"), g("patch_embed.patch_embed.bias")
+        nf = "norm_frame" if self.frame else "norm"
+        o.norm_w, o.norm_b = g(nf + ".weight"), g(nf + ".bias")
+        for i in range(self.depth):
+            b, l = f"blocks.{i}.", o.layer[i]
+            l.ln1_w, l.ln1_b, l.qkv_w = g(b + "norm1.weight"), g(b + "norm1.bias"), g(b + "attn.qkv.weight")
+            l.proj_w, l.proj_b = g(b + "attn.proj.weight"), g(b + "attn.proj.bias")
+            l.ln2_w, l.ln2_b = g(b + "norm2.weight"), g(b + "norm2.bias")
+            l.fc1_w, l.fc1_b = g(b + "mlp.fc1.weight"), g(b + "mlp.fc1.bias")
+            l.fc2_w, l.fc2_b = g(b + "mlp.fc2.weight"), g(b + "mlp.fc2.bias")
+        return o
+
+    def param_view(self, net: str, name: str, grad: bool = False) -> torch.Tensor:
+        off, shape = self.layout.entries[name]
+        buf = (self.g32 if grad else self.p32) if net == "student" else self.t32
+        return buf[off:off + math.prod(shape)].view(*shape)
+
+    def load_weights(self, W: Dict[str, torch.Tensor]):
+        """state_dict-keyed ('student.encoder...', 'teacher.projector...') fp32 tensors -> flat buffers + BN buffers."""
+        with torch.no_grad():
+            for net in ("student", "teacher"):
+                for name in self.layout.entries:
+                    if net == "teacher" and name.startswith("predictor."):
+                        continue
+                    self.param_view(net, name).copy_(W[f"{net}.{name}"].to(self.device))
+            for key, bufs in self.bn_buffers.items():
+                for b in bufs:
+                    k = f"{key}.1.{b}"
+                    if k in W:
+                        bufs[b].copy_(W[k].to(self.device))
+        self.sync_shadows(force=True)
+
+    def init_weights(self, seed: int = 0):
+        """Random init with the reference's distributions, drawn on the device: encoder Linear weights, cls/pos/mask
+        tokens ~ trunc_normal(std 0.02, +-2 absolute), biases 0, LayerNorm (1,0)  (audio_transformer.py:116-129,
+        modules/transformer.py:80-84); projector / predictor Linear keep torch's default kaiming-uniform(a=sqrt 5)
+        = U(-1/sqrt(fan_in), 1/sqrt(fan_in)), BatchNorm (1,0)  (byol.py:6-22).  Teacher = copy of the student minus the
+        predictor, BN buffers included (atst.py:22)."""
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        with torch.no_grad():
+            for name, (off, shape) in self.layout.entries.items():
+                v = self.param_view("student", name)
+                if name.startswith("encoder."):
+                    if name.endswith(".bias"):
+                        v.zero_()
+                    elif len(shape) == 1:
+                        v.fill_(1.0)
+                    else:
+                        v.normal_(0.0, 0.02, generator=g).clamp_(-2.0, 2.0)
+                else:
+                    if name.endswith("1.weight"):
+                        v.fill_(1.0)
+                    elif name.endswith("1.bias"):
+                        v.zero_()
+                    else:
+                        bound = 1.0 / math.sqrt(shape[1])
+                        v.uniform_(-bound, bound, generator=g)
+            self.t32.copy_(self.p32[:self.layout.n_teacher])
+            for b in ("running_mean", "running_var", "num_batches_tracked"):
+                self.bn_buffers["teacher.projector"][b].copy_(self.bn_buffers["student.projector"][b])
+        self.sync_shadows(force=True)
+
+    def sync_shadows(self, force: bool = False):
+        """Refresh bf16 shadows (and W^T copies) if the fp32 masters were modified through torch (version counters)."""
+        ver = (self.p32._version, self.t32._version)
+        if not force and ver == self._synced_version:
+            return
+        st = hip.stream()
+        hip.call("atst_cast_bf16", hip.ptr(self.p32), self.p32.numel(), hip.ptr(self.p16), st)
+        hip.call("atst_cast_bf16", hip.ptr(self.t32), self.t32.numel(), hip.ptr(self.t16), st)
+        self._refresh_transposes()
+        self._synced_version = (self.p32._version, self.t32._version)
+
+    def _refresh_transposes(self):
+        st = hip.stream()
+        for name, (off, shape) in self.layout.entries.items():
+            if len(shape) == 2:
+                hip.call("atst_transpose_bf16_2d", self.p16.data_ptr() + 2 * off, shape[0], shape[1],
+                         self.p16t.data_ptr() + 2 * off, st)
+
+    # ---------------------------------------------------------------------------------------------------------------
+    def _pass(self, net: str, S: int, width: int, train: bool, slot: int) -> EncoderPass:
+        key = (net, S, width, train, slot)
+        if key not in self._passes:
+            self._passes[key] = EncoderPass(self, net, S, width, train)
+        return self._passes[key]
+
+    def drop_path_scales(self, S: int, keep: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """[depth,2,S] fp32 factors keep/keep_prob.  keep (0/1, [depth,2,S]) may be injected for parity tests; otherwise
+        drawn like the reference: floor(keep_prob + U[0,1)) per sample, per branch (modules/transformer.py:48-56)."""
+        rates = torch.tensor(self.dpr, device=self.device).view(-1, 1, 1)
+        if keep is None:
+            keep = torch.floor((1.0 - rates) + torch.rand(self.depth, 2, S, device=self.device))
+        else:
+            keep = keep.to(self.device, torch.float32)
+        return (keep / (1.0 - rates)).contiguous()
+
+    def _valid(self, lengths: torch.Tensor, use_cls: int) -> torch.Tensor:
+        l = lengths.to(self.device, torch.int64)
+        return (((l - l % 4) // 4) + use_cls).to(torch.int32).contiguous()        # ref: audio_transformer.py:70-71,194
+
+    def _run_net(self, net: str, mels, lengths, masks, mask_input: bool, keep, train: bool):
+        """MultiCropWrapper.forward: encoder per width-group -> rows for the head (view-major).
+        ref: audiossl/models/atst/byol.py:103-121 ; methods/atstframe/byol.py:118-138."""
+        feats, groups = [], []
+        use_cls = 0 if self.frame else 1
+        for gi, (a, b) in enumerate(group_views([m.shape[-1] for m in mels])):
+            mel = torch.cat([m.to(self.device, torch.float32) for m in mels[a:b]]).contiguous()
+            S, width = mel.shape[0], mel.shape[-1]
+            ep = self._pass(net, S, width, train, gi)
+            valid = self._valid(torch.cat([torch.as_tensor(l) for l in lengths[a:b]]), use_cls)
+            rowflag = None
+            if self.frame:
+                mk = torch.cat([torch.as_tensor(m) for m in masks[a:b]]).to(self.device).bool()      # [S, n_tok]
+                if mask_input:
+                    rowflag = torch.zeros(S, ep.NP, dtype=torch.uint8, device=self.device)
+                    rowflag[:, :mk.shape[1]] = mk
+                    rowflag = rowflag.reshape(-1).contiguous()
+                sel = mk & (torch.arange(mk.shape[1], device=self.device)[None, :] < valid[:, None])
+                s_idx, n_idx = sel.nonzero(as_tuple=True)                                     # row-major (b, n) order
+                rows = (s_idx * ep.NP + n_idx).to(torch.int32).contiguous()
+            else:
+                rows = (torch.arange(S, device=self.device, dtype=torch.int32) * ep.NP).contiguous()
+            dp = self.drop_path_scales(S, None if keep is None else keep[gi]) if self.dpr[-1] > 0 or keep is not None else None
+            out16 = ep.forward(mel, valid, rowflag, dp)
+            f = torch.empty(rows.numel(), self.cfg["embed_dim"], device=self.device)
+            hip.call("atst_gather_rows_bf16", hip.ptr(out16), hip.ptr(rows), rows.numel(), self.cfg["embed_dim"], hip.ptr(f), hip.stream())
+            feats.append(f)
+            groups.append((ep, rows))
+        return torch.cat(feats) if len(feats) > 1 else feats[0], groups
+
+    def forward(self, mels: List[torch.Tensor], lengths: List[torch.Tensor], masks: Optional[List[torch.Tensor]] = None,
+                keep_teacher=None, keep_student=None, train: bool = True):
+        """teacher(first 2 views / unmasked) -> student(all views / masked) -> loss.  Returns (loss, std_s, std_t) as
+        0-dim device tensors; saves what backward() needs.  ref: models/atst/atst.py:24-28, atstframe/model.py:68-72."""
+        self.sync_shadows()
+        nt = len(mels) if self.frame else 2
+        tf, _ = self._run_net("teacher", mels[:nt], lengths[:nt], None if masks is None else masks[:nt], False, keep_teacher, False)
+        t_out = self.heads["teacher.projector"].forward(tf, False)
+        sf, groups = self._run_net("student", mels, lengths, masks, True, keep_student, train)
+        z = self.heads["student.projector"].forward(sf, train)
+        s_out = self.heads["student.predictor"].forward(z, train)
+        ncrops = 2 if self.frame else self.ncrops
+        if s_out.shape[0] % ncrops or t_out.shape[0] % 2 or s_out.shape[0] // ncrops != t_out.shape[0] // 2:
+            raise hip.HipError("views must contribute equal row counts (chunk() semantics of ByolLoss)")
+        B = t_out.shape[0] // 2
+        self._ds = torch.empty_like(s_out)
+        hip.call("atst_byol_loss_f32", hip.ptr(s_out), hip.ptr(t_out), B, ncrops, HEAD_OUT, hip.ptr(self._acc), hip.ptr(self._ds),
+                 hip.ptr(self._stats), hip.stream())
+        npairs = 2 * ncrops - 2
+        loss = 2.0 - 2.0 * self._acc[0] / (npairs * B)
+        stats, ns, ntc = self._stats, float(s_out.shape[0]), float(t_out.shape[0])
+        if self.world > 1:                                      # one fused all-reduce instead of the reference's six
+            pack = torch.cat([stats.reshape(-1), torch.tensor([ns, ntc], device=self.device)])
+            dist.all_reduce(pack)
+            stats, ns, ntc = pack[:-2].view(4, HEAD_OUT), float(pack[-2]), float(pack[-1])
+
+        def std(sums, sq, n):                                   # ref: byol.py:42-53
+            return torch.sqrt(sq / (n - 1) - sums ** 2 / (n * (n - 1)) + 1e-6).mean()
+        self._student_groups = groups
+        self.last_outputs = (s_out, t_out)
+        return loss, std(stats[0], stats[1], ns), std(stats[2], stats[3], ntc)
+
+    def backward(self, grad_scale=1.0, zero_grad: bool = True):
+        """Autograd of forward() wrt every student parameter, accumulated into the flat gradient buffer.
+        grad_scale may be a python float or a 0-dim device tensor (the upstream d(loss))."""
+        if zero_grad:
+            self.g32.zero_()
+        self._grads_summed = False
+        if isinstance(grad_scale, torch.Tensor):
+            ds = self._ds * grad_scale.to(self._ds.dtype)
+        else:
+            ds = self._ds if grad_scale == 1.0 else self._ds * float(grad_scale)
+        dz = self.heads["student.predictor"].backward(ds)
+        df = self.heads["student.projector"].backward(dz)
+        r0 = 0
+        for ep, rows in self._student_groups:
+            n = rows.numel()
+            ep.dout.zero_()
+            hip.call("atst_scatter_rows_bf16", hip.ptr(df[r0:r0 + n].contiguous()), hip.ptr(rows), n, self.cfg["embed_dim"],
+                     hip.ptr(ep.dout), hip.stream())
+            ep.backward()
+            r0 += n
+
+    def allreduce_grads(self):
+        """DDP: sum student gradients over ranks (RCCL over xGMI); the 1/world mean is folded into the optimizer kernel."""
+        if self.world > 1:
+            dist.all_reduce(self.g32)
+            self._grads_summed = True
+
+    def optimizer_step(self, lr: float, wd: float, ema_m: Optional[float], betas=(0.9, 0.999), eps: float = 1e-6):
+        """HF-AdamW over the two parameter groups + EMA teacher + bf16 shadow refresh in one pass.
+        ref: transformers AdamW via methods/atst/model.py:44-48 ; atst.py:29-34."""
+        self.opt_step += 1
+        t = self.opt_step
+        step_size = lr * math.sqrt(1.0 - betas[1] ** t) / (1.0 - betas[0] ** t)
+        do_ema = ema_m is not None
+        hip.call("atst_adamw_ema_step", hip.ptr(self.p32), hip.ptr(self.g32), hip.ptr(self.m32), hip.ptr(self.v32),
+                 hip.ptr(self.t32) if do_ema else None, hip.ptr(self.p16), hip.ptr(self.t16) if do_ema else None,
+                 hip.ptr(self.flags), self.layout.n_student, self.layout.n_teacher, lr, wd, betas[0], betas[1], eps, step_size,
+                 ema_m if do_ema else 1.0, (1.0 / self.world) if self._grads_summed else 1.0, hip.stream())
+        self._refresh_transposes()
+        self._synced_version = (self.p32._version, self.t32._version)
+
+    def ema_update(self, m: float):
+        """ATST.update_teacher(m) alone (compat path when an external optimizer stepped the student)."""
+        self.sync_shadows()
+        hip.call("atst_adamw_ema_step", hip.ptr(self.p32), hip.ptr(self.g32), hip.ptr(self.m32), hip.ptr(self.v32), hip.ptr(self.t32),
+                 hip.ptr(self.p16), hip.ptr(self.t16), hip.ptr(self.flags_ema_only), self.layout.n_student, self.layout.n_teacher,
+                 0.0, 0.0, 0.9, 0.999, 1e-6, 0.0, m, 1.0, hip.stream())

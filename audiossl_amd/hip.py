@@ -72,6 +72,10 @@ _SIGS = {
     "atst_encoder_dout": (C.c_void_p, [C.POINTER(Encoder)]),
     "atst_encoder_block_out": (C.c_void_p, [C.POINTER(Encoder), C.c_int]),
     "atst_encoder_tokens": (C.c_void_p, [C.POINTER(Encoder)]),
+    "atst_profile_enable": (C.c_int, [C.c_int]),
+    "atst_profile_kinds": (C.c_int, []),
+    "atst_profile_name": (C.c_char_p, [C.c_int]),
+    "atst_profile_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
 }
 
 _lib = None

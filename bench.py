@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Headline benchmark: ATST-small pre-training clips/s on synthetic 10 s @ 16 kHz waveforms (BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload clip6|clip2|frame] [--batch B]
+
+One timed step = mel front end of every view (HIP) -> teacher fwd -> student fwd -> loss -> student bwd ->
+(RCCL all-reduce of student grads at N>1) -> fused HF-AdamW + EMA teacher.  Inputs (12 s waveform buffers) are resident
+in HBM before the timed region.  Prints ONE JSON line on rank 0 (contract in the task statement): metric / value /
+roofline (dominant kernel, live HIP-event timing from inside libatst_hip.so) / cpu_baseline (oracle on host cores).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def flops_per_clip(workload: str, d=384, depth=12) -> float:
+    """Algorithmic GEMM FLOPs per clip (SURVEY.md 8(d) / BASELINE.md 2): fwd = 1x, bwd = 2x, padding not counted."""
+    def enc(N, P):
+        return depth * (24 * N * d * d + 4 * N * N * d) + 2 * P * 256 * d
+    proj, pred = 2 * (d * 4096 + 4096 * 256), 2 * (256 * 4096 + 4096 * 256)
+    if workload == "clip2":
+        return 2 * enc(251, 250) + 3 * 2 * enc(251, 250) + 2 * proj + 3 * 2 * (proj + pred)
+    if workload == "clip6":
+        g, l = enc(251, 250), enc(26, 25)
+        return 2 * g + 3 * (2 * g + 4 * l) + 2 * proj + 3 * 6 * (proj + pred)
+    if workload == "frame":
+        g, rows = enc(250, 250), 163
+        return 2 * g + 3 * 2 * g + rows * (2 * proj + 3 * 2 * (proj + pred))
+    raise ValueError(workload)
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """The reference's algorithm on the host cores: the CPU oracle (plain fp32 torch restatement pinned to the
+    reference by tests/test_oracle_golden.py) on BASELINE.json configs[0]: B=2 clips x 2 views, 10 s, mel front end +
+    teacher fwd + student fwd/bwd + HF-AdamW + EMA.  Bounded sample: 1 warm-up + up to 4 timed steps per setting."""
+    from oracle import atst_oracle as O
+    ncpu = os.cpu_count() or 1
+    out = {}
+    for label, threads in (("all", min(ncpu, 64)), ("one", 1)):
+        torch.set_num_threads(threads)
+        W = O.recipe_weights("small", seed=0)
+        leaves = {k: v.requires_grad_(True) for k, v in W.items()
+                  if k.startswith("student.") and v.dtype == torch.float32 and "running" not in k}
+        st = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in leaves.items()}
+        reg, _ = O.param_groups([(k[len("student."):], tuple(v.shape)) for k, v in leaves.items()])
+        wave = O.recipe_wave(2, 192000, seed=1234)
+        times, t_end = [], time.time() + seconds_budget / 2
+        for step in range(1, 6):
+            t0 = time.time()
+            mels = [O.log_mel(wave[:, o:o + 160000]) for o in (1000, 20000)]
+            lens = [torch.full((2,), 1001)] * 2
+            loss, _, _ = O.atst_forward(W, mels, lens, "small", 2)
+            for v in leaves.values():
+                v.grad = None
+            loss.backward()
+            with torch.no_grad():
+                for k, v in leaves.items():
+                    if v.grad is not None:
+                        O.hf_adamw_step(v, v.grad, st[k][0], st[k][1], step, 5e-4, 0.04 if k[len("student."):] in reg else 0.0)
+            for v in leaves.values():
+                v.requires_grad_(False)
+            O.ema_update(W, 0.99)
+            for v in leaves.values():
+                v.requires_grad_(True)
+            if step > 1:
+                times.append(time.time() - t0)
+            if time.time() > t_end and times:
+                break
+        times.sort()
+        out[label] = (2.0 / times[len(times) // 2], threads, len(times))
+    torch.set_num_threads(min(ncpu, 64))
+    v, c, n = out["all"]
+    return {"value": round(v, 3), "unit": "clips/s", "cores": c, "kind": "port",
+            "sample": f"oracle (fp32 torch CPU restatement), configs[0]: B=2 clips x 2 views x 10 s, mel + teacher fwd + "
+                      f"student fwd/bwd + HF-AdamW + EMA, median of {n} steps after 1 warm-up",
+            "one_thread_value": round(out["one"][0], 3), "one_thread_note": "reference as shipped pins OMP/MKL to 1 thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="clip6", choices=["clip6", "clip2", "frame"])
+    ap.add_argument("--batch", type=int, default=256, help="clips per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+
+    from audiossl_amd import hip
+    from audiossl_amd.engine import AtstEngine
+    from audiossl_amd.frontend import LogMelFrontend
+    from audiossl_amd.utils.common import cosine_scheduler_step
+    lib = hip.load()
+
+    B, frame = args.batch, args.workload == "frame"
+    ncrops = 6 if args.workload == "clip6" else 2
+    eng = AtstEngine("small", frame=frame, ncrops=ncrops)
+    eng.init_weights(seed=0)
+    fe = LogMelFrontend(1024 if not frame else 640)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    buf = torch.clamp(0.1 * torch.randn(B, 192000, device=dev, generator=g), -1.0, 1.0)      # 12 s, resident in HBM
+    total = args.warmup + args.steps + 2
+    lr_tab = cosine_scheduler_step(5e-4 * world * B / 256, 1e-6, 39100, 1300)
+    wd_tab = cosine_scheduler_step(0.04, 0.4, 39100, 0)
+    ema_tab = cosine_scheduler_step(0.99, 1, 39100, 0)
+    cpu_gen = torch.Generator().manual_seed(99 + rank)
+    offs = torch.randint(0, 192000 - 160000, (total, 6), generator=cpu_gen).tolist()
+    masks = None
+    if frame:
+        import numpy as np
+        rs = np.random.RandomState(1234 + rank)
+        from audiossl_amd.methods.atstframe.random_mask import block_mask
+        m = torch.from_numpy(np.stack([block_mask(250, 0.65, 5, rng=rs) for _ in range(B)])).to(dev)
+        masks = [m, m]
+
+    def step(k):
+        o = offs[k]
+        if frame:
+            mel = fe(buf[:, o[0]:o[0] + 160000])
+            mels, lens = [mel, mel], [torch.full((B,), 1001)] * 2
+        else:
+            mels = [fe(buf[:, o[v]:o[v] + 160000]) for v in range(2)]
+            lens = [torch.full((B,), 1001)] * 2
+            if ncrops == 6:                                  # 4 local views of 1 s -> 101 frames -> 25 patches + CLS
+                mels += [fe(buf[:, o[2 + v]:o[2 + v] + 16000]) for v in range(4)]
+                lens += [torch.full((B,), 101)] * 4
+        loss, _, _ = eng.forward(mels, lens, masks)
+        eng.backward()
+        eng.allreduce_grads()
+        eng.optimizer_step(float(lr_tab[k]), float(wd_tab[k]), float(ema_tab[k + 1]))
+        return loss
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k)
+    sync()
+    if not args.no_profile:
+        lib.atst_profile_enable(1)
+    t0 = time.perf_counter()
+    for k in range(args.warmup, args.warmup + args.steps):
+        loss = step(k)
+    sync()
+    dt = time.perf_counter() - t0
+    lib.atst_profile_enable(0)
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+    loss_val = float(loss)
+
+    roof, kernels = None, []
+    if not args.no_profile:
+        nk = lib.atst_profile_kinds()
+        ms, work, cnt = (C.c_double * nk)(), (C.c_double * nk)(), (C.c_longlong * nk)()
+        hip.check(lib.atst_profile_collect(ms, work, cnt), "atst_profile_collect")
+        for i in range(nk):
+            if cnt[i]:
+                name = lib.atst_profile_name(i).decode()
+                mfma = "gemm" in name or "attn" in name
+                rate = work[i] / (ms[i] * 1e-3) / (1e12 if mfma else 1e9)
+                kernels.append({"kernel": name, "launches": int(cnt[i]), "avg_us": round(ms[i] / cnt[i] * 1e3, 2),
+                                "total_ms": round(ms[i], 3), "bound": "mfma" if mfma else "hbm",
+                                "achieved": round(rate, 2), "unit": "TFLOP/s" if mfma else "GB/s"})
+        kernels.sort(key=lambda r: -r["total_ms"])
+        if kernels:
+            d = kernels[0]
+            peak = PEAK_BF16_TFLOPS if d["bound"] == "mfma" else PEAK_HBM_GBS
+            roof = {"bound": d["bound"], "kernel": d["kernel"], "achieved": d["achieved"], "peak": peak, "unit": d["unit"],
+                    "frac": round(d["achieved"] / peak, 4), "traffic": None, "avg_launch_us": d["avg_us"],
+                    "launches": d["launches"], "share_of_timed_kernel_ms": round(d["total_ms"] / sum(r["total_ms"] for r in kernels), 3)}
+
+    if rank == 0:
+        clips = B * world * args.steps
+        value = clips / dt
+        fpc = flops_per_clip(args.workload)
+        out = {"metric": "pretrain clips/sec (10s@16kHz, ATST-small)", "value": round(value, 2), "unit": "clips/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": {"clip6": "ATST-small clip-level, 2 global (10 s) + 4 local (1 s) views",
+                                       "clip2": "ATST-small clip-level, 2 views (10 s)",
+                                       "frame": "ATST-Frame small, masked frame objective (10 s)"}[args.workload] +
+                          ", synthetic AudioSet-shaped 10s@16kHz waveforms, mel front end inside the timed step",
+                          "clips_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                          "optimizer": "HF-AdamW + EMA teacher (fused)", "drop_path": 0.1},
+               "flops_per_clip_G": round(fpc / 1e9, 2), "step_tflops": round(value * fpc / 1e12, 2),
+               "mfma_roofline_frac_step": round(value * fpc / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
+               "loss": round(loss_val, 5), "roofline": roof, "kernels": kernels[:8]}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -120,6 +120,12 @@ int atst_encoder_bwd(const atst_encoder_t* e, void* stream);
 const float* atst_encoder_block_out(const atst_encoder_t* e, int i);
 const float* atst_encoder_tokens(const atst_encoder_t* e);
 
+/* ---- in-library kernel timing (HIP events on the launch stream); used by bench.py for the roofline object ---------- */
+int atst_profile_enable(int on);
+int atst_profile_kinds(void);
+const char* atst_profile_name(int kind);
+int atst_profile_collect(double* ms, double* work, long long* launches);   /* arrays of atst_profile_kinds() */
+
 #ifdef __cplusplus
 }
 #endif

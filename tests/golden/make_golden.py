@@ -126,7 +126,7 @@ def gen_clip(name, ncrops, widths, lengths, B=2, seed_w=0, seed_x=1, seed_dp=7, 
     rates = O.drop_path_rates(12)
     arrs = dict(B=B, ncrops=ncrops, widths=np.array(widths), lengths=np.array(lengths), seed_w=seed_w, seed_x=seed_x,
                 loss=loss.item(), std_s=std_s.item(), std_t=std_t.item(),
-                teacher_out=t_out.detach().numpy(), student_out=s_out.detach().numpy())
+                teacher_out=t_out.detach().numpy()[:8], student_out=s_out.detach().numpy()[:8])
     if drop:
         groups = O.group_views(widths)
         # teacher: groups over first 2 views ; student: over all views.  11*2 draws per group pass.
@@ -215,6 +215,29 @@ def gen_frame(name="frame_small"):
     save(name, **arrs)
 
 
+def gen_encoder_grad(name="clip_encoder_grad"):
+    """Encoder-only gradient pin that does not pass through the tiny-batch BatchNorm (which is ill-conditioned at B=2,
+    see DESIGN.md "Precision"): L = sum(CLS * R) for a fixed R, full-depth AST_small, ragged lengths, DropPath on."""
+    from audiossl.models.atst.audio_transformer import AST_small
+    torch.manual_seed(3)
+    enc = AST_small()
+    W = O.recipe_weights("small", seed=21)
+    enc.load_state_dict({k[len("student.encoder."):]: v for k, v in W.items() if k.startswith("student.encoder.")})
+    enc.train()
+    S = 4
+    mel = O.recipe_mel(S, 1001, seed=23)
+    length = torch.tensor([1001, 777, 1001, 530])
+    R = torch.from_numpy(np.random.default_rng(29).standard_normal((S, 384)).astype(np.float32))
+    torch.manual_seed(31)
+    with RandRecorder() as rr:
+        cls = enc(mel, length=length)
+    (cls * R).sum().backward()
+    arrs = dict(S=S, length=length.numpy(), cls=cls.detach().numpy(),
+                keep=keep_from_draws(rr.draws, 12, O.drop_path_rates(12)).numpy())
+    arrs.update(grad_digest(enc.named_parameters()))
+    save(name, **arrs)
+
+
 def gen_sched(name="schedules"):
     lr = ref_common.cosine_scheduler_step(5e-4 * 4 * 384 / 256, 1e-6, 39100, 1300)
     wd = ref_common.cosine_scheduler_step(0.04, 0.4, 39100, 0)
@@ -231,7 +254,7 @@ def gen_sched(name="schedules"):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["blocks", "clip2", "clip2_nodrop", "clip6", "frame", "sched"]
+    which = sys.argv[1:] or ["blocks", "clip2", "clip2_nodrop", "clip6", "frame", "sched", "encgrad", "clip2_b16", "clip2_b64"]
     if "blocks" in which:
         gen_blocks()
     if "clip2" in which:
@@ -241,6 +264,16 @@ if __name__ == "__main__":
     if "clip6" in which:
         gen_clip("clip_small_6crops", 6, [1001, 1001, 101, 101, 101, 101],
                  [[1001, 1001], [1001, 1001], [101, 101], [101, 77], [101, 101], [101, 101]], seed_x=41)
+    if "encgrad" in which:
+        gen_encoder_grad()
+    if "clip2_b16" in which:
+        L = [1001] * 16
+        L2 = [1001 - 40 * (i % 5) for i in range(16)]
+        gen_clip("clip_small_2views_b16", 2, [1001, 1001], [L, L2], B=16, seed_x=51)
+    if "clip2_b64" in which:
+        L = [1001] * 64
+        L2 = [1001 - 40 * (i % 5) for i in range(64)]
+        gen_clip("clip_small_2views_b64", 2, [1001, 1001], [L, L2], B=64, seed_x=71)
     if "frame" in which:
         gen_frame()
     if "sched" in which:
