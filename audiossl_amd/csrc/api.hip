@@ -83,6 +83,9 @@ int atst_colsum_bf16_f32(const uint16_t* x, int M, int N, int ld, float* out, vo
   return atst_colsum_bf16(CBF(x), M, N, ld, out, ST(stream));
 }
 int atst_cast_bf16(const float* x, size_t n, uint16_t* y, void* stream) { return atst_cast_f32_bf16(x, n, BF(y), ST(stream)); }
+int atst_split3_bf16(const float* x, int R, int K, int b_layout, uint16_t* y, void* stream) {
+  return atst_split3(x, R, K, b_layout, BF(y), ST(stream));
+}
 int atst_transpose_bf16_2d(const uint16_t* src, int rows, int cols, uint16_t* dst, void* stream) {
   return atst_transpose_bf16(CBF(src), rows, cols, BF(dst), ST(stream));
 }
@@ -93,6 +96,10 @@ int atst_bn_stats_f32(const float* h, int R, int N, float* mean, float* m2, void
 int atst_bn_apply_relu_bf16(const float* h, const float* mean, const float* rstd, const float* gamma, const float* beta,
                             int R, int N, uint16_t* y, void* stream) {
   return atst_bn_apply_relu(h, mean, rstd, gamma, beta, R, N, BF(y), ST(stream));
+}
+int atst_bn_apply_relu_split3_bf16(const float* h, const float* mean, const float* rstd, const float* gamma,
+                                   const float* beta, int R, int N, uint16_t* y, void* stream) {
+  return atst_bn_apply_relu_split3(h, mean, rstd, gamma, beta, R, N, BF(y), ST(stream));
 }
 int atst_bn_relu_bwd_sums(const float* dy, const float* h, const float* mean, const float* rstd, const float* gamma,
                           const float* beta, int R, int N, float* sum_dy, float* sum_dy_xhat, void* stream) {

@@ -15,43 +15,61 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int LDS_LD = BK + 8;                 // 72 bf16 = 144 B row stride: 16-B aligned, conflict-free b128 reads
-constexpr int TILE_ELEMS = BM * LDS_LD;        // per operand per buffer
-constexpr int GEMM_LDS_BYTES = 2 * 2 * TILE_ELEMS * 2;   // 73,728 B -> 2 blocks / CU
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int NSTAGE = 4;                      // LDS ring: tile kt is consumed while kt+1, kt+2 are in flight and kt+3 is issued
+constexpr int OP_BYTES = BM * BK * 2;          // 8 KiB per operand per stage, rows of 64 B (4 x 16-B chunks), XOR-swizzled
+constexpr int STAGE_BYTES = 2 * OP_BYTES;
+constexpr int GEMM_LDS_BYTES = 128 * (BN + 4) * 4;   // 67,584 B (epilogue staging tile >= 4 stages x 16 KiB) -> 2 blocks / CU
 
+constexpr int C_LD = BN + 4;                   // fp32 epilogue staging tile [128][132] = 67,584 B (re-uses the operand LDS)
+
+// Epilogue on 4 consecutive columns of one row (vector loads / stores; the accumulator tile is staged through LDS so
+// that every global access is a full 16-B (fp32) or 8-B (bf16) piece of a contiguous row segment).
 template <int EPI>
-DEVFN void epilogue(const GemmArgs& p, int row, int col, float v) {
+DEVFN void epilogue4(const GemmArgs& p, int row, int col, f32x4 v) {
   const size_t idx = (size_t)row * p.ldc + col;
+  auto st_bf16 = [](void* base, size_t i, const f32x4& x) {
+    bf16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = f2bf(x[e]);
+    *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(base) + i) = o;
+  };
   if constexpr (EPI == EPI_BF16) {
-    if (p.bias) v += p.bias[col];
-    reinterpret_cast<bf16*>(p.C)[idx] = f2bf(v);
+    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + col);
+    st_bf16(p.C, idx, v);
   } else if constexpr (EPI == EPI_F32) {
-    if (p.bias) v += p.bias[col];
-    reinterpret_cast<float*>(p.C)[idx] = v;
+    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + col);
+    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + idx) = v;
   } else if constexpr (EPI == EPI_BIAS_GELU) {
-    v += p.bias[col];
-    reinterpret_cast<bf16*>(p.C)[idx] = f2bf(v);                 // pre-activation u (saved for backward)
-    reinterpret_cast<bf16*>(p.C2)[idx] = f2bf(gelu_f(v));        // activation a
+    v += *reinterpret_cast<const f32x4*>(p.bias + col);
+    st_bf16(p.C, idx, v);                                         // pre-activation u (saved for backward)
+    f32x4 a;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[e] = gelu_f(v[e]);
+    st_bf16(p.C2, idx, a);                                        // activation a
   } else if constexpr (EPI == EPI_RESID) {
     const float s = p.row_scale ? p.row_scale[row / p.rows_per_seq] : 1.0f;
-    reinterpret_cast<float*>(p.C)[idx] = p.resid[idx] + s * (v + p.bias[col]);
+    const f32x4 r = *reinterpret_cast<const f32x4*>(p.resid + idx);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + col);
+    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + idx) = r + s * (v + b);
   } else if constexpr (EPI == EPI_DGELU) {
-    const float u = bf2f(p.U[idx]);
-    reinterpret_cast<bf16*>(p.C)[idx] = f2bf(v * gelu_grad_f(u));
+    const bf16x4 u = *reinterpret_cast<const bf16x4*>(p.U + idx);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(bf2f(u[e]));
+    st_bf16(p.C, idx, v);
   } else if constexpr (EPI == EPI_PATCH) {
     const int tok = row % p.rows_per_seq;
-    const float t = p.table[(size_t)tok * p.N + col];
-    float o = v + t;
-    if (p.rowflag && p.rowflag[row]) o = t - p.bias[col] + p.alt[col];   // mask-token substitution (ATST-Frame)
-    reinterpret_cast<float*>(p.C)[idx] = o;
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p.table + (size_t)tok * p.N + col);
+    f32x4 o = v + t;
+    if (p.rowflag && p.rowflag[row])                               // mask-token substitution (ATST-Frame)
+      o = t - *reinterpret_cast<const f32x4*>(p.bias + col) + *reinterpret_cast<const f32x4*>(p.alt + col);
+    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + idx) = o;
   }
 }
 
 template <int EPI>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  bf16* smem = reinterpret_cast<bf16*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1, hi = lane >> 5, l31 = lane & 31;
 
@@ -60,28 +78,28 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
   const int id = xcd_remap(blockIdx.x, ntm * ntn);
   const int m0 = (id / ntn) * BM, n0 = (id % ntn) * BN;
 
-  // staging map: 1024 16-B chunks per operand tile, 4 per thread
-  int s_row[4], s_col[4];
+  // Operand tiles go HBM/L2 -> LDS directly (global_load_lds, 16 B per lane, 1 KiB per wave-instruction, no staging
+  // registers), three K-tiles ahead of the MFMAs.  LDS rows are 64 B; chunk c of row r is stored at chunk
+  // c ^ ((r >> 2) & 3) so that the 16-lane groups of ds_read_b128 hit 16 distinct 16-B bank slots; the permutation is
+  // applied to the per-lane *source* address (the LDS destination of global_load_lds is lane-linear).
+  typedef const void __attribute__((address_space(1))) * gptr_t;
+  typedef void __attribute__((address_space(3))) * lptr_t;
+  char* lds = smem_raw;
+  const bf16* srcA[2]; const bf16* srcB[2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { const int c = tid + 256 * i; s_row[i] = c >> 3; s_col[i] = (c & 7) * 8; }
-  const bf16* gA[4]; const bf16* gB[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int ra = m0 + s_row[i]; ra = ra < p.M ? ra : p.M - 1;          // clamp: rows >= M are never stored
-    gA[i] = p.A + (size_t)ra * p.lda + s_col[i];
-    gB[i] = p.B + (size_t)(n0 + s_row[i]) * p.ldb + s_col[i];
+  for (int j = 0; j < 2; ++j) {
+    const int row = (wid * 2 + j) * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ ((row >> 2) & 3);
+    int ra = m0 + row; ra = ra < p.M ? ra : p.M - 1;              // clamp: rows >= M are never stored
+    srcA[j] = p.A + (size_t)ra * p.lda + c * 8;
+    srcB[j] = p.B + (size_t)(n0 + row) * p.ldb + c * 8;
   }
-  bf16x8 ra[4], rb[4];
-  auto gload = [&](int kt) {
+  auto issue = [&](int kt) {
+    char* st = lds + (kt & (NSTAGE - 1)) * STAGE_BYTES + wid * 2048;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { ra[i] = ld_frag(gA[i] + kt * BK); rb[i] = ld_frag(gB[i] + kt * BK); }
-  };
-  auto swrite = [&](int buf) {
-    bf16* sA = smem + buf * 2 * TILE_ELEMS; bf16* sB = sA + TILE_ELEMS;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<bf16x8*>(sA + s_row[i] * LDS_LD + s_col[i]) = ra[i];
-      *reinterpret_cast<bf16x8*>(sB + s_row[i] * LDS_LD + s_col[i]) = rb[i];
+    for (int j = 0; j < 2; ++j) {
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcA[j] + kt * BK), (lptr_t)(st + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcB[j] + kt * BK), (lptr_t)(st + OP_BYTES + j * 1024), 16, 0, 0);
     }
   };
 
@@ -94,37 +112,48 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = p.K / BK;
-  gload(0);
-  swrite(0);
-  __syncthreads();
+  const int xr = (l31 >> 2) & 3;                                  // swizzle key of this lane's fragment rows
+  const int offA = (wm * 64 + l31) * 64, offB = OP_BYTES + (wn * 64 + l31) * 64;
+  issue(0);
+  if (nk > 1) issue(1);
+  if (nk > 2) issue(2);
   for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);                       // HBM latency hides under this tile's MFMAs
-    const bf16* sA = smem + buf * 2 * TILE_ELEMS + (wm * 64 + l31) * LDS_LD + hi * 8;
-    const bf16* sB = smem + buf * 2 * TILE_ELEMS + TILE_ELEMS + (wn * 64 + l31) * LDS_LD + hi * 8;
+    // my share of tile kt has landed (4 loads per tile per wave, in order) ; barrier => everyone's has, and everyone is
+    // done reading stage (kt-1)&3, which the next issue overwrites
+    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (kt + 3 < nk) issue(kt + 3);
+    const char* st = lds + (kt & (NSTAGE - 1)) * STAGE_BYTES;
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
-      bf16x8 a0 = ld_frag(sA + ks * 16), a1 = ld_frag(sA + 32 * LDS_LD + ks * 16);
-      bf16x8 b0 = ld_frag(sB + ks * 16), b1 = ld_frag(sB + 32 * LDS_LD + ks * 16);
+      const int co = ((ks * 2 + hi) ^ xr) << 4;
+      bf16x8 a0 = *reinterpret_cast<const bf16x8*>(st + offA + co), a1 = *reinterpret_cast<const bf16x8*>(st + offA + 32 * 64 + co);
+      bf16x8 b0 = *reinterpret_cast<const bf16x8*>(st + offB + co), b1 = *reinterpret_cast<const bf16x8*>(st + offB + 32 * 64 + co);
       acc[0][0] = mfma32(a0, b0, acc[0][0]);
       acc[0][1] = mfma32(a0, b1, acc[0][1]);
       acc[1][0] = mfma32(a1, b0, acc[1][0]);
       acc[1][1] = mfma32(a1, b1, acc[1][1]);
     }
-    if (kt + 1 < nk) swrite(buf ^ 1);
-    __syncthreads();
   }
+  asm volatile("s_barrier" ::: "memory");                         // all operand reads done before the tile is staged
 
+  // stage the 128x128 fp32 tile through LDS (all operand reads finished at the loop's last barrier)
+  float* sC = reinterpret_cast<float*>(smem_raw);
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m0 + wm * 64 + mi * 32 + crow32(r, hi);
-      if (row < p.M) {
+    for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) epilogue<EPI>(p, row, n0 + wn * 64 + ni * 32 + l31, acc[mi][ni][r]);
-      }
-    }
+      for (int r = 0; r < 16; ++r)
+        sC[(wm * 64 + mi * 32 + crow32(r, hi)) * C_LD + wn * 64 + ni * 32 + l31] = acc[mi][ni][r];
+  __syncthreads();
+  const int c4 = (tid & 31) * 4, r8 = tid >> 5;
+#pragma unroll 4
+  for (int pass = 0; pass < BM / 8; ++pass) {
+    const int rl = pass * 8 + r8, row = m0 + rl;
+    if (row < p.M) epilogue4<EPI>(p, row, n0 + c4, *reinterpret_cast<const f32x4*>(sC + rl * C_LD + c4));
+  }
 }
 
 // ---- wgrad: dW[n,k] += sum_m dY[m,n] X[m,k] -------------------------------------------------------------------------
@@ -133,7 +162,7 @@ constexpr int W_LD = 128 + 16;                  // 144 bf16 = 288 B row stride
 constexpr int W_TILE = WM * W_LD;
 constexpr int WGRAD_LDS_BYTES = 2 * 2 * W_TILE * 2;   // 73,728 B
 
-__global__ __launch_bounds__(256) void gemm_tn_kernel(WgradArgs p) {
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(WgradArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   bf16* smem = reinterpret_cast<bf16*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;

@@ -39,6 +39,21 @@ __global__ void bn_apply_relu_kernel(const float* __restrict__ h, const float* _
   }
 }
 
+// same, but emits the split-bf16 operand [hi | lo | hi] (row stride 3N) for the following Linear (see split3_kernel)
+__global__ void bn_apply_relu_split3_kernel(const float* __restrict__ h, const float* __restrict__ mean,
+                                            const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                            const float* __restrict__ beta, size_t total, int N, bf16* __restrict__ y) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % N);
+    const size_t r = i / N;
+    float v = (h[i] - mean[c]) * rstd[c] * gamma[c] + beta[c];
+    v = v > 0.f ? v : 0.f;
+    const bf16 hi = f2bf(v), lo = f2bf(v - bf2f(hi));
+    bf16* o = y + r * 3 * (size_t)N + c;
+    o[0] = hi; o[N] = lo; o[2 * (size_t)N] = hi;
+  }
+}
+
 __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ h,
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -70,6 +85,22 @@ __global__ void bn_bwd_dx_kernel(const float* __restrict__ dy, const float* __re
     const float xh = (h[i] - mean[c]) * rstd[c];
     const float d = (xh * gamma[c] + beta[c] > 0.f) ? dy[i] : 0.f;
     dh[i] = f2bf(gamma[c] * rstd[c] * (d - sum_dy[c] * inv_count - xh * sum_dy_xhat[c] * inv_count));
+  }
+}
+
+// Split-bf16 operand for the Linear that feeds BatchNorm+ReLU.  x = hi + lo with hi = bf16(x), lo = bf16(x - hi);
+// writing A' = [hi | lo | hi] and B' = [hi | hi | lo] side by side along K makes ONE bf16 MFMA GEMM over 3K compute
+// x_hi W_hi + x_lo W_hi + x_hi W_lo, i.e. the product to ~2^-16 relative.  Needed because the ReLU gate behind the
+// BatchNorm is discontinuous: a 2^-9 perturbation of h flips ~0.3 % of the gates and moves the gradient by ~sqrt of that
+// (measured 4-11 %, DESIGN.md "Precision"); at 2^-16 the effect is below the rest of the bf16 pipeline.
+__global__ void split3_kernel(const float* __restrict__ x, int R, int K, int b_layout, bf16* __restrict__ y) {
+  const size_t total = (size_t)R * K;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / K; const int k = (int)(i % K);
+    const float v = x[i];
+    const bf16 hi = f2bf(v), lo = f2bf(v - bf2f(hi));
+    bf16* o = y + r * 3 * (size_t)K + k;
+    o[0] = hi; o[K] = b_layout ? hi : lo; o[2 * (size_t)K] = b_layout ? lo : hi;
   }
 }
 
@@ -141,6 +172,13 @@ int atst_bn_apply_relu(const float* h, const float* mean, const float* rstd, con
   hipLaunchKernelGGL(bn_apply_relu_kernel, dim3(grid), dim3(256), 0, st, h, mean, rstd, gamma, beta, total, N, y);
   return (int)hipGetLastError();
 }
+int atst_bn_apply_relu_split3(const float* h, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                              int R, int N, bf16* y, hipStream_t st) {
+  const size_t total = (size_t)R * N;
+  int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(bn_apply_relu_split3_kernel, dim3(grid), dim3(256), 0, st, h, mean, rstd, gamma, beta, total, N, y);
+  return (int)hipGetLastError();
+}
 int atst_bn_relu_bwd(const float* dy, const float* h, const float* mean, const float* rstd, const float* gamma,
                      const float* beta, int R, int N, float* sum_dy, float* sum_dy_xhat, hipStream_t st) {
   if (N % 64 || R <= 0) return ATST_EINVAL;
@@ -157,6 +195,13 @@ int atst_bn_bwd_dx(const float* dy, const float* h, const float* mean, const flo
   int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3(grid), dim3(256), 0, st, dy, h, mean, rstd, gamma, beta, sum_dy, sum_dy_xhat,
                      inv_count, total, N, dh);
+  return (int)hipGetLastError();
+}
+int atst_split3(const float* x, int R, int K, int b_layout, bf16* y, hipStream_t st) {
+  const size_t total = (size_t)R * K;
+  if (total == 0) return ATST_OK;
+  int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(split3_kernel, dim3(grid), dim3(256), 0, st, x, R, K, b_layout, y);
   return (int)hipGetLastError();
 }
 int atst_cast_f32_bf16(const float* x, size_t n, bf16* y, hipStream_t st) {

@@ -70,12 +70,15 @@ int atst_token_grad(const float* dx0, const uint8_t* rowflag, int S, int NP, int
 int atst_bn_stats(const float* h, int R, int N, float* mean, float* m2, hipStream_t st);
 int atst_bn_apply_relu(const float* h, const float* mean, const float* rstd, const float* gamma, const float* beta,
                        int R, int N, bf16* y, hipStream_t st);
+int atst_bn_apply_relu_split3(const float* h, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                              int R, int N, bf16* y, hipStream_t st);
 int atst_bn_relu_bwd(const float* dy, const float* h, const float* mean, const float* rstd, const float* gamma,
                      const float* beta, int R, int N, float* sum_dy, float* sum_dy_xhat, hipStream_t st);
 int atst_bn_bwd_dx(const float* dy, const float* h, const float* mean, const float* rstd, const float* gamma,
                    const float* beta, const float* sum_dy, const float* sum_dy_xhat, float inv_count, int R, int N,
                    bf16* dh, hipStream_t st);
 int atst_cast_f32_bf16(const float* x, size_t n, bf16* y, hipStream_t st);
+int atst_split3(const float* x, int R, int K, int b_layout, bf16* y, hipStream_t st);
 int atst_byol_loss(const float* student, const float* teacher, int B, int ncrops, int D, float* loss, float* dstudent,
                    float* stats, hipStream_t st);
 

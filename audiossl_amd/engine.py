@@ -166,10 +166,16 @@ class HeadPass:
     def forward(self, x: torch.Tensor, train: bool) -> torch.Tensor:
         eng, R = self.eng, x.shape[0]
         dev, st = x.device, hip.stream()
-        x16 = torch.empty(R, self.in_dim, dtype=torch.bfloat16, device=dev)
-        hip.call("atst_cast_bf16", hip.ptr(x), R * self.in_dim, hip.ptr(x16), st)
+        # split-bf16 operands ([hi|lo|hi] x [hi|hi|lo] along K): the Linear in front of BatchNorm+ReLU is evaluated to
+        # ~2^-16 so that bf16 noise does not flip ReLU gates (DESIGN.md "Precision")
+        K = self.in_dim
+        x3 = torch.empty(R, 3 * K, dtype=torch.bfloat16, device=dev)
+        hip.call("atst_split3_bf16", hip.ptr(x), R, K, 0, hip.ptr(x3), st)
+        w3 = torch.empty(HEAD_HIDDEN, 3 * K, dtype=torch.bfloat16, device=dev)
+        hip.call("atst_split3_bf16", hip.ptr(self._w("0.weight", f32=True)), HEAD_HIDDEN, K, 1, hip.ptr(w3), st)
         h = torch.empty(R, HEAD_HIDDEN, device=dev)
-        _gemm(x16, self._w("0.weight"), R, HEAD_HIDDEN, self.in_dim, hip.EPI_F32, h)
+        _gemm(x3, w3, R, HEAD_HIDDEN, 3 * K, hip.EPI_F32, h)
+        x16 = x3                                            # columns [0,K) = bf16(x): wgrad operand, ld = 3K
         mean, m2 = torch.empty(HEAD_HIDDEN, device=dev), torch.empty(HEAD_HIDDEN, device=dev)
         hip.call("atst_bn_stats_f32", hip.ptr(h), R, HEAD_HIDDEN, hip.ptr(mean), hip.ptr(m2), st)
         count = float(R)
@@ -191,11 +197,15 @@ class HeadPass:
             bn["running_mean"].mul_(1 - BN_MOMENTUM).add_(mean, alpha=BN_MOMENTUM)
             bn["running_var"].mul_(1 - BN_MOMENTUM).add_(m2 / max(count - 1.0, 1.0), alpha=BN_MOMENTUM)
             bn["num_batches_tracked"] += 1
-        y16 = torch.empty(R, HEAD_HIDDEN, dtype=torch.bfloat16, device=dev)
-        hip.call("atst_bn_apply_relu_bf16", hip.ptr(h), hip.ptr(mean), hip.ptr(rstd), hip.ptr(self._w("1.weight", f32=True)),
-                 hip.ptr(self._w("1.bias", f32=True)), R, HEAD_HIDDEN, hip.ptr(y16), st)
+        # second Linear also in split-bf16: its output feeds the next head's BatchNorm+ReLU gates
+        y3 = torch.empty(R, 3 * HEAD_HIDDEN, dtype=torch.bfloat16, device=dev)
+        hip.call("atst_bn_apply_relu_split3_bf16", hip.ptr(h), hip.ptr(mean), hip.ptr(rstd), hip.ptr(self._w("1.weight", f32=True)),
+                 hip.ptr(self._w("1.bias", f32=True)), R, HEAD_HIDDEN, hip.ptr(y3), st)
+        w3b = torch.empty(HEAD_OUT, 3 * HEAD_HIDDEN, dtype=torch.bfloat16, device=dev)
+        hip.call("atst_split3_bf16", hip.ptr(self._w("3.weight", f32=True)), HEAD_OUT, HEAD_HIDDEN, 1, hip.ptr(w3b), st)
         out = torch.empty(R, HEAD_OUT, device=dev)
-        _gemm(y16, self._w("3.weight"), R, HEAD_OUT, HEAD_HIDDEN, hip.EPI_F32, out)
+        _gemm(y3, w3b, R, HEAD_OUT, 3 * HEAD_HIDDEN, hip.EPI_F32, out)
+        y16 = y3                                            # columns [0, 4096) = bf16(y), ld = 3 * 4096
         if train:
             self.saved = (x16, h, mean, rstd, y16, count)
         return out
@@ -206,7 +216,7 @@ class HeadPass:
         R, dev, st = x16.shape[0], x16.device, hip.stream()
         d16 = torch.empty(R, HEAD_OUT, dtype=torch.bfloat16, device=dev)
         hip.call("atst_cast_bf16", hip.ptr(dout), R * HEAD_OUT, hip.ptr(d16), st)
-        _wgrad(d16, y16, R, HEAD_OUT, HEAD_HIDDEN, self._w("3.weight", grad=True))
+        _wgrad(d16, y16, R, HEAD_OUT, HEAD_HIDDEN, self._w("3.weight", grad=True), ldx=3 * HEAD_HIDDEN)
         dy = torch.empty(R, HEAD_HIDDEN, device=dev)
         _gemm(d16, self._w("3.weight", transposed=True), R, HEAD_HIDDEN, HEAD_OUT, hip.EPI_F32, dy)
         gamma, beta = self._w("1.weight", f32=True), self._w("1.bias", f32=True)
@@ -222,7 +232,7 @@ class HeadPass:
         dh16 = torch.empty(R, HEAD_HIDDEN, dtype=torch.bfloat16, device=dev)
         hip.call("atst_bn_bwd_dx_bf16", hip.ptr(dy), hip.ptr(h), hip.ptr(mean), hip.ptr(rstd), hip.ptr(gamma), hip.ptr(beta),
                  hip.ptr(s1), hip.ptr(s2), 1.0 / count, R, HEAD_HIDDEN, hip.ptr(dh16), st)
-        _wgrad(dh16, x16, R, HEAD_HIDDEN, self.in_dim, self._w("0.weight", grad=True))
+        _wgrad(dh16, x16, R, HEAD_HIDDEN, self.in_dim, self._w("0.weight", grad=True), ldx=3 * self.in_dim)
         dx = torch.empty(R, self.in_dim, device=dev)
         _gemm(dh16, self._w("0.weight", transposed=True), R, self.in_dim, HEAD_HIDDEN, hip.EPI_F32, dx)
         self.saved = None
@@ -234,8 +244,8 @@ def _gemm(A, B, M, N, K, epi, out):
              None, None, None, None, hip.stream())
 
 
-def _wgrad(dY, X, M, N, K, dW):
-    hip.call("atst_gemm_tn_bf16", hip.ptr(dY), hip.ptr(X), M, N, K, N, K, hip.ptr(dW), K, 0, hip.stream())
+def _wgrad(dY, X, M, N, K, dW, ldx=None):
+    hip.call("atst_gemm_tn_bf16", hip.ptr(dY), hip.ptr(X), M, N, K, N, K if ldx is None else ldx, hip.ptr(dW), K, 0, hip.stream())
 
 
 def group_views(widths: Sequence[int]) -> List[Tuple[int, int]]:

@@ -60,12 +60,18 @@ int atst_gather_rows_bf16(const uint16_t* src, const int* rows, int R, int C, fl
 int atst_scatter_rows_bf16(const float* src, const int* rows, int R, int C, uint16_t* dst, void* stream);
 int atst_colsum_bf16_f32(const uint16_t* x, int M, int N, int ld, float* out, void* stream);
 int atst_cast_bf16(const float* x, size_t n, uint16_t* y, void* stream);
+/* split-bf16 operand [R,3K]: [hi|lo|hi] (b_layout 0, activations) or [hi|hi|lo] (b_layout 1, weights): one bf16 GEMM over
+ * 3K then yields x W^T to ~2^-16; used for the Linear in front of BatchNorm+ReLU (byol.py:13-16) */
+int atst_split3_bf16(const float* x, int R, int K, int b_layout, uint16_t* y, void* stream);
 int atst_transpose_bf16_2d(const uint16_t* src, int rows, int cols, uint16_t* dst, void* stream);
 
 /* build_mlp's BatchNorm1d(train)+ReLU: audiossl/models/atst/byol.py:13-16                                            */
 int atst_bn_stats_f32(const float* h, int R, int N, float* mean, float* m2, void* stream);
 int atst_bn_apply_relu_bf16(const float* h, const float* mean, const float* rstd, const float* gamma, const float* beta,
                             int R, int N, uint16_t* y, void* stream);
+/* same, output as split-bf16 operand [R, 3N] = [hi | lo | hi] for the following Linear */
+int atst_bn_apply_relu_split3_bf16(const float* h, const float* mean, const float* rstd, const float* gamma,
+                                   const float* beta, int R, int N, uint16_t* y, void* stream);
 int atst_bn_relu_bwd_sums(const float* dy, const float* h, const float* mean, const float* rstd, const float* gamma,
                           const float* beta, int R, int N, float* sum_dy, float* sum_dy_xhat, void* stream);
 int atst_bn_bwd_dx_bf16(const float* dy, const float* h, const float* mean, const float* rstd, const float* gamma,

@@ -74,7 +74,7 @@ def test_depth2_blocks(golden_dir):
     assert rel(cls.numpy(), G["cls"]) < 1e-5
 
 
-@pytest.mark.parametrize("name", ["clip_small_2views", "clip_small_2views_nodrop", "clip_small_6crops"])
+@pytest.mark.parametrize("name", ["clip_small_2views", "clip_small_2views_nodrop", "clip_small_6crops", "clip_small_2views_b16"])
 def test_clip_step(golden_dir, name):
     G = load(golden_dir, name)
     B, ncrops = int(G["B"]), int(G["ncrops"])
@@ -102,6 +102,20 @@ def test_clip_step(golden_dir, name):
               "teacher.projector.1.running_var"):
         v = W[k].reshape(-1)
         assert rel(v[sample_idx(v.numel())].numpy(), G["ema/" + k]) < 1e-6, k
+
+
+def test_encoder_grad(golden_dir):
+    """Well-conditioned encoder-only pin: L = sum(CLS * R), ragged lengths, DropPath injected."""
+    G = load(golden_dir, "clip_encoder_grad")
+    S = int(G["S"])
+    W = O.recipe_weights("small", seed=21)
+    leaves = [(k[len("student.encoder."):], v.requires_grad_(True)) for k, v in W.items() if k.startswith("student.encoder.")]
+    R = torch.from_numpy(np.random.default_rng(29).standard_normal((S, 384)).astype(np.float32))
+    cls = O.encoder_forward(W, "student.encoder.", O.recipe_mel(S, 1001, seed=23), torch.from_numpy(G["length"]), "small",
+                            keep=torch.from_numpy(G["keep"]))
+    (cls * R).sum().backward()
+    assert rel(cls.detach().numpy(), G["cls"]) < 1e-5
+    grad_check(G, leaves)
 
 
 def test_frame_step(golden_dir):

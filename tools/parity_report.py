@@ -26,7 +26,7 @@ def table(eng, G, only_encoder=False, strip=""):
     tot = sum(r[3] for r in rows)
     print(f"   weighted mean rel {sum(r[1]*r[3] for r in rows)/tot:.3e}  max {max(r[1] for r in rows):.3e}")
     for r in rows:
-        if any(t in r[0] for t in ("cls_token", "pos_embed", "patch_embed", "blocks.0.", "blocks.6.attn.qkv", "blocks.11.", "norm.", "projector", "predictor", "mask_embed")):
+        if any(t in r[0] for t in ("cls_token", "pos_embed", "patch_embed.patch_embed.weight", "blocks.0.attn.qkv", "blocks.6.attn.qkv", "blocks.11.mlp.fc2.weight", "norm.weight", "projector", "predictor", "mask_embed")):
             print(f"   {r[0]:45s} rel {r[1]:.3e}  norm {r[2]:+.2e}")
 
 def clip(name):
@@ -42,7 +42,7 @@ def clip(name):
         ks = [torch.from_numpy(G[f"keep_s{i}"]) for i in range(len(O.group_views(widths)))]
     loss, ss, st = eng.forward(mels, lens, None, kt, ks); eng.backward()
     so, to = eng.last_outputs
-    print(f"[{name}] loss {loss.item():.6f}/{float(G['loss']):.6f} std_s {ss.item():.5f}/{float(G['std_s']):.5f} out rel {rel(so.cpu().numpy(), G['student_out']):.2e} {rel(to.cpu().numpy(), G['teacher_out']):.2e}")
+    print(f"[{name}] loss {loss.item():.6f}/{float(G['loss']):.6f} std_s {ss.item():.5f}/{float(G['std_s']):.5f} out rel {rel(so.cpu().numpy()[:8], G['student_out']):.2e} {rel(to.cpu().numpy()[:8], G['teacher_out']):.2e}")
     table(eng, G)
 
 def encgrad():
@@ -62,5 +62,5 @@ def encgrad():
 
 if __name__ == "__main__":
     encgrad()
-    for n in ("clip_small_2views_b16", "clip_small_2views", "clip_small_6crops"):
+    for n in ("clip_small_2views_b64", "clip_small_2views_b16", "clip_small_2views", "clip_small_6crops"):
         clip(n)
