@@ -11,6 +11,11 @@ LIB = os.path.join(LIBDIR, "libatst_hip.so")
 SOURCES = ["api.hip", "engine.hip", "gemm.hip", "layernorm.hip", "attention.hip", "tokens.hip", "head.hip", "optim.hip",
            "frontend.hip", "profile.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
+if os.environ.get("ATST_ABLATE"):          # experiment builds only (tools/gemm_bench.py)
+    FLAGS.append("-DATST_ABLATE=" + os.environ["ATST_ABLATE"])
+for _k in ("ATST_BK", "ATST_NSTAGE"):
+    if os.environ.get(_k):
+        FLAGS.append(f"-D{_k}=" + os.environ[_k])
 
 
 def _hipcc():

@@ -12,14 +12,23 @@
 #include "common.h"
 #include "kernels.h"
 #include "profile.h"
+#ifndef ATST_ABLATE
+#define ATST_ABLATE 0      // experiment switch (tools only): 1 no stores, 3 no stores + no MFMA, 4 no stores + no loads
+#endif
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int NSTAGE = 4;                      // LDS ring: tile kt is consumed while kt+1, kt+2 are in flight and kt+3 is issued
+#ifndef ATST_BK
+#define ATST_BK 32
+#endif
+#ifndef ATST_NSTAGE
+#define ATST_NSTAGE 2
+#endif
+constexpr int BM = 128, BN = 128, BK = ATST_BK;
+constexpr int NSTAGE = ATST_NSTAGE;                      // LDS ring: tile kt is consumed while kt+1 is in flight and kt+2 is issued
 constexpr int OP_BYTES = BM * BK * 2;          // 8 KiB per operand per stage, rows of 64 B (4 x 16-B chunks), XOR-swizzled
 constexpr int STAGE_BYTES = 2 * OP_BYTES;
-constexpr int GEMM_LDS_BYTES = 128 * (BN + 4) * 4;   // 67,584 B (epilogue staging tile >= 4 stages x 16 KiB) -> 2 blocks / CU
+constexpr int GEMM_LDS_BYTES = NSTAGE * STAGE_BYTES > 64 * (BN + 4) * 4 ? NSTAGE * STAGE_BYTES : 64 * (BN + 4) * 4;  // 49,152 B -> 3 blocks / CU; the epilogue stages 64 rows at a time (33,792 B)
 
 constexpr int C_LD = BN + 4;                   // fp32 epilogue staging tile [128][132] = 67,584 B (re-uses the operand LDS)
 
@@ -68,7 +77,7 @@ DEVFN void epilogue4(const GemmArgs& p, int row, int col, f32x4 v) {
 }
 
 template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
+__global__ __launch_bounds__(256, (GEMM_LDS_BYTES <= 40960 ? 4 : GEMM_LDS_BYTES <= 53248 ? 3 : 2)) void gemm_nt_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1, hi = lane >> 5, l31 = lane & 31;
@@ -85,19 +94,24 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   typedef const void __attribute__((address_space(1))) * gptr_t;
   typedef void __attribute__((address_space(3))) * lptr_t;
   char* lds = smem_raw;
-  const bf16* srcA[2]; const bf16* srcB[2];
+  constexpr int ROWB = BK * 2;                      // LDS row bytes (64 or 128)
+  constexpr int CPR = ROWB / 16;                    // 16-B chunks per row (4 or 8)
+  constexpr int RPI = 1024 / ROWB;                  // rows per wave-instruction (16 or 8)
+  constexpr int IPW = BM / RPI / 4;                 // instructions per wave per operand tile (2 or 4)
+  constexpr int KSH = BK == 32 ? 2 : 1;             // swizzle key = (row >> KSH) & (CPR - 1)
+  const bf16* srcA[IPW]; const bf16* srcB[IPW];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int row = (wid * 2 + j) * 16 + (lane >> 2);
-    const int c = (lane & 3) ^ ((row >> 2) & 3);
+  for (int j = 0; j < IPW; ++j) {
+    const int row = (wid * IPW + j) * RPI + lane / CPR;
+    const int c = (lane & (CPR - 1)) ^ ((row >> KSH) & (CPR - 1));
     int ra = m0 + row; ra = ra < p.M ? ra : p.M - 1;              // clamp: rows >= M are never stored
     srcA[j] = p.A + (size_t)ra * p.lda + c * 8;
     srcB[j] = p.B + (size_t)(n0 + row) * p.ldb + c * 8;
   }
   auto issue = [&](int kt) {
-    char* st = lds + (kt & (NSTAGE - 1)) * STAGE_BYTES + wid * 2048;
+    char* st = lds + (kt % NSTAGE) * STAGE_BYTES + wid * IPW * 1024;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < IPW; ++j) {
       __builtin_amdgcn_global_load_lds((gptr_t)(srcA[j] + kt * BK), (lptr_t)(st + j * 1024), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gptr_t)(srcB[j] + kt * BK), (lptr_t)(st + OP_BYTES + j * 1024), 16, 0, 0);
     }
@@ -112,47 +126,63 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = p.K / BK;
-  const int xr = (l31 >> 2) & 3;                                  // swizzle key of this lane's fragment rows
-  const int offA = (wm * 64 + l31) * 64, offB = OP_BYTES + (wn * 64 + l31) * 64;
+  const int xr = (l31 >> KSH) & (CPR - 1);                        // swizzle key of this lane's fragment rows
+  const int offA = (wm * 64 + l31) * ROWB, offB = OP_BYTES + (wn * 64 + l31) * ROWB;
   issue(0);
-  if (nk > 1) issue(1);
-  if (nk > 2) issue(2);
+  if (NSTAGE > 2 && nk > 1) issue(1);
   for (int kt = 0; kt < nk; ++kt) {
     // my share of tile kt has landed (4 loads per tile per wave, in order) ; barrier => everyone's has, and everyone is
-    // done reading stage (kt-1)&3, which the next issue overwrites
-    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-    else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    // done reading stage (kt-1)%3, which the next issue overwrites
+    if (NSTAGE > 2 && kt + 1 < nk) {
+      if (IPW == 2) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    }
     else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    if (kt + 3 < nk) issue(kt + 3);
-    const char* st = lds + (kt & (NSTAGE - 1)) * STAGE_BYTES;
+#if ATST_ABLATE != 4
+    if (kt + NSTAGE - 1 < nk) issue(kt + NSTAGE - 1);
+#endif
+    const char* st = lds + (kt % NSTAGE) * STAGE_BYTES;
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       const int co = ((ks * 2 + hi) ^ xr) << 4;
-      bf16x8 a0 = *reinterpret_cast<const bf16x8*>(st + offA + co), a1 = *reinterpret_cast<const bf16x8*>(st + offA + 32 * 64 + co);
-      bf16x8 b0 = *reinterpret_cast<const bf16x8*>(st + offB + co), b1 = *reinterpret_cast<const bf16x8*>(st + offB + 32 * 64 + co);
+      bf16x8 a0 = *reinterpret_cast<const bf16x8*>(st + offA + co), a1 = *reinterpret_cast<const bf16x8*>(st + offA + 32 * ROWB + co);
+      bf16x8 b0 = *reinterpret_cast<const bf16x8*>(st + offB + co), b1 = *reinterpret_cast<const bf16x8*>(st + offB + 32 * ROWB + co);
+#if ATST_ABLATE == 3
+      asm volatile("" :: "v"(a0), "v"(a1), "v"(b0), "v"(b1));
+#else
       acc[0][0] = mfma32(a0, b0, acc[0][0]);
       acc[0][1] = mfma32(a0, b1, acc[0][1]);
       acc[1][0] = mfma32(a1, b0, acc[1][0]);
       acc[1][1] = mfma32(a1, b1, acc[1][1]);
+#endif
     }
   }
   asm volatile("s_barrier" ::: "memory");                         // all operand reads done before the tile is staged
 
-  // stage the 128x128 fp32 tile through LDS (all operand reads finished at the loop's last barrier)
+  // stage the fp32 tile through LDS, 64 rows at a time (all operand reads finished at the barrier above)
   float* sC = reinterpret_cast<float*>(smem_raw);
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        sC[(wm * 64 + mi * 32 + crow32(r, hi)) * C_LD + wn * 64 + ni * 32 + l31] = acc[mi][ni][r];
-  __syncthreads();
   const int c4 = (tid & 31) * 4, r8 = tid >> 5;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if (wm == half) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            sC[(mi * 32 + crow32(r, hi)) * C_LD + wn * 64 + ni * 32 + l31] = acc[mi][ni][r];
+    }
+    __syncthreads();
 #pragma unroll 4
-  for (int pass = 0; pass < BM / 8; ++pass) {
-    const int rl = pass * 8 + r8, row = m0 + rl;
-    if (row < p.M) epilogue4<EPI>(p, row, n0 + c4, *reinterpret_cast<const f32x4*>(sC + rl * C_LD + c4));
+    for (int pass = 0; pass < 8; ++pass) {
+      const int rl = pass * 8 + r8, row = m0 + half * 64 + rl;
+#if ATST_ABLATE
+      if (sC[rl * C_LD + c4] != 12345.678f) continue;                // experiment builds: no epilogue stores
+#endif
+      if (row < p.M) epilogue4<EPI>(p, row, n0 + c4, *reinterpret_cast<const f32x4*>(sC + rl * C_LD + c4));
+    }
+    if (half == 0) __syncthreads();
   }
 }
 

@@ -15,7 +15,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 import torch.distributed as dist
 
-from . import hip
+from . import hip, parallel
 
 ARCH = {"small": dict(embed_dim=384, depth=12, num_heads=6), "base": dict(embed_dim=768, depth=12, num_heads=12)}
 ALIGN = 256          # every tensor starts on a 256-element boundary of the flat buffers (one flag byte per chunk)
@@ -178,18 +178,8 @@ class HeadPass:
         x16 = x3                                            # columns [0,K) = bf16(x): wgrad operand, ld = 3K
         mean, m2 = torch.empty(HEAD_HIDDEN, device=dev), torch.empty(HEAD_HIDDEN, device=dev)
         hip.call("atst_bn_stats_f32", hip.ptr(h), R, HEAD_HIDDEN, hip.ptr(mean), hip.ptr(m2), st)
-        count = float(R)
-        if eng.world > 1:
-            # SyncBatchNorm: exchange [mean, M2, count], combine with the parallel-variance formula (count-weighted,
-            # so ragged per-rank row counts of ATST-Frame are handled)
-            pack = torch.cat([mean, m2, torch.tensor([count], device=dev)])
-            allp = [torch.empty_like(pack) for _ in range(eng.world)]
-            dist.all_gather(allp, pack)
-            allp = torch.stack(allp)
-            means, m2s, cnts = allp[:, :HEAD_HIDDEN], allp[:, HEAD_HIDDEN:2 * HEAD_HIDDEN], allp[:, -1:]
-            count = float(cnts.sum())
-            mean = (means * cnts).sum(0) / count
-            m2 = (m2s + cnts * (means - mean) ** 2).sum(0)
+        # SyncBatchNorm: count-weighted combine over ranks (ragged per-rank row counts of ATST-Frame are handled)
+        mean, m2, count = parallel.combine_bn_stats(mean, m2, float(R))
         var = m2 / count
         rstd = torch.rsqrt(var + BN_EPS)
         bn = eng.bn_buffers[f"{self.net}.{self.which}"]
@@ -225,10 +215,7 @@ class HeadPass:
                  R, HEAD_HIDDEN, hip.ptr(s1), hip.ptr(s2), st)
         self._w("1.bias", grad=True).add_(s1)          # local sums: DDP averages parameter gradients afterwards
         self._w("1.weight", grad=True).add_(s2)
-        if eng.world > 1:
-            pack = torch.cat([s1, s2])
-            dist.all_reduce(pack)
-            s1, s2 = pack[:HEAD_HIDDEN].contiguous(), pack[HEAD_HIDDEN:].contiguous()
+        s1, s2 = parallel.allreduce_bn_backward_sums(s1, s2)
         dh16 = torch.empty(R, HEAD_HIDDEN, dtype=torch.bfloat16, device=dev)
         hip.call("atst_bn_bwd_dx_bf16", hip.ptr(dy), hip.ptr(h), hip.ptr(mean), hip.ptr(rstd), hip.ptr(gamma), hip.ptr(beta),
                  hip.ptr(s1), hip.ptr(s2), 1.0 / count, R, HEAD_HIDDEN, hip.ptr(dh16), st)
@@ -465,17 +452,11 @@ class AtstEngine:
                  hip.ptr(self._stats), hip.stream())
         npairs = 2 * ncrops - 2
         loss = 2.0 - 2.0 * self._acc[0] / (npairs * B)
-        stats, ns, ntc = self._stats, float(s_out.shape[0]), float(t_out.shape[0])
-        if self.world > 1:                                      # one fused all-reduce instead of the reference's six
-            pack = torch.cat([stats.reshape(-1), torch.tensor([ns, ntc], device=self.device)])
-            dist.all_reduce(pack)
-            stats, ns, ntc = pack[:-2].view(4, HEAD_OUT), float(pack[-2]), float(pack[-1])
-
-        def std(sums, sq, n):                                   # ref: byol.py:42-53
-            return torch.sqrt(sq / (n - 1) - sums ** 2 / (n * (n - 1)) + 1e-6).mean()
+        # one fused all-reduce instead of the reference's six (byol.py:48-50, twice)
+        stats, ns, ntc = parallel.allreduce_monitor_sums(self._stats, float(s_out.shape[0]), float(t_out.shape[0]))
         self._student_groups = groups
         self.last_outputs = (s_out, t_out)
-        return loss, std(stats[0], stats[1], ns), std(stats[2], stats[3], ntc)
+        return loss, parallel.feature_std(stats[0], stats[1], ns), parallel.feature_std(stats[2], stats[3], ntc)
 
     def backward(self, grad_scale=1.0, zero_grad: bool = True):
         """Autograd of forward() wrt every student parameter, accumulated into the flat gradient buffer.
@@ -500,9 +481,7 @@ class AtstEngine:
 
     def allreduce_grads(self):
         """DDP: sum student gradients over ranks (RCCL over xGMI); the 1/world mean is folded into the optimizer kernel."""
-        if self.world > 1:
-            dist.all_reduce(self.g32)
-            self._grads_summed = True
+        self._grads_summed = parallel.allreduce_sum_(self.g32)
 
     def optimizer_step(self, lr: float, wd: float, ema_m: Optional[float], betas=(0.9, 0.999), eps: float = 1e-6):
         """HF-AdamW over the two parameter groups + EMA teacher + bf16 shadow refresh in one pass.

@@ -1,0 +1,74 @@
+"""Cross-rank pieces of the data-parallel step (one process per GPU, torch.distributed: RCCL over xGMI on the GPU box,
+gloo in the CPU tests).  The path shards by clips; the only exchanges are
+
+  * SyncBatchNorm statistics of the three head BatchNorms (Trainer(sync_batchnorm=True), methods/atst/train.py:22):
+    forward  all_gather [mean, M2, count]       -> count-weighted parallel-variance combine (ragged counts allowed)
+    backward all_reduce [sum_dy, sum_dy_xhat]   -> global dx ; parameter gradients stay local (DDP averages them)
+  * one all-reduce (sum) of the flat student-gradient buffer; the 1/world mean is folded into the optimizer kernel
+  * one fused all-reduce of the monitor sums (the reference issues six: models/atst/byol.py:42-53)
+
+These functions are device-agnostic torch code on tiny tensors (plumbing); everything heavy stays in the HIP library."""
+from __future__ import annotations
+
+from typing import Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def world_size() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def combine_bn_stats(mean: torch.Tensor, m2: torch.Tensor, count: float) -> Tuple[torch.Tensor, torch.Tensor, float]:
+    """Local per-feature (mean, M2 = sum (x-mean)^2, row count) -> global (mean, M2, count) over all ranks
+    (Chan et al. parallel variance).  Identity at world size 1."""
+    if world_size() == 1:
+        return mean, m2, float(count)
+    n = mean.numel()
+    pack = torch.cat([mean, m2, torch.tensor([float(count)], device=mean.device, dtype=mean.dtype)])
+    gathered = [torch.empty_like(pack) for _ in range(world_size())]
+    dist.all_gather(gathered, pack)
+    allp = torch.stack(gathered)
+    means, m2s, cnts = allp[:, :n], allp[:, n:2 * n], allp[:, -1:]
+    total = float(cnts.sum())
+    gmean = (means * cnts).sum(0) / total
+    gm2 = (m2s + cnts * (means - gmean) ** 2).sum(0)
+    return gmean, gm2, total
+
+
+def allreduce_bn_backward_sums(sum_dy: torch.Tensor, sum_dy_xhat: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Global sums for the BatchNorm input gradient; the local sums remain the (to-be-averaged) gamma/beta gradients."""
+    if world_size() == 1:
+        return sum_dy, sum_dy_xhat
+    n = sum_dy.numel()
+    pack = torch.cat([sum_dy, sum_dy_xhat])
+    dist.all_reduce(pack)
+    return pack[:n].contiguous(), pack[n:].contiguous()
+
+
+def allreduce_monitor_sums(stats: torch.Tensor, n_student: float, n_teacher: float):
+    """[4, D] column sums / square sums of normalised student & teacher rows + the two row counts, one all-reduce."""
+    if world_size() == 1:
+        return stats, float(n_student), float(n_teacher)
+    pack = torch.cat([stats.reshape(-1), torch.tensor([n_student, n_teacher], device=stats.device, dtype=stats.dtype)])
+    dist.all_reduce(pack)
+    return pack[:-2].view_as(stats), float(pack[-2]), float(pack[-1])
+
+
+def feature_std(sums: torch.Tensor, sq_sums: torch.Tensor, n: float) -> torch.Tensor:
+    """mean_d sqrt(unbiased var_d + 1e-6) from global sums.  ref: audiossl/models/atst/byol.py:42-53."""
+    return torch.sqrt(sq_sums / (n - 1) - sums ** 2 / (n * (n - 1)) + 1e-6).mean()
+
+
+def allreduce_sum_(flat_grad: torch.Tensor) -> bool:
+    """In-place sum of the flat gradient buffer over ranks; returns True when a reduction happened."""
+    if world_size() == 1:
+        return False
+    dist.all_reduce(flat_grad)
+    return True
+
+
+def shard(n_items: int, rank: int, world: int) -> range:
+    """Strided shard of a non-shuffled index list, like the DistributedSampler Lightning injects."""
+    return range(rank, n_items - n_items % world, world)
