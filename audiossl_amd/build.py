@@ -13,9 +13,7 @@ SOURCES = ["api.hip", "engine.hip", "gemm.hip", "layernorm.hip", "attention.hip"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
 if os.environ.get("ATST_ABLATE"):          # experiment builds only (tools/gemm_bench.py)
     FLAGS.append("-DATST_ABLATE=" + os.environ["ATST_ABLATE"])
-for _k in ("ATST_BK", "ATST_NSTAGE"):
-    if os.environ.get(_k):
-        FLAGS.append(f"-D{_k}=" + os.environ[_k])
+
 
 
 def _hipcc():

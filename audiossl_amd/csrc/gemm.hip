@@ -13,23 +13,12 @@
 #include "kernels.h"
 #include "profile.h"
 #ifndef ATST_ABLATE
-#define ATST_ABLATE 0      // experiment switch (tools only): 1 no stores, 3 no stores + no MFMA, 4 no stores + no loads
+#define ATST_ABLATE 0      // experiment switch (tools only), all without stores: 1 full, 3 loads+ds_read, 4 ds_read+MFMA, 5 loads only, 6 MFMA only
 #endif
 
 namespace {
 
-#ifndef ATST_BK
-#define ATST_BK 32
-#endif
-#ifndef ATST_NSTAGE
-#define ATST_NSTAGE 2
-#endif
-constexpr int BM = 128, BN = 128, BK = ATST_BK;
-constexpr int NSTAGE = ATST_NSTAGE;                      // LDS ring: tile kt is consumed while kt+1 is in flight and kt+2 is issued
-constexpr int OP_BYTES = BM * BK * 2;          // 8 KiB per operand per stage, rows of 64 B (4 x 16-B chunks), XOR-swizzled
-constexpr int STAGE_BYTES = 2 * OP_BYTES;
-constexpr int GEMM_LDS_BYTES = NSTAGE * STAGE_BYTES > 64 * (BN + 4) * 4 ? NSTAGE * STAGE_BYTES : 64 * (BN + 4) * 4;  // 49,152 B -> 3 blocks / CU; the epilogue stages 64 rows at a time (33,792 B)
-
+constexpr int BN = 128, BK = 32;               // BK = 32: 64-B LDS rows (4 x 16-B chunks), XOR-swizzled
 constexpr int C_LD = BN + 4;                   // fp32 epilogue staging tile [128][132] = 67,584 B (re-uses the operand LDS)
 
 // Epilogue on 4 consecutive columns of one row (vector loads / stores; the accumulator tile is staged through LDS so
@@ -76,113 +65,152 @@ DEVFN void epilogue4(const GemmArgs& p, int row, int col, f32x4 v) {
   }
 }
 
-template <int EPI>
-__global__ __launch_bounds__(256, (GEMM_LDS_BYTES <= 40960 ? 4 : GEMM_LDS_BYTES <= 53248 ? 3 : 2)) void gemm_nt_kernel(GemmArgs p) {
+// Geometry of one instantiation: BMT x 128 output tile, waves in a (BMT/WTM) x 2 grid, each wave WTM x 64
+// (WTM = 128 halves the LDS fragment traffic per MFMA: 6 fragment reads feed 8 MFMAs instead of 4 feeding 4).
+template <int BMT, int NSTG, int WTM> struct NtGeo {
+  static constexpr int WAVES = (BMT / WTM) * 2, THREADS = WAVES * 64, MI = WTM / 32;
+  static constexpr int A_BYTES = BMT * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+  static constexpr int EPI_BYTES = 64 * C_LD * 4;                       // 64 rows of the fp32 tile at a time
+  static constexpr int LDS = NSTG * STAGE > EPI_BYTES ? NSTG * STAGE : EPI_BYTES;
+  static constexpr int A_IPW = (BMT / 16) / WAVES, B_IPW_NUM = BN / 16;  // 1-KiB load instructions (16 rows) per wave
+  static constexpr int BLOCKS_PER_CU = 163840 / LDS > 4 ? 4 : 163840 / LDS;
+  static constexpr int WPS = BLOCKS_PER_CU * WAVES / 4 > 8 ? 8 : BLOCKS_PER_CU * WAVES / 4;   // waves per SIMD to plan for
+};
+
+template <int EPI, int BMT, int NSTG, int WTM>
+__global__ __launch_bounds__((NtGeo<BMT, NSTG, WTM>::THREADS), (NtGeo<BMT, NSTG, WTM>::WPS)) void gemm_nt_kernel(GemmArgs p) {
+  using G = NtGeo<BMT, NSTG, WTM>;
+  constexpr int MI = G::MI;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1, hi = lane >> 5, l31 = lane & 31;
 
   const int ntn = p.N / BN;
-  const int ntm = (p.M + BM - 1) / BM;
+  const int ntm = (p.M + BMT - 1) / BMT;
   const int id = xcd_remap(blockIdx.x, ntm * ntn);
-  const int m0 = (id / ntn) * BM, n0 = (id % ntn) * BN;
+  const int m0 = (id / ntn) * BMT, n0 = (id % ntn) * BN;
 
-  // Operand tiles go HBM/L2 -> LDS directly (global_load_lds, 16 B per lane, 1 KiB per wave-instruction, no staging
-  // registers), three K-tiles ahead of the MFMAs.  LDS rows are 64 B; chunk c of row r is stored at chunk
+  // Operand tiles go HBM/L2 -> LDS directly (global_load_lds, 16 B per lane, 1 KiB = 16 rows per wave-instruction, no
+  // staging registers), NSTG-1 K-tiles ahead of the MFMAs.  LDS rows are 64 B; chunk c of row r is stored at chunk
   // c ^ ((r >> 2) & 3) so that the 16-lane groups of ds_read_b128 hit 16 distinct 16-B bank slots; the permutation is
   // applied to the per-lane *source* address (the LDS destination of global_load_lds is lane-linear).
   typedef const void __attribute__((address_space(1))) * gptr_t;
   typedef void __attribute__((address_space(3))) * lptr_t;
   char* lds = smem_raw;
-  constexpr int ROWB = BK * 2;                      // LDS row bytes (64 or 128)
-  constexpr int CPR = ROWB / 16;                    // 16-B chunks per row (4 or 8)
-  constexpr int RPI = 1024 / ROWB;                  // rows per wave-instruction (16 or 8)
-  constexpr int IPW = BM / RPI / 4;                 // instructions per wave per operand tile (2 or 4)
-  constexpr int KSH = BK == 32 ? 2 : 1;             // swizzle key = (row >> KSH) & (CPR - 1)
-  const bf16* srcA[IPW]; const bf16* srcB[IPW];
+  constexpr int NB_PER_WAVE = (G::B_IPW_NUM + G::WAVES - 1) / G::WAVES;     // 2 (4 waves) or 1 (8 waves)
+  const bf16* srcA[G::A_IPW]; const bf16* srcB[NB_PER_WAVE];
+  const int lrow = lane >> 2, lchunk = lane & 3;
 #pragma unroll
-  for (int j = 0; j < IPW; ++j) {
-    const int row = (wid * IPW + j) * RPI + lane / CPR;
-    const int c = (lane & (CPR - 1)) ^ ((row >> KSH) & (CPR - 1));
+  for (int j = 0; j < G::A_IPW; ++j) {
+    const int row = (wid * G::A_IPW + j) * 16 + lrow;
     int ra = m0 + row; ra = ra < p.M ? ra : p.M - 1;              // clamp: rows >= M are never stored
-    srcA[j] = p.A + (size_t)ra * p.lda + c * 8;
-    srcB[j] = p.B + (size_t)(n0 + row) * p.ldb + c * 8;
+    srcA[j] = p.A + (size_t)ra * p.lda + (lchunk ^ ((row >> 2) & 3)) * 8;
   }
-  auto issue = [&](int kt) {
-    char* st = lds + (kt % NSTAGE) * STAGE_BYTES + wid * IPW * 1024;
 #pragma unroll
-    for (int j = 0; j < IPW; ++j) {
-      __builtin_amdgcn_global_load_lds((gptr_t)(srcA[j] + kt * BK), (lptr_t)(st + j * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(srcB[j] + kt * BK), (lptr_t)(st + OP_BYTES + j * 1024), 16, 0, 0);
-    }
+  for (int j = 0; j < NB_PER_WAVE; ++j) {
+    const int row = (wid * NB_PER_WAVE + j) * 16 + lrow;
+    srcB[j] = p.B + (size_t)(n0 + row) * p.ldb + (lchunk ^ ((row >> 2) & 3)) * 8;
+  }
+  constexpr int LOADS_PER_TILE = G::A_IPW + NB_PER_WAVE;          // per wave, in issue order
+  auto issue = [&](int kt) {
+    char* st = lds + (kt % NSTG) * G::STAGE;
+#pragma unroll
+    for (int j = 0; j < G::A_IPW; ++j)
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcA[j] + kt * BK), (lptr_t)(st + (wid * G::A_IPW + j) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NB_PER_WAVE; ++j)
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcB[j] + kt * BK), (lptr_t)(st + G::A_BYTES + (wid * NB_PER_WAVE + j) * 1024), 16, 0, 0);
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[MI][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = p.K / BK;
-  const int xr = (l31 >> KSH) & (CPR - 1);                        // swizzle key of this lane's fragment rows
-  const int offA = (wm * 64 + l31) * ROWB, offB = OP_BYTES + (wn * 64 + l31) * ROWB;
-  issue(0);
-  if (NSTAGE > 2 && nk > 1) issue(1);
+  const int xr = (l31 >> 2) & 3;                                  // swizzle key of this lane's fragment rows
+  const int offA = (wm * WTM + l31) * 64, offB = G::A_BYTES + (wn * 64 + l31) * 64;
+#pragma unroll
+  for (int t = 0; t < NSTG - 1; ++t)
+    if (t < nk) issue(t);
   for (int kt = 0; kt < nk; ++kt) {
-    // my share of tile kt has landed (4 loads per tile per wave, in order) ; barrier => everyone's has, and everyone is
-    // done reading stage (kt-1)%3, which the next issue overwrites
-    if (NSTAGE > 2 && kt + 1 < nk) {
-      if (IPW == 2) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    // my share of tile kt has landed (loads complete in order; the younger NSTG-2 tiles may still be in flight);
+    // barrier => everyone's share has, and everyone is done reading stage (kt-1) % NSTG, which the next issue overwrites
+    const int younger = nk - 1 - kt < NSTG - 2 ? nk - 1 - kt : NSTG - 2;
+    switch ((younger > 0 ? younger : 0) * LOADS_PER_TILE) {       // vmcnt needs an immediate
+      case 0: asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory"); break;
+      case 8: asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory"); break;
     }
-    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-#if ATST_ABLATE != 4
-    if (kt + NSTAGE - 1 < nk) issue(kt + NSTAGE - 1);
+#if ATST_ABLATE != 4 && ATST_ABLATE != 6
+    if (kt + NSTG - 1 < nk) issue(kt + NSTG - 1);
 #endif
-    const char* st = lds + (kt % NSTAGE) * STAGE_BYTES;
+    const char* st = lds + (kt % NSTG) * G::STAGE;
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       const int co = ((ks * 2 + hi) ^ xr) << 4;
-      bf16x8 a0 = *reinterpret_cast<const bf16x8*>(st + offA + co), a1 = *reinterpret_cast<const bf16x8*>(st + offA + 32 * ROWB + co);
-      bf16x8 b0 = *reinterpret_cast<const bf16x8*>(st + offB + co), b1 = *reinterpret_cast<const bf16x8*>(st + offB + 32 * ROWB + co);
-#if ATST_ABLATE == 3
-      asm volatile("" :: "v"(a0), "v"(a1), "v"(b0), "v"(b1));
+      bf16x8 af[MI];
+#if ATST_ABLATE == 5 || ATST_ABLATE == 6
+      bf16x8 b0, b1;                                               // no LDS reads: operands are whatever is in registers
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) asm volatile("" : "=v"(af[mi]));
+      asm volatile("" : "=v"(b0), "=v"(b1));
+      (void)st; (void)co;
 #else
-      acc[0][0] = mfma32(a0, b0, acc[0][0]);
-      acc[0][1] = mfma32(a0, b1, acc[0][1]);
-      acc[1][0] = mfma32(a1, b0, acc[1][0]);
-      acc[1][1] = mfma32(a1, b1, acc[1][1]);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const bf16x8*>(st + offA + mi * 32 * 64 + co);
+      bf16x8 b0 = *reinterpret_cast<const bf16x8*>(st + offB + co), b1 = *reinterpret_cast<const bf16x8*>(st + offB + 32 * 64 + co);
+#endif
+#if ATST_ABLATE == 3 || ATST_ABLATE == 5
+      asm volatile("" :: "v"(af[0]), "v"(af[MI - 1]), "v"(b0), "v"(b1));
+#else
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        acc[mi][0] = mfma32(af[mi], b0, acc[mi][0]);
+        acc[mi][1] = mfma32(af[mi], b1, acc[mi][1]);
+      }
 #endif
     }
   }
   asm volatile("s_barrier" ::: "memory");                         // all operand reads done before the tile is staged
 
-  // stage the fp32 tile through LDS, 64 rows at a time (all operand reads finished at the barrier above)
+  // stage the fp32 tile through LDS, 64 rows at a time (part p = rows [64p, 64p+64) of the block tile)
   float* sC = reinterpret_cast<float*>(smem_raw);
-  const int c4 = (tid & 31) * 4, r8 = tid >> 5;
+  constexpr int RPP = G::THREADS / 32;                            // rows stored per pass
+  const int c4 = (tid & 31) * 4, rr = tid >> 5;
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    if (wm == half) {
+  for (int part = 0; part < BMT / 64; ++part) {
+    if (wm == part / (WTM / 64)) {
+      constexpr int SUBS = WTM / 64;
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int sub = 0; sub < SUBS; ++sub) {
+        if (sub != part % SUBS) continue;
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            sC[(mi * 32 + crow32(r, hi)) * C_LD + wn * 64 + ni * 32 + l31] = acc[mi][ni][r];
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              sC[(mi * 32 + crow32(r, hi)) * C_LD + wn * 64 + ni * 32 + l31] = acc[sub * 2 + mi][ni][r];
+      }
     }
     __syncthreads();
 #pragma unroll 4
-    for (int pass = 0; pass < 8; ++pass) {
-      const int rl = pass * 8 + r8, row = m0 + half * 64 + rl;
+    for (int pass = 0; pass < 64 / RPP; ++pass) {
+      const int rl = pass * RPP + rr, row = m0 + part * 64 + rl;
 #if ATST_ABLATE
       if (sC[rl * C_LD + c4] != 12345.678f) continue;                // experiment builds: no epilogue stores
 #endif
       if (row < p.M) epilogue4<EPI>(p, row, n0 + c4, *reinterpret_cast<const f32x4*>(sC + rl * C_LD + c4));
     }
-    if (half == 0) __syncthreads();
+    if (part + 1 < BMT / 64) __syncthreads();
   }
 }
 
@@ -270,21 +298,35 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(WgradArgs p) {
     }
 }
 
-template <int EPI>
-int launch_nt(const GemmArgs& a, hipStream_t st) {
+int g_nt_variant = -1;    // -1 auto ; 0: 128x128 2-stage ; 1: 128x128 3-stage ; 2: 256x128 8 waves ; 3: 256x128 4 waves of 128x64
+
+template <int EPI, int BMT, int NSTG, int WTM>
+int launch_nt_cfg(const GemmArgs& a, hipStream_t st) {
+  using G = NtGeo<BMT, NSTG, WTM>;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, BMT, NSTG, WTM>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  const int nblk = ((a.M + BM - 1) / BM) * (a.N / BN);
+  const int nblk = ((a.M + BMT - 1) / BMT) * (a.N / BN);
   ProfScope ps(PK_GEMM_NT0 + EPI, 2.0 * a.M * a.N * a.K, st);
-  hipLaunchKernelGGL(gemm_nt_kernel<EPI>, dim3(nblk), dim3(256), GEMM_LDS_BYTES, st, a);
+  hipLaunchKernelGGL((gemm_nt_kernel<EPI, BMT, NSTG, WTM>), dim3(nblk), dim3(G::THREADS), G::LDS, st, a);
   return (int)hipGetLastError();
+}
+template <int EPI>
+int launch_nt(const GemmArgs& a, hipStream_t st) {
+  int v = g_nt_variant;
+  if (v < 0) v = a.K <= 512 ? 0 : 1;
+  if (v == 3) return launch_nt_cfg<EPI, 256, 3, 128>(a, st);
+  if (v == 2) return launch_nt_cfg<EPI, 256, 3, 64>(a, st);
+  if (v == 1) return launch_nt_cfg<EPI, 128, 3, 64>(a, st);
+  return launch_nt_cfg<EPI, 128, 2, 64>(a, st);
 }
 
 }  // namespace
+
+void atst_gemm_nt_set_variant(int v) { g_nt_variant = v; }
 
 int atst_gemm_nt(const GemmArgs& a, hipStream_t st) {
   if (a.M <= 0 || a.N % BN || a.K % BK || a.lda % 8 || a.ldb % 8) return ATST_EINVAL;

@@ -20,6 +20,7 @@ struct GemmArgs {
   const float* alt;                  // EPI_PATCH: mask_embed [N]
 };
 int atst_gemm_nt(const GemmArgs& a, hipStream_t st);
+void atst_gemm_nt_set_variant(int v);     // tuning hook: -1 auto, 0/1/2 fixed tile configuration
 
 struct WgradArgs {
   const bf16* dY; const bf16* X;     // dY [M, >=N] ldy ; X [M, >=K] ldx

@@ -294,6 +294,8 @@ class AtstEngine:
         self._stats = torch.zeros(4, HEAD_OUT, device=dev)
         self._student_groups = None
         self._grads_summed = False
+        self.overlap_teacher = True
+        self._side = torch.cuda.Stream(device=self.device)
 
     # ---------------------------------------------------------------------------------------------------------------
     def _build_offsets(self) -> hip.EncOff:
@@ -438,11 +440,24 @@ class AtstEngine:
         0-dim device tensors; saves what backward() needs.  ref: models/atst/atst.py:24-28, atstframe/model.py:68-72."""
         self.sync_shadows()
         nt = len(mels) if self.frame else 2
-        tf, _ = self._run_net("teacher", mels[:nt], lengths[:nt], None if masks is None else masks[:nt], False, keep_teacher, False)
-        t_out = self.heads["teacher.projector"].forward(tf, False)
+        mels = [m.to(self.device, torch.float32) for m in mels]
+        # The teacher pass has no data dependence on the student pass: it runs on a second HIP stream so that kernels of
+        # the two passes interleave on the chip (one kernel's epilogue-store phase overlaps the other's load phase).
+        main = torch.cuda.current_stream()
+        if self.overlap_teacher:
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                tf, _ = self._run_net("teacher", mels[:nt], lengths[:nt], None if masks is None else masks[:nt], False, keep_teacher, False)
+                t_out = self.heads["teacher.projector"].forward(tf, False)
+        else:
+            tf, _ = self._run_net("teacher", mels[:nt], lengths[:nt], None if masks is None else masks[:nt], False, keep_teacher, False)
+            t_out = self.heads["teacher.projector"].forward(tf, False)
         sf, groups = self._run_net("student", mels, lengths, masks, True, keep_student, train)
         z = self.heads["student.projector"].forward(sf, train)
         s_out = self.heads["student.predictor"].forward(z, train)
+        if self.overlap_teacher:
+            main.wait_stream(self._side)
+        self._teacher_keep = (tf, t_out)
         ncrops = 2 if self.frame else self.ncrops
         if s_out.shape[0] % ncrops or t_out.shape[0] % 2 or s_out.shape[0] // ncrops != t_out.shape[0] // 2:
             raise hip.HipError("views must contribute equal row counts (chunk() semantics of ByolLoss)")

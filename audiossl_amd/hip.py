@@ -41,6 +41,7 @@ class Encoder(C.Structure):
 
 _SIGS = {
     "atst_version": (C.c_int, []),
+    "atst_tune_gemm_variant": (C.c_int, [C.c_int]),
     "atst_mel_frontend_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "atst_gemm_nt_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,

@@ -25,6 +25,8 @@ extern "C" {
 enum { ATST_EPI_BF16 = 0, ATST_EPI_F32 = 1, ATST_EPI_BIAS_GELU = 2, ATST_EPI_RESID = 3, ATST_EPI_DGELU = 4, ATST_EPI_PATCH = 5 };
 
 int atst_version(void);
+/* tuning hook for gemm_nt: -1 auto (default), 0 = 128x128 tile 2-stage, 1 = 128x128 3-stage, 2 = 256x128 3-stage */
+int atst_tune_gemm_variant(int v);
 
 /* ---- front end: torchaudio MelSpectrogram -> AmplitudeToDB(top_db=80) -> MinMax ---------------------------------
  * replaces audiossl/methods/atst/transform.py:14-33 (`self.mel_feature`) / methods/atstframe/transform.py:16-41.

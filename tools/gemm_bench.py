@@ -6,6 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from audiossl_amd import hip
 hip.load()
 dev = "cuda"
+if os.environ.get("VARIANT"): hip.load().atst_tune_gemm_variant(int(os.environ["VARIANT"]))
 M = int(os.environ.get("M", 131072))
 def t_ms(fn, n=20):
     for _ in range(3): fn()
@@ -50,3 +51,8 @@ nt(384, 384, hip.EPI_BF16, "proj dgrad")
 nt(384, 1152, hip.EPI_BF16, "qkv dgrad")
 tn(384, 1536, "fc2 wgrad"); tn(1536, 384, "fc1 wgrad"); tn(384, 384, "proj wgrad"); tn(1152, 384, "qkv wgrad")
 attn()
+if os.environ.get("EXTRA"):
+    for spec in os.environ["EXTRA"].split(","):
+        m_, n_, k_ = (int(v) for v in spec.split("x"))
+        M = m_
+        nt(n_, k_, hip.EPI_BF16, f"extra M={m_}")
