@@ -23,11 +23,11 @@ int atst_mel_frontend_f32(const float* wave, int n_clips, int n_samples, int win
 int atst_gemm_nt_bf16(const uint16_t* A, const uint16_t* B, int M, int N, int K, int lda, int ldb, int epi,
                       void* C, int ldc, void* C2, const float* bias, const float* resid, const float* row_scale,
                       int rows_per_seq, const uint16_t* U, const float* table, const uint8_t* rowflag, const float* alt,
-                      void* stream) {
+                      float* colsum, void* stream) {
   GemmArgs a{};
   a.A = CBF(A); a.B = CBF(B); a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.epi = epi; a.C = C; a.ldc = ldc;
   a.C2 = C2; a.bias = bias; a.resid = resid; a.row_scale = row_scale; a.rows_per_seq = rows_per_seq > 0 ? rows_per_seq : 1;
-  a.U = CBF(U); a.table = table; a.rowflag = rowflag; a.alt = alt;
+  a.U = CBF(U); a.table = table; a.rowflag = rowflag; a.alt = alt; a.colsum = colsum;
   if ((epi == EPI_BIAS_GELU && (!bias || !C2)) || (epi == EPI_RESID && (!bias || !resid)) || (epi == EPI_DGELU && !U) ||
       (epi == EPI_PATCH && (!table || !bias)))
     return ATST_EINVAL;

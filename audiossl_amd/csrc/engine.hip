@@ -67,10 +67,10 @@ inline const bf16* B16(const uint16_t* p) { return reinterpret_cast<const bf16*>
 
 int gemm(const bf16* A, const bf16* B, int M, int N, int K, int epi, void* C, hipStream_t st, const float* bias = nullptr,
          const float* resid = nullptr, const float* row_scale = nullptr, int rps = 1, void* C2 = nullptr,
-         const bf16* U = nullptr) {
+         const bf16* U = nullptr, float* colsum = nullptr) {
   GemmArgs a{};
   a.A = A; a.B = B; a.M = M; a.N = N; a.K = K; a.lda = K; a.ldb = K; a.epi = epi; a.C = C; a.ldc = N; a.C2 = C2;
-  a.bias = bias; a.resid = resid; a.row_scale = row_scale; a.rows_per_seq = rps; a.U = U;
+  a.bias = bias; a.resid = resid; a.row_scale = row_scale; a.rows_per_seq = rps; a.U = U; a.colsum = colsum;
   return atst_gemm_nt(a, st);
 }
 int wgrad(const bf16* dY, const bf16* X, int M, int N, int K, float* dW, hipStream_t st) {
@@ -135,7 +135,7 @@ extern "C" int atst_encoder_fwd(const atst_encoder_t* e, void* stream) {
     RUN(atst_attn_fwd(at, st));
     RUN(gemm(l.o, q + lo.proj_w, M, C, C, EPI_RESID, w.x[2 * i + 1], st, p + lo.proj_b, w.x[2 * i], s1, NP));
     RUN(atst_ln_fwd(w.x[2 * i + 1], p + lo.ln2_w, p + lo.ln2_b, l.h2, l.mean2, l.rstd2, M, C, st));
-    RUN(gemm(l.h2, q + lo.fc1_w, M, 4 * C, C, EPI_BIAS_GELU, l.u, st, p + lo.fc1_b, nullptr, nullptr, 1, l.a));
+    RUN(gemm(l.h2, q + lo.fc1_w, M, 4 * C, C, EPI_BIAS_GELU, e->train ? l.u : nullptr, st, p + lo.fc1_b, nullptr, nullptr, 1, l.a));
     RUN(gemm(l.a, q + lo.fc2_w, M, C, 4 * C, EPI_RESID, w.x[2 * i + 2], st, p + lo.fc2_b, w.x[2 * i + 1], s2, NP));
   }
   RUN(atst_ln_fwd(w.x[2 * e->depth], p + o.norm_w, p + o.norm_b, w.hN, w.meanN, w.rstdN, M, C, st));
@@ -167,8 +167,7 @@ extern "C" int atst_encoder_bwd(const atst_encoder_t* e, void* stream) {
     const LayerWs& l = w.L[i];
     // ---- MLP branch: x_out = x_mid + s2 * (fc2(gelu(fc1(LN2(x_mid)))) + b2) ; w.g = s2 * d(x_out)
     RUN(wgrad(w.g, l.a, M, C, 4 * C, G + lo.fc2_w, st));
-    RUN(gemm(w.g, qt + lo.fc2_w, M, 4 * C, C, EPI_DGELU, w.du, st, nullptr, nullptr, nullptr, 1, nullptr, l.u));
-    RUN(atst_colsum_bf16(w.du, M, 4 * C, 4 * C, G + lo.fc1_b, st));
+    RUN(gemm(w.g, qt + lo.fc2_w, M, 4 * C, C, EPI_DGELU, w.du, st, nullptr, nullptr, nullptr, 1, nullptr, l.u, G + lo.fc1_b));
     RUN(wgrad(w.du, l.h2, M, 4 * C, C, G + lo.fc1_w, st));
     RUN(gemm(w.du, qt + lo.fc1_w, M, C, 4 * C, EPI_BF16, w.dh, st));
     {

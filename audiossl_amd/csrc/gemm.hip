@@ -24,7 +24,7 @@ constexpr int C_LD = BN + 4;                   // fp32 epilogue staging tile [12
 // Epilogue on 4 consecutive columns of one row (vector loads / stores; the accumulator tile is staged through LDS so
 // that every global access is a full 16-B (fp32) or 8-B (bf16) piece of a contiguous row segment).
 template <int EPI>
-DEVFN void epilogue4(const GemmArgs& p, int row, int col, f32x4 v) {
+DEVFN void epilogue4(const GemmArgs& p, int row, int col, f32x4 v, f32x4& written) {
   const size_t idx = (size_t)row * p.ldc + col;
   auto st_bf16 = [](void* base, size_t i, const f32x4& x) {
     bf16x4 o;
@@ -40,7 +40,7 @@ DEVFN void epilogue4(const GemmArgs& p, int row, int col, f32x4 v) {
     *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + idx) = v;
   } else if constexpr (EPI == EPI_BIAS_GELU) {
     v += *reinterpret_cast<const f32x4*>(p.bias + col);
-    st_bf16(p.C, idx, v);                                         // pre-activation u (saved for backward)
+    if (p.C) st_bf16(p.C, idx, v);                                // pre-activation u (saved for backward; skipped in inference)
     f32x4 a;
 #pragma unroll
     for (int e = 0; e < 4; ++e) a[e] = gelu_f(v[e]);
@@ -55,6 +55,7 @@ DEVFN void epilogue4(const GemmArgs& p, int row, int col, f32x4 v) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(bf2f(u[e]));
     st_bf16(p.C, idx, v);
+    written = v;
   } else if constexpr (EPI == EPI_PATCH) {
     const int tok = row % p.rows_per_seq;
     const f32x4 t = *reinterpret_cast<const f32x4*>(p.table + (size_t)tok * p.N + col);
@@ -185,6 +186,7 @@ __global__ __launch_bounds__((NtGeo<BMT, NSTG, WTM>::THREADS), (NtGeo<BMT, NSTG,
   float* sC = reinterpret_cast<float*>(smem_raw);
   constexpr int RPP = G::THREADS / 32;                            // rows stored per pass
   const int c4 = (tid & 31) * 4, rr = tid >> 5;
+  f32x4 csum = {0.f, 0.f, 0.f, 0.f};                              // EPI_DGELU: column sums of du = fc1 bias gradient
 #pragma unroll
   for (int part = 0; part < BMT / 64; ++part) {
     if (wm == part / (WTM / 64)) {
@@ -208,9 +210,26 @@ __global__ __launch_bounds__((NtGeo<BMT, NSTG, WTM>::THREADS), (NtGeo<BMT, NSTG,
 #if ATST_ABLATE
       if (sC[rl * C_LD + c4] != 12345.678f) continue;                // experiment builds: no epilogue stores
 #endif
-      if (row < p.M) epilogue4<EPI>(p, row, n0 + c4, *reinterpret_cast<const f32x4*>(sC + rl * C_LD + c4));
+      if (row < p.M) {
+        f32x4 wv = {0.f, 0.f, 0.f, 0.f};
+        epilogue4<EPI>(p, row, n0 + c4, *reinterpret_cast<const f32x4*>(sC + rl * C_LD + c4), wv);
+        if constexpr (EPI == EPI_DGELU) csum += wv;
+      }
     }
     if (part + 1 < BMT / 64) __syncthreads();
+  }
+  if constexpr (EPI == EPI_DGELU) {
+    if (p.colsum) {                                               // block-reduce over the RPP row groups, one atomic per column
+      __syncthreads();
+      *reinterpret_cast<f32x4*>(sC + rr * BN + c4) = csum;
+      __syncthreads();
+      if (tid < BN) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < RPP; ++g) t += sC[g * BN + tid];
+        atomicAdd(p.colsum + n0 + tid, t);
+      }
+    }
   }
 }
 

@@ -18,6 +18,7 @@ struct GemmArgs {
   const float* table;                // EPI_PATCH: [rows_per_seq, N] per-token additive table
   const uint8_t* rowflag;            // EPI_PATCH: [M] 1 = replace by mask token (or null)
   const float* alt;                  // EPI_PATCH: mask_embed [N]
+  float* colsum;                     // EPI_DGELU: optional fp32 [N] accumulator of the column sums of the output (bias gradient)
 };
 int atst_gemm_nt(const GemmArgs& a, hipStream_t st);
 void atst_gemm_nt_set_variant(int v);     // tuning hook: -1 auto, 0/1/2 fixed tile configuration

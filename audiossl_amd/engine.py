@@ -228,7 +228,7 @@ class HeadPass:
 
 def _gemm(A, B, M, N, K, epi, out):
     hip.call("atst_gemm_nt_bf16", hip.ptr(A), hip.ptr(B), M, N, K, K, K, epi, hip.ptr(out), N, None, None, None, None, 1,
-             None, None, None, None, hip.stream())
+             None, None, None, None, None, hip.stream())
 
 
 def _wgrad(dY, X, M, N, K, dW, ldx=None):

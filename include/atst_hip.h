@@ -42,7 +42,7 @@ int atst_mel_frontend_f32(const float* wave, int n_clips, int n_samples, int win
 int atst_gemm_nt_bf16(const uint16_t* A, const uint16_t* B, int M, int N, int K, int lda, int ldb, int epi,
                       void* C, int ldc, void* C2, const float* bias, const float* resid, const float* row_scale,
                       int rows_per_seq, const uint16_t* U, const float* table, const uint8_t* rowflag, const float* alt,
-                      void* stream);
+                      float* colsum /* EPI_DGELU: optional [N] += column sums of the output */, void* stream);
 /* dW[N,K] += dY[M,N]^T X[M,K]  (fp32 accumulate); autograd of the same nn.Linear calls.                              */
 int atst_gemm_tn_bf16(const uint16_t* dY, const uint16_t* X, int M, int N, int K, int ldy, int ldx, float* dW, int ldw,
                       int m_per_split, void* stream);

@@ -46,7 +46,8 @@ def gemm_nt(A, B, epi, out_dtype, **kw):
     C2 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV) if epi == hip.EPI_BIAS_GELU else None
     hip.call("atst_gemm_nt_bf16", hip.ptr(A), hip.ptr(B), M, N, K, K, K, epi, hip.ptr(Cout), N, hip.ptr(C2),
              hip.ptr(kw.get("bias")), hip.ptr(kw.get("resid")), hip.ptr(kw.get("row_scale")), kw.get("rps", 1),
-             hip.ptr(kw.get("U")), hip.ptr(kw.get("table")), hip.ptr(kw.get("rowflag")), hip.ptr(kw.get("alt")), hip.stream())
+             hip.ptr(kw.get("U")), hip.ptr(kw.get("table")), hip.ptr(kw.get("rowflag")), hip.ptr(kw.get("alt")), hip.ptr(kw.get("colsum")),
+             hip.stream())
     return Cout, C2
 
 
@@ -78,10 +79,12 @@ def test_gemm_nt_epilogues():
     assert relerr(x, want) < 2e-5
     # dgelu
     U = bf(rnd(M, N, seed=5))
-    d, _ = gemm_nt(A, B, hip.EPI_DGELU, torch.bfloat16, U=U)
+    cs = torch.full((N,), 0.25, device=DEV)
+    d, _ = gemm_nt(A, B, hip.EPI_DGELU, torch.bfloat16, U=U, colsum=cs)
     uf = U.float().requires_grad_(True)
     torch.nn.functional.gelu(uf).backward(ref)
     assert relerr(d.float(), uf.grad) < 5e-3
+    assert relerr(cs, uf.grad.sum(0) + 0.25) < 2e-3                  # fused fc1-bias gradient (column sums of du)
     # patch epilogue: per-token table + mask-token substitution
     table = rnd(rps, N, seed=6)
     flag = (torch.arange(M, device=DEV) % 5 == 0).to(torch.uint8)

@@ -23,7 +23,7 @@ def nt(N, K, epi, label):
     C2 = torch.empty(M, N, device=dev, dtype=torch.bfloat16) if epi == hip.EPI_BIAS_GELU else None
     scale = torch.ones(M // 256, device=dev)
     f = lambda: hip.call("atst_gemm_nt_bf16", hip.ptr(A), hip.ptr(B), M, N, K, K, K, epi, hip.ptr(out), N, hip.ptr(C2), hip.ptr(bias),
-                         hip.ptr(resid), hip.ptr(scale) if resid is not None else None, int(os.environ.get('RPS', 256)), hip.ptr(U), None, None, None, hip.stream())
+                         hip.ptr(resid), hip.ptr(scale) if resid is not None else None, int(os.environ.get('RPS', 256)), hip.ptr(U), None, None, None, None, hip.stream())
     ms = t_ms(f); fl = 2.0 * M * N * K
     print(f"  nt {label:22s} N={N:5d} K={K:5d}  {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TF/s")
 def tn(N, K, label):

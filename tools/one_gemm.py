@@ -14,5 +14,5 @@ out = torch.empty(M, N, device="cuda", dtype=torch.float32); C2 = torch.empty(M,
 scale = torch.ones(M // 256, device="cuda")
 for _ in range(5):
     hip.call("atst_gemm_nt_bf16", hip.ptr(A), hip.ptr(B), M, N, K, K, K, epi, hip.ptr(out), N, hip.ptr(C2), hip.ptr(bias),
-             hip.ptr(resid), hip.ptr(scale), 256, hip.ptr(U), None, None, None, hip.stream())
+             hip.ptr(resid), hip.ptr(scale), 256, hip.ptr(U), None, None, None, None, hip.stream())
 torch.cuda.synchronize()
