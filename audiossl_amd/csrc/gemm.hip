@@ -317,6 +317,95 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(WgradArgs p) {
     }
 }
 
+// ---- wgrad, LDS-DMA pipeline -----------------------------------------------------------------------------------------
+// Same math as gemm_tn_kernel, for the common case where every split is a whole number of 32-row stages: both operand
+// tiles ([32 m][128] bf16, 256-B rows) go HBM/L2 -> LDS by global_load_lds (2-stage ring, 32 KB, 4 blocks / CU); the
+// 16-B chunk c of row r is stored at chunk c ^ (2 * (r & 3)) (applied to the per-lane source address) so that the
+// 4-row x 16-column blocks fetched by ds_read_b64_tr_b16 fall on distinct banks.
+constexpr int GM = 32;                          // contraction rows per stage
+constexpr int G_OP = GM * 256;                  // bytes per operand per stage
+constexpr int G_STAGE = 2 * G_OP;
+constexpr int WGRAD_GLDS_BYTES = 2 * G_STAGE;   // 32,768 B
+
+DEVFN bf16x8 ld_frag_tr_swz(const char* X, int r0, int c0, int lane) {
+  const int a = lane & 15, g = lane >> 4;
+  const int row = r0 + 4 * (g >> 1) + (a >> 2);
+  const int col = c0 + (g & 1) * 16 + 4 * (a & 3);                 // element column; 8 elements per 16-B chunk
+  const int pch = (col >> 3) ^ ((row & 3) << 1);
+  const bf16* ptr = reinterpret_cast<const bf16*>(X + row * 256 + pch * 16) + (col & 7);
+  s16x4 lo = lds_tr4(ptr);
+  s16x4 hi = lds_tr4(ptr + 8 * 128);                               // +8 rows: same swizzle key
+  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+  u.s.a = lo; u.s.b = hi;
+  return u.v;
+}
+
+__global__ __launch_bounds__(256, 4) void gemm_tn_glds_kernel(WgradArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  typedef const void __attribute__((address_space(1))) * gptr_t;
+  typedef void __attribute__((address_space(3))) * lptr_t;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wn = wid >> 1, wk = wid & 1, hi = lane >> 5, l31 = lane & 31;
+  const int ntn = p.N / 128, ntk = p.K / 128;
+  const int tile = blockIdx.x % (ntn * ntk), split = blockIdx.x / (ntn * ntk);
+  const int n0 = (tile / ntk) * 128, k0 = (tile % ntk) * 128;
+  const int m_begin = split * p.m_per_split;
+  int m_end = m_begin + p.m_per_split; if (m_end > p.M) m_end = p.M;
+  if (m_begin >= m_end) return;
+  const int nst = (m_end - m_begin) / GM;
+
+  // each wave-instruction moves 4 rows x 256 B; 8 per operand tile -> 2 per wave per operand
+  const bf16* srcY[2]; const bf16* srcX[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = (wid * 2 + j) * 4 + (lane >> 4);
+    const int c = (lane & 15) ^ ((row & 3) << 1);
+    srcY[j] = p.dY + (size_t)(m_begin + row) * p.ldy + n0 + c * 8;
+    srcX[j] = p.X + (size_t)(m_begin + row) * p.ldx + k0 + c * 8;
+  }
+  auto issue = [&](int st) {
+    char* base = smem_raw + (st & 1) * G_STAGE + wid * 2048;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcY[j] + (size_t)st * GM * p.ldy), (lptr_t)(base + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcX[j] + (size_t)st * GM * p.ldx), (lptr_t)(base + G_OP + j * 1024), 16, 0, 0);
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  issue(0);
+  for (int st = 0; st < nst; ++st) {
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // stage st landed everywhere; stage st-1 no longer read
+    if (st + 1 < nst) issue(st + 1);
+    const char* sY = smem_raw + (st & 1) * G_STAGE; const char* sX = sY + G_OP;
+#pragma unroll
+    for (int ms = 0; ms < GM / 16; ++ms) {
+      bf16x8 a0 = ld_frag_tr_swz(sY, ms * 16, wn * 64, lane), a1 = ld_frag_tr_swz(sY, ms * 16, wn * 64 + 32, lane);
+      bf16x8 b0 = ld_frag_tr_swz(sX, ms * 16, wk * 64, lane), b1 = ld_frag_tr_swz(sX, ms * 16, wk * 64 + 32, lane);
+      acc[0][0] = mfma32(a0, b0, acc[0][0]);
+      acc[0][1] = mfma32(a0, b1, acc[0][1]);
+      acc[1][0] = mfma32(a1, b0, acc[1][0]);
+      acc[1][1] = mfma32(a1, b1, acc[1][1]);
+    }
+  }
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + wn * 64 + ni * 32 + crow32(r, hi);
+#pragma unroll
+      for (int ki = 0; ki < 2; ++ki)
+        atomicAdd(p.dW + (size_t)n * p.ldw + k0 + wk * 64 + ki * 32 + l31, acc[ni][ki][r]);
+    }
+}
+
+int g_tn_glds = 0;        // wgrad: 1 = LDS-DMA kernel when shapes allow (tuning hook 101); measured 7 % slower than register staging
 int g_nt_variant = -1;    // -1 auto ; 0: 128x128 2-stage ; 1: 128x128 3-stage ; 2: 256x128 8 waves ; 3: 256x128 4 waves of 128x64
 
 template <int EPI, int BMT, int NSTG, int WTM>
@@ -345,7 +434,7 @@ int launch_nt(const GemmArgs& a, hipStream_t st) {
 
 }  // namespace
 
-void atst_gemm_nt_set_variant(int v) { g_nt_variant = v; }
+void atst_gemm_nt_set_variant(int v) { if (v >= 100) g_tn_glds = v - 100; else g_nt_variant = v; }
 
 int atst_gemm_nt(const GemmArgs& a, hipStream_t st) {
   if (a.M <= 0 || a.N % BN || a.K % BK || a.lda % 8 || a.ldb % 8) return ATST_EINVAL;
@@ -381,6 +470,9 @@ int atst_gemm_tn(const WgradArgs& a, hipStream_t st) {
   const int splits = (p.M + p.m_per_split - 1) / p.m_per_split;
   const int nblk = (p.N / 128) * (p.K / 128) * splits;
   ProfScope ps(PK_GEMM_TN, 2.0 * p.M * p.N * p.K, st);
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3(nblk), dim3(256), WGRAD_LDS_BYTES, st, p);
+  if (p.M % GM == 0 && p.m_per_split % GM == 0 && g_tn_glds)
+    hipLaunchKernelGGL(gemm_tn_glds_kernel, dim3(nblk), dim3(256), WGRAD_GLDS_BYTES, st, p);
+  else
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(nblk), dim3(256), WGRAD_LDS_BYTES, st, p);
   return (int)hipGetLastError();
 }
