@@ -29,6 +29,21 @@ except Exception:                                       # noqa: BLE001
         def log(self, name, value, **kw):
             self.logged[name] = value
 
+        def on_after_backward(self):
+            pass
+
+        @classmethod
+        def load_from_checkpoint(cls, checkpoint_path, map_location=None, strict=True, **kwargs):
+            """Lightning-format checkpoint -> module (keys as written by Lightning's ModelCheckpoint and by
+            audiossl_amd.trainer.save_checkpoint; ref consumer: methods/atst/downstream/train_freeze.py:27-35)."""
+            from ...trainer import load_checkpoint
+            ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+            hp = dict(ckpt.get("hyper_parameters", {}))
+            hp.update(kwargs)
+            module = cls(**hp)
+            load_checkpoint(checkpoint_path, module, strict=strict)
+            return module
+
         def save_hyperparameters(self, **kw):
             import inspect
             frame = inspect.currentframe().f_back

@@ -13,7 +13,14 @@ from ...engine import AtstEngine
 
 
 class _Node(nn.Module):
-    """Structural container (the reference's Block / Attention / Mlp / Sequential nodes hold parameters only here)."""
+    """Structural container (the reference's Block / Attention / Mlp / Sequential nodes hold parameters only here).
+    Index access mirrors nn.ModuleList / nn.Sequential (``encoder.blocks[3]``, ``projector[0]``)."""
+
+    def __getitem__(self, i):
+        return self._modules[str(i)]
+
+    def __len__(self):
+        return len(self._modules)
 
 
 def _attach(root: nn.Module, dotted: str, tensor: torch.Tensor, buffer: bool = False, requires_grad: bool = True):
@@ -28,6 +35,79 @@ def _attach(root: nn.Module, dotted: str, tensor: torch.Tensor, buffer: bool = F
         m.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=requires_grad))
 
 
+class EncoderView(_Node):
+    """``model.{student,teacher}.encoder``: parameter container + the reference's inference API, evaluated by the HIP
+    encoder in eval semantics (no DropPath).  ref: audiossl/models/atst/audio_transformer.py:188-221 (forward),
+    :235-255 (get_intermediate_layers), :257-366 (get_intermediate_layers_chunks / get_cls_avg)."""
+
+    def _bind(self, engine, net):
+        self._eng, self._netname = [engine], net
+        self.embed_dim = engine.cfg["embed_dim"]
+        self.use_cls = not engine.frame
+        self.nprompt = 0
+
+    @torch.no_grad()
+    def _blocks(self, x, length, n):
+        """-> (list of LN(x_i) [S, NP, C] fp32 for the last n blocks, patch_length [S], n_tok)."""
+        from ... import hip
+        eng = self._eng[0]
+        eng.sync_shadows()
+        x = x.to(eng.device, torch.float32).contiguous()
+        S, width = x.shape[0], x.shape[-1]
+        ep = eng._pass(self._netname, S, width, True, 1000 + width)
+        if length is None:
+            length = torch.full((S,), width, dtype=torch.int64)
+        valid = eng._valid(torch.as_tensor(length), ep.use_cls)             # reference patch_length (+CLS), NOT clipped to the chunk
+        ep.forward(x, torch.clamp(valid, max=ep.n_tok + ep.use_cls).contiguous(), None, None)
+        C = eng.cfg["embed_dim"]
+        nf = "encoder.norm_frame" if eng.frame else "encoder.norm"
+        gw, gb = eng.param_view(self._netname, nf + ".weight"), eng.param_view(self._netname, nf + ".bias")
+        outs = []
+        y = torch.empty(ep.M, C, dtype=torch.bfloat16, device=eng.device)
+        mean, rstd = torch.empty(ep.M, device=eng.device), torch.empty(ep.M, device=eng.device)
+        for i in range(eng.depth - n, eng.depth):
+            hip.call("atst_layernorm_fwd", hip.ptr(ep.block_out(i)), hip.ptr(gw), hip.ptr(gb), hip.ptr(y), hip.ptr(mean), hip.ptr(rstd),
+                     ep.M, C, hip.stream())
+            outs.append(y.float().view(S, ep.NP, C)[:, :ep.n_tok + ep.use_cls].clone())
+        return outs, (valid - ep.use_cls).long(), ep.n_tok
+
+    def forward(self, x, mask_index=None, length=None, avg=False):
+        outs, plen, _ = self._blocks(x, length, 1)
+        y = outs[0]
+        if self.use_cls:
+            return y[:, 0]
+        m = (torch.arange(y.shape[1], device=y.device)[None, :] < plen[:, None]).unsqueeze(-1)
+        return (y * m).sum(1) / plen[:, None]
+
+    def get_intermediate_layers(self, x, length, n=1):
+        outs, _, _ = self._blocks(x, length, n)
+        if not self.use_cls:
+            outs = [torch.cat([torch.zeros_like(o[:, :1]), o], dim=1) for o in outs]
+        return outs
+
+    def get_intermediate_layers_chunks(self, x, length, n=1, chunk_len=601, avgpool=True):
+        total = x.shape[-1]
+        length = torch.as_tensor(length).to(self._eng[0].device)
+        cls_c, avg_c, marks = [], [], []
+        for i in range(total // chunk_len + 1):
+            start, end = i * chunk_len, min((i + 1) * chunk_len, total)
+            if end <= start:
+                continue
+            cur = torch.clip(length - i * chunk_len, 0)
+            mark = (cur > 0) if i == 0 else (cur > chunk_len // 2)
+            outs, plen, _ = self._blocks(x[..., start:end], cur.cpu(), n)
+            off = 1 if self.use_cls else 0
+            lm = (torch.arange(outs[0].shape[1] - off, device=outs[0].device)[None, :] < plen[:, None]).unsqueeze(-1)
+            cls_c.append(torch.stack([o[:, 0] if self.use_cls else torch.zeros_like(o[:, 0]) for o in outs]))
+            avg_c.append(torch.stack([(o[:, off:] * lm).sum(1) / (plen[:, None] + 1e-6) for o in outs]))
+            marks.append(mark.float())
+        w = torch.stack(marks)[:, None, :, None]                        # [chunks, 1, S, 1]
+        cls = (torch.stack(cls_c) * w).sum(0) / w.sum(0)                # [n, S, C]
+        avg = (torch.stack(avg_c) * w).sum(0) / w.sum(0)
+        parts = list(cls) + (list(avg) if avgpool else [])
+        return torch.cat(parts, dim=-1)
+
+
 class _Net(_Node):
     """MultiCropWrapper-shaped view of one network (encoder, projector[, predictor]). ref: byol.py:82-121."""
 
@@ -36,6 +116,8 @@ class _Net(_Node):
         self._engine_ref = [engine]            # list: keep the engine out of the module tree
         self._net = net
         student = net == "student"
+        self.add_module("encoder", EncoderView())
+        self.encoder._bind(engine, net)
         for name in engine.layout.entries:
             if not student and name.startswith("predictor."):
                 continue
@@ -44,7 +126,6 @@ class _Net(_Node):
                 which = name.split(".")[0]
                 for b, t in engine.bn_buffers[f"{net}.{which}"].items():
                     _attach(self, f"{which}.1.{b}", t, buffer=True)
-        self.encoder.embed_dim = engine.cfg["embed_dim"]
         if not student:
             self.predictor = nn.Identity()
 

@@ -1,0 +1,92 @@
+"""Minimal trainer with Lightning 2.2's automatic-optimisation hook order, used when
+pytorch_lightning is not installed:  schedule()+training_step -> zero_grad -> backward -> on_after_backward (grad
+all-reduce) -> optimizer.step -> global_step += 1 -> on_train_batch_end (EMA, index = post-increment step).
+Writes / reads Lightning-format checkpoint dicts (keys consumed by the reference's downstream tools:
+``state_dict`` with ``model.`` prefix, ``hyper_parameters``, ``pytorch-lightning_version``, ``global_step``, ``epoch``,
+``optimizer_states``; ref: audiossl/methods/atst/train.py:25-35, downstream/train_freeze.py:27-35)."""
+from __future__ import annotations
+
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+LIGHTNING_VERSION = "2.2.1"                           # setup.cfg:22 of the reference
+
+
+def save_checkpoint(path, module, optimizer=None, epoch=0):
+    sd = {k: v.detach().cpu() for k, v in module.state_dict().items()}
+    eng = module.model.engine
+    ckpt = {"state_dict": sd, "hyper_parameters": dict(getattr(module, "hparams", {})), "global_step": int(module.global_step),
+            "epoch": int(epoch), "pytorch-lightning_version": LIGHTNING_VERSION, "loops": {}, "callbacks": {},
+            "lr_schedulers": [],
+            "optimizer_states": [{"flat_exp_avg": eng.m32.cpu(), "flat_exp_avg_sq": eng.v32.cpu(), "step": eng.opt_step,
+                                  "layout": "audiossl_amd.FlatLayout"}]}
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    torch.save(ckpt, path)
+
+
+def load_checkpoint(path, module, strict=True):
+    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    assert "pytorch-lightning_version" in ckpt, "not a Lightning-format checkpoint"
+    module.load_state_dict(ckpt["state_dict"], strict=strict)
+    module.model.engine.sync_shadows(force=True)
+    module.global_step = int(ckpt.get("global_step", 0))
+    st = (ckpt.get("optimizer_states") or [None])[0]
+    if st and st.get("layout") == "audiossl_amd.FlatLayout":
+        eng = module.model.engine
+        eng.m32.copy_(st["flat_exp_avg"]); eng.v32.copy_(st["flat_exp_avg_sq"]); eng.opt_step = int(st["step"])
+    return ckpt
+
+
+class Trainer:
+    def __init__(self, max_steps=-1, max_epochs=None, default_root_dir=None, every_n_epochs=20, log_every_n_steps=50,
+                 batch_hook=None, **_ignored):
+        self.max_steps, self.max_epochs = max_steps, max_epochs
+        self.root, self.every_n_epochs, self.log_every = default_root_dir, every_n_epochs, log_every_n_steps
+        self.batch_hook = batch_hook                       # e.g. ATSTBatchViews: waveform views -> mel views on the GPU
+        self.optimizers = []
+        self.rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.history = []
+
+    def fit(self, model, datamodule=None, train_dataloaders=None, ckpt_path=None):
+        model.trainer = self
+        self.optimizers = model.configure_optimizers()
+        opt = self.optimizers[0]
+        if ckpt_path and os.path.exists(ckpt_path):
+            load_checkpoint(ckpt_path, model)
+        loader = train_dataloaders if train_dataloaders is not None else datamodule.train_dataloader(self.rank, self.world)
+        dev = model.model.engine.device
+        epoch, t0 = 0, time.time()
+        while True:
+            for batch_idx, batch in enumerate(loader):
+                (views, lengths), labels = batch[0], batch[1]
+                views = [v.to(dev, non_blocking=True) for v in views]
+                if self.batch_hook is not None and views[0].dim() == 3:            # [B,1,n] waveforms -> mel views
+                    views = self.batch_hook(views, lengths)
+                loss = model.training_step(((views, lengths), labels), batch_idx)
+                opt.zero_grad()
+                loss.backward()
+                model.on_after_backward()
+                opt.step()
+                model.global_step += 1
+                model.on_train_batch_end(loss, batch, batch_idx)
+                if self.rank == 0 and model.global_step % self.log_every == 0:
+                    rec = {k: (float(v) if torch.is_tensor(v) else v) for k, v in model.logged.items()}
+                    rec["it/s"] = model.global_step / (time.time() - t0)
+                    self.history.append(rec)
+                    print(" ".join(f"{k}={v:.5g}" if isinstance(v, float) else f"{k}={v}" for k, v in rec.items()), flush=True)
+                if 0 < self.max_steps <= model.global_step:
+                    break
+            epoch += 1
+            done = (0 < self.max_steps <= model.global_step) or (self.max_epochs and epoch >= self.max_epochs)
+            if self.root and self.rank == 0:
+                if epoch % self.every_n_epochs == 0:
+                    save_checkpoint(os.path.join(self.root, f"checkpoint-epoch={epoch - 1:05d}.ckpt"), model, opt, epoch)
+                if done or epoch % self.every_n_epochs == 0:
+                    save_checkpoint(os.path.join(self.root, "last.ckpt"), model, opt, epoch)
+            if done:
+                break
+        return model

@@ -238,6 +238,24 @@ def gen_encoder_grad(name="clip_encoder_grad"):
     save(name, **arrs)
 
 
+def gen_infer(name="clip_inference_api"):
+    """Inference API consumed by the downstream harness (downstream/model.py:34-41), eval mode."""
+    from audiossl.models.atst.audio_transformer import AST_small
+    enc = AST_small()
+    W = O.recipe_weights("small", seed=33)
+    enc.load_state_dict({k[len("student.encoder."):]: v for k, v in W.items() if k.startswith("student.encoder.")})
+    enc.eval()
+    x = O.recipe_mel(2, 1001, seed=35)
+    length = torch.tensor([1001, 700])
+    with torch.no_grad():
+        emb = enc.get_intermediate_layers_chunks(x, length, 2, 601, True)
+        emb_cls = enc.get_intermediate_layers_chunks(x, length, 1, 601, False)
+        layers = enc.get_intermediate_layers(x, length, 2)
+        cls = enc(x, length=length)
+    save(name, length=length.numpy(), emb=emb.numpy(), emb_cls=emb_cls.numpy(), cls=cls.numpy(),
+         layer_last=layers[-1].numpy()[:, ::10, ::4], layer_prev=layers[0].numpy()[:, ::10, ::4])
+
+
 def gen_sched(name="schedules"):
     lr = ref_common.cosine_scheduler_step(5e-4 * 4 * 384 / 256, 1e-6, 39100, 1300)
     wd = ref_common.cosine_scheduler_step(0.04, 0.4, 39100, 0)
@@ -254,7 +272,7 @@ def gen_sched(name="schedules"):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["blocks", "clip2", "clip2_nodrop", "clip6", "frame", "sched", "encgrad", "clip2_b16", "clip2_b64"]
+    which = sys.argv[1:] or ["blocks", "clip2", "clip2_nodrop", "clip6", "frame", "sched", "encgrad", "clip2_b16", "clip2_b64", "infer"]
     if "blocks" in which:
         gen_blocks()
     if "clip2" in which:
@@ -266,6 +284,8 @@ if __name__ == "__main__":
                  [[1001, 1001], [1001, 1001], [101, 101], [101, 77], [101, 101], [101, 101]], seed_x=41)
     if "encgrad" in which:
         gen_encoder_grad()
+    if "infer" in which:
+        gen_infer()
     if "clip2_b16" in which:
         L = [1001] * 16
         L2 = [1001 - 40 * (i % 5) for i in range(16)]
