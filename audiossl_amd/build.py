@@ -13,6 +13,8 @@ SOURCES = ["api.hip", "engine.hip", "gemm.hip", "layernorm.hip", "attention.hip"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
 if os.environ.get("ATST_ABLATE"):          # experiment builds only (tools/gemm_bench.py)
     FLAGS.append("-DATST_ABLATE=" + os.environ["ATST_ABLATE"])
+if os.environ.get("ATST_NT_STORES"):
+    FLAGS.append("-DATST_NT_STORES=" + os.environ["ATST_NT_STORES"])
 
 
 

@@ -12,6 +12,9 @@
 #include "common.h"
 #include "kernels.h"
 #include "profile.h"
+#ifndef ATST_NT_STORES
+#define ATST_NT_STORES 1    // epilogue outputs / residual reads are streamed once: non-temporal, so they do not evict operand panels from L2
+#endif
 #ifndef ATST_ABLATE
 #define ATST_ABLATE 0      // experiment switch (tools only), all without stores: 1 full, 3 loads+ds_read, 4 ds_read+MFMA, 5 loads only, 6 MFMA only
 #endif
@@ -30,14 +33,25 @@ DEVFN void epilogue4(const GemmArgs& p, int row, int col, f32x4 v, f32x4& writte
     bf16x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = f2bf(x[e]);
+#if ATST_NT_STORES
+    __builtin_nontemporal_store(o, reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(base) + i));   // streamed once: keep L2 for operands
+#else
     *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(base) + i) = o;
+#endif
+  };
+  auto st_f32 = [](void* base, size_t i, const f32x4& x) {
+#if ATST_NT_STORES
+    __builtin_nontemporal_store(x, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + i));
+#else
+    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + i) = x;
+#endif
   };
   if constexpr (EPI == EPI_BF16) {
     if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + col);
     st_bf16(p.C, idx, v);
   } else if constexpr (EPI == EPI_F32) {
     if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + col);
-    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + idx) = v;
+    st_f32(p.C, idx, v);
   } else if constexpr (EPI == EPI_BIAS_GELU) {
     v += *reinterpret_cast<const f32x4*>(p.bias + col);
     if (p.C) st_bf16(p.C, idx, v);                                // pre-activation u (saved for backward; skipped in inference)
@@ -47,11 +61,19 @@ DEVFN void epilogue4(const GemmArgs& p, int row, int col, f32x4 v, f32x4& writte
     st_bf16(p.C2, idx, a);                                        // activation a
   } else if constexpr (EPI == EPI_RESID) {
     const float s = p.row_scale ? p.row_scale[row / p.rows_per_seq] : 1.0f;
+#if ATST_NT_STORES
+    const f32x4 r = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p.resid + idx));
+#else
     const f32x4 r = *reinterpret_cast<const f32x4*>(p.resid + idx);
+#endif
     const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + col);
-    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + idx) = r + s * (v + b);
+    st_f32(p.C, idx, r + s * (v + b));
   } else if constexpr (EPI == EPI_DGELU) {
+#if ATST_NT_STORES
+    const bf16x4 u = __builtin_nontemporal_load(reinterpret_cast<const bf16x4*>(p.U + idx));
+#else
     const bf16x4 u = *reinterpret_cast<const bf16x4*>(p.U + idx);
+#endif
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(bf2f(u[e]));
     st_bf16(p.C, idx, v);
@@ -86,6 +108,10 @@ __global__ __launch_bounds__((NtGeo<BMT, NSTG, WTM>::THREADS), (NtGeo<BMT, NSTG,
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1, hi = lane >> 5, l31 = lane & 31;
 
+  if (p.stagger > 0 && blockIdx.x < 256 * G::BLOCKS_PER_CU) {     // experiment: de-phase the first round of co-resident blocks
+    const int ph = (blockIdx.x >> 3) & 3;
+    for (int i = 0; i < ph * p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  }
   const int ntn = p.N / BN;
   const int ntm = (p.M + BMT - 1) / BMT;
   const int id = xcd_remap(blockIdx.x, ntm * ntn);
@@ -434,9 +460,11 @@ int launch_nt(const GemmArgs& a, hipStream_t st) {
 
 }  // namespace
 
-void atst_gemm_nt_set_variant(int v) { if (v >= 100) g_tn_glds = v - 100; else g_nt_variant = v; }
+int g_stagger = 0;
+void atst_gemm_nt_set_variant(int v) { if (v >= 200) g_stagger = v - 200; else if (v >= 100) g_tn_glds = v - 100; else g_nt_variant = v; }
 
-int atst_gemm_nt(const GemmArgs& a, hipStream_t st) {
+int atst_gemm_nt(const GemmArgs& a0, hipStream_t st) {
+  GemmArgs a = a0; a.stagger = g_stagger;
   if (a.M <= 0 || a.N % BN || a.K % BK || a.lda % 8 || a.ldb % 8) return ATST_EINVAL;
   switch (a.epi) {
     case EPI_BF16: return launch_nt<EPI_BF16>(a, st);

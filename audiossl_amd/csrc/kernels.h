@@ -18,6 +18,7 @@ struct GemmArgs {
   const float* table;                // EPI_PATCH: [rows_per_seq, N] per-token additive table
   const uint8_t* rowflag;            // EPI_PATCH: [M] 1 = replace by mask token (or null)
   const float* alt;                  // EPI_PATCH: mask_embed [N]
+  int stagger;                       // experiment knob (0 = off)
   float* colsum;                     // EPI_DGELU: optional fp32 [N] accumulator of the column sums of the output (bias gradient)
 };
 int atst_gemm_nt(const GemmArgs& a, hipStream_t st);
