@@ -259,6 +259,113 @@ __global__ __launch_bounds__((NtGeo<BMT, NSTG, WTM>::THREADS), (NtGeo<BMT, NSTG,
   }
 }
 
+// ---- 128 x 384 tile: 8 waves (2 x 4), each 64 x 96 = 2 x 3 accumulators ---------------------------------------------
+// Every N on this path (384, 1152, 1536, 768...) is a multiple of 384.  Per 32-deep K step the block stages 8 KB of A
+// and 24 KB of B for three 128x128 units of output: 10.7 KB / unit instead of 16 KB for the square tile -- operand
+// staging (L2 -> LDS, ~14 TB/s chip-wide) is what bounds these GEMMs, see DESIGN.md.  For N = 384 one block owns whole
+// output rows.
+namespace row384 {
+constexpr int BMR = 128, BNR = 384, WAVES = 8, THREADS = 512, NSTG = 2;
+constexpr int A_BYTES = BMR * BK * 2, B_BYTES = BNR * BK * 2, STAGE = A_BYTES + B_BYTES;        // 8 + 24 KB
+constexpr int CLD = BNR + 4;
+constexpr int EPI_BYTES = 32 * CLD * 4;                                                           // 49,664 B
+constexpr int LDS = NSTG * STAGE > EPI_BYTES ? NSTG * STAGE : EPI_BYTES;                          // 65,536 B -> 2 blocks / CU
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 4) void gemm_nt_row384_kernel(GemmArgs p) {
+  using namespace row384;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  typedef const void __attribute__((address_space(1))) * gptr_t;
+  typedef void __attribute__((address_space(3))) * lptr_t;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 2, wn = wid & 3, hi = lane >> 5, l31 = lane & 31;
+  const int ntn = p.N / BNR;
+  const int ntm = (p.M + BMR - 1) / BMR;
+  const int id = xcd_remap(blockIdx.x, ntm * ntn);
+  const int m0 = (id / ntn) * BMR, n0 = (id % ntn) * BNR;
+
+  char* lds = smem_raw;
+  const int lrow = lane >> 2, lchunk = lane & 3;
+  const bf16* srcA; const bf16* srcB[3];
+  {
+    const int row = wid * 16 + lrow;
+    int ra = m0 + row; ra = ra < p.M ? ra : p.M - 1;
+    srcA = p.A + (size_t)ra * p.lda + (lchunk ^ ((row >> 2) & 3)) * 8;
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int row = (wid * 3 + j) * 16 + lrow;
+    srcB[j] = p.B + (size_t)(n0 + row) * p.ldb + (lchunk ^ ((row >> 2) & 3)) * 8;
+  }
+  auto issue = [&](int kt) {
+    char* st = lds + (kt % NSTG) * STAGE;
+    __builtin_amdgcn_global_load_lds((gptr_t)(srcA + kt * BK), (lptr_t)(st + wid * 1024), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcB[j] + kt * BK), (lptr_t)(st + A_BYTES + (wid * 3 + j) * 1024), 16, 0, 0);
+  };
+  f32x16 acc[2][3];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = p.K / BK;
+  const int xr = (l31 >> 2) & 3;
+  const int offA = (wm * 64 + l31) * 64, offB = A_BYTES + (wn * 96 + l31) * 64;
+  issue(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // tile kt landed everywhere; stage (kt-1)&1 free
+    if (kt + 1 < nk) issue(kt + 1);
+    const char* st = lds + (kt % NSTG) * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      const int co = ((ks * 2 + hi) ^ xr) << 4;
+      const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(st + offA + co), a1 = *reinterpret_cast<const bf16x8*>(st + offA + 32 * 64 + co);
+      bf16x8 bf[3];
+#pragma unroll
+      for (int ni = 0; ni < 3; ++ni) bf[ni] = *reinterpret_cast<const bf16x8*>(st + offB + ni * 32 * 64 + co);
+#pragma unroll
+      for (int ni = 0; ni < 3; ++ni) {
+        acc[0][ni] = mfma32(a0, bf[ni], acc[0][ni]);
+        acc[1][ni] = mfma32(a1, bf[ni], acc[1][ni]);
+      }
+    }
+  }
+  asm volatile("s_barrier" ::: "memory");
+
+  // epilogue: 32 output rows at a time through LDS, full 384-column rows, 16-B accesses
+  float* sC = reinterpret_cast<float*>(smem_raw);
+#pragma unroll
+  for (int part = 0; part < 4; ++part) {
+    if (wm == (part >> 1)) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        if (mi != (part & 1)) continue;
+#pragma unroll
+        for (int ni = 0; ni < 3; ++ni)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            sC[crow32(r, hi) * CLD + wn * 96 + ni * 32 + l31] = acc[mi][ni][r];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int idx = tid + THREADS * i, rl = idx / 96, c4 = (idx % 96) * 4;
+      const int row = m0 + part * 32 + rl;
+      if (row < p.M) {
+        f32x4 wv;
+        epilogue4<EPI>(p, row, n0 + c4, *reinterpret_cast<const f32x4*>(sC + rl * CLD + c4), wv);
+      }
+    }
+    if (part < 3) __syncthreads();
+  }
+}
+
 // ---- wgrad: dW[n,k] += sum_m dY[m,n] X[m,k] -------------------------------------------------------------------------
 constexpr int WM = 64;                          // contraction rows per stage
 constexpr int W_LD = 128 + 16;                  // 144 bf16 = 288 B row stride
@@ -431,6 +538,7 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_glds_kernel(WgradArgs p) {
     }
 }
 
+int g_row384_auto = 1;      // use the 128x384 tile whenever N % 384 == 0 (tuning hook 300 turns it off)
 int g_tn_glds = 0;        // wgrad: 1 = LDS-DMA kernel when shapes allow (tuning hook 101); measured 7 % slower than register staging
 int g_nt_variant = -1;    // -1 auto ; 0: 128x128 2-stage ; 1: 128x128 3-stage ; 2: 256x128 8 waves ; 3: 256x128 4 waves of 128x64
 
@@ -449,8 +557,24 @@ int launch_nt_cfg(const GemmArgs& a, hipStream_t st) {
   return (int)hipGetLastError();
 }
 template <int EPI>
+int launch_nt_row384(const GemmArgs& a, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_row384_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, row384::LDS);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  const int nblk = ((a.M + row384::BMR - 1) / row384::BMR) * (a.N / row384::BNR);
+  ProfScope ps(PK_GEMM_NT0 + EPI, 2.0 * a.M * a.N * a.K, st);
+  hipLaunchKernelGGL(gemm_nt_row384_kernel<EPI>, dim3(nblk), dim3(row384::THREADS), row384::LDS, st, a);
+  return (int)hipGetLastError();
+}
+template <int EPI>
 int launch_nt(const GemmArgs& a, hipStream_t st) {
   int v = g_nt_variant;
+  if constexpr (EPI != EPI_DGELU) {
+    if ((v == 4 || (v < 0 && g_row384_auto)) && a.N % 384 == 0) return launch_nt_row384<EPI>(a, st);
+  }
   if (v < 0) v = a.K <= 512 ? 0 : 1;
   if (v == 3) return launch_nt_cfg<EPI, 256, 3, 128>(a, st);
   if (v == 2) return launch_nt_cfg<EPI, 256, 3, 64>(a, st);
@@ -461,7 +585,7 @@ int launch_nt(const GemmArgs& a, hipStream_t st) {
 }  // namespace
 
 int g_stagger = 0;
-void atst_gemm_nt_set_variant(int v) { if (v >= 200) g_stagger = v - 200; else if (v >= 100) g_tn_glds = v - 100; else g_nt_variant = v; }
+void atst_gemm_nt_set_variant(int v) { if (v >= 300) g_row384_auto = v - 300; else if (v >= 200) g_stagger = v - 200; else if (v >= 100) g_tn_glds = v - 100; else g_nt_variant = v; }
 
 int atst_gemm_nt(const GemmArgs& a0, hipStream_t st) {
   GemmArgs a = a0; a.stagger = g_stagger;
