@@ -67,10 +67,12 @@ inline const bf16* B16(const uint16_t* p) { return reinterpret_cast<const bf16*>
 
 int gemm(const bf16* A, const bf16* B, int M, int N, int K, int epi, void* C, hipStream_t st, const float* bias = nullptr,
          const float* resid = nullptr, const float* row_scale = nullptr, int rps = 1, void* C2 = nullptr,
-         const bf16* U = nullptr, float* colsum = nullptr) {
+         const bf16* U = nullptr, float* colsum = nullptr, const float* ln_g = nullptr, const float* ln_b = nullptr,
+         bf16* ln_out = nullptr, float* ln_mean = nullptr, float* ln_rstd = nullptr) {
   GemmArgs a{};
   a.A = A; a.B = B; a.M = M; a.N = N; a.K = K; a.lda = K; a.ldb = K; a.epi = epi; a.C = C; a.ldc = N; a.C2 = C2;
   a.bias = bias; a.resid = resid; a.row_scale = row_scale; a.rows_per_seq = rps; a.U = U; a.colsum = colsum;
+  a.ln_gamma = ln_g; a.ln_beta = ln_b; a.ln_out = ln_out; a.ln_mean = ln_mean; a.ln_rstd = ln_rstd;
   return atst_gemm_nt(a, st);
 }
 int wgrad(const bf16* dY, const bf16* X, int M, int N, int K, float* dW, hipStream_t st) {
@@ -114,6 +116,7 @@ extern "C" int atst_encoder_fwd(const atst_encoder_t* e, void* stream) {
   const float* p = e->p32; const bf16* q = B16(e->p16);
   const atst_enc_off_t& o = e->off;
 
+  const bool fuse_ln = C == 384;                    // N == 384: the residual GEMM blocks own whole rows
   RUN(atst_patchify(e->mel, S, e->width, NP, e->use_cls, w.patches, st));
   RUN(atst_token_table(e->use_cls ? p + o.cls_token : nullptr, p + o.pos_embed, p + o.patch_b, NP, e->n_tok, C, e->use_cls, w.table, st));
   {
@@ -128,17 +131,30 @@ extern "C" int atst_encoder_fwd(const atst_encoder_t* e, void* stream) {
     const LayerWs& l = w.L[i];
     const float* s1 = e->dp_scale ? e->dp_scale + (size_t)(2 * i) * S : nullptr;
     const float* s2 = e->dp_scale ? e->dp_scale + (size_t)(2 * i + 1) * S : nullptr;
-    RUN(atst_ln_fwd(w.x[2 * i], p + lo.ln1_w, p + lo.ln1_b, l.h1, l.mean1, l.rstd1, M, C, st));
+    if (i == 0 || !fuse_ln) RUN(atst_ln_fwd(w.x[2 * i], p + lo.ln1_w, p + lo.ln1_b, l.h1, l.mean1, l.rstd1, M, C, st));
     RUN(gemm(l.h1, q + lo.qkv_w, M, 3 * C, C, EPI_BF16, l.qkv, st));
     AttnArgs at{};
     at.qkv = l.qkv; at.valid = e->valid; at.o = l.o; at.lse = l.lse; at.S = S; at.H = e->H; at.NP = NP;
     RUN(atst_attn_fwd(at, st));
-    RUN(gemm(l.o, q + lo.proj_w, M, C, C, EPI_RESID, w.x[2 * i + 1], st, p + lo.proj_b, w.x[2 * i], s1, NP));
-    RUN(atst_ln_fwd(w.x[2 * i + 1], p + lo.ln2_w, p + lo.ln2_b, l.h2, l.mean2, l.rstd2, M, C, st));
+    if (fuse_ln) {                                  // proj + residual + LN2 in one kernel
+      RUN(gemm(l.o, q + lo.proj_w, M, C, C, EPI_RESID, w.x[2 * i + 1], st, p + lo.proj_b, w.x[2 * i], s1, NP, nullptr, nullptr,
+               nullptr, p + lo.ln2_w, p + lo.ln2_b, l.h2, l.mean2, l.rstd2));
+    } else {
+      RUN(gemm(l.o, q + lo.proj_w, M, C, C, EPI_RESID, w.x[2 * i + 1], st, p + lo.proj_b, w.x[2 * i], s1, NP));
+      RUN(atst_ln_fwd(w.x[2 * i + 1], p + lo.ln2_w, p + lo.ln2_b, l.h2, l.mean2, l.rstd2, M, C, st));
+    }
     RUN(gemm(l.h2, q + lo.fc1_w, M, 4 * C, C, EPI_BIAS_GELU, e->train ? l.u : nullptr, st, p + lo.fc1_b, nullptr, nullptr, 1, l.a));
-    RUN(gemm(l.a, q + lo.fc2_w, M, C, 4 * C, EPI_RESID, w.x[2 * i + 2], st, p + lo.fc2_b, w.x[2 * i + 1], s2, NP));
+    if (fuse_ln) {                                  // fc2 + residual + (LN1 of the next block | final norm)
+      const bool last = i + 1 == e->depth;
+      const LayerWs& nl = w.L[last ? i : i + 1];
+      RUN(gemm(l.a, q + lo.fc2_w, M, C, 4 * C, EPI_RESID, w.x[2 * i + 2], st, p + lo.fc2_b, w.x[2 * i + 1], s2, NP, nullptr, nullptr,
+               nullptr, p + (last ? o.norm_w : o.layer[i + 1].ln1_w), p + (last ? o.norm_b : o.layer[i + 1].ln1_b),
+               last ? w.hN : nl.h1, last ? w.meanN : nl.mean1, last ? w.rstdN : nl.rstd1));
+    } else {
+      RUN(gemm(l.a, q + lo.fc2_w, M, C, 4 * C, EPI_RESID, w.x[2 * i + 2], st, p + lo.fc2_b, w.x[2 * i + 1], s2, NP));
+    }
   }
-  RUN(atst_ln_fwd(w.x[2 * e->depth], p + o.norm_w, p + o.norm_b, w.hN, w.meanN, w.rstdN, M, C, st));
+  if (!fuse_ln) RUN(atst_ln_fwd(w.x[2 * e->depth], p + o.norm_w, p + o.norm_b, w.hN, w.meanN, w.rstdN, M, C, st));
   return ATST_OK;
 }
 

@@ -353,6 +353,48 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_row384_kernel(GemmArgs p) {
       }
     }
     __syncthreads();
+    if constexpr (EPI == EPI_RESID) {
+      if (p.ln_out) {
+        // Fused residual + LayerNorm of the NEXT sub-layer (N == 384: the block owns whole rows): one wave per row,
+        // x_new = resid + s (acc + bias) -> fp32 stream ; h = LN(x_new) -> bf16 operand of the next GEMM ; row statistics
+        // saved for the LayerNorm backward.  Replaces a separate HBM pass (ln_fwd_kernel) over x.
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int rl = wid * 4 + q, row = m0 + part * 32 + rl;
+          if (row >= p.M) continue;
+          const float sc = p.row_scale ? p.row_scale[row / p.rows_per_seq] : 1.0f;
+          float v[6];
+          float sum = 0.f;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const int col = k * 128 + lane * 2;
+            const f32x2 a2 = *reinterpret_cast<const f32x2*>(sC + rl * CLD + col);
+            const f32x2 r2 = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p.resid + (size_t)row * p.ldc + col));
+            const f32x2 b2 = *reinterpret_cast<const f32x2*>(p.bias + col);
+            f32x2 o = r2 + sc * (a2 + b2);
+            __builtin_nontemporal_store(o, reinterpret_cast<f32x2*>(reinterpret_cast<float*>(p.C) + (size_t)row * p.ldc + col));
+            v[2 * k] = o[0]; v[2 * k + 1] = o[1]; sum += o[0] + o[1];
+          }
+          const float mu = wave_sum(sum) * (1.0f / 384.0f);
+          float qd = 0.f;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) { const float d = v[k] - mu; qd += d * d; }
+          const float rs = rsqrtf(wave_sum(qd) * (1.0f / 384.0f) + 1e-6f);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const int col = k * 128 + lane * 2;
+            const f32x2 g2 = *reinterpret_cast<const f32x2*>(p.ln_gamma + col), be2 = *reinterpret_cast<const f32x2*>(p.ln_beta + col);
+            bf16x2 h;
+            h[0] = f2bf((v[2 * k] - mu) * rs * g2[0] + be2[0]);
+            h[1] = f2bf((v[2 * k + 1] - mu) * rs * g2[1] + be2[1]);
+            *reinterpret_cast<bf16x2*>(p.ln_out + (size_t)row * 384 + col) = h;
+          }
+          if (lane == 0) { p.ln_mean[row] = mu; p.ln_rstd[row] = rs; }
+        }
+        if (part < 3) __syncthreads();
+        continue;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       const int idx = tid + THREADS * i, rl = idx / 96, c4 = (idx % 96) * 4;
@@ -571,6 +613,10 @@ int launch_nt_row384(const GemmArgs& a, hipStream_t st) {
 }
 template <int EPI>
 int launch_nt(const GemmArgs& a, hipStream_t st) {
+  if (a.ln_out) {                                                 // fused LayerNorm needs the block to own whole rows
+    if (EPI != EPI_RESID || a.N != 384 || !a.ln_gamma || !a.ln_beta || !a.ln_mean || !a.ln_rstd) return ATST_EINVAL;
+    if constexpr (EPI == EPI_RESID) return launch_nt_row384<EPI>(a, st);
+  }
   int v = g_nt_variant;
   if constexpr (EPI != EPI_DGELU) {
     if ((v == 4 || (v < 0 && g_row384_auto)) && a.N % 384 == 0) return launch_nt_row384<EPI>(a, st);
