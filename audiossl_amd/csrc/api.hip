@@ -11,7 +11,7 @@
 extern "C" {
 
 int atst_version(void) { return 100; }
-int atst_tune_gemm_variant(int v) { atst_gemm_nt_set_variant(v); return 0; }
+int atst_tune_gemm_variant(int v) { if (v >= 400) atst_attn_set_variant(v - 400); else atst_gemm_nt_set_variant(v); return 0; }
 
 int atst_mel_frontend_f32(const float* wave, int n_clips, int n_samples, int win_length, const float* window,
                           const float* fb_weights, const int* fb_start, const int* fb_len, int fb_maxlen,

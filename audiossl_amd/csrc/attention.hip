@@ -129,6 +129,103 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Forward, NP = 256, one block (8 waves) per SEQUENCE looping over its heads: K/V of head h+1 (and the next Q fragments)
+// are fetched into registers while head h is computed and are written to the other LDS buffer afterwards, so the HBM
+// latency of the 64 KB K/V panel is hidden behind the MFMAs of the previous head (the per-(sequence, head) kernel above
+// exposes it once per block).  Wave w owns the 32-query chunk w.
+constexpr int F256_BUF = 2 * 256 * A_LD * 2;            // bytes of one K+V buffer (73,728)
+
+__global__ __launch_bounds__(512, 2) void attn_fwd256_kernel(AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int NP = 256;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+  const int H = p.H, C = H * HD;
+  const size_t ld = 3 * (size_t)C;
+  const int s = blockIdx.x;
+  const bf16* base = p.qkv + (size_t)s * NP * ld;
+  const int valid = p.valid[s];
+  const int ntile = (valid + 31) / 32 < 8 ? (valid + 31) / 32 : 8;
+  const float scale = 0.125f;
+  const int q0 = wid * 32;
+
+  bf16x8 stg[8], qn[4];
+  auto gload = [&](int h) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = tid + 512 * i, mat = c >> 11, r = (c >> 3) & 255, k = (c & 7) * 8;
+      stg[i] = ld_frag(base + (size_t)r * ld + (1 + mat) * C + h * HD + k);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qn[ks] = ld_frag(base + (size_t)(q0 + l31) * ld + h * HD + ks * 16 + hi * 8);
+  };
+  auto swrite = [&](int buf) {
+    bf16* dst = reinterpret_cast<bf16*>(smem_raw + buf * F256_BUF);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = tid + 512 * i, mat = c >> 11, r = (c >> 3) & 255, k = (c & 7) * 8;
+      *reinterpret_cast<bf16x8*>(dst + mat * (NP * A_LD) + r * A_LD + k) = stg[i];
+    }
+  };
+  gload(0);
+  swrite(0);
+  __syncthreads();
+  for (int h = 0; h < H; ++h) {
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = qn[ks];
+    if (h + 1 < H) gload(h + 1);                                   // in flight during this head's MFMAs
+    const bf16* sK = reinterpret_cast<const bf16*>(smem_raw + (h & 1) * F256_BUF);
+    const bf16* sV = sK + NP * A_LD;
+    float m_run = -1e30f, l_run = 0.f;
+    f32x16 o0, o1; zero16(o0); zero16(o1);
+    for (int j = 0; j < ntile; ++j) {
+      f32x16 sc; zero16(sc);
+      const bf16* kr = sK + (j * 32 + l31) * A_LD + hi * 8;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) sc = mfma32(ld_frag(kr + ks * 16), qf[ks], sc);
+      float pv[16];
+      float mx = -1e30f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kv = j * 32 + crow32(r, hi);
+        pv[r] = sc[r] * scale + (kv >= valid ? MASK_NEG : 0.f);
+        mx = fmaxf(mx, pv[r]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = exp2f((m_run - m_new) * LOG2E);
+      float rs = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { pv[r] = exp2f((pv[r] - m_new) * LOG2E); rs += pv[r]; }
+      rs += __shfl_xor(rs, 32, 64);
+      l_run = l_run * alpha + rs;
+      m_run = m_new;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const bf16x8 pf = pack8(pv + 8 * t);
+        o0 = mfma32(ld_frag_tr(sV, A_LD, j * 32 + 16 * t, 0, lane), pf, o0);
+        o1 = mfma32(ld_frag_tr(sV, A_LD, j * 32 + 16 * t, 32, lane), pf, o1);
+      }
+    }
+    const float inv = 1.0f / l_run;
+    bf16* orow = p.o + ((size_t)s * NP + q0 + l31) * C + h * HD;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 a, b;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { a[e] = f2bf(o0[4 * g + e] * inv); b[e] = f2bf(o1[4 * g + e] * inv); }
+      *reinterpret_cast<bf16x4*>(orow + 8 * g + 4 * hi) = a;
+      *reinterpret_cast<bf16x4*>(orow + 32 + 8 * g + 4 * hi) = b;
+    }
+    if (hi == 0) p.lse[((size_t)s * H + h) * NP + q0 + l31] = m_run + __logf(l_run);
+    if (h + 1 < H) swrite((h + 1) & 1);                            // buffer (h+1)&1 was last read for head h-1
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // backward part 1: dK, dV.  LDS: Q [NP][72], dO [NP][72], lse[NP], D[NP] per pair.
 template <int NP>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
@@ -350,8 +447,22 @@ int launch_bwd(const AttnArgs& a, hipStream_t st) {
 }
 }  // namespace
 
+int g_fwd256 = 1;          // per-sequence head-loop kernel for NP = 256 (tuning hook 400 turns it off)
+void atst_attn_set_variant(int v) { g_fwd256 = v; }
+
 int atst_attn_fwd(const AttnArgs& a, hipStream_t st) {
   if (a.S <= 0) return ATST_OK;
+  if (a.NP == 256 && g_fwd256) {
+    static bool done = false;
+    if (!done) {
+      hipError_t e = hipFuncSetAttribute((const void*)attn_fwd256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * F256_BUF);
+      if (e != hipSuccess) return (int)e;
+      done = true;
+    }
+    ProfScope ps(PK_ATTN_FWD, 4.0 * a.S * a.H * 256.0 * 256.0 * HD, st);
+    hipLaunchKernelGGL(attn_fwd256_kernel, dim3(a.S), dim3(512), 2 * F256_BUF, st, a);
+    return (int)hipGetLastError();
+  }
   switch (a.NP) {
     case 256: return launch_fwd<256>(a, st);
     case 128: return launch_fwd<128>(a, st);

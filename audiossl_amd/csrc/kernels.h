@@ -61,6 +61,7 @@ struct AttnArgs {
 };
 int atst_attn_fwd(const AttnArgs& a, hipStream_t st);
 int atst_attn_bwd(const AttnArgs& a, hipStream_t st);
+void atst_attn_set_variant(int v);
 
 // token plumbing
 int atst_patchify(const float* mel, int S, int width, int NP, int use_cls, bf16* out, hipStream_t st);

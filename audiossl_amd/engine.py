@@ -294,7 +294,7 @@ class AtstEngine:
         self._stats = torch.zeros(4, HEAD_OUT, device=dev)
         self._student_groups = None
         self._grads_summed = False
-        self.overlap_teacher = True
+        self.overlap_teacher = False     # side-stream teacher pass: measured no gain (full-chip kernels serialise), off by default
         self._side = torch.cuda.Stream(device=self.device)
 
     # ---------------------------------------------------------------------------------------------------------------

@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="clips per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--no-overlap", action="store_true", help="run the teacher pass on the main stream")
+    ap.add_argument("--overlap", action="store_true", help="run the teacher pass on a second HIP stream")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -119,7 +119,7 @@ def main():
     ncrops = 6 if args.workload == "clip6" else 2
     eng = AtstEngine("small", frame=frame, ncrops=ncrops)
     eng.init_weights(seed=0)
-    eng.overlap_teacher = not args.no_overlap
+    eng.overlap_teacher = args.overlap
     fe = LogMelFrontend(1024 if not frame else 640)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     buf = torch.clamp(0.1 * torch.randn(B, 192000, device=dev, generator=g), -1.0, 1.0)      # 12 s, resident in HBM
