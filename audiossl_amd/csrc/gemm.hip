@@ -492,6 +492,90 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(WgradArgs p) {
     }
 }
 
+// ---- wgrad, 128 x 384 output tile: 8 waves (2 x 4), each 64 x 96 -----------------------------------------------------
+// Same register-staged / transpose-read scheme as gemm_tn_kernel, but one block covers 128 n x 384 k of dW, so the
+// operands staged per contraction row drop from 512 B per 128x128 unit to 1024 B per three units (K is 384 or 1536 on
+// this path).  32 contraction rows per stage, 2 stages, 69.6 KB LDS -> 2 blocks / CU.
+namespace tn384 {
+constexpr int RM = 32, Y_LD = 128 + 16, X_LD = 384 + 16;             // 288-B and 800-B rows: both = 8 dwords mod 64 banks
+constexpr int Y_TILE = RM * Y_LD, X_TILE = RM * X_LD, STAGE = Y_TILE + X_TILE;   // elements
+constexpr int LDS = 2 * STAGE * 2;                                    // 69,632 B
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_tn_row384_kernel(WgradArgs p) {
+  using namespace tn384;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  bf16* smem = reinterpret_cast<bf16*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wn = wid >> 2, wk = wid & 3, hi = lane >> 5, l31 = lane & 31;
+  const int ntn = p.N / 128, ntk = p.K / 384;
+  const int tile = blockIdx.x % (ntn * ntk), split = blockIdx.x / (ntn * ntk);
+  const int n0 = (tile / ntk) * 128, k0 = (tile % ntk) * 384;
+  const int m_begin = split * p.m_per_split;
+  int m_end = m_begin + p.m_per_split; if (m_end > p.M) m_end = p.M;
+  if (m_begin >= m_end) return;
+  const int nst = (m_end - m_begin + RM - 1) / RM;
+
+  // staging map: thread t moves dY chunk t and X chunks t, t+512, t+1024 (16 B each)
+  const int yr = tid >> 4, yc = (tid & 15) * 8;
+  int xr[3], xc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { const int c = tid + 512 * i; xr[i] = c / 48; xc[i] = (c % 48) * 8; }
+  bf16x8 ry, rx[3];
+  auto gload = [&](int st) {
+    const int mb = m_begin + st * RM;
+    bf16x8 z;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) z[e] = f2bf(0.f);
+    ry = (mb + yr < m_end) ? ld_frag(p.dY + (size_t)(mb + yr) * p.ldy + n0 + yc) : z;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) rx[i] = (mb + xr[i] < m_end) ? ld_frag(p.X + (size_t)(mb + xr[i]) * p.ldx + k0 + xc[i]) : z;
+  };
+  auto swrite = [&](int buf) {
+    bf16* sY = smem + buf * STAGE; bf16* sX = sY + Y_TILE;
+    *reinterpret_cast<bf16x8*>(sY + yr * Y_LD + yc) = ry;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) *reinterpret_cast<bf16x8*>(sX + xr[i] * X_LD + xc[i]) = rx[i];
+  };
+  f32x16 acc[2][3];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  gload(0);
+  swrite(0);
+  __syncthreads();
+  for (int st = 0; st < nst; ++st) {
+    const int buf = st & 1;
+    if (st + 1 < nst) gload(st + 1);
+    const bf16* sY = smem + buf * STAGE; const bf16* sX = sY + Y_TILE;
+#pragma unroll
+    for (int ms = 0; ms < RM / 16; ++ms) {
+      const bf16x8 a0 = ld_frag_tr(sY, Y_LD, ms * 16, wn * 64, lane), a1 = ld_frag_tr(sY, Y_LD, ms * 16, wn * 64 + 32, lane);
+#pragma unroll
+      for (int ki = 0; ki < 3; ++ki) {
+        const bf16x8 b = ld_frag_tr(sX, X_LD, ms * 16, wk * 96 + ki * 32, lane);
+        acc[0][ki] = mfma32(a0, b, acc[0][ki]);
+        acc[1][ki] = mfma32(a1, b, acc[1][ki]);
+      }
+    }
+    if (st + 1 < nst) swrite(buf ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + wn * 64 + ni * 32 + crow32(r, hi);
+#pragma unroll
+      for (int ki = 0; ki < 3; ++ki)
+        atomicAdd(p.dW + (size_t)n * p.ldw + k0 + wk * 96 + ki * 32 + l31, acc[ni][ki][r]);
+    }
+}
+
 // ---- wgrad, LDS-DMA pipeline -----------------------------------------------------------------------------------------
 // Same math as gemm_tn_kernel, for the common case where every split is a whole number of 32-row stages: both operand
 // tiles ([32 m][128] bf16, 256-B rows) go HBM/L2 -> LDS by global_load_lds (2-stage ring, 32 KB, 4 blocks / CU); the
@@ -581,6 +665,7 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_glds_kernel(WgradArgs p) {
 }
 
 int g_row384_auto = 1;      // use the 128x384 tile whenever N % 384 == 0 (tuning hook 300 turns it off)
+int g_tn_wide = 0;        // wgrad: 128x384 output tiles when K % 384 == 0 (tuning hook 103 = on); measured no net gain over 128x128
 int g_tn_glds = 0;        // wgrad: 1 = LDS-DMA kernel when shapes allow (tuning hook 101); measured 7 % slower than register staging
 int g_nt_variant = -1;    // -1 auto ; 0: 128x128 2-stage ; 1: 128x128 3-stage ; 2: 256x128 8 waves ; 3: 256x128 4 waves of 128x64
 
@@ -631,7 +716,7 @@ int launch_nt(const GemmArgs& a, hipStream_t st) {
 }  // namespace
 
 int g_stagger = 0;
-void atst_gemm_nt_set_variant(int v) { if (v >= 300) g_row384_auto = v - 300; else if (v >= 200) g_stagger = v - 200; else if (v >= 100) g_tn_glds = v - 100; else g_nt_variant = v; }
+void atst_gemm_nt_set_variant(int v) { if (v >= 300) g_row384_auto = v - 300; else if (v >= 200) g_stagger = v - 200; else if (v >= 102) g_tn_wide = v - 102; else if (v >= 100) g_tn_glds = v - 100; else g_nt_variant = v; }
 
 int atst_gemm_nt(const GemmArgs& a0, hipStream_t st) {
   GemmArgs a = a0; a.stagger = g_stagger;
@@ -649,26 +734,31 @@ int atst_gemm_nt(const GemmArgs& a0, hipStream_t st) {
 
 int atst_gemm_tn(const WgradArgs& a, hipStream_t st) {
   if (a.M <= 0 || a.N % 128 || a.K % 128 || a.ldy % 8 || a.ldx % 8) return ATST_EINVAL;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WGRAD_LDS_BYTES);
-    if (e != hipSuccess) return (int)e;
-    attr_done = true;
-  }
   WgradArgs p = a;
+  const bool wide = g_tn_wide && a.K % 384 == 0;                  // 128 x 384 output tiles
+  const int tiles = wide ? (a.N / 128) * (a.K / 384) : (a.N / 128) * (a.K / 128);
   if (p.m_per_split <= 0) {
-    // aim for ~4 blocks per CU; keep splits a multiple of the stage depth
-    const int tiles = (a.N / 128) * (a.K / 128);
-    int splits = (1024 + tiles - 1) / tiles;
+    // aim for a few blocks per CU; keep splits a multiple of the stage depth
+    int splits = ((wide ? 768 : 1024) + tiles - 1) / tiles;
     int mps = (a.M + splits - 1) / splits;
     mps = ((mps + WM - 1) / WM) * WM;
     if (mps < 4 * WM) mps = 4 * WM;
     p.m_per_split = mps;
   }
   const int splits = (p.M + p.m_per_split - 1) / p.m_per_split;
-  const int nblk = (p.N / 128) * (p.K / 128) * splits;
+  const int nblk = tiles * splits;
   ProfScope ps(PK_GEMM_TN, 2.0 * p.M * p.N * p.K, st);
-  if (p.M % GM == 0 && p.m_per_split % GM == 0 && g_tn_glds)
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WGRAD_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_tn_row384_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, tn384::LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_tn_glds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WGRAD_GLDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  if (wide)
+    hipLaunchKernelGGL(gemm_tn_row384_kernel, dim3(nblk), dim3(512), tn384::LDS, st, p);
+  else if (p.M % GM == 0 && p.m_per_split % GM == 0 && g_tn_glds)
     hipLaunchKernelGGL(gemm_tn_glds_kernel, dim3(nblk), dim3(256), WGRAD_GLDS_BYTES, st, p);
   else
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(nblk), dim3(256), WGRAD_LDS_BYTES, st, p);
