@@ -666,6 +666,7 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_glds_kernel(WgradArgs p) {
 
 int g_row384_auto = 1;      // use the 128x384 tile whenever N % 384 == 0 (tuning hook 300 turns it off)
 int g_tn_wide = 0;        // wgrad: 128x384 output tiles when K % 384 == 0 (tuning hook 103 = on); measured no net gain over 128x128
+int g_tn_rounds = 1;      // wgrad grid = this many rounds of 512 resident blocks (tuning hook 110 + r); 1 measured best (-20 %)
 int g_tn_glds = 0;        // wgrad: 1 = LDS-DMA kernel when shapes allow (tuning hook 101); measured 7 % slower than register staging
 int g_nt_variant = -1;    // -1 auto ; 0: 128x128 2-stage ; 1: 128x128 3-stage ; 2: 256x128 8 waves ; 3: 256x128 4 waves of 128x64
 
@@ -716,7 +717,7 @@ int launch_nt(const GemmArgs& a, hipStream_t st) {
 }  // namespace
 
 int g_stagger = 0;
-void atst_gemm_nt_set_variant(int v) { if (v >= 300) g_row384_auto = v - 300; else if (v >= 200) g_stagger = v - 200; else if (v >= 102) g_tn_wide = v - 102; else if (v >= 100) g_tn_glds = v - 100; else g_nt_variant = v; }
+void atst_gemm_nt_set_variant(int v) { if (v >= 300) g_row384_auto = v - 300; else if (v >= 200) g_stagger = v - 200; else if (v >= 110) g_tn_rounds = v - 110; else if (v >= 102) g_tn_wide = v - 102; else if (v >= 100) g_tn_glds = v - 100; else g_nt_variant = v; }
 
 int atst_gemm_nt(const GemmArgs& a0, hipStream_t st) {
   GemmArgs a = a0; a.stagger = g_stagger;
@@ -739,7 +740,10 @@ int atst_gemm_tn(const WgradArgs& a, hipStream_t st) {
   const int tiles = wide ? (a.N / 128) * (a.K / 384) : (a.N / 128) * (a.K / 128);
   if (p.m_per_split <= 0) {
     // aim for a few blocks per CU; keep splits a multiple of the stage depth
-    int splits = ((wide ? 768 : 1024) + tiles - 1) / tiles;
+    // 2 blocks / CU are resident (512 slots): pick the split count so that the grid is just under a whole number of
+    // rounds (a 1044-block grid costs three rounds for two rounds of work)
+    int splits = (g_tn_rounds * 512) / tiles;
+    if (splits < 1) splits = 1;
     int mps = (a.M + splits - 1) / splits;
     mps = ((mps + WM - 1) / WM) * WM;
     if (mps < 4 * WM) mps = 4 * WM;
