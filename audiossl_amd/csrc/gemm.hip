@@ -265,16 +265,21 @@ __global__ __launch_bounds__((NtGeo<BMT, NSTG, WTM>::THREADS), (NtGeo<BMT, NSTG,
 // staging (L2 -> LDS, ~14 TB/s chip-wide) is what bounds these GEMMs, see DESIGN.md.  For N = 384 one block owns whole
 // output rows.
 namespace row384 {
-constexpr int BMR = 128, BNR = 384, WAVES = 8, THREADS = 512, NSTG = 2;
-constexpr int A_BYTES = BMR * BK * 2, B_BYTES = BNR * BK * 2, STAGE = A_BYTES + B_BYTES;        // 8 + 24 KB
-constexpr int CLD = BNR + 4;
-constexpr int EPI_BYTES = 32 * CLD * 4;                                                           // 49,664 B
-constexpr int LDS = NSTG * STAGE > EPI_BYTES ? NSTG * STAGE : EPI_BYTES;                          // 65,536 B -> 2 blocks / CU
+constexpr int BNR = 384, WAVES = 8, THREADS = 512, NSTG = 2, CLD = BNR + 4;
+constexpr int B_BYTES = BNR * BK * 2, EPI_BYTES = 32 * CLD * 4;                                   // 24 KB ; 49,664 B
+template <int MI> struct Geo {                 // MI = 32-row accumulator blocks per wave: 2 -> 128-row tile, 4 -> 256-row tile
+  static constexpr int BMR = 64 * MI, A_BYTES = BMR * BK * 2, STAGE = A_BYTES + B_BYTES;         // 32 KB / 40 KB per stage
+  static constexpr int LDS = NSTG * STAGE > EPI_BYTES ? NSTG * STAGE : EPI_BYTES;                // 64 KB / 80 KB -> 2 blocks / CU
+  static constexpr int A_IPW = (BMR / 16) / WAVES;                                               // 1 or 2 A load instructions per wave
+};
 }
 
-template <int EPI>
-__global__ __launch_bounds__(512, 4) void gemm_nt_row384_kernel(GemmArgs p) {
+// MI = 4 (256 x 384 tile, each wave 128 x 96 = 12 accumulators): 40 KB staged per 6 units of output = 6.7 KB / unit.
+template <int EPI, int MI>
+__global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(GemmArgs p) {
   using namespace row384;
+  using RG = row384::Geo<MI>;
+  constexpr int BMR = RG::BMR, A_BYTES = RG::A_BYTES, STAGE = RG::STAGE;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   typedef const void __attribute__((address_space(1))) * gptr_t;
   typedef void __attribute__((address_space(3))) * lptr_t;
@@ -287,11 +292,12 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_row384_kernel(GemmArgs p) {
 
   char* lds = smem_raw;
   const int lrow = lane >> 2, lchunk = lane & 3;
-  const bf16* srcA; const bf16* srcB[3];
-  {
-    const int row = wid * 16 + lrow;
+  const bf16* srcA[RG::A_IPW]; const bf16* srcB[3];
+#pragma unroll
+  for (int j = 0; j < RG::A_IPW; ++j) {
+    const int row = (wid * RG::A_IPW + j) * 16 + lrow;
     int ra = m0 + row; ra = ra < p.M ? ra : p.M - 1;
-    srcA = p.A + (size_t)ra * p.lda + (lchunk ^ ((row >> 2) & 3)) * 8;
+    srcA[j] = p.A + (size_t)ra * p.lda + (lchunk ^ ((row >> 2) & 3)) * 8;
   }
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
@@ -300,14 +306,16 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_row384_kernel(GemmArgs p) {
   }
   auto issue = [&](int kt) {
     char* st = lds + (kt % NSTG) * STAGE;
-    __builtin_amdgcn_global_load_lds((gptr_t)(srcA + kt * BK), (lptr_t)(st + wid * 1024), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < RG::A_IPW; ++j)
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcA[j] + kt * BK), (lptr_t)(st + (wid * RG::A_IPW + j) * 1024), 16, 0, 0);
 #pragma unroll
     for (int j = 0; j < 3; ++j)
       __builtin_amdgcn_global_load_lds((gptr_t)(srcB[j] + kt * BK), (lptr_t)(st + A_BYTES + (wid * 3 + j) * 1024), 16, 0, 0);
   };
-  f32x16 acc[2][3];
+  f32x16 acc[MI][3];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j)
 #pragma unroll
@@ -315,7 +323,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_row384_kernel(GemmArgs p) {
 
   const int nk = p.K / BK;
   const int xr = (l31 >> 2) & 3;
-  const int offA = (wm * 64 + l31) * 64, offB = A_BYTES + (wn * 96 + l31) * 64;
+  const int offA = (wm * 32 * MI + l31) * 64, offB = A_BYTES + (wn * 96 + l31) * 64;
   issue(0);
   for (int kt = 0; kt < nk; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // tile kt landed everywhere; stage (kt-1)&1 free
@@ -324,27 +332,28 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_row384_kernel(GemmArgs p) {
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       const int co = ((ks * 2 + hi) ^ xr) << 4;
-      const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(st + offA + co), a1 = *reinterpret_cast<const bf16x8*>(st + offA + 32 * 64 + co);
-      bf16x8 bf[3];
+      bf16x8 af[MI], bf[3];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const bf16x8*>(st + offA + mi * 32 * 64 + co);
 #pragma unroll
       for (int ni = 0; ni < 3; ++ni) bf[ni] = *reinterpret_cast<const bf16x8*>(st + offB + ni * 32 * 64 + co);
 #pragma unroll
-      for (int ni = 0; ni < 3; ++ni) {
-        acc[0][ni] = mfma32(a0, bf[ni], acc[0][ni]);
-        acc[1][ni] = mfma32(a1, bf[ni], acc[1][ni]);
-      }
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 3; ++ni) acc[mi][ni] = mfma32(af[mi], bf[ni], acc[mi][ni]);
     }
   }
   asm volatile("s_barrier" ::: "memory");
 
   // epilogue: 32 output rows at a time through LDS, full 384-column rows, 16-B accesses
   float* sC = reinterpret_cast<float*>(smem_raw);
+  constexpr int NPART = 2 * MI;
 #pragma unroll
-  for (int part = 0; part < 4; ++part) {
-    if (wm == (part >> 1)) {
+  for (int part = 0; part < NPART; ++part) {
+    if (wm == part / MI) {
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        if (mi != (part & 1)) continue;
+      for (int mi = 0; mi < MI; ++mi) {
+        if (mi != part % MI) continue;
 #pragma unroll
         for (int ni = 0; ni < 3; ++ni)
 #pragma unroll
@@ -391,7 +400,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_row384_kernel(GemmArgs p) {
           }
           if (lane == 0) { p.ln_mean[row] = mu; p.ln_rstd[row] = rs; }
         }
-        if (part < 3) __syncthreads();
+        if (part < NPART - 1) __syncthreads();
         continue;
       }
     }
@@ -404,7 +413,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_row384_kernel(GemmArgs p) {
         epilogue4<EPI>(p, row, n0 + c4, *reinterpret_cast<const f32x4*>(sC + rl * CLD + c4), wv);
       }
     }
-    if (part < 3) __syncthreads();
+    if (part < NPART - 1) __syncthreads();
   }
 }
 
@@ -666,6 +675,7 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_glds_kernel(WgradArgs p) {
 
 int g_row384_auto = 1;      // use the 128x384 tile whenever N % 384 == 0 (tuning hook 300 turns it off)
 int g_tn_wide = 0;        // wgrad: 128x384 output tiles when K % 384 == 0 (tuning hook 103 = on); measured no net gain over 128x128
+int g_row384_tall = 1;      // 256 x 384 tiles for large M (tuning hook 302 = off, 303 = on)
 int g_tn_rounds = 1;      // wgrad grid = this many rounds of 512 resident blocks (tuning hook 110 + r); 1 measured best (-20 %)
 int g_tn_glds = 0;        // wgrad: 1 = LDS-DMA kernel when shapes allow (tuning hook 101); measured 7 % slower than register staging
 int g_nt_variant = -1;    // -1 auto ; 0: 128x128 2-stage ; 1: 128x128 3-stage ; 2: 256x128 8 waves ; 3: 256x128 4 waves of 128x64
@@ -688,13 +698,19 @@ template <int EPI>
 int launch_nt_row384(const GemmArgs& a, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_row384_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, row384::LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_row384_kernel<EPI, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, row384::Geo<2>::LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt_row384_kernel<EPI, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, row384::Geo<4>::LDS);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  const int nblk = ((a.M + row384::BMR - 1) / row384::BMR) * (a.N / row384::BNR);
   ProfScope ps(PK_GEMM_NT0 + EPI, 2.0 * a.M * a.N * a.K, st);
-  hipLaunchKernelGGL(gemm_nt_row384_kernel<EPI>, dim3(nblk), dim3(row384::THREADS), row384::LDS, st, a);
+  if (g_row384_tall && EPI == EPI_BF16 && a.M >= 8192 && (a.K >= 768 || a.N >= 768)) {   // 256-row tiles: -20 % for the plain bf16 GEMMs in the real step; the epilogue-heavy variants do not gain
+    const int nblk = ((a.M + 255) / 256) * (a.N / row384::BNR);
+    hipLaunchKernelGGL((gemm_nt_row384_kernel<EPI, 4>), dim3(nblk), dim3(row384::THREADS), row384::Geo<4>::LDS, st, a);
+  } else {
+    const int nblk = ((a.M + 127) / 128) * (a.N / row384::BNR);
+    hipLaunchKernelGGL((gemm_nt_row384_kernel<EPI, 2>), dim3(nblk), dim3(row384::THREADS), row384::Geo<2>::LDS, st, a);
+  }
   return (int)hipGetLastError();
 }
 template <int EPI>
@@ -717,7 +733,7 @@ int launch_nt(const GemmArgs& a, hipStream_t st) {
 }  // namespace
 
 int g_stagger = 0;
-void atst_gemm_nt_set_variant(int v) { if (v >= 300) g_row384_auto = v - 300; else if (v >= 200) g_stagger = v - 200; else if (v >= 110) g_tn_rounds = v - 110; else if (v >= 102) g_tn_wide = v - 102; else if (v >= 100) g_tn_glds = v - 100; else g_nt_variant = v; }
+void atst_gemm_nt_set_variant(int v) { if (v >= 302) g_row384_tall = v - 302; else if (v >= 300) g_row384_auto = v - 300; else if (v >= 200) g_stagger = v - 200; else if (v >= 110) g_tn_rounds = v - 110; else if (v >= 102) g_tn_wide = v - 102; else if (v >= 100) g_tn_glds = v - 100; else g_nt_variant = v; }
 
 int atst_gemm_nt(const GemmArgs& a0, hipStream_t st) {
   GemmArgs a = a0; a.stagger = g_stagger;
