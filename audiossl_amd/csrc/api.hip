@@ -64,10 +64,10 @@ int atst_attention_fwd(const uint16_t* qkv, const int* valid, uint16_t* o, float
 }
 
 int atst_attention_bwd(const uint16_t* qkv, const int* valid, const uint16_t* o, const float* lse, const uint16_t* d_o,
-                       uint16_t* dqkv, int S, int H, int NP, void* stream) {
+                       uint16_t* dqkv, float* dscratch, int S, int H, int NP, void* stream) {
   AttnArgs a{};
   a.qkv = CBF(qkv); a.valid = valid; a.o = BF(const_cast<uint16_t*>(o)); a.lse = const_cast<float*>(lse);
-  a.d_o = CBF(d_o); a.dqkv = BF(dqkv); a.S = S; a.H = H; a.NP = NP;
+  a.d_o = CBF(d_o); a.dqkv = BF(dqkv); a.dscratch = dscratch; a.S = S; a.H = H; a.NP = NP;
   return atst_attn_bwd(a, ST(stream));
 }
 

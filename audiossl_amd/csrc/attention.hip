@@ -406,6 +406,190 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward, NP = 256, one block (8 waves) per SEQUENCE looping over its heads.  Q, K, V, dO of the current head are all
+// LDS-resident (4 x 36 KB) so that both halves of the backward -- dK/dV (wave = 32 keys) and dQ (wave = 32 queries) --
+// read every operand on-chip after ONE staging pass (the two-kernel version stages Q,dO and K,V separately and re-reads
+// the per-wave fragments from HBM).  The next head's panels are prefetched into registers during the dQ phase.  D = rowsum(dO * O) comes from attn_rowdot_kernel.
+constexpr int B256_MAT = 256 * A_LD;                               // elements of one staged matrix
+constexpr int B256_LDS = 4 * B256_MAT * 2 + 2 * 256 * 4;           // 149,504 B
+
+__global__ void attn_rowdot_kernel(const bf16* __restrict__ d_o, const bf16* __restrict__ o, float* __restrict__ D,
+                                   int S, int H, int NP) {
+  // one wave per token row: D[s,h,q] = sum_d dO[s,q,h,d] * O[s,q,h,d]
+  const int lane = threadIdx.x & 63;
+  const long row = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (row >= (long)S * NP) return;
+  const int C = H * HD;
+  const int s = (int)(row / NP), q = (int)(row % NP);
+  for (int c = lane; c < C / 8; c += 64) {                          // 8 elements per lane-chunk; a head = 8 chunks
+    const bf16x8 a = ld_frag(d_o + row * C + c * 8), b = ld_frag(o + row * C + c * 8);
+    float d = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) d += bf2f(a[e]) * bf2f(b[e]);
+    d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+    if ((lane & 7) == 0) D[((size_t)s * H + (c >> 3)) * NP + q] = d;
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void attn_bwd256_kernel(AttnArgs p, const float* __restrict__ Dg) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int NP = 256;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+  const int H = p.H, C = H * HD;
+  const size_t ld = 3 * (size_t)C;
+  const int s = blockIdx.x;
+  bf16* sQ = reinterpret_cast<bf16*>(smem_raw);
+  bf16* sK = sQ + B256_MAT; bf16* sV = sK + B256_MAT; bf16* sDO = sV + B256_MAT;
+  float* sLse = reinterpret_cast<float*>(sDO + B256_MAT);
+  float* sD = sLse + NP;
+  const bf16* qkv = p.qkv + (size_t)s * NP * ld;
+  const bf16* dob = p.d_o + (size_t)s * NP * C;
+  const int valid = p.valid[s];
+  const int ntile = (valid + 31) / 32 < 8 ? (valid + 31) / 32 : 8;
+  const float scale = 0.125f;
+
+  // prefetch registers: {Q, dO} and {K, V} of the next head, 8 x 16 B per thread each ; lse / D one float per thread
+  bf16x8 pa[8], pb[8];
+  float plse = 0.f, pd = 0.f;
+  auto load_qdo = [&](int h) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = tid + 512 * i, mat = c >> 11, r = (c >> 3) & 255, k = (c & 7) * 8;
+      pa[i] = mat == 0 ? ld_frag(qkv + (size_t)r * ld + h * HD + k) : ld_frag(dob + (size_t)r * C + h * HD + k);
+    }
+    if (tid < NP) { plse = p.lse[((size_t)s * H + h) * NP + tid]; pd = Dg[((size_t)s * H + h) * NP + tid]; }
+  };
+  auto load_kv = [&](int h) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = tid + 512 * i, mat = c >> 11, r = (c >> 3) & 255, k = (c & 7) * 8;
+      pb[i] = ld_frag(qkv + (size_t)r * ld + (1 + mat) * C + h * HD + k);
+    }
+  };
+  auto store_lds = [&]() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = tid + 512 * i, mat = c >> 11, r = (c >> 3) & 255, k = (c & 7) * 8;
+      *reinterpret_cast<bf16x8*>((mat == 0 ? sQ : sDO) + r * A_LD + k) = pa[i];
+      *reinterpret_cast<bf16x8*>((mat == 0 ? sK : sV) + r * A_LD + k) = pb[i];
+    }
+    if (tid < NP) { sLse[tid] = plse; sD[tid] = pd; }
+  };
+  load_qdo(0);
+  load_kv(0);
+  for (int h = 0; h < H; ++h) {
+    store_lds();
+    __syncthreads();
+    // ---------------- dK, dV : this wave owns keys [32 wid, 32 wid + 32)
+    {
+      const int k0 = wid * 32;
+      bf16* dkrow = p.dqkv + ((size_t)s * NP + k0 + l31) * ld + C + h * HD;
+      bf16* dvrow = dkrow + C;
+      f32x16 dk0, dk1, dv0, dv1; zero16(dk0); zero16(dk1); zero16(dv0); zero16(dv1);
+      if (k0 < valid) {
+        bf16x8 kf[4], vf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          kf[ks] = ld_frag(sK + (k0 + l31) * A_LD + ks * 16 + hi * 8);
+          vf[ks] = ld_frag(sV + (k0 + l31) * A_LD + ks * 16 + hi * 8);
+        }
+        const float kbias = (k0 + l31 >= valid) ? MASK_NEG : 0.f;
+        for (int i = 0; i < 8; ++i) {
+          f32x16 sc, dp; zero16(sc); zero16(dp);
+          const bf16* qr = sQ + (i * 32 + l31) * A_LD + hi * 8;
+          const bf16* dr = sDO + (i * 32 + l31) * A_LD + hi * 8;
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            sc = mfma32(ld_frag(qr + ks * 16), kf[ks], sc);
+            dp = mfma32(ld_frag(dr + ks * 16), vf[ks], dp);
+          }
+          float pv[16], ds[16];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(sLse + i * 32 + 8 * g + 4 * hi);
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(sD + i * 32 + 8 * g + 4 * hi);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int r = 4 * g + e;
+              const float pr = exp2f((sc[r] * scale + kbias - l4[e]) * LOG2E);
+              pv[r] = pr;
+              ds[r] = pr * (dp[r] - d4[e]) * scale;
+            }
+          }
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const bf16x8 pf = pack8(pv + 8 * t), dsf = pack8(ds + 8 * t);
+            dv0 = mfma32(ld_frag_tr(sDO, A_LD, i * 32 + 16 * t, 0, lane), pf, dv0);
+            dv1 = mfma32(ld_frag_tr(sDO, A_LD, i * 32 + 16 * t, 32, lane), pf, dv1);
+            dk0 = mfma32(ld_frag_tr(sQ, A_LD, i * 32 + 16 * t, 0, lane), dsf, dk0);
+            dk1 = mfma32(ld_frag_tr(sQ, A_LD, i * 32 + 16 * t, 32, lane), dsf, dk1);
+          }
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 a, b, c, d;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a[e] = f2bf(dk0[4 * g + e]); b[e] = f2bf(dk1[4 * g + e]);
+          c[e] = f2bf(dv0[4 * g + e]); d[e] = f2bf(dv1[4 * g + e]);
+        }
+        *reinterpret_cast<bf16x4*>(dkrow + 8 * g + 4 * hi) = a;
+        *reinterpret_cast<bf16x4*>(dkrow + 32 + 8 * g + 4 * hi) = b;
+        *reinterpret_cast<bf16x4*>(dvrow + 8 * g + 4 * hi) = c;
+        *reinterpret_cast<bf16x4*>(dvrow + 32 + 8 * g + 4 * hi) = d;
+      }
+    }
+    // ---------------- dQ : this wave owns queries [32 wid, 32 wid + 32)
+    if (h + 1 < H) { load_qdo(h + 1); load_kv(h + 1); }            // both in flight during the dQ phase (fewer live registers than dK/dV)
+    {
+      const int q0 = wid * 32;
+      bf16x8 qf[4], dof[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        qf[ks] = ld_frag(sQ + (q0 + l31) * A_LD + ks * 16 + hi * 8);
+        dof[ks] = ld_frag(sDO + (q0 + l31) * A_LD + ks * 16 + hi * 8);
+      }
+      const float Dq = sD[q0 + l31], lse = sLse[q0 + l31];
+      f32x16 dq0, dq1; zero16(dq0); zero16(dq1);
+      for (int j = 0; j < ntile; ++j) {
+        f32x16 sc, dp; zero16(sc); zero16(dp);
+        const bf16* kr = sK + (j * 32 + l31) * A_LD + hi * 8;
+        const bf16* vr = sV + (j * 32 + l31) * A_LD + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          sc = mfma32(ld_frag(kr + ks * 16), qf[ks], sc);
+          dp = mfma32(ld_frag(vr + ks * 16), dof[ks], dp);
+        }
+        float ds[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kv = j * 32 + crow32(r, hi);
+          const float pr = exp2f((sc[r] * scale + (kv >= valid ? MASK_NEG : 0.f) - lse) * LOG2E);
+          ds[r] = pr * (dp[r] - Dq) * scale;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const bf16x8 dsf = pack8(ds + 8 * t);
+          dq0 = mfma32(ld_frag_tr(sK, A_LD, j * 32 + 16 * t, 0, lane), dsf, dq0);
+          dq1 = mfma32(ld_frag_tr(sK, A_LD, j * 32 + 16 * t, 32, lane), dsf, dq1);
+        }
+      }
+      bf16* dqrow = p.dqkv + ((size_t)s * NP + q0 + l31) * ld + h * HD;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 a, b;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] = f2bf(dq0[4 * g + e]); b[e] = f2bf(dq1[4 * g + e]); }
+        *reinterpret_cast<bf16x4*>(dqrow + 8 * g + 4 * hi) = a;
+        *reinterpret_cast<bf16x4*>(dqrow + 32 + 8 * g + 4 * hi) = b;
+      }
+    }
+    __syncthreads();                                               // everyone is done with this head's LDS image
+  }
+}
+
 template <int NP> int fwd_lds() { return Geo<NP>::G * 2 * Geo<NP>::LDS_MAT * 2; }
 template <int NP> int dkv_lds() { return Geo<NP>::G * (2 * Geo<NP>::LDS_MAT * 2 + 2 * NP * 4); }
 
@@ -447,8 +631,9 @@ int launch_bwd(const AttnArgs& a, hipStream_t st) {
 }
 }  // namespace
 
+int g_bwd256 = 1;          // merged per-sequence backward kernel for NP = 256 (tuning hook 402/403)
 int g_fwd256 = 1;          // per-sequence head-loop kernel for NP = 256 (tuning hook 400 turns it off)
-void atst_attn_set_variant(int v) { g_fwd256 = v; }
+void atst_attn_set_variant(int v) { if (v >= 2) g_bwd256 = v - 2; else g_fwd256 = v; }
 
 int atst_attn_fwd(const AttnArgs& a, hipStream_t st) {
   if (a.S <= 0) return ATST_OK;
@@ -473,6 +658,19 @@ int atst_attn_fwd(const AttnArgs& a, hipStream_t st) {
 }
 int atst_attn_bwd(const AttnArgs& a, hipStream_t st) {
   if (a.S <= 0) return ATST_OK;
+  if (a.NP == 256 && g_bwd256 && a.dscratch) {
+    static bool done = false;
+    if (!done) {
+      hipError_t e = hipFuncSetAttribute((const void*)attn_bwd256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, B256_LDS);
+      if (e != hipSuccess) return (int)e;
+      done = true;
+    }
+    const long rows = (long)a.S * 256;
+    hipLaunchKernelGGL(attn_rowdot_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, a.d_o, (const bf16*)a.o, a.dscratch, a.S, a.H, 256);
+    ProfScope ps(PK_ATTN_BWD_DKV, 14.0 * a.S * a.H * 256.0 * 256.0 * HD, st);
+    hipLaunchKernelGGL(attn_bwd256_kernel, dim3(a.S), dim3(512), B256_LDS, st, a, (const float*)a.dscratch);
+    return (int)hipGetLastError();
+  }
   switch (a.NP) {
     case 256: return launch_bwd<256>(a, st);
     case 128: return launch_bwd<128>(a, st);

@@ -20,6 +20,7 @@ struct Ws {
   // backward scratch
   float *dxA, *dxB;
   bf16 *g, *dh, *du, *dqkv, *d_o, *dout;
+  float* dscr;
   size_t bytes;
 };
 
@@ -56,6 +57,7 @@ Ws carve(void* ws, int S, int NP, int C, int H, int depth, int train) {
     w.dxA = c.take<float>(M * C); w.dxB = c.take<float>(M * C);
     w.g = c.take<bf16>(M * C); w.dh = c.take<bf16>(M * C); w.du = c.take<bf16>(M * 4 * C);
     w.dqkv = c.take<bf16>(M * 3 * C); w.d_o = c.take<bf16>(M * C); w.dout = c.take<bf16>(M * C);
+    w.dscr = c.take<float>((size_t)S * H * NP);
   }
   w.bytes = (c.off + 255) & ~(size_t)255;
   return w;
@@ -198,7 +200,7 @@ extern "C" int atst_encoder_bwd(const atst_encoder_t* e, void* stream) {
     RUN(wgrad(w.g, l.o, M, C, C, G + lo.proj_w, st));
     RUN(gemm(w.g, qt + lo.proj_w, M, C, C, EPI_BF16, w.d_o, st));
     AttnArgs at{};
-    at.qkv = l.qkv; at.valid = e->valid; at.o = l.o; at.lse = l.lse; at.d_o = w.d_o; at.dqkv = w.dqkv;
+    at.qkv = l.qkv; at.valid = e->valid; at.o = l.o; at.lse = l.lse; at.d_o = w.d_o; at.dqkv = w.dqkv; at.dscratch = w.dscr;
     at.S = S; at.H = e->H; at.NP = NP;
     RUN(atst_attn_bwd(at, st));
     RUN(wgrad(w.dqkv, l.h1, M, 3 * C, C, G + lo.qkv_w, st));

@@ -57,6 +57,7 @@ struct AttnArgs {
   float* lse;                        // fwd out [S, H, NP]
   const bf16* d_o;                   // bwd in  [S*NP, C]
   bf16* dqkv;                        // bwd out [S*NP, 3*C]
+  float* dscratch;                   // bwd scratch [S, H, NP] fp32 (rowsum(dO*O)); null -> two-kernel backward
   int S, H, NP;
 };
 int atst_attn_fwd(const AttnArgs& a, hipStream_t st);

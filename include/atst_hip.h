@@ -54,8 +54,9 @@ int atst_layernorm_bwd(const uint16_t* dy, const float* x, const float* mean, co
                        float* dgamma, float* dbeta, float* dbias_up, int M, int C, void* stream);
 /* Attention.forward + get_attention_mask: audiossl/modules/transformer.py:107-121,152-159                            */
 int atst_attention_fwd(const uint16_t* qkv, const int* valid, uint16_t* o, float* lse, int S, int H, int NP, void* stream);
+/* dscratch: optional fp32 [S,H,NP] scratch (rowsum(dO*O)); when given and NP == 256 the merged per-sequence kernel runs */
 int atst_attention_bwd(const uint16_t* qkv, const int* valid, const uint16_t* o, const float* lse, const uint16_t* d_o,
-                       uint16_t* dqkv, int S, int H, int NP, void* stream);
+                       uint16_t* dqkv, float* dscratch, int S, int H, int NP, void* stream);
 /* PatchEmbed_v2 gather: audiossl/models/atst/audio_transformer.py:56-75 (bit-exact index map, bf16 values)          */
 int atst_patchify_bf16(const float* mel, int S, int width, int NP, int use_cls, uint16_t* out, void* stream);
 int atst_gather_rows_bf16(const uint16_t* src, const int* rows, int R, int C, float* dst, void* stream);

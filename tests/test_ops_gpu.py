@@ -159,14 +159,16 @@ def test_attention(NP, valid):
     rowvalid = (torch.arange(NP, device=DEV)[None, :] < vt[:, None]).reshape(-1, 1).float()
     d_o = bf(rnd(S * NP, C, seed=2) * rowvalid)
     ref.backward(d_o.float())
-    dqkv = torch.empty_like(qkv)
-    hip.call("atst_attention_bwd", hip.ptr(qkv), hip.ptr(vt), hip.ptr(o), hip.ptr(lse), hip.ptr(d_o), hip.ptr(dqkv), S, H, NP, hip.stream())
-    got, want = dqkv.float().reshape(S * NP, 3, C), qr.grad.reshape(S * NP, 3, C)
-    for i, name in enumerate("qkv"):
-        assert relerr(got[:, i], want[:, i]) < 1.5e-2, name
-    # keys beyond `valid` receive exactly zero gradient
-    inval = (rowvalid == 0).reshape(-1)
-    assert float(got[inval][:, 1:].abs().max()) == 0.0 if inval.any() else True
+    for scratch in (None, torch.empty(S, H, NP, device=DEV)):          # two-kernel path / merged per-sequence kernel (NP = 256)
+        dqkv = torch.full_like(qkv, float("nan"))
+        hip.call("atst_attention_bwd", hip.ptr(qkv), hip.ptr(vt), hip.ptr(o), hip.ptr(lse), hip.ptr(d_o), hip.ptr(dqkv), hip.ptr(scratch),
+                 S, H, NP, hip.stream())
+        got, want = dqkv.float().reshape(S * NP, 3, C), qr.grad.reshape(S * NP, 3, C)
+        for i, name in enumerate("qkv"):
+            assert relerr(got[:, i], want[:, i]) < 1.5e-2, (name, scratch is not None)
+        # keys beyond `valid` receive exactly zero gradient
+        inval = (rowvalid == 0).reshape(-1)
+        assert float(got[inval][:, 1:].abs().max()) == 0.0 if inval.any() else True
 
 
 def test_patchify_bit_exact():

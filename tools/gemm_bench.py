@@ -38,10 +38,10 @@ def attn():
     S, H, NP = M // 256, 6, 256
     qkv = torch.randn(S * NP, 1152, device=dev).bfloat16(); valid = torch.full((S,), 251, dtype=torch.int32, device=dev)
     o = torch.empty(S * NP, 384, device=dev, dtype=torch.bfloat16); lse = torch.empty(S, H, NP, device=dev)
-    d_o = torch.randn(S * NP, 384, device=dev).bfloat16(); dqkv = torch.empty_like(qkv)
+    d_o = torch.randn(S * NP, 384, device=dev).bfloat16(); dqkv = torch.empty_like(qkv); scr = torch.empty(S, H, NP, device=dev)
     ms = t_ms(lambda: hip.call("atst_attention_fwd", hip.ptr(qkv), hip.ptr(valid), hip.ptr(o), hip.ptr(lse), S, H, NP, hip.stream()))
     print(f"  attn fwd  {ms*1e3:8.1f} us  {4.0*S*H*251*251*64/ms/1e9:7.1f} TF/s (algorithmic)")
-    ms = t_ms(lambda: hip.call("atst_attention_bwd", hip.ptr(qkv), hip.ptr(valid), hip.ptr(o), hip.ptr(lse), hip.ptr(d_o), hip.ptr(dqkv), S, H, NP, hip.stream()))
+    ms = t_ms(lambda: hip.call("atst_attention_bwd", hip.ptr(qkv), hip.ptr(valid), hip.ptr(o), hip.ptr(lse), hip.ptr(d_o), hip.ptr(dqkv), hip.ptr(scr) if os.environ.get("ATTNB", "1") == "1" else None, S, H, NP, hip.stream()))
     print(f"  attn bwd  {ms*1e3:8.1f} us  {8.0*S*H*251*251*64/ms/1e9:7.1f} TF/s (algorithmic, 2x fwd)")
 print(f"M={M}")
 nt(1152, 384, hip.EPI_BF16, "qkv fwd")
