@@ -429,7 +429,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(WgradArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wn = wid >> 1, wk = wid & 1, hi = lane >> 5, l31 = lane & 31;
   const int ntn = p.N / 128, ntk = p.K / 128;
-  int id = blockIdx.x;
+  // XCD-aware order: all output tiles of one M-split (they stream the SAME dY / X rows) run on one XCD, so each
+  // row is fetched from HBM once per XCD-resident split instead of once per tile (PMC: 3.3x over-fetch without this)
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
   const int tile = id % (ntn * ntk), split = id / (ntn * ntk);
   const int n0 = (tile / ntk) * 128, k0 = (tile % ntk) * 128;
   const int m_begin = split * p.m_per_split;
