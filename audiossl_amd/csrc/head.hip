@@ -108,50 +108,64 @@ __global__ void cast_kernel(const float* __restrict__ x, size_t n, bf16* __restr
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = f2bf(x[i]);
 }
 
-// One wave per row.  Rows [0, ncrops*B) are student rows (view-major), rows [ncrops*B, ncrops*B + 2B) teacher rows.
-// acc[0] += sum over pairs <t_hat, s_hat> ; stats[0..D) student col sums, [D..2D) student col sq-sums, [2D..4D) teacher.
+// One wave per row, grid-stride.  Rows [0, ncrops*B) are student rows (view-major), rows [ncrops*B, ncrops*B + 2B)
+// teacher rows.  acc[0] += sum over pairs <t_hat, s_hat> ; stats[0..D) student col sums, [D..2D) student col sq-sums,
+// [2D..4D) teacher.  Monitor sums are kept in registers across the rows a wave visits and reduced once per block
+// (ATST-Frame has ~170 k rows: one atomic per row-element serialised the whole kernel).
 __global__ __launch_bounds__(256) void byol_loss_kernel(const float* __restrict__ student, const float* __restrict__ teacher,
                                                         int B, int ncrops, float coef, float* __restrict__ acc,
                                                         float* __restrict__ dstudent, float* __restrict__ stats) {
   constexpr int D = 256;
-  const int lane = threadIdx.x & 63;
-  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int ns = ncrops * B;
-  if (row >= ns + 2 * B) return;
-  if (row >= ns) {                                        // teacher row: monitors only
-    const f32x4 t = *reinterpret_cast<const f32x4*>(teacher + (size_t)(row - ns) * D + lane * 4);
-    const float n = fmaxf(sqrtf(wave_sum(t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3])), 1e-12f);
+  __shared__ float red[4][4 * D];
+  __shared__ float racc[4];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int ns = ncrops * B, total = ns + 2 * B;
+  float st[4][4];                                          // [student sum, student sq, teacher sum, teacher sq][4 columns of this lane]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) st[a][e] = 0.f;
+  float dots = 0.f;
+  for (int row = wave; row < total; row += nwaves) {
+    if (row >= ns) {                                       // teacher row: monitors only
+      const f32x4 t = *reinterpret_cast<const f32x4*>(teacher + (size_t)(row - ns) * D + lane * 4);
+      const float n = fmaxf(sqrtf(wave_sum(t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3])), 1e-12f);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float v = t[e] / n; st[2][e] += v; st[3][e] += v * v; }
+      continue;
+    }
+    const int iv = row / B, b = row % B;
+    const f32x4 s = *reinterpret_cast<const f32x4*>(student + (size_t)row * D + lane * 4);
+    const float ns_ = fmaxf(sqrtf(wave_sum(s[0] * s[0] + s[1] * s[1] + s[2] * s[2] + s[3] * s[3])), 1e-12f);
+    float sh[4], T[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sh[e] = s[e] / ns_;
+    for (int iq = 0; iq < 2; ++iq) {
+      if (iq == iv) continue;
+      const f32x4 t = *reinterpret_cast<const f32x4*>(teacher + (size_t)(iq * B + b) * D + lane * 4);
+      const float n = fmaxf(sqrtf(wave_sum(t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3])), 1e-12f);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) T[e] += t[e] / n;
+    }
+    const float dot = wave_sum(T[0] * sh[0] + T[1] * sh[1] + T[2] * sh[2] + T[3] * sh[3]);
+    f32x4 g;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float v = t[e] / n;
-      atomicAdd(stats + 2 * D + lane * 4 + e, v);
-      atomicAdd(stats + 3 * D + lane * 4 + e, v * v);
+      g[e] = -coef * (T[e] - sh[e] * dot) / ns_;
+      st[0][e] += sh[e]; st[1][e] += sh[e] * sh[e];
     }
-    return;
+    *reinterpret_cast<f32x4*>(dstudent + (size_t)row * D + lane * 4) = g;
+    dots += dot;
   }
-  const int iv = row / B, b = row % B;
-  const f32x4 s = *reinterpret_cast<const f32x4*>(student + (size_t)row * D + lane * 4);
-  const float ns_ = fmaxf(sqrtf(wave_sum(s[0] * s[0] + s[1] * s[1] + s[2] * s[2] + s[3] * s[3])), 1e-12f);
-  float sh[4], T[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int e = 0; e < 4; ++e) sh[e] = s[e] / ns_;
-  for (int iq = 0; iq < 2; ++iq) {
-    if (iq == iv) continue;
-    const f32x4 t = *reinterpret_cast<const f32x4*>(teacher + (size_t)(iq * B + b) * D + lane * 4);
-    const float n = fmaxf(sqrtf(wave_sum(t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3])), 1e-12f);
+  for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) T[e] += t[e] / n;
-  }
-  const float dot = wave_sum(T[0] * sh[0] + T[1] * sh[1] + T[2] * sh[2] + T[3] * sh[3]);
-  f32x4 g;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    g[e] = -coef * (T[e] - sh[e] * dot) / ns_;
-    atomicAdd(stats + lane * 4 + e, sh[e]);
-    atomicAdd(stats + D + lane * 4 + e, sh[e] * sh[e]);
-  }
-  *reinterpret_cast<f32x4*>(dstudent + (size_t)row * D + lane * 4) = g;
-  if (lane == 0) atomicAdd(acc, dot);
+    for (int e = 0; e < 4; ++e) red[wid][a * D + lane * 4 + e] = st[a][e];
+  if (lane == 0) racc[wid] = dots;
+  __syncthreads();
+  for (int i = threadIdx.x; i < 4 * D; i += blockDim.x) atomicAdd(stats + i, red[0][i] + red[1][i] + red[2][i] + red[3][i]);
+  if (threadIdx.x == 0) atomicAdd(acc, racc[0] + racc[1] + racc[2] + racc[3]);
 }
 }  // namespace
 
@@ -218,6 +232,7 @@ int atst_byol_loss(const float* student, const float* teacher, int B, int ncrops
   hipMemsetAsync(loss, 0, sizeof(float), st);
   hipMemsetAsync(stats, 0, 4 * D * sizeof(float), st);
   const int rows = (ncrops + 2) * B;
-  hipLaunchKernelGGL(byol_loss_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, student, teacher, B, ncrops, coef, loss, dstudent, stats);
+  int grid = (rows + 3) / 4; if (grid > 512) grid = 512;
+  hipLaunchKernelGGL(byol_loss_kernel, dim3(grid), dim3(256), 0, st, student, teacher, B, ncrops, coef, loss, dstudent, stats);
   return (int)hipGetLastError();
 }
