@@ -603,7 +603,7 @@ int launch_fwd(const AttnArgs& a, hipStream_t st) {
     done = true;
   }
   const int nblk = (a.S * a.H + Geo<NP>::G - 1) / Geo<NP>::G;
-  ProfScope ps(PK_ATTN_FWD, 4.0 * a.S * a.H * (double)NP * NP * HD, st);     // QK^T + PV on the padded geometry
+  ProfScope ps(PK_ATTN_FWD, 4.0 * a.S * a.H * (double)NP * NP * HD, st, 8.0 * a.S * a.H * (double)NP * HD);     // QK^T + PV on the padded geometry
   hipLaunchKernelGGL(attn_fwd_kernel<NP>, dim3(nblk), dim3(256), lds, st, a);
   return (int)hipGetLastError();
 }
@@ -620,11 +620,11 @@ int launch_bwd(const AttnArgs& a, hipStream_t st) {
   }
   const int nblk = (a.S * a.H + Geo<NP>::G - 1) / Geo<NP>::G;
   {
-    ProfScope ps(PK_ATTN_BWD_DKV, 8.0 * a.S * a.H * (double)NP * NP * HD, st);   // S, dP, dV, dK
+    ProfScope ps(PK_ATTN_BWD_DKV, 8.0 * a.S * a.H * (double)NP * NP * HD, st, 12.0 * a.S * a.H * (double)NP * HD);   // S, dP, dV, dK
     hipLaunchKernelGGL(attn_bwd_dkv_kernel<NP>, dim3(nblk), dim3(256), lds1, st, a);
   }
   {
-    ProfScope ps(PK_ATTN_BWD_DQ, 6.0 * a.S * a.H * (double)NP * NP * HD, st);    // S, dP (recomputed), dQ
+    ProfScope ps(PK_ATTN_BWD_DQ, 6.0 * a.S * a.H * (double)NP * NP * HD, st, 10.0 * a.S * a.H * (double)NP * HD);    // S, dP (recomputed), dQ
     hipLaunchKernelGGL(attn_bwd_dq_kernel<NP>, dim3(nblk), dim3(256), lds2, st, a);
   }
   return (int)hipGetLastError();
@@ -644,7 +644,7 @@ int atst_attn_fwd(const AttnArgs& a, hipStream_t st) {
       if (e != hipSuccess) return (int)e;
       done = true;
     }
-    ProfScope ps(PK_ATTN_FWD, 4.0 * a.S * a.H * 256.0 * 256.0 * HD, st);
+    ProfScope ps(PK_ATTN_FWD, 4.0 * a.S * a.H * 256.0 * 256.0 * HD, st, 8.0 * a.S * a.H * 256.0 * HD);
     hipLaunchKernelGGL(attn_fwd256_kernel, dim3(a.S), dim3(512), 2 * F256_BUF, st, a);
     return (int)hipGetLastError();
   }
@@ -667,7 +667,7 @@ int atst_attn_bwd(const AttnArgs& a, hipStream_t st) {
     }
     const long rows = (long)a.S * 256;
     hipLaunchKernelGGL(attn_rowdot_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, a.d_o, (const bf16*)a.o, a.dscratch, a.S, a.H, 256);
-    ProfScope ps(PK_ATTN_BWD_DKV, 14.0 * a.S * a.H * 256.0 * 256.0 * HD, st);
+    ProfScope ps(PK_ATTN_BWD_DKV, 14.0 * a.S * a.H * 256.0 * 256.0 * HD, st, 16.0 * a.S * a.H * 256.0 * HD);
     hipLaunchKernelGGL(attn_bwd256_kernel, dim3(a.S), dim3(512), B256_LDS, st, a, (const float*)a.dscratch);
     return (int)hipGetLastError();
   }

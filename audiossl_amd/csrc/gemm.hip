@@ -682,6 +682,20 @@ int g_tn_rounds = 1;      // wgrad grid = this many rounds of 512 resident block
 int g_tn_glds = 0;        // wgrad: 1 = LDS-DMA kernel when shapes allow (tuning hook 101); measured 7 % slower than register staging
 int g_nt_variant = -1;    // -1 auto ; 0: 128x128 2-stage ; 1: 128x128 3-stage ; 2: 256x128 8 waves ; 3: 256x128 4 waves of 128x64
 
+// Algorithmic HBM bytes of one nt GEMM: both operands once, every epilogue input once, every output once.
+template <int EPI>
+double nt_bytes(const GemmArgs& a) {
+  const double mn = (double)a.M * a.N;
+  double b = 2.0 * a.K * ((double)a.M + a.N);
+  if (EPI == EPI_BF16) b += 2.0 * mn;
+  if (EPI == EPI_F32) b += 4.0 * mn;
+  if (EPI == EPI_BIAS_GELU) b += 2.0 * mn + (a.C2 ? 2.0 * mn : 0.0);
+  if (EPI == EPI_RESID) b += 8.0 * mn + (a.ln_out ? 2.0 * mn : 0.0);
+  if (EPI == EPI_DGELU) b += 4.0 * mn;
+  if (EPI == EPI_PATCH) b += 4.0 * mn;
+  return b;
+}
+
 template <int EPI, int BMT, int NSTG, int WTM>
 int launch_nt_cfg(const GemmArgs& a, hipStream_t st) {
   using G = NtGeo<BMT, NSTG, WTM>;
@@ -692,7 +706,7 @@ int launch_nt_cfg(const GemmArgs& a, hipStream_t st) {
     attr_done = true;
   }
   const int nblk = ((a.M + BMT - 1) / BMT) * (a.N / BN);
-  ProfScope ps(PK_GEMM_NT0 + EPI, 2.0 * a.M * a.N * a.K, st);
+  ProfScope ps(PK_GEMM_NT0 + EPI, 2.0 * a.M * a.N * a.K, st, nt_bytes<EPI>(a));
   hipLaunchKernelGGL((gemm_nt_kernel<EPI, BMT, NSTG, WTM>), dim3(nblk), dim3(G::THREADS), G::LDS, st, a);
   return (int)hipGetLastError();
 }
@@ -705,7 +719,7 @@ int launch_nt_row384(const GemmArgs& a, hipStream_t st) {
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  ProfScope ps(PK_GEMM_NT0 + EPI, 2.0 * a.M * a.N * a.K, st);
+  ProfScope ps(PK_GEMM_NT0 + EPI, 2.0 * a.M * a.N * a.K, st, nt_bytes<EPI>(a));
   if (g_row384_tall && EPI == EPI_BF16 && a.M >= 8192 && (a.K >= 768 || a.N >= 768)) {   // 256-row tiles: -20 % for the plain bf16 GEMMs in the real step; the epilogue-heavy variants do not gain
     const int nblk = ((a.M + 255) / 256) * (a.N / row384::BNR);
     hipLaunchKernelGGL((gemm_nt_row384_kernel<EPI, 4>), dim3(nblk), dim3(row384::THREADS), row384::Geo<4>::LDS, st, a);
@@ -769,7 +783,7 @@ int atst_gemm_tn(const WgradArgs& a, hipStream_t st) {
   }
   const int splits = (p.M + p.m_per_split - 1) / p.m_per_split;
   const int nblk = tiles * splits;
-  ProfScope ps(PK_GEMM_TN, 2.0 * p.M * p.N * p.K, st);
+  ProfScope ps(PK_GEMM_TN, 2.0 * p.M * p.N * p.K, st, 2.0 * p.M * ((double)p.N + p.K) + 4.0 * p.N * p.K);
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WGRAD_LDS_BYTES);

@@ -3,11 +3,11 @@
 #include "../../include/atst_hip.h"
 
 namespace {
-struct Rec { hipEvent_t e0, e1; int kind; double work; };
+struct Rec { hipEvent_t e0, e1; int kind; double work, bytes; };
 bool g_on = false;
 std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_pool;
-hipEvent_t g_cur0; int g_kind; double g_work;
+hipEvent_t g_cur0; int g_kind; double g_work, g_bytes;
 const char* const NAMES[PK_COUNT] = {
   "gemm_nt_kernel<0:bf16>", "gemm_nt_kernel<1:f32>", "gemm_nt_kernel<2:bias_gelu>", "gemm_nt_kernel<3:resid>",
   "gemm_nt_kernel<4:dgelu>", "gemm_nt_kernel<5:patch>", "gemm_tn_kernel", "attn_fwd_kernel", "attn_bwd_dkv_kernel",
@@ -19,29 +19,29 @@ hipEvent_t get_event() {
 }  // namespace
 
 bool prof_on() { return g_on; }
-void prof_begin(int kind, double work, hipStream_t st) {
-  g_cur0 = get_event(); g_kind = kind; g_work = work;
+void prof_begin(int kind, double work, double bytes, hipStream_t st) {
+  g_cur0 = get_event(); g_kind = kind; g_work = work; g_bytes = bytes;
   hipEventRecord(g_cur0, st);
 }
 void prof_end(hipStream_t st) {
   hipEvent_t e1 = get_event();
   hipEventRecord(e1, st);
-  g_recs.push_back(Rec{g_cur0, e1, g_kind, g_work});
+  g_recs.push_back(Rec{g_cur0, e1, g_kind, g_work, g_bytes});
 }
 
 extern "C" int atst_profile_enable(int on) { g_on = on != 0; return 0; }
 extern "C" int atst_profile_kinds(void) { return PK_COUNT; }
 extern "C" const char* atst_profile_name(int kind) { return kind >= 0 && kind < PK_COUNT ? NAMES[kind] : ""; }
 // Synchronises on every recorded event, accumulates per-kind milliseconds / work / launch counts, clears the records.
-extern "C" int atst_profile_collect(double* ms, double* work, long long* launches) {
-  for (int k = 0; k < PK_COUNT; ++k) { ms[k] = 0; work[k] = 0; launches[k] = 0; }
+extern "C" int atst_profile_collect(double* ms, double* work, double* bytes, long long* launches) {
+  for (int k = 0; k < PK_COUNT; ++k) { ms[k] = 0; work[k] = 0; bytes[k] = 0; launches[k] = 0; }
   for (const Rec& r : g_recs) {
     hipError_t e = hipEventSynchronize(r.e1);
     if (e != hipSuccess) return (int)e;
     float t = 0.f;
     e = hipEventElapsedTime(&t, r.e0, r.e1);
     if (e != hipSuccess) return (int)e;
-    ms[r.kind] += t; work[r.kind] += r.work; launches[r.kind] += 1;
+    ms[r.kind] += t; work[r.kind] += r.work; bytes[r.kind] += r.bytes; launches[r.kind] += 1;
     g_pool.push_back(r.e0); g_pool.push_back(r.e1);
   }
   g_recs.clear();

@@ -78,7 +78,7 @@ _SIGS = {
     "atst_profile_enable": (C.c_int, [C.c_int]),
     "atst_profile_kinds": (C.c_int, []),
     "atst_profile_name": (C.c_char_p, [C.c_int]),
-    "atst_profile_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
+    "atst_profile_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
 }
 
 _lib = None

@@ -181,23 +181,42 @@ def main():
     roof, kernels = None, []
     if not args.no_profile:
         nk = lib.atst_profile_kinds()
-        ms, work, cnt = (C.c_double * nk)(), (C.c_double * nk)(), (C.c_longlong * nk)()
-        hip.check(lib.atst_profile_collect(ms, work, cnt), "atst_profile_collect")
+        ms, work, byts, cnt = (C.c_double * nk)(), (C.c_double * nk)(), (C.c_double * nk)(), (C.c_longlong * nk)()
+        hip.check(lib.atst_profile_collect(ms, work, byts, cnt), "atst_profile_collect")
+        ridge = PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)          # FLOP per HBM byte where the two roofs meet
         for i in range(nk):
             if cnt[i]:
                 name = lib.atst_profile_name(i).decode()
-                mfma = "gemm" in name or "attn" in name
-                rate = work[i] / (ms[i] * 1e-3) / (1e12 if mfma else 1e9)
-                kernels.append({"kernel": name, "launches": int(cnt[i]), "avg_us": round(ms[i] / cnt[i] * 1e3, 2),
-                                "total_ms": round(ms[i], 3), "bound": "mfma" if mfma else "hbm",
-                                "achieved": round(rate, 2), "unit": "TFLOP/s" if mfma else "GB/s"})
+                has_flops = "gemm" in name or "attn" in name
+                # a kernel whose algorithmic intensity is below the ridge is bounded by HBM, whatever unit executes it
+                mfma = has_flops and work[i] / byts[i] >= ridge
+                secs = ms[i] * 1e-3
+                rec = {"kernel": name, "launches": int(cnt[i]), "avg_us": round(ms[i] / cnt[i] * 1e3, 2),
+                       "total_ms": round(ms[i], 3), "bound": "mfma" if mfma else "hbm",
+                       "achieved": round(work[i] / secs / 1e12 if mfma else byts[i] / secs / 1e9, 2),
+                       "unit": "TFLOP/s" if mfma else "GB/s", "bytes_per_launch": round(byts[i] / cnt[i])}
+                if has_flops:
+                    rec["tflops"] = round(work[i] / secs / 1e12, 2)
+                    rec["flop_per_byte"] = round(work[i] / byts[i], 1)
+                kernels.append(rec)
         kernels.sort(key=lambda r: -r["total_ms"])
         if kernels:
             d = kernels[0]
             peak = PEAK_BF16_TFLOPS if d["bound"] == "mfma" else PEAK_HBM_GBS
             roof = {"bound": d["bound"], "kernel": d["kernel"], "achieved": d["achieved"], "peak": peak, "unit": d["unit"],
-                    "frac": round(d["achieved"] / peak, 4), "traffic": None, "avg_launch_us": d["avg_us"],
-                    "launches": d["launches"], "share_of_timed_kernel_ms": round(d["total_ms"] / sum(r["total_ms"] for r in kernels), 3)}
+                    "frac": round(d["achieved"] / peak, 4), "traffic": None, "algorithmic_bytes_per_launch": d["bytes_per_launch"],
+                    "avg_launch_us": d["avg_us"], "launches": d["launches"],
+                    "share_of_timed_kernel_ms": round(d["total_ms"] / sum(r["total_ms"] for r in kernels), 3)}
+            if "tflops" in d:
+                roof["tflops"], roof["flop_per_byte"] = d["tflops"], d["flop_per_byte"]
+            # HBM bytes per launch from the committed PMC passes of this same command (rocprofv3 cannot collect
+            # counters while the step is being timed); tools/round_measure.sh regenerates the file.
+            tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"traffic_{args.workload}.json")
+            if os.path.exists(tf) and args.batch == 256:
+                t = json.load(open(tf))["kernels"].get(d["kernel"])
+                if t:
+                    roof["traffic"] = t["traffic_bytes_per_launch"]
+                    roof["traffic_source"] = f"profiles/traffic_{args.workload}.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
 
     if rank == 0:
         clips = B * world * args.steps

@@ -133,7 +133,7 @@ const float* atst_encoder_tokens(const atst_encoder_t* e);
 int atst_profile_enable(int on);
 int atst_profile_kinds(void);
 const char* atst_profile_name(int kind);
-int atst_profile_collect(double* ms, double* work, long long* launches);   /* arrays of atst_profile_kinds() */
+int atst_profile_collect(double* ms, double* work, double* bytes, long long* launches);   /* arrays of atst_profile_kinds(); work = FLOPs for MFMA kinds, bytes = algorithmic HBM bytes */
 
 #ifdef __cplusplus
 }
