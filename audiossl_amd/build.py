@@ -11,6 +11,10 @@ LIB = os.path.join(LIBDIR, "libatst_hip.so")
 SOURCES = ["api.hip", "engine.hip", "gemm.hip", "layernorm.hip", "attention.hip", "tokens.hip", "head.hip", "optim.hip",
            "frontend.hip", "profile.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
+if os.environ.get("ATST_INTERLEAVE"):
+    FLAGS.append("-DATST_INTERLEAVE=" + os.environ["ATST_INTERLEAVE"])
+if os.environ.get("ATST_TALL_STAGES"):
+    FLAGS.append("-DATST_TALL_STAGES=" + os.environ["ATST_TALL_STAGES"])
 if os.environ.get("ATST_ABLATE"):          # experiment builds only (tools/gemm_bench.py)
     FLAGS.append("-DATST_ABLATE=" + os.environ["ATST_ABLATE"])
 if os.environ.get("ATST_NT_STORES"):

@@ -16,75 +16,96 @@
 #define ATST_NT_STORES 1    // epilogue outputs / residual reads are streamed once: non-temporal, so they do not evict operand panels from L2
 #endif
 #ifndef ATST_ABLATE
-#define ATST_ABLATE 0      // experiment switch (tools only), all without stores: 1 full, 3 loads+ds_read, 4 ds_read+MFMA, 5 loads only, 6 MFMA only
+#define ATST_ABLATE 0      // experiment switch (tools only), all without stores: 1 full, 3 loads+ds_read, 4 ds_read+MFMA, 5 loads only, 6 MFMA only; 7 (row384): epilogue only
 #endif
+
+#include <type_traits>
 
 namespace {
 
 constexpr int BN = 128, BK = 32;               // BK = 32: 64-B LDS rows (4 x 16-B chunks), XOR-swizzled
 constexpr int C_LD = BN + 4;                   // fp32 epilogue staging tile [128][132] = 67,584 B (re-uses the operand LDS)
 
-// Epilogue on 4 consecutive columns of one row (vector loads / stores; the accumulator tile is staged through LDS so
-// that every global access is a full 16-B (fp32) or 8-B (bf16) piece of a contiguous row segment).
-template <int EPI>
-DEVFN void epilogue4(const GemmArgs& p, int row, int col, f32x4 v, f32x4& written) {
+// Epilogue on 8 consecutive columns of one row.  The accumulator tile is staged through LDS so that every global access
+// is a 16-B piece of a contiguous row segment, and the epilogue runs in two phases per staged part: (1) epi_fetch8 issues
+// every global LOAD the part needs (residual / saved pre-activation / token table) into registers, (2) epilogue8 computes
+// and stores.  On gfx9 loads and stores retire through one in-order counter (vmcnt): a load issued after a store cannot be
+// waited on without also waiting for that store to be acknowledged by L2, so a load -> store -> load -> store sequence
+// costs one full memory round trip per store (measured: that was ~half of every GEMM's time).
+struct EpiAux { f32x4 a0, a1; float s; };
+
+template <int EPI, bool SCALE = true>
+DEVFN void epi_fetch8(const GemmArgs& p, int row, int col, EpiAux& x) {
   const size_t idx = (size_t)row * p.ldc + col;
-  auto st_bf16 = [](void* base, size_t i, const f32x4& x) {
-    bf16x4 o;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = f2bf(x[e]);
+  if constexpr (EPI == EPI_RESID) {
+    x.a0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p.resid + idx));
+    x.a1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p.resid + idx + 4));
+    if constexpr (SCALE) x.s = p.row_scale ? p.row_scale[row / p.rows_per_seq] : 1.0f;   // else: the caller supplies it
+  } else if constexpr (EPI == EPI_DGELU) {
+    x.a0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p.U + idx));       // 8 bf16 pre-activations
+  } else if constexpr (EPI == EPI_PATCH) {
+    const int tok = row % p.rows_per_seq;
+    x.a0 = *reinterpret_cast<const f32x4*>(p.table + (size_t)tok * p.N + col);
+    x.a1 = *reinterpret_cast<const f32x4*>(p.table + (size_t)tok * p.N + col + 4);
+    x.s = (p.rowflag && p.rowflag[row]) ? 1.0f : 0.0f;
+  }
+}
+
+// bias of the 8 columns starting at col (zeros when the GEMM has none)
+DEVFN void epi_bias8(const GemmArgs& p, int col, f32x4& b0, f32x4& b1) {
+  b0 = f32x4{0.f, 0.f, 0.f, 0.f}; b1 = b0;
+  if (p.bias) { b0 = *reinterpret_cast<const f32x4*>(p.bias + col); b1 = *reinterpret_cast<const f32x4*>(p.bias + col + 4); }
+}
+
+template <int EPI>
+DEVFN void epilogue8(const GemmArgs& p, int row, int col, f32x4 v0, f32x4 v1, const f32x4& b0, const f32x4& b1, const EpiAux& x,
+                     f32x4& w0, f32x4& w1) {
+  const size_t idx = (size_t)row * p.ldc + col;
+  auto st_bf16 = [](void* base, size_t i, const f32x4& lo, const f32x4& hi4) {
+    const float t[8] = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+    const bf16x8 o = pack8(t);
 #if ATST_NT_STORES
-    __builtin_nontemporal_store(o, reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(base) + i));   // streamed once: keep L2 for operands
+    __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(base) + i));   // streamed once: keep L2 for operands
 #else
-    *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(base) + i) = o;
+    *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(base) + i) = o;
 #endif
   };
-  auto st_f32 = [](void* base, size_t i, const f32x4& x) {
+  auto st_f32 = [](void* base, size_t i, const f32x4& lo, const f32x4& hi4) {
 #if ATST_NT_STORES
-    __builtin_nontemporal_store(x, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + i));
+    __builtin_nontemporal_store(lo, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + i));
+    __builtin_nontemporal_store(hi4, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + i + 4));
 #else
-    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + i) = x;
+    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + i) = lo;
+    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + i + 4) = hi4;
 #endif
   };
   if constexpr (EPI == EPI_BF16) {
-    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + col);
-    st_bf16(p.C, idx, v);
+    st_bf16(p.C, idx, v0 + b0, v1 + b1);
   } else if constexpr (EPI == EPI_F32) {
-    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + col);
-    st_f32(p.C, idx, v);
+    st_f32(p.C, idx, v0 + b0, v1 + b1);
   } else if constexpr (EPI == EPI_BIAS_GELU) {
-    v += *reinterpret_cast<const f32x4*>(p.bias + col);
-    if (p.C) st_bf16(p.C, idx, v);                                // pre-activation u (saved for backward; skipped in inference)
-    f32x4 a;
+    v0 += b0; v1 += b1;
+    if (p.C) st_bf16(p.C, idx, v0, v1);                            // pre-activation u (saved for backward; skipped in inference)
+    f32x4 g0, g1;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) a[e] = gelu_f(v[e]);
-    st_bf16(p.C2, idx, a);                                        // activation a
+    for (int e = 0; e < 4; ++e) { g0[e] = gelu_f(v0[e]); g1[e] = gelu_f(v1[e]); }
+    st_bf16(p.C2, idx, g0, g1);                                    // activation a
   } else if constexpr (EPI == EPI_RESID) {
-    const float s = p.row_scale ? p.row_scale[row / p.rows_per_seq] : 1.0f;
-#if ATST_NT_STORES
-    const f32x4 r = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p.resid + idx));
-#else
-    const f32x4 r = *reinterpret_cast<const f32x4*>(p.resid + idx);
-#endif
-    const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + col);
-    st_f32(p.C, idx, r + s * (v + b));
+    st_f32(p.C, idx, x.a0 + x.s * (v0 + b0), x.a1 + x.s * (v1 + b1));
   } else if constexpr (EPI == EPI_DGELU) {
-#if ATST_NT_STORES
-    const bf16x4 u = __builtin_nontemporal_load(reinterpret_cast<const bf16x4*>(p.U + idx));
-#else
-    const bf16x4 u = *reinterpret_cast<const bf16x4*>(p.U + idx);
-#endif
+    const bf16x8 u = __builtin_bit_cast(bf16x8, x.a0);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(bf2f(u[e]));
-    st_bf16(p.C, idx, v);
-    written = v;
+    for (int e = 0; e < 4; ++e) { v0[e] *= gelu_grad_f(bf2f(u[e])); v1[e] *= gelu_grad_f(bf2f(u[4 + e])); }
+    st_bf16(p.C, idx, v0, v1);
+    w0 = v0; w1 = v1;
   } else if constexpr (EPI == EPI_PATCH) {
-    const int tok = row % p.rows_per_seq;
-    const f32x4 t = *reinterpret_cast<const f32x4*>(p.table + (size_t)tok * p.N + col);
-    f32x4 o = v + t;
-    if (p.rowflag && p.rowflag[row])                               // mask-token substitution (ATST-Frame)
-      o = t - *reinterpret_cast<const f32x4*>(p.bias + col) + *reinterpret_cast<const f32x4*>(p.alt + col);
-    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + idx) = o;
+    f32x4 o0 = v0 + x.a0, o1 = v1 + x.a1;
+    if (x.s != 0.f) {                                              // mask-token substitution (ATST-Frame)
+      o0 = x.a0 - b0 + *reinterpret_cast<const f32x4*>(p.alt + col);
+      o1 = x.a1 - b1 + *reinterpret_cast<const f32x4*>(p.alt + col + 4);
+    }
+    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + idx) = o0;
+    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + idx + 4) = o1;
   }
 }
 
@@ -210,11 +231,20 @@ __global__ __launch_bounds__((NtGeo<BMT, NSTG, WTM>::THREADS), (NtGeo<BMT, NSTG,
 
   // stage the fp32 tile through LDS, 64 rows at a time (part p = rows [64p, 64p+64) of the block tile)
   float* sC = reinterpret_cast<float*>(smem_raw);
-  constexpr int RPP = G::THREADS / 32;                            // rows stored per pass
-  const int c4 = (tid & 31) * 4, rr = tid >> 5;
-  f32x4 csum = {0.f, 0.f, 0.f, 0.f};                              // EPI_DGELU: column sums of du = fc1 bias gradient
+  constexpr int RPP = G::THREADS / 16;                            // rows stored per pass (8 columns per thread)
+  constexpr int NPASS = 64 / RPP;
+  const int c8 = (tid & 15) * 8, rr = tid >> 4;
+  f32x4 bias0, bias1;
+  epi_bias8(p, n0 + c8, bias0, bias1);
+  f32x4 csum0 = {0.f, 0.f, 0.f, 0.f}, csum1 = csum0;              // EPI_DGELU: column sums of du = fc1 bias gradient
 #pragma unroll
   for (int part = 0; part < BMT / 64; ++part) {
+    EpiAux aux[NPASS];
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {                    // phase 1: every global load of this part (in flight over the staging)
+      const int row = m0 + part * 64 + pass * RPP + rr;
+      if (row < p.M) epi_fetch8<EPI>(p, row, n0 + c8, aux[pass]);
+    }
     if (wm == part / (WTM / 64)) {
       constexpr int SUBS = WTM / 64;
 #pragma unroll
@@ -230,16 +260,17 @@ __global__ __launch_bounds__((NtGeo<BMT, NSTG, WTM>::THREADS), (NtGeo<BMT, NSTG,
       }
     }
     __syncthreads();
-#pragma unroll 4
-    for (int pass = 0; pass < 64 / RPP; ++pass) {
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {                    // phase 2: compute + stores only
       const int rl = pass * RPP + rr, row = m0 + part * 64 + rl;
 #if ATST_ABLATE
-      if (sC[rl * C_LD + c4] != 12345.678f) continue;                // experiment builds: no epilogue stores
+      if (sC[rl * C_LD + c8] != 12345.678f) continue;                // experiment builds: no epilogue stores
 #endif
       if (row < p.M) {
-        f32x4 wv = {0.f, 0.f, 0.f, 0.f};
-        epilogue4<EPI>(p, row, n0 + c4, *reinterpret_cast<const f32x4*>(sC + rl * C_LD + c4), wv);
-        if constexpr (EPI == EPI_DGELU) csum += wv;
+        f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = w0;
+        epilogue8<EPI>(p, row, n0 + c8, *reinterpret_cast<const f32x4*>(sC + rl * C_LD + c8),
+                       *reinterpret_cast<const f32x4*>(sC + rl * C_LD + c8 + 4), bias0, bias1, aux[pass], w0, w1);
+        if constexpr (EPI == EPI_DGELU) { csum0 += w0; csum1 += w1; }
       }
     }
     if (part + 1 < BMT / 64) __syncthreads();
@@ -247,7 +278,8 @@ __global__ __launch_bounds__((NtGeo<BMT, NSTG, WTM>::THREADS), (NtGeo<BMT, NSTG,
   if constexpr (EPI == EPI_DGELU) {
     if (p.colsum) {                                               // block-reduce over the RPP row groups, one atomic per column
       __syncthreads();
-      *reinterpret_cast<f32x4*>(sC + rr * BN + c4) = csum;
+      *reinterpret_cast<f32x4*>(sC + rr * BN + c8) = csum0;
+      *reinterpret_cast<f32x4*>(sC + rr * BN + c8 + 4) = csum1;
       __syncthreads();
       if (tid < BN) {
         float t = 0.f;
@@ -265,21 +297,30 @@ __global__ __launch_bounds__((NtGeo<BMT, NSTG, WTM>::THREADS), (NtGeo<BMT, NSTG,
 // staging (L2 -> LDS, ~14 TB/s chip-wide) is what bounds these GEMMs, see DESIGN.md.  For N = 384 one block owns whole
 // output rows.
 namespace row384 {
-constexpr int BNR = 384, WAVES = 8, THREADS = 512, NSTG = 2, CLD = BNR + 4;
+constexpr int BNR = 384, WAVES = 8, THREADS = 512, CLD = BNR + 4;
+#ifndef ATST_TALL_STAGES
+#define ATST_TALL_STAGES 3
+#endif
+#ifndef ATST_INTERLEAVE
+#define ATST_INTERLEAVE 1      // LDS-DMA issue spread between the MFMA groups (0: in front of them; experiment builds)
+#endif
 constexpr int B_BYTES = BNR * BK * 2, EPI_BYTES = 32 * CLD * 4;                                   // 24 KB ; 49,664 B
 template <int MI> struct Geo {                 // MI = 32-row accumulator blocks per wave: 2 -> 128-row tile, 4 -> 256-row tile
   static constexpr int BMR = 64 * MI, A_BYTES = BMR * BK * 2, STAGE = A_BYTES + B_BYTES;         // 32 KB / 40 KB per stage
-  static constexpr int LDS = NSTG * STAGE > EPI_BYTES ? NSTG * STAGE : EPI_BYTES;                // 64 KB / 80 KB -> 2 blocks / CU
+  // K-tiles are ~1.8 us from issue to landing under load: the 128-row tile keeps 2 blocks x 1 tile in flight per CU, the
+  // 256-row tile (one block per CU) needs a deeper ring to cover that latency (2 stages measured latency-bound, 36 % MFMA)
+  static constexpr int NSTG = MI == 4 ? ATST_TALL_STAGES : 2;
+  static constexpr int LDS = NSTG * STAGE > EPI_BYTES + 8192 ? NSTG * STAGE : EPI_BYTES + 8192;  // 64 KB (2 blocks / CU) ; 120 KB
   static constexpr int A_IPW = (BMR / 16) / WAVES;                                               // 1 or 2 A load instructions per wave
 };
 }
 
 // MI = 4 (256 x 384 tile, each wave 128 x 96 = 12 accumulators): 40 KB staged per 6 units of output = 6.7 KB / unit.
-template <int EPI, int MI>
+template <int EPI, int MI, bool LN = false>
 __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(GemmArgs p) {
   using namespace row384;
   using RG = row384::Geo<MI>;
-  constexpr int BMR = RG::BMR, A_BYTES = RG::A_BYTES, STAGE = RG::STAGE;
+  constexpr int BMR = RG::BMR, A_BYTES = RG::A_BYTES, STAGE = RG::STAGE, NSTG = RG::NSTG;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   typedef const void __attribute__((address_space(1))) * gptr_t;
   typedef void __attribute__((address_space(3))) * lptr_t;
@@ -321,66 +362,159 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+#if ATST_ABLATE == 7
+  const int nk = p.K < 0 ? 1 : 0;                                // experiment builds: epilogue only
+#else
   const int nk = p.K / BK;
+#endif
   const int xr = (l31 >> 2) & 3;
   const int offA = (wm * 32 * MI + l31) * 64, offB = A_BYTES + (wn * 96 + l31) * 64;
-  issue(0);
-  for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // tile kt landed everywhere; stage (kt-1)&1 free
-    if (kt + 1 < nk) issue(kt + 1);
+  constexpr int LOADS_PER_TILE = RG::A_IPW + 3;                   // per wave, in issue order
+  constexpr bool ILV = ATST_INTERLEAVE && MI == 4;                // the 128-row tile has no registers to spare for the pinned order
+  auto issue_one = [&](int kt, int j) {                           // j-th load instruction of tile kt
+    char* st = lds + (kt % NSTG) * STAGE;
+    if (j < RG::A_IPW)
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcA[j < RG::A_IPW ? j : 0] + kt * BK), (lptr_t)(st + (wid * RG::A_IPW + j) * 1024), 16, 0, 0);
+    else
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcB[j >= RG::A_IPW ? j - RG::A_IPW : 0] + kt * BK), (lptr_t)(st + A_BYTES + (wid * 3 + j - RG::A_IPW) * 1024), 16, 0, 0);
+  };
+  // One K-tile of MFMAs.  ISSUE: the loads of tile kt + NSTG - 1 are spread BETWEEN the MFMA groups instead of in front
+  // of them: every wave leaves the barrier at the same moment, and eight waves x 4-5 LDS-DMA instructions queue on the
+  // CU's one address path for longer than the tile's MFMAs take -- issued up front, each (in-order) wave reaches its
+  // MFMAs only after that queue drains and the matrix pipes idle (measured: loads-only 104 us + MFMA-only 91 us gave
+  // 162 us); behind an already-issued MFMA group the same wait is hidden.
+  auto tile = [&](int kt, auto issue_tag) {
+    constexpr bool ISSUE = decltype(issue_tag)::value;
     const char* st = lds + (kt % NSTG) * STAGE;
+    int slot = 0;
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       const int co = ((ks * 2 + hi) ^ xr) << 4;
       bf16x8 af[MI], bf[3];
+#if ATST_ABLATE == 5 || ATST_ABLATE == 6
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) asm volatile("" : "=v"(af[mi]));   // no LDS reads: operands are whatever is in registers
+#pragma unroll
+      for (int ni = 0; ni < 3; ++ni) asm volatile("" : "=v"(bf[ni]));
+      (void)st; (void)co;
+#else
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const bf16x8*>(st + offA + mi * 32 * 64 + co);
 #pragma unroll
       for (int ni = 0; ni < 3; ++ni) bf[ni] = *reinterpret_cast<const bf16x8*>(st + offB + ni * 32 * 64 + co);
+#endif
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
+      for (int mi = 0; mi < MI; ++mi) {
+#if ATST_ABLATE == 3 || ATST_ABLATE == 5
+        asm volatile("" :: "v"(af[mi]), "v"(bf[0]), "v"(bf[1]), "v"(bf[2]));
+#else
 #pragma unroll
         for (int ni = 0; ni < 3; ++ni) acc[mi][ni] = mfma32(af[mi], bf[ni], acc[mi][ni]);
+#endif
+#if ATST_ABLATE != 4 && ATST_ABLATE != 6
+        if (ILV && ISSUE && slot < LOADS_PER_TILE) {
+          __builtin_amdgcn_sched_barrier(0);
+          issue_one(kt + NSTG - 1, slot);
+          __builtin_amdgcn_sched_barrier(0);
+          ++slot;
+        }
+#endif
+      }
     }
+  };
+#pragma unroll
+  for (int t = 0; t < NSTG - 1; ++t)
+    if (t < nk) issue(t);
+  const int nfull = nk - (NSTG - 1) > 0 ? nk - (NSTG - 1) : 0;    // tiles that still have a successor to fetch
+  for (int kt = 0; kt < nfull; ++kt) {
+    // my share of tile kt has landed (loads retire in order; the younger NSTG-2 tiles may still be in flight); barrier =>
+    // everyone's has, and everyone is done reading stage (kt-1) % NSTG, which the next issue overwrites
+    if constexpr (NSTG == 2) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    else if constexpr ((NSTG - 2) * LOADS_PER_TILE == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    else if constexpr ((NSTG - 2) * LOADS_PER_TILE == 5) asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory");
+    else if constexpr ((NSTG - 2) * LOADS_PER_TILE == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    else if constexpr ((NSTG - 2) * LOADS_PER_TILE == 10) asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#if ATST_ABLATE != 4 && ATST_ABLATE != 6
+    if (!ILV) issue(kt + NSTG - 1);
+#endif
+    tile(kt, std::true_type{});
+  }
+  for (int kt = nfull; kt < nk; ++kt) {                           // drain: nothing left to fetch
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    tile(kt, std::false_type{});
   }
   asm volatile("s_barrier" ::: "memory");
 
-  // epilogue: 32 output rows at a time through LDS, full 384-column rows, 16-B accesses
+  // Epilogue: the fp32 tile goes through LDS 32 rows at a time so that every global access is a 16-B piece of a full
+  // 384-column row.  Part (mi, h) takes 16 rows of accumulator block mi from EVERY wave (two 16-row groups, one per
+  // wave row), so all waves retire the same 24 accumulator registers per part and the registers freed by the dump hold
+  // that part's global loads (residual / saved activations), which are issued as one batch before the staging barrier
+  // while the stores follow it (see epi_fetch8).
   float* sC = reinterpret_cast<float*>(smem_raw);
+  float* sBias = sC + 32 * CLD;                                   // bias of this block's 384 columns (zeros when absent)
+  float* sGamma = sBias + BNR; float* sBeta = sGamma + BNR;       // fused LayerNorm affine parameters
+  float* sScale = sBeta + BNR;                                    // per-row DropPath scale of this block's rows
   constexpr int NPART = 2 * MI;
+  constexpr bool fused_ln = LN && EPI == EPI_RESID;
+  if (tid < BNR) {                                                // visible after the first staging barrier
+    sBias[tid] = p.bias ? p.bias[n0 + tid] : 0.f;
+    if (fused_ln) { sGamma[tid] = p.ln_gamma[tid]; sBeta[tid] = p.ln_beta[tid]; }
+  }
+  if constexpr (EPI == EPI_RESID) {
+    if (tid < BMR) { const int row = m0 + tid; sScale[tid] = (p.row_scale && row < p.M) ? p.row_scale[row / p.rows_per_seq] : 1.0f; }
+  }
 #pragma unroll
   for (int part = 0; part < NPART; ++part) {
-    if (wm == part / MI) {
+    const int mi = part >> 1, h = part & 1;
+    auto tile_row = [&](int rl) { return (rl >> 4) * (32 * MI) + mi * 32 + h * 16 + (rl & 15); };   // staged row -> row of the block tile
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        if (mi != part % MI) continue;
+    for (int ni = 0; ni < 3; ++ni)
 #pragma unroll
-        for (int ni = 0; ni < 3; ++ni)
+      for (int r8 = 0; r8 < 8; ++r8) {
+        const int lrow = wm * 16 + (r8 & 3) + 8 * (r8 >> 2) + 4 * hi;
+        sC[lrow * CLD + wn * 96 + ni * 32 + l31] = acc[mi][ni][h * 8 + r8];
+      }
+    EpiAux aux[fused_ln ? 1 : 3];
+    f32x2 rres[fused_ln ? 4 : 1][3];
+    if constexpr (fused_ln) {
+      {
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            sC[crow32(r, hi) * CLD + wn * 96 + ni * 32 + l31] = acc[mi][ni][r];
+        for (int q = 0; q < 4; ++q) {
+          const int row = m0 + tile_row(wid * 4 + q);
+          if (row < p.M) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+              rres[q][k] = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p.resid + (size_t)row * p.ldc + k * 128 + lane * 2));
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int idx = tid + THREADS * i, row = m0 + tile_row(idx / 48);
+        if (row < p.M) epi_fetch8<EPI, false>(p, row, n0 + (idx % 48) * 8, aux[i]);
       }
     }
     __syncthreads();
-    if constexpr (EPI == EPI_RESID) {
-      if (p.ln_out) {
+    if constexpr (fused_ln) {
+      {
         // Fused residual + LayerNorm of the NEXT sub-layer (N == 384: the block owns whole rows): one wave per row,
         // x_new = resid + s (acc + bias) -> fp32 stream ; h = LN(x_new) -> bf16 operand of the next GEMM ; row statistics
         // saved for the LayerNorm backward.  Replaces a separate HBM pass (ln_fwd_kernel) over x.
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int rl = wid * 4 + q, row = m0 + part * 32 + rl;
+          const int rl = wid * 4 + q, trow = tile_row(rl), row = m0 + trow;
           if (row >= p.M) continue;
-          const float sc = p.row_scale ? p.row_scale[row / p.rows_per_seq] : 1.0f;
+          const float sc = sScale[trow];
           float v[6];
           float sum = 0.f;
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
             const int col = k * 128 + lane * 2;
             const f32x2 a2 = *reinterpret_cast<const f32x2*>(sC + rl * CLD + col);
-            const f32x2 r2 = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p.resid + (size_t)row * p.ldc + col));
-            const f32x2 b2 = *reinterpret_cast<const f32x2*>(p.bias + col);
-            f32x2 o = r2 + sc * (a2 + b2);
+            const f32x2 b2 = *reinterpret_cast<const f32x2*>(sBias + col);
+            f32x2 o = rres[q][k] + sc * (a2 + b2);
             __builtin_nontemporal_store(o, reinterpret_cast<f32x2*>(reinterpret_cast<float*>(p.C) + (size_t)row * p.ldc + col));
             v[2 * k] = o[0]; v[2 * k + 1] = o[1]; sum += o[0] + o[1];
           }
@@ -392,25 +526,29 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
             const int col = k * 128 + lane * 2;
-            const f32x2 g2 = *reinterpret_cast<const f32x2*>(p.ln_gamma + col), be2 = *reinterpret_cast<const f32x2*>(p.ln_beta + col);
-            bf16x2 h;
-            h[0] = f2bf((v[2 * k] - mu) * rs * g2[0] + be2[0]);
-            h[1] = f2bf((v[2 * k + 1] - mu) * rs * g2[1] + be2[1]);
-            *reinterpret_cast<bf16x2*>(p.ln_out + (size_t)row * 384 + col) = h;
+            const f32x2 g2 = *reinterpret_cast<const f32x2*>(sGamma + col), be2 = *reinterpret_cast<const f32x2*>(sBeta + col);
+            bf16x2 hv;
+            hv[0] = f2bf((v[2 * k] - mu) * rs * g2[0] + be2[0]);
+            hv[1] = f2bf((v[2 * k + 1] - mu) * rs * g2[1] + be2[1]);
+            *reinterpret_cast<bf16x2*>(p.ln_out + (size_t)row * 384 + col) = hv;
           }
           if (lane == 0) { p.ln_mean[row] = mu; p.ln_rstd[row] = rs; }
         }
-        if (part < NPART - 1) __syncthreads();
-        continue;
       }
-    }
+    } else {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int idx = tid + THREADS * i, rl = idx / 96, c4 = (idx % 96) * 4;
-      const int row = m0 + part * 32 + rl;
-      if (row < p.M) {
-        f32x4 wv;
-        epilogue4<EPI>(p, row, n0 + c4, *reinterpret_cast<const f32x4*>(sC + rl * CLD + c4), wv);
+      for (int i = 0; i < 3; ++i) {
+        const int idx = tid + THREADS * i, rl = idx / 48, c8 = (idx % 48) * 8;
+        const int trow = tile_row(rl), row = m0 + trow;
+#if ATST_ABLATE != 0 && ATST_ABLATE != 7
+        if (sC[rl * CLD + c8] != 12345.678f) continue;               // experiment builds: no epilogue stores
+#endif
+        if (row < p.M) {
+          f32x4 w0, w1;
+          if constexpr (EPI == EPI_RESID) aux[i].s = sScale[trow];
+          epilogue8<EPI>(p, row, n0 + c8, *reinterpret_cast<const f32x4*>(sC + rl * CLD + c8), *reinterpret_cast<const f32x4*>(sC + rl * CLD + c8 + 4),
+                         *reinterpret_cast<const f32x4*>(sBias + c8), *reinterpret_cast<const f32x4*>(sBias + c8 + 4), aux[i], w0, w1);
+        }
       }
     }
     if (part < NPART - 1) __syncthreads();
@@ -677,7 +815,7 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_glds_kernel(WgradArgs p) {
 
 int g_row384_auto = 1;      // use the 128x384 tile whenever N % 384 == 0 (tuning hook 300 turns it off)
 int g_tn_wide = 0;        // wgrad: 128x384 output tiles when K % 384 == 0 (tuning hook 103 = on); measured no net gain over 128x128
-int g_row384_tall = 1;      // 256 x 384 tiles for large M (tuning hook 302 = off, 303 = on)
+int g_row384_tall = 2;      // 256 x 384 tiles for M >= 8192: 2 = every epilogue, 1 = plain bf16 GEMMs only, 0 = never (tuning hooks 304 / 303 / 302)
 int g_tn_rounds = 1;      // wgrad grid = this many rounds of 512 resident blocks (tuning hook 110 + r); 1 measured best (-20 %)
 int g_tn_glds = 0;        // wgrad: 1 = LDS-DMA kernel when shapes allow (tuning hook 101); measured 7 % slower than register staging
 int g_nt_variant = -1;    // -1 auto ; 0: 128x128 2-stage ; 1: 128x128 3-stage ; 2: 256x128 8 waves ; 3: 256x128 4 waves of 128x64
@@ -710,24 +848,28 @@ int launch_nt_cfg(const GemmArgs& a, hipStream_t st) {
   hipLaunchKernelGGL((gemm_nt_kernel<EPI, BMT, NSTG, WTM>), dim3(nblk), dim3(G::THREADS), G::LDS, st, a);
   return (int)hipGetLastError();
 }
-template <int EPI>
-int launch_nt_row384(const GemmArgs& a, hipStream_t st) {
+template <int EPI, int MI, bool LN>
+int launch_nt_row384_cfg(const GemmArgs& a, hipStream_t st) {
+  using RG = row384::Geo<MI>;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_row384_kernel<EPI, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, row384::Geo<2>::LDS);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt_row384_kernel<EPI, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, row384::Geo<4>::LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_row384_kernel<EPI, MI, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, RG::LDS);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  ProfScope ps(PK_GEMM_NT0 + EPI, 2.0 * a.M * a.N * a.K, st, nt_bytes<EPI>(a));
-  if (g_row384_tall && EPI == EPI_BF16 && a.M >= 8192 && (a.K >= 768 || a.N >= 768)) {   // 256-row tiles: -20 % for the plain bf16 GEMMs in the real step; the epilogue-heavy variants do not gain
-    const int nblk = ((a.M + 255) / 256) * (a.N / row384::BNR);
-    hipLaunchKernelGGL((gemm_nt_row384_kernel<EPI, 4>), dim3(nblk), dim3(row384::THREADS), row384::Geo<4>::LDS, st, a);
-  } else {
-    const int nblk = ((a.M + 127) / 128) * (a.N / row384::BNR);
-    hipLaunchKernelGGL((gemm_nt_row384_kernel<EPI, 2>), dim3(nblk), dim3(row384::THREADS), row384::Geo<2>::LDS, st, a);
-  }
+  const int nblk = ((a.M + RG::BMR - 1) / RG::BMR) * (a.N / row384::BNR);
+  hipLaunchKernelGGL((gemm_nt_row384_kernel<EPI, MI, LN>), dim3(nblk), dim3(row384::THREADS), RG::LDS, st, a);
   return (int)hipGetLastError();
+}
+template <int EPI>
+int launch_nt_row384(const GemmArgs& a, hipStream_t st) {
+  ProfScope ps(PK_GEMM_NT0 + EPI, 2.0 * a.M * a.N * a.K, st, nt_bytes<EPI>(a));
+  // 256-row tiles: the operand ring of one block covers twice the output (6.7 vs 10.7 KB staged per 128x128 unit)
+  const bool tall = a.M >= 8192 && (g_row384_tall == 2 || (g_row384_tall == 1 && EPI == EPI_BF16 && (a.K >= 768 || a.N >= 768)));
+  if constexpr (EPI == EPI_RESID) {
+    if (a.ln_out) return tall ? launch_nt_row384_cfg<EPI, 4, true>(a, st) : launch_nt_row384_cfg<EPI, 2, true>(a, st);
+  }
+  return tall ? launch_nt_row384_cfg<EPI, 4, false>(a, st) : launch_nt_row384_cfg<EPI, 2, false>(a, st);
 }
 template <int EPI>
 int launch_nt(const GemmArgs& a, hipStream_t st) {
