@@ -455,11 +455,13 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
   float* sBias = sC + 32 * CLD;                                   // bias of this block's 384 columns (zeros when absent)
   float* sGamma = sBias + BNR; float* sBeta = sGamma + BNR;       // fused LayerNorm affine parameters
   float* sScale = sBeta + BNR;                                    // per-row DropPath scale of this block's rows
+  float* sCol = sGamma;                                           // EPI_DGELU: column sums of du (fc1 bias gradient); no LN there
   constexpr int NPART = 2 * MI;
   constexpr bool fused_ln = LN && EPI == EPI_RESID;
   if (tid < BNR) {                                                // visible after the first staging barrier
     sBias[tid] = p.bias ? p.bias[n0 + tid] : 0.f;
     if (fused_ln) { sGamma[tid] = p.ln_gamma[tid]; sBeta[tid] = p.ln_beta[tid]; }
+    if (EPI == EPI_DGELU) sCol[tid] = 0.f;
   }
   if constexpr (EPI == EPI_RESID) {
     if (tid < BMR) { const int row = m0 + tid; sScale[tid] = (p.row_scale && row < p.M) ? p.row_scale[row / p.rows_per_seq] : 1.0f; }
@@ -548,10 +550,22 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
           if constexpr (EPI == EPI_RESID) aux[i].s = sScale[trow];
           epilogue8<EPI>(p, row, n0 + c8, *reinterpret_cast<const f32x4*>(sC + rl * CLD + c8), *reinterpret_cast<const f32x4*>(sC + rl * CLD + c8 + 4),
                          *reinterpret_cast<const f32x4*>(sBias + c8), *reinterpret_cast<const f32x4*>(sBias + c8 + 4), aux[i], w0, w1);
+          if constexpr (EPI == EPI_DGELU) {
+            if (p.colsum) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { atomicAdd(sCol + c8 + e, w0[e]); atomicAdd(sCol + c8 + 4 + e, w1[e]); }
+            }
+          }
         }
       }
     }
     if (part < NPART - 1) __syncthreads();
+  }
+  if constexpr (EPI == EPI_DGELU) {
+    if (p.colsum) {
+      __syncthreads();
+      if (tid < BNR) atomicAdd(p.colsum + n0 + tid, sCol[tid]);
+    }
   }
 }
 
@@ -818,6 +832,7 @@ int g_tn_wide = 0;        // wgrad: 128x384 output tiles when K % 384 == 0 (tuni
 int g_row384_tall = 2;      // 256 x 384 tiles for M >= 8192: 2 = every epilogue, 1 = plain bf16 GEMMs only, 0 = never (tuning hooks 304 / 303 / 302)
 int g_tn_rounds = 1;      // wgrad grid = this many rounds of 512 resident blocks (tuning hook 110 + r); 1 measured best (-20 %)
 int g_tn_glds = 0;        // wgrad: 1 = LDS-DMA kernel when shapes allow (tuning hook 101); measured 7 % slower than register staging
+int g_dgelu_row384 = 0;   // dGELU GEMM on the row-384 tile (tuning hook 307 = on): measured slower (LDS-atomic column sums, 78.8 vs 70.5 ms/step)
 int g_nt_variant = -1;    // -1 auto ; 0: 128x128 2-stage ; 1: 128x128 3-stage ; 2: 256x128 8 waves ; 3: 256x128 4 waves of 128x64
 
 // Algorithmic HBM bytes of one nt GEMM: both operands once, every epilogue input once, every output once.
@@ -878,9 +893,7 @@ int launch_nt(const GemmArgs& a, hipStream_t st) {
     if constexpr (EPI == EPI_RESID) return launch_nt_row384<EPI>(a, st);
   }
   int v = g_nt_variant;
-  if constexpr (EPI != EPI_DGELU) {
-    if ((v == 4 || (v < 0 && g_row384_auto)) && a.N % 384 == 0) return launch_nt_row384<EPI>(a, st);
-  }
+  if ((v == 4 || (v < 0 && g_row384_auto)) && a.N % 384 == 0 && (EPI != EPI_DGELU || g_dgelu_row384)) return launch_nt_row384<EPI>(a, st);
   if (v < 0) v = a.K <= 512 ? 0 : 1;
   if (v == 3) return launch_nt_cfg<EPI, 256, 3, 128>(a, st);
   if (v == 2) return launch_nt_cfg<EPI, 256, 3, 64>(a, st);
@@ -891,7 +904,7 @@ int launch_nt(const GemmArgs& a, hipStream_t st) {
 }  // namespace
 
 int g_stagger = 0;
-void atst_gemm_nt_set_variant(int v) { if (v >= 302) g_row384_tall = v - 302; else if (v >= 300) g_row384_auto = v - 300; else if (v >= 200) g_stagger = v - 200; else if (v >= 110) g_tn_rounds = v - 110; else if (v >= 102) g_tn_wide = v - 102; else if (v >= 100) g_tn_glds = v - 100; else g_nt_variant = v; }
+void atst_gemm_nt_set_variant(int v) { if (v >= 306) g_dgelu_row384 = v - 306; else if (v >= 302) g_row384_tall = v - 302; else if (v >= 300) g_row384_auto = v - 300; else if (v >= 200) g_stagger = v - 200; else if (v >= 110) g_tn_rounds = v - 110; else if (v >= 102) g_tn_wide = v - 102; else if (v >= 100) g_tn_glds = v - 100; else g_nt_variant = v; }
 
 int atst_gemm_nt(const GemmArgs& a0, hipStream_t st) {
   GemmArgs a = a0; a.stagger = g_stagger;
