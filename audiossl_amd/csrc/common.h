@@ -37,11 +37,11 @@ DEVFN float wave_max(float v) {
 // between cdf and pdf.
 DEVFN void gelu_parts(float x, float& cdf, float& ex) {
   const float z = fabsf(x) * 0.70710678118654752f;
-  const float t = __frcp_rn(1.0f + 0.3275911f * z);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);   // v_rcp_f32 (1 ulp); __frcp_rn expands to a 10-instruction IEEE division
   ex = __expf(-z * z);                                  // = exp(-x^2 / 2)
-  const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
-  const float erf_abs = 1.0f - poly * ex;
-  cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
+  // half the A&S coefficients: h = 0.5 erfc(|x| / sqrt 2) ; Phi(x) = h for x < 0, 1 - h otherwise (no cancellation in the tail)
+  const float h = ((((0.5307027145f * t - 0.7265760135f) * t + 0.7107068705f) * t - 0.142248368f) * t + 0.127414796f) * t * ex;
+  cdf = x < 0.f ? h : 1.0f - h;
 }
 DEVFN float gelu_f(float x) { float c, e; gelu_parts(x, c, e); return x * c; }
 DEVFN float gelu_grad_f(float x) { float c, e; gelu_parts(x, c, e); return c + x * 0.3989422804014327f * e; }
