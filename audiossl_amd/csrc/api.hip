@@ -42,6 +42,17 @@ int atst_gemm_tn_bf16(const uint16_t* dY, const uint16_t* X, int M, int N, int K
   return atst_gemm_tn(a, ST(stream));
 }
 
+int atst_gemm_tn_group_bf16(const atst_wgrad_t* items, int n, void* stream) {
+  if (!items || n < 1 || n > ATST_WGRAD_GROUP_MAX) return ATST_EINVAL;
+  WgradArgs a[ATST_WGRAD_GROUP_MAX] = {};
+  for (int i = 0; i < n; ++i) {
+    a[i].dY = CBF(items[i].dY); a[i].X = CBF(items[i].X); a[i].dW = items[i].dW;
+    a[i].M = items[i].M; a[i].N = items[i].N; a[i].K = items[i].K;
+    a[i].ldy = items[i].ldy; a[i].ldx = items[i].ldx; a[i].ldw = items[i].ldw; a[i].m_per_split = 0;
+  }
+  return atst_gemm_tn_group(a, n, ST(stream));
+}
+
 int atst_layernorm_fwd(const float* x, const float* gamma, const float* beta, uint16_t* y, float* mean, float* rstd,
                        int M, int C, void* stream) {
   return atst_ln_fwd(x, gamma, beta, BF(y), mean, rstd, M, C, ST(stream));

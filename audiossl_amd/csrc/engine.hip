@@ -19,7 +19,7 @@ struct Ws {
   bf16* hN; float *meanN, *rstdN;
   // backward scratch
   float *dxA, *dxB;
-  bf16 *g, *dh, *du, *dqkv, *d_o, *dout;
+  bf16 *g, *g2, *dh, *du, *dqkv, *d_o, *dout;
   float* dscr;
   size_t bytes;
 };
@@ -55,7 +55,7 @@ Ws carve(void* ws, int S, int NP, int C, int H, int depth, int train) {
   w.hN = c.take<bf16>(M * C); w.meanN = c.take<float>(M); w.rstdN = c.take<float>(M);
   if (train) {
     w.dxA = c.take<float>(M * C); w.dxB = c.take<float>(M * C);
-    w.g = c.take<bf16>(M * C); w.dh = c.take<bf16>(M * C); w.du = c.take<bf16>(M * 4 * C);
+    w.g = c.take<bf16>(M * C); w.g2 = c.take<bf16>(M * C); w.dh = c.take<bf16>(M * C); w.du = c.take<bf16>(M * 4 * C);
     w.dqkv = c.take<bf16>(M * 3 * C); w.d_o = c.take<bf16>(M * C); w.dout = c.take<bf16>(M * C);
     w.dscr = c.take<float>((size_t)S * H * NP);
   }
@@ -184,26 +184,35 @@ extern "C" int atst_encoder_bwd(const atst_encoder_t* e, void* stream) {
     const atst_layer_off_t& lo = o.layer[i];
     const LayerWs& l = w.L[i];
     // ---- MLP branch: x_out = x_mid + s2 * (fc2(gelu(fc1(LN2(x_mid)))) + b2) ; w.g = s2 * d(x_out)
-    RUN(wgrad(w.g, l.a, M, C, 4 * C, G + lo.fc2_w, st));
+    // The block's four weight gradients are independent of everything downstream: they are launched together after the
+    // attention backward (atst_gemm_tn_group), which is why the two residual-branch gradients live in separate buffers.
     RUN(gemm(w.g, qt + lo.fc2_w, M, 4 * C, C, EPI_DGELU, w.du, st, nullptr, nullptr, nullptr, 1, nullptr, l.u, G + lo.fc1_b));
-    RUN(wgrad(w.du, l.h2, M, 4 * C, C, G + lo.fc1_w, st));
     RUN(gemm(w.du, qt + lo.fc1_w, M, C, 4 * C, EPI_BF16, w.dh, st));
     {
       LnBwdArgs a{};
       a.dy = w.dh; a.x = w.x[2 * i + 1]; a.mean = l.mean2; a.rstd = l.rstd2; a.gamma = p + lo.ln2_w; a.dres = cur;
-      a.dx = oth; a.g = w.g; a.row_scale = dps(i, 0); a.rows_per_seq = NP;
+      a.dx = oth; a.g = w.g2; a.row_scale = dps(i, 0); a.rows_per_seq = NP;
       a.dgamma = G + lo.ln2_w; a.dbeta = G + lo.ln2_b; a.dbias_up = G + lo.proj_b; a.M = M; a.C = C;
       RUN(atst_ln_bwd(a, st));
       float* t = cur; cur = oth; oth = t;
     }
     // ---- attention branch: x_mid = x_in + s1 * (proj(attn(LN1(x_in))) + bp) ; w.g = s1 * d(x_mid)
-    RUN(wgrad(w.g, l.o, M, C, C, G + lo.proj_w, st));
-    RUN(gemm(w.g, qt + lo.proj_w, M, C, C, EPI_BF16, w.d_o, st));
+    RUN(gemm(w.g2, qt + lo.proj_w, M, C, C, EPI_BF16, w.d_o, st));
     AttnArgs at{};
     at.qkv = l.qkv; at.valid = e->valid; at.o = l.o; at.lse = l.lse; at.d_o = w.d_o; at.dqkv = w.dqkv; at.dscratch = w.dscr;
     at.S = S; at.H = e->H; at.NP = NP;
     RUN(atst_attn_bwd(at, st));
-    RUN(wgrad(w.dqkv, l.h1, M, 3 * C, C, G + lo.qkv_w, st));
+    {
+      WgradArgs wg[4] = {};
+      auto set = [&](int k, const bf16* dY, const bf16* X, int N, int K, float* dW) {
+        wg[k].dY = dY; wg[k].X = X; wg[k].M = M; wg[k].N = N; wg[k].K = K; wg[k].ldy = N; wg[k].ldx = K; wg[k].dW = dW; wg[k].ldw = K;
+      };
+      set(0, w.du, l.h2, 4 * C, C, G + lo.fc1_w);
+      set(1, w.g, l.a, C, 4 * C, G + lo.fc2_w);
+      set(2, w.dqkv, l.h1, 3 * C, C, G + lo.qkv_w);
+      set(3, w.g2, l.o, C, C, G + lo.proj_w);
+      RUN(atst_gemm_tn_group(wg, 4, st));
+    }
     RUN(gemm(w.dqkv, qt + lo.qkv_w, M, C, 3 * C, EPI_BF16, w.dh, st));
     {
       LnBwdArgs a{};

@@ -301,6 +301,9 @@ constexpr int BNR = 384, WAVES = 8, THREADS = 512, CLD = BNR + 4;
 #ifndef ATST_TALL_STAGES
 #define ATST_TALL_STAGES 3
 #endif
+#ifndef ATST_TN_ISSUE
+#define ATST_TN_ISSUE 1        // tall wgrad: 1 next stage's LDS-DMA in front of the MFMAs (2-stage ring: they need the whole stage to land; measured best), 0 one per MFMA group, 2 two per group
+#endif
 #ifndef ATST_INTERLEAVE
 #define ATST_INTERLEAVE 1      // LDS-DMA issue spread between the MFMA groups (0: in front of them; experiment builds)
 #endif
@@ -571,9 +574,9 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
 
 // ---- wgrad: dW[n,k] += sum_m dY[m,n] X[m,k] -------------------------------------------------------------------------
 constexpr int WM = 64;                          // contraction rows per stage
-constexpr int W_LD = 128 + 16;                  // 144 bf16 = 288 B row stride
+constexpr int W_LD = 128 + 32;                  // 160 bf16 = 320 B row stride: 4 consecutive rows x 64 B (one ds_read_b64_tr_b16 half) on 4 distinct bank windows
 constexpr int W_TILE = WM * W_LD;
-constexpr int WGRAD_LDS_BYTES = 2 * 2 * W_TILE * 2;   // 73,728 B
+constexpr int WGRAD_LDS_BYTES = 2 * 2 * W_TILE * 2;   // 81,920 B: two blocks fill the CU's 160 KB exactly
 
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(WgradArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -827,6 +830,162 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_glds_kernel(WgradArgs p) {
     }
 }
 
+// ---- wgrad, 192 x 384 output tile, LDS-DMA ring ----------------------------------------------------------------------
+// dW[n0:+192, k0:+384] += dY[m, n]^T X[m, k] over one M-split.  8 waves (2 x 4), each 96 x 96 = 9 accumulators.  A stage
+// is 64 contraction rows of both operands, row-major as they lie in HBM ([64][192] and [64][384] bf16 = 24 + 48 KB),
+// brought in by global_load_lds (9 x 1 KiB per wave) into a 2-stage ring (144 KB, one block per CU); the 16-B chunks of a
+// row are XOR-permuted (tr_swz, applied to the per-lane source address) so that the 4-row x 32-column blocks fetched by
+// ds_read_b64_tr_b16 -- the hardware transpose that turns the m-major image into MFMA fragments -- fall on distinct banks.  36.9 KB staged per 64 rows of a 192x384 tile = 8.2 KB per 128x128 unit, against
+// 16 KB for the square tile: the wgrad GEMMs are bound by that L2 -> LDS traffic.
+namespace tnt {
+constexpr int TN = 192, TK = 384, RM = 64;
+constexpr int PY = TN * 2, PX = TK * 2;                               // row pitches in bytes
+constexpr int Y_BYTES = RM * PY, X_BYTES = RM * PX, STAGE = Y_BYTES + X_BYTES;   // 24,576 + 49,152
+constexpr int LDS = 2 * STAGE;                                        // 147,456 B
+}
+
+// ds_read_b64_tr_b16 is serviced 32 lanes at a time = 4 rows x 64 B of the image, over 64 banks (256 B): the four rows
+// must land in four different 64-B windows.  768-B pitch (== 0 mod 256): window index ^= row & 3; 384-B pitch (rows
+// alternate between offsets 0 and 128): window index ^= (row >> 1) & 1.
+template <int P> DEVFN int tr_swz(int row) { return P % 256 == 0 ? (row & 3) << 2 : ((row >> 1) & 1) << 2; }
+template <int P>
+DEVFN bf16x8 ld_frag_tr_p(const char* X, int r0, int c0, int lane) {
+  const int a = lane & 15, g = lane >> 4;
+  const int row = r0 + 4 * (g >> 1) + (a >> 2);
+  const int col = c0 + (g & 1) * 16 + 4 * (a & 3);                 // element column; 8 elements per 16-B chunk
+  const int pch = (col >> 3) ^ tr_swz<P>(row);
+  const bf16* ptr = reinterpret_cast<const bf16*>(X + row * P + pch * 16) + (col & 7);
+  s16x4 lo = lds_tr4(ptr);
+  s16x4 hi = lds_tr4(ptr + 8 * (P / 2));                           // +8 rows: same swizzle key
+  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+  u.s.a = lo; u.s.b = hi;
+  return u.v;
+}
+
+// one (tile, split) of one problem
+DEVFN void tn_tall_body(const WgradArgs& p, int tile, int split, char* smem_raw) {
+  using namespace tnt;
+  typedef const void __attribute__((address_space(1))) * gptr_t;
+  typedef void __attribute__((address_space(3))) * lptr_t;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wn = wid >> 2, wk = wid & 3, hi = lane >> 5, l31 = lane & 31;
+  const int ntk = p.K / TK;
+  const int n0 = (tile / ntk) * TN, k0 = (tile % ntk) * TK;
+  const int m_begin = split * p.m_per_split;
+  int m_end = m_begin + p.m_per_split; if (m_end > p.M) m_end = p.M;
+  if (m_begin >= m_end) return;
+  const int nst = (m_end - m_begin) / RM;
+
+  // lane -> (row, chunk) of the linear stage image; element offsets from the split's first row
+  int offY[3], offX[6];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int q = (wid * 3 + j) * 64 + lane, row = q / 24, c = (q % 24) ^ tr_swz<PY>(row);
+    offY[j] = row * p.ldy + n0 + c * 8;
+  }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int q = (wid * 6 + j) * 64 + lane, row = q / 48, c = (q % 48) ^ tr_swz<PX>(row);
+    offX[j] = row * p.ldx + k0 + c * 8;
+  }
+  const bf16* baseY = p.dY + (size_t)m_begin * p.ldy;
+  const bf16* baseX = p.X + (size_t)m_begin * p.ldx;
+  auto issue_one = [&](int st, int j) {
+    char* buf = smem_raw + (st & 1) * STAGE;
+    if (j < 3)
+      __builtin_amdgcn_global_load_lds((gptr_t)(baseY + (size_t)st * RM * p.ldy + offY[j < 3 ? j : 0]), (lptr_t)(buf + (wid * 3 + j) * 1024), 16, 0, 0);
+    else
+      __builtin_amdgcn_global_load_lds((gptr_t)(baseX + (size_t)st * RM * p.ldx + offX[j >= 3 ? j - 3 : 0]), (lptr_t)(buf + Y_BYTES + (wid * 6 + j - 3) * 1024), 16, 0, 0);
+  };
+  f32x16 acc[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+  for (int j = 0; j < 9; ++j) issue_one(0, j);
+  for (int st = 0; st < nst; ++st) {
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // stage st landed everywhere; the other buffer is free
+    const char* sY = smem_raw + (st & 1) * STAGE; const char* sX = sY + Y_BYTES;
+    const bool more = st + 1 < nst;
+    int slot = 0;
+#if ATST_TN_ISSUE == 1
+    if (more) {
+#pragma unroll
+      for (int j = 0; j < 9; ++j) issue_one(st + 1, j);
+    }
+#endif
+#pragma unroll
+    for (int ms = 0; ms < RM / 16; ++ms) {
+      bf16x8 a[3], b[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) a[i] = ld_frag_tr_p<PY>(sY, ms * 16, wn * 96 + i * 32, lane);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) b[i] = ld_frag_tr_p<PX>(sX, ms * 16, wk * 96 + i * 32, lane);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+#if ATST_TN_ISSUE == 0
+        if (slot < 9) {                                           // next stage's loads go between the MFMA groups
+          __builtin_amdgcn_sched_barrier(0);
+          if (more) issue_one(st + 1, slot);
+          __builtin_amdgcn_sched_barrier(0);
+          ++slot;
+        }
+#elif ATST_TN_ISSUE == 2
+        if (slot < 9) {                                           // two per group: all issued within the first 40 % of the stage
+          __builtin_amdgcn_sched_barrier(0);
+          if (more) { issue_one(st + 1, slot); if (slot + 1 < 9) issue_one(st + 1, slot + 1); }
+          __builtin_amdgcn_sched_barrier(0);
+          slot += 2;
+        }
+#endif
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + wn * 96 + i * 32 + crow32(r, hi);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+#if ATST_ABLATE == 8
+        if (acc[i][j][r] != 12345.678f) continue;                   // experiment builds: no atomics
+#endif
+        atomicAdd(p.dW + (size_t)n * p.ldw + k0 + wk * 96 + j * 32 + l31, acc[i][j][r]);
+      }
+    }
+}
+
+
+__global__ __launch_bounds__(512, 2) void gemm_tn_tall_kernel(WgradArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int ntiles = (p.N / tnt::TN) * (p.K / tnt::TK);
+  const int id = xcd_remap(blockIdx.x, gridDim.x);                // all tiles of one M-split on one XCD (they stream the same rows)
+  tn_tall_body(p, id % ntiles, id / ntiles, smem_raw);
+}
+
+// Several weight gradients in ONE launch (the four of a transformer block): the grid is one round of the chip however
+// many problems share it, so each problem needs 1/n-th of the M-splits it would need alone -- and the fp32 atomics that
+// combine the splits (measured ~1.5 TB/s, 45-50 us per GEMM when each is launched alone) shrink by the same factor.
+struct WgradGroup { WgradArgs it[ATST_WGRAD_GROUP_MAX]; int first_tile[ATST_WGRAD_GROUP_MAX + 1]; int n; };
+__global__ __launch_bounds__(512, 2) void gemm_tn_tall_group_kernel(WgradGroup g) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int ntiles = g.first_tile[g.n];
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int t = id % ntiles, split = id / ntiles;
+  int k = 0;
+#pragma unroll
+  for (int i = 1; i < ATST_WGRAD_GROUP_MAX; ++i) if (i < g.n && t >= g.first_tile[i]) k = i;
+  tn_tall_body(g.it[k], t - g.first_tile[k], split, smem_raw);
+}
+
+int g_tn_tall = 1;        // wgrad: 192 x 384 LDS-DMA tile when N % 192 == 0, K % 384 == 0, M % 64 == 0 (tuning hook 105 = off, 106 = on)
 int g_row384_auto = 1;      // use the 128x384 tile whenever N % 384 == 0 (tuning hook 300 turns it off)
 int g_tn_wide = 0;        // wgrad: 128x384 output tiles when K % 384 == 0 (tuning hook 103 = on); measured no net gain over 128x128
 int g_row384_tall = 2;      // 256 x 384 tiles for M >= 8192: 2 = every epilogue, 1 = plain bf16 GEMMs only, 0 = never (tuning hooks 304 / 303 / 302)
@@ -904,7 +1063,7 @@ int launch_nt(const GemmArgs& a, hipStream_t st) {
 }  // namespace
 
 int g_stagger = 0;
-void atst_gemm_nt_set_variant(int v) { if (v >= 306) g_dgelu_row384 = v - 306; else if (v >= 302) g_row384_tall = v - 302; else if (v >= 300) g_row384_auto = v - 300; else if (v >= 200) g_stagger = v - 200; else if (v >= 110) g_tn_rounds = v - 110; else if (v >= 102) g_tn_wide = v - 102; else if (v >= 100) g_tn_glds = v - 100; else g_nt_variant = v; }
+void atst_gemm_nt_set_variant(int v) { if (v >= 306) g_dgelu_row384 = v - 306; else if (v >= 302) g_row384_tall = v - 302; else if (v >= 300) g_row384_auto = v - 300; else if (v >= 200) g_stagger = v - 200; else if (v >= 110) g_tn_rounds = v - 110; else if (v >= 105) g_tn_tall = v - 105; else if (v >= 102 && v < 104) g_tn_wide = v - 102; else if (v >= 100) g_tn_glds = v - 100; else g_nt_variant = v; }
 
 int atst_gemm_nt(const GemmArgs& a0, hipStream_t st) {
   GemmArgs a = a0; a.stagger = g_stagger;
@@ -920,9 +1079,28 @@ int atst_gemm_nt(const GemmArgs& a0, hipStream_t st) {
   return ATST_EINVAL;
 }
 
+bool tn_tall_ok(const WgradArgs& a);
+
 int atst_gemm_tn(const WgradArgs& a, hipStream_t st) {
   if (a.M <= 0 || a.N % 128 || a.K % 128 || a.ldy % 8 || a.ldx % 8) return ATST_EINVAL;
   WgradArgs p = a;
+  if (tn_tall_ok(a) && a.m_per_split <= 0) {
+    const int tiles = (a.N / tnt::TN) * (a.K / tnt::TK);
+    int splits = 256 / tiles; if (splits < 1) splits = 1;        // one block per CU, one round
+    int mps = (a.M + splits - 1) / splits;
+    mps = ((mps + tnt::RM - 1) / tnt::RM) * tnt::RM;
+    p.m_per_split = mps;
+    const int nblk = tiles * ((a.M + mps - 1) / mps);
+    ProfScope ps(PK_GEMM_TN, 2.0 * p.M * p.N * p.K, st, 2.0 * p.M * ((double)p.N + p.K) + 4.0 * p.N * p.K);
+    static bool tall_attr = false;
+    if (!tall_attr) {
+      hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_tall_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, tnt::LDS);
+      if (e != hipSuccess) return (int)e;
+      tall_attr = true;
+    }
+    hipLaunchKernelGGL(gemm_tn_tall_kernel, dim3(nblk), dim3(512), tnt::LDS, st, p);
+    return (int)hipGetLastError();
+  }
   const bool wide = g_tn_wide && a.K % 384 == 0;                  // 128 x 384 output tiles
   const int tiles = wide ? (a.N / 128) * (a.K / 384) : (a.N / 128) * (a.K / 128);
   if (p.m_per_split <= 0) {
@@ -955,3 +1133,47 @@ int atst_gemm_tn(const WgradArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(nblk), dim3(256), WGRAD_LDS_BYTES, st, p);
   return (int)hipGetLastError();
 }
+
+bool tn_tall_ok(const WgradArgs& a) {
+  return g_tn_tall && a.N % tnt::TN == 0 && a.K % tnt::TK == 0 && a.M % tnt::RM == 0 && a.M >= 8192 && a.ldy % 8 == 0 && a.ldx % 8 == 0;
+}
+
+int atst_gemm_tn_group(const WgradArgs* items, int n, hipStream_t st) {
+  if (n < 1 || n > ATST_WGRAD_GROUP_MAX) return ATST_EINVAL;
+  bool tall = true;
+  for (int i = 0; i < n; ++i) tall = tall && tn_tall_ok(items[i]);
+  if (!tall || n == 1) {                                          // shapes outside the tall tile: one launch each
+    for (int i = 0; i < n; ++i) { const int rc = atst_gemm_tn(items[i], st); if (rc) return rc; }
+    return ATST_OK;
+  }
+  WgradGroup g{};
+  g.n = n;
+  int tiles = 0; double flops = 0, bytes = 0;
+  for (int i = 0; i < n; ++i) {
+    g.it[i] = items[i];
+    g.first_tile[i] = tiles;
+    tiles += (items[i].N / tnt::TN) * (items[i].K / tnt::TK);
+    flops += 2.0 * items[i].M * items[i].N * items[i].K;
+    bytes += 2.0 * items[i].M * ((double)items[i].N + items[i].K) + 4.0 * items[i].N * items[i].K;
+  }
+  for (int i = n; i <= ATST_WGRAD_GROUP_MAX; ++i) g.first_tile[i] = tiles;
+  int splits = 256 / tiles; if (splits < 1) splits = 1;          // one block per CU, one round
+  int max_splits = 1;
+  for (int i = 0; i < n; ++i) {
+    int mps = (items[i].M + splits - 1) / splits;
+    mps = ((mps + tnt::RM - 1) / tnt::RM) * tnt::RM;
+    g.it[i].m_per_split = mps;
+    const int sp = (items[i].M + mps - 1) / mps;
+    if (sp > max_splits) max_splits = sp;
+  }
+  ProfScope ps(PK_GEMM_TN, flops, st, bytes);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_tall_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, tnt::LDS);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(gemm_tn_tall_group_kernel, dim3(tiles * max_splits), dim3(512), tnt::LDS, st, g);
+  return (int)hipGetLastError();
+}
+

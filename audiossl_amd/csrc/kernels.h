@@ -33,6 +33,8 @@ struct WgradArgs {
   int m_per_split;                   // 0 = auto
 };
 int atst_gemm_tn(const WgradArgs& a, hipStream_t st);
+#define ATST_WGRAD_GROUP_MAX 4
+int atst_gemm_tn_group(const WgradArgs* items, int n, hipStream_t st);   // independent weight gradients sharing one launch
 
 // LayerNorm (eps 1e-6), C in {384, 768}
 int atst_ln_fwd(const float* x, const float* gamma, const float* beta, bf16* y, float* mean, float* rstd, int M, int C, hipStream_t st);

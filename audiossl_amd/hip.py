@@ -22,6 +22,11 @@ class HipError(RuntimeError):
     pass
 
 
+class Wgrad(C.Structure):
+    """atst_wgrad_t (include/atst_hip.h)."""
+    _fields_ = [("dY", C.c_void_p), ("X", C.c_void_p), ("dW", C.c_void_p)] + [(n, C.c_int) for n in ("M", "N", "K", "ldy", "ldx", "ldw")]
+
+
 class LayerOff(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("ln1_w", "ln1_b", "qkv_w", "proj_w", "proj_b", "ln2_w", "ln2_b", "fc1_w", "fc1_b",
                                          "fc2_w", "fc2_b")]
@@ -49,6 +54,7 @@ _SIGS = {
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "atst_gemm_tn_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                     C.c_int, C.c_void_p]),
+    "atst_gemm_tn_group_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "atst_layernorm_fwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p]),
     "atst_layernorm_bwd": (C.c_int, [C.c_void_p] * 9 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_void_p]),
     "atst_attention_fwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]),

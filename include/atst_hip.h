@@ -46,6 +46,10 @@ int atst_gemm_nt_bf16(const uint16_t* A, const uint16_t* B, int M, int N, int K,
 /* dW[N,K] += dY[M,N]^T X[M,K]  (fp32 accumulate); autograd of the same nn.Linear calls.                              */
 int atst_gemm_tn_bf16(const uint16_t* dY, const uint16_t* X, int M, int N, int K, int ldy, int ldx, float* dW, int ldw,
                       int m_per_split, void* stream);
+/* Up to 4 independent weight gradients in one launch (the four nn.Linear of a Block, modules/transformer.py:124-150):
+ * each dW_i[N_i,K_i] += dY_i^T X_i.  Same result as n calls of atst_gemm_tn_bf16; fewer M-splits, fewer atomics.        */
+typedef struct { const uint16_t* dY; const uint16_t* X; float* dW; int M, N, K, ldy, ldx, ldw; } atst_wgrad_t;
+int atst_gemm_tn_group_bf16(const atst_wgrad_t* items, int n, void* stream);
 /* nn.LayerNorm(eps=1e-6): audiossl/modules/transformer.py:128,132 ; audio_transformer.py:113                         */
 int atst_layernorm_fwd(const float* x, const float* gamma, const float* beta, uint16_t* y, float* mean, float* rstd,
                        int M, int C, void* stream);

@@ -95,13 +95,31 @@ def test_gemm_nt_epilogues():
     assert relerr(t, want) < 2e-5
 
 
-@pytest.mark.parametrize("M,N,K,split", [(1000, 256, 384, 0), (64, 128, 128, 0), (4099, 384, 256, 512), (777, 1152, 384, 0)])
+@pytest.mark.parametrize("M,N,K,split", [(1000, 256, 384, 0), (64, 128, 128, 0), (4099, 384, 256, 512), (777, 1152, 384, 0),
+                                         (8192, 384, 384, 0), (16384 + 64, 1152, 384, 0), (8192 + 128, 384, 1536, 0)])   # last three: 192x384 LDS-DMA tile
 def test_gemm_tn(M, N, K, split):
     dY, X = bf(rnd(M, N, seed=1)), bf(rnd(M, K, seed=2))
     dW = torch.full((N, K), 0.5, device=DEV)
     hip.call("atst_gemm_tn_bf16", hip.ptr(dY), hip.ptr(X), M, N, K, N, K, hip.ptr(dW), K, split, hip.stream())
     ref = dY.float().t() @ X.float() + 0.5
     assert relerr(dW, ref) < 2e-5
+
+
+@pytest.mark.parametrize("M", [8192, 1000])          # 192x384 LDS-DMA tiles in one launch / per-problem fallback
+def test_gemm_tn_group(M):
+    import ctypes as C
+    shapes = [(1536, 384), (384, 1536), (1152, 384), (384, 384)]
+    items = (hip.Wgrad * 4)()
+    keep, want = [], []
+    for i, (N, K) in enumerate(shapes):
+        dY, X = bf(rnd(M, N, seed=10 + i)), bf(rnd(M, K, seed=20 + i))
+        dW = torch.full((N, K), 0.25, device=DEV)
+        keep.append((dY, X, dW))
+        want.append(dY.float().t() @ X.float() + 0.25)
+        items[i] = hip.Wgrad(hip.ptr(dY), hip.ptr(X), hip.ptr(dW), M, N, K, N, K, K)
+    hip.call("atst_gemm_tn_group_bf16", C.cast(items, C.c_void_p), 4, hip.stream())
+    for (dY, X, dW), ref in zip(keep, want):
+        assert relerr(dW, ref) < 2e-5
 
 
 @pytest.mark.parametrize("C", [384, 768])
