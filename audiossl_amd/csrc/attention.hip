@@ -226,6 +226,153 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256_kernel(AttnArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Forward, NP = 256, second version: same block-per-sequence head loop, but
+//  * K and V of head h+1 go HBM -> LDS by global_load_lds while head h is computed (no staging registers, no ds_write
+//    pass): [256][64] bf16 images with 128-B rows, double buffered (2 x 64 KB).  16-B chunk c of row r sits at chunk
+//    c ^ ((r >> 1) & 7) for K (ds_read_b128 fragments: the 16 rows of a service group hit 16 distinct 16-B bank slots)
+//    and at c ^ (4 ((r >> 1) & 1)) for V (ds_read_b64_tr_b16: 4 rows x 64 B per half-wave on 4 distinct bank windows);
+//  * the whole 32 x 256 score strip of a wave stays in registers (8 accumulator tiles), so the softmax is the plain
+//    two-pass one: no running-max rescale of the output accumulators, one exp2 and one FMA per score, and the key mask
+//    is applied only in the tile that straddles valid[s].  The online version spent ~3.3x the MFMA time in VALU work.
+constexpr int F2_MAT = 256 * 128;                       // bytes of one [256][64] bf16 image
+constexpr int F2_BUF = 2 * F2_MAT;                      // K + V of one head
+
+DEVFN bf16x8 ld_frag_tr_v(const char* X, int r0, int c0, int lane) {
+  const int a = lane & 15, g = lane >> 4;
+  const int row = r0 + 4 * (g >> 1) + (a >> 2);
+  const int col = c0 + (g & 1) * 16 + 4 * (a & 3);
+  const int pch = (col >> 3) ^ (((row >> 1) & 1) << 2);
+  const bf16* ptr = reinterpret_cast<const bf16*>(X + row * 128 + pch * 16) + (col & 7);
+  s16x4 lo = lds_tr4(ptr);
+  s16x4 hi = lds_tr4(ptr + 8 * 64);                                // +8 rows: same key
+  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+  u.s.a = lo; u.s.b = hi;
+  return u.v;
+}
+
+__global__ __launch_bounds__(512, 2) void attn_fwd256v2_kernel(AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  typedef const void __attribute__((address_space(1))) * gptr_t;
+  typedef void __attribute__((address_space(3))) * lptr_t;
+  constexpr int NP = 256;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+  const int H = p.H, C = H * HD;
+  const size_t ld = 3 * (size_t)C;
+  const int s = blockIdx.x;
+  const bf16* base = p.qkv + (size_t)s * NP * ld;
+  const int valid = p.valid[s];
+  const int ntile = (valid + 31) / 32 < 8 ? (valid + 31) / 32 : 8;
+  const int q0 = wid * 32;
+  const float c1 = 0.125f * LOG2E;                                 // softmax scale folded into the exp2 argument
+
+  // LDS-DMA: instruction i of a wave moves 8 rows x 128 B; per head each wave moves rows [32 wid, 32 wid + 32) of K and V
+  int offK[4], offV[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wid * 32 + i * 8 + (lane >> 3), pc = lane & 7;
+    offK[i] = row * (int)ld + C + (pc ^ ((row >> 1) & 7)) * 8;
+    offV[i] = row * (int)ld + 2 * C + (pc ^ (((row >> 1) & 1) << 2)) * 8;
+  }
+  auto issue = [&](int h) {
+    char* buf = smem_raw + (h & 1) * F2_BUF;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((gptr_t)(base + offK[i] + h * HD), (lptr_t)(buf + (wid * 4 + i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(base + offV[i] + h * HD), (lptr_t)(buf + F2_MAT + (wid * 4 + i) * 1024), 16, 0, 0);
+    }
+  };
+  bf16x8 qn[4];
+  auto qload = [&](int h) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qn[ks] = ld_frag(base + (size_t)(q0 + l31) * ld + h * HD + ks * 16 + hi * 8);
+  };
+  // lane-only parts of the swizzled fragment addresses (tile offsets are compile-time constants added by the reads)
+  int kofs[4], vofs[2];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) kofs[ks] = l31 * 128 + (((ks * 2 + hi) ^ ((l31 >> 1) & 7)) << 4);
+  {
+    const int a = lane & 15, g = lane >> 4;
+    const int lrow = 4 * (g >> 1) + (a >> 2), lcol = (g & 1) * 16 + 4 * (a & 3), swz = ((lrow >> 1) & 1) << 2;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) vofs[c] = lrow * 128 + (((c * 4 + (lcol >> 3)) ^ swz) << 4) + (lcol & 7) * 2;
+  }
+  auto vfrag = [&](const char* sV, int r0, int c) {                // V^T fragment: keys r0..r0+15, head dims 32c..32c+31
+    const bf16* ptr = reinterpret_cast<const bf16*>(sV + vofs[c] + r0 * 128);
+    union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+    u.s.a = lds_tr4(ptr); u.s.b = lds_tr4(ptr + 8 * 64);
+    return u.v;
+  };
+  // bit r of mbits: accumulator register r of the LAST key tile is a padded key.  One per-lane word instead of 16
+  // compare masks per tile: those are loop-invariant, get hoisted out of the head loop and spill the scalar registers.
+  unsigned mbits = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) mbits |= ((ntile - 1) * 32 + crow32(r, hi) >= valid ? 1u : 0u) << r;
+  asm volatile("" : "+v"(mbits));
+  issue(0);
+  qload(0);
+  for (int h = 0; h < H; ++h) {
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = qn[ks];
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // head h landed everywhere; buffer (h+1)&1 no longer read
+    if (h + 1 < H) { issue(h + 1); qload(h + 1); }
+    const char* sK = smem_raw + (h & 1) * F2_BUF;
+    const char* sV = sK + F2_MAT;
+    // pass 1: the wave's 32 x 256 score strip (raw q.k, scale folded into the exponent) and its row maximum
+    f32x16 sc[8];
+    float mx = -3.0e38f;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j < ntile) {
+        sc[j] = mfma32(*reinterpret_cast<const bf16x8*>(sK + kofs[0] + j * 4096), qf[0], zero);   // C = inline 0: no accumulator clears
+#pragma unroll
+        for (int ks = 1; ks < 4; ++ks)
+          sc[j] = mfma32(*reinterpret_cast<const bf16x8*>(sK + kofs[ks] + j * 4096), qf[ks], sc[j]);
+        if (j == ntile - 1) {                                      // the only tile that can hold padded keys
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if ((mbits >> r) & 1u) sc[j][r] = -3.0e38f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[j][r]);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float c0 = -mx * c1;
+    // pass 2: p = exp2(c1 s - c1 max) ; O^T += V^T P^T
+    float rs = 0.f;
+    f32x16 o0, o1; zero16(o0); zero16(o1);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j < ntile) {
+        float pv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { pv[r] = __builtin_amdgcn_exp2f(fmaf(sc[j][r], c1, c0)); rs += pv[r]; }   // raw v_exp_f32: argument <= 0, underflow to 0 is the wanted result (exp2f adds a 4-instruction denormal-range fix-up)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const bf16x8 pf = pack8(pv + 8 * t);
+          o0 = mfma32(vfrag(sV, j * 32 + 16 * t, 0), pf, o0);
+          o1 = mfma32(vfrag(sV, j * 32 + 16 * t, 1), pf, o1);
+        }
+      }
+    }
+    rs += __shfl_xor(rs, 32, 64);
+    const float inv = 1.0f / rs;
+    bf16* orow = p.o + ((size_t)s * NP + q0 + l31) * C + h * HD;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 a, b;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { a[e] = f2bf(o0[4 * g + e] * inv); b[e] = f2bf(o1[4 * g + e] * inv); }
+      *reinterpret_cast<bf16x4*>(orow + 8 * g + 4 * hi) = a;
+      *reinterpret_cast<bf16x4*>(orow + 32 + 8 * g + 4 * hi) = b;
+    }
+    if (hi == 0) p.lse[((size_t)s * H + h) * NP + q0 + l31] = mx * 0.125f + __logf(rs);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // backward part 1: dK, dV.  LDS: Q [NP][72], dO [NP][72], lse[NP], D[NP] per pair.
 template <int NP>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
@@ -632,11 +779,22 @@ int launch_bwd(const AttnArgs& a, hipStream_t st) {
 }  // namespace
 
 int g_bwd256 = 1;          // merged per-sequence backward kernel for NP = 256 (tuning hook 402/403)
-int g_fwd256 = 1;          // per-sequence head-loop kernel for NP = 256 (tuning hook 400 turns it off)
-void atst_attn_set_variant(int v) { if (v >= 2) g_bwd256 = v - 2; else g_fwd256 = v; }
+int g_fwd256 = 2;          // NP = 256 forward: 2 = two-pass softmax + LDS-DMA head loop, 1 = online-softmax head loop, 0 = per-(sequence, head) kernel (tuning hooks 404 / 401 / 400)
+void atst_attn_set_variant(int v) { if (v == 4) g_fwd256 = 2; else if (v >= 2) g_bwd256 = v - 2; else g_fwd256 = v; }
 
 int atst_attn_fwd(const AttnArgs& a, hipStream_t st) {
   if (a.S <= 0) return ATST_OK;
+  if (a.NP == 256 && g_fwd256 == 2 && (size_t)a.NP * 3 * a.H * HD * 2 < (1u << 30)) {
+    static bool done2 = false;
+    if (!done2) {
+      hipError_t e = hipFuncSetAttribute((const void*)attn_fwd256v2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * F2_BUF);
+      if (e != hipSuccess) return (int)e;
+      done2 = true;
+    }
+    ProfScope ps(PK_ATTN_FWD, 4.0 * a.S * a.H * 256.0 * 256.0 * HD, st, 8.0 * a.S * a.H * 256.0 * HD);
+    hipLaunchKernelGGL(attn_fwd256v2_kernel, dim3(a.S), dim3(512), 2 * F2_BUF, st, a);
+    return (int)hipGetLastError();
+  }
   if (a.NP == 256 && g_fwd256) {
     static bool done = false;
     if (!done) {
