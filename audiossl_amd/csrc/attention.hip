@@ -44,6 +44,41 @@ DEVFN void stage_rows(bf16* sm, const bf16* g, size_t ld, int t, int nthr) {
   }
 }
 
+// v_exp_f32 as is.  exp2f() adds a compare / two selects / ldexp around it for results in the denormal range; every use
+// here has an argument <= ~0 whose underflow to 0 is the wanted result.
+DEVFN float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// Store one 64-wide bf16 row per lane pair from two C-layout accumulator tiles (t0: columns 0..31, t1: 32..63 of the row
+// owned by lane & 31).  A lane holds 4-element groups {8g + 4 hi .. +3}; v_permlane32_swap trades groups between the
+// two half-waves so that every lane ends up with two complete 8-element (16-B) pieces per tile: 4 dwordx4 stores per
+// row instead of 8 dwordx2 (the row-per-lane store tail is issue-bound: -18 % on the forward kernel).
+DEVFN unsigned pack2(float a, float b) { bf16x2 t; t[0] = f2bf(a); t[1] = f2bf(b); return __builtin_bit_cast(unsigned, t); }
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+DEVFN void store_row64(bf16* row, const f32x16& t0, const f32x16& t1, float mul, int hi) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const f32x16& v = t == 0 ? t0 : t1;
+    unsigned P[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      P[g][0] = pack2(v[4 * g] * mul, v[4 * g + 1] * mul);
+      P[g][1] = pack2(v[4 * g + 2] * mul, v[4 * g + 3] * mul);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int w = 0; w < 2; ++w) {
+        auto r = __builtin_amdgcn_permlane32_swap(P[k][w], P[k + 2][w], false, false);   // P[k].upper <-> P[k+2].lower
+        P[k][w] = r[0]; P[k + 2][w] = r[1];
+      }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      u32x4 o = {P[k][0], P[k][1], P[k + 2][0], P[k + 2][1]};
+      *reinterpret_cast<u32x4*>(row + t * 32 + 16 * hi + 8 * k) = o;
+    }
+  }
+}
+
 DEVFN void zero16(f32x16& a) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) a[r] = 0.f;
@@ -98,10 +133,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
       }
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run, mx);
-      const float alpha = exp2f((m_run - m_new) * LOG2E);
+      const float alpha = fast_exp2((m_run - m_new) * LOG2E);
       float rs = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { pv[r] = exp2f((pv[r] - m_new) * LOG2E); rs += pv[r]; }
+      for (int r = 0; r < 16; ++r) { pv[r] = fast_exp2((pv[r] - m_new) * LOG2E); rs += pv[r]; }
       rs += __shfl_xor(rs, 32, 64);
       l_run = l_run * alpha + rs;
       m_run = m_new;
@@ -193,10 +228,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256_kernel(AttnArgs p) {
       }
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run, mx);
-      const float alpha = exp2f((m_run - m_new) * LOG2E);
+      const float alpha = fast_exp2((m_run - m_new) * LOG2E);
       float rs = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { pv[r] = exp2f((pv[r] - m_new) * LOG2E); rs += pv[r]; }
+      for (int r = 0; r < 16; ++r) { pv[r] = fast_exp2((pv[r] - m_new) * LOG2E); rs += pv[r]; }
       rs += __shfl_xor(rs, 32, 64);
       l_run = l_run * alpha + rs;
       m_run = m_new;
@@ -360,14 +395,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256v2_kernel(AttnArgs p) {
     rs += __shfl_xor(rs, 32, 64);
     const float inv = 1.0f / rs;
     bf16* orow = p.o + ((size_t)s * NP + q0 + l31) * C + h * HD;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      bf16x4 a, b;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { a[e] = f2bf(o0[4 * g + e] * inv); b[e] = f2bf(o1[4 * g + e] * inv); }
-      *reinterpret_cast<bf16x4*>(orow + 8 * g + 4 * hi) = a;
-      *reinterpret_cast<bf16x4*>(orow + 32 + 8 * g + 4 * hi) = b;
-    }
+#ifdef ATST_ABLATE_ATTN_STORE
+    if (rs == 12345.678f)                                           // experiment builds: no output stores
+#endif
+    store_row64(orow, o0, o1, inv, hi);
     if (hi == 0) p.lse[((size_t)s * H + h) * NP + q0 + l31] = mx * 0.125f + __logf(rs);
   }
 }
@@ -445,7 +476,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int r = 4 * g + e;
-            const float pr = exp2f((sc[r] * scale + kbias - l4[e]) * LOG2E);
+            const float pr = fast_exp2((sc[r] * scale + kbias - l4[e]) * LOG2E);
             pv[r] = pr;
             ds[r] = pr * (dp[r] - d4[e]) * scale;
           }
@@ -531,7 +562,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int kv = j * 32 + crow32(r, hi);
-        const float pr = exp2f((sc[r] * scale + (kv >= valid ? MASK_NEG : 0.f) - lse) * LOG2E);
+        const float pr = fast_exp2((sc[r] * scale + (kv >= valid ? MASK_NEG : 0.f) - lse) * LOG2E);
         ds[r] = pr * (dp[r] - D) * scale;
       }
 #pragma unroll
@@ -621,8 +652,14 @@ __global__ __launch_bounds__(512, 2) void attn_bwd256_kernel(AttnArgs p, const f
       *reinterpret_cast<bf16x8*>((mat == 0 ? sQ : sDO) + r * A_LD + k) = pa[i];
       *reinterpret_cast<bf16x8*>((mat == 0 ? sK : sV) + r * A_LD + k) = pb[i];
     }
-    if (tid < NP) { sLse[tid] = plse; sD[tid] = pd; }
+    if (tid < NP) { sLse[tid] = -plse * LOG2E; sD[tid] = pd; }       // exponent offset of P = exp2(c1 s - lse log2 e)
   };
+  const float c1 = scale * LOG2E;
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  unsigned mbits = 0;                                               // padded keys of the last key tile (dQ phase), one bit per accumulator register
+#pragma unroll
+  for (int r = 0; r < 16; ++r) mbits |= ((ntile - 1) * 32 + crow32(r, hi) >= valid ? 1u : 0u) << r;
+  asm volatile("" : "+v"(mbits));
   load_qdo(0);
   load_kv(0);
   for (int h = 0; h < H; ++h) {
@@ -641,17 +678,19 @@ __global__ __launch_bounds__(512, 2) void attn_bwd256_kernel(AttnArgs p, const f
           kf[ks] = ld_frag(sK + (k0 + l31) * A_LD + ks * 16 + hi * 8);
           vf[ks] = ld_frag(sV + (k0 + l31) * A_LD + ks * 16 + hi * 8);
         }
-        const float kbias = (k0 + l31 >= valid) ? MASK_NEG : 0.f;
+        const float kbias = (k0 + l31 >= valid) ? -3.0e38f : 0.f;  // padded key: P = 0 (reference: exp(-10000 + ...) == 0 in fp32)
         for (int i = 0; i < 8; ++i) {
-          f32x16 sc, dp; zero16(sc); zero16(dp);
+          f32x16 sc, dp;
           const bf16* qr = sQ + (i * 32 + l31) * A_LD + hi * 8;
           const bf16* dr = sDO + (i * 32 + l31) * A_LD + hi * 8;
+          sc = mfma32(ld_frag(qr), kf[0], zero);
+          dp = mfma32(ld_frag(dr), vf[0], zero);
 #pragma unroll
-          for (int ks = 0; ks < 4; ++ks) {
+          for (int ks = 1; ks < 4; ++ks) {
             sc = mfma32(ld_frag(qr + ks * 16), kf[ks], sc);
             dp = mfma32(ld_frag(dr + ks * 16), vf[ks], dp);
           }
-          float pv[16], ds[16];
+          float pv[16], ds[16];                                    // ds without the softmax scale: applied once to dK at the end
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const f32x4 l4 = *reinterpret_cast<const f32x4*>(sLse + i * 32 + 8 * g + 4 * hi);
@@ -659,9 +698,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd256_kernel(AttnArgs p, const f
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const int r = 4 * g + e;
-              const float pr = exp2f((sc[r] * scale + kbias - l4[e]) * LOG2E);
+              const float pr = fast_exp2(fmaf(sc[r], c1, l4[e]) + kbias);
               pv[r] = pr;
-              ds[r] = pr * (dp[r] - d4[e]) * scale;
+              ds[r] = pr * (dp[r] - d4[e]);
             }
           }
 #pragma unroll
@@ -674,19 +713,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd256_kernel(AttnArgs p, const f
           }
         }
       }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        bf16x4 a, b, c, d;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          a[e] = f2bf(dk0[4 * g + e]); b[e] = f2bf(dk1[4 * g + e]);
-          c[e] = f2bf(dv0[4 * g + e]); d[e] = f2bf(dv1[4 * g + e]);
-        }
-        *reinterpret_cast<bf16x4*>(dkrow + 8 * g + 4 * hi) = a;
-        *reinterpret_cast<bf16x4*>(dkrow + 32 + 8 * g + 4 * hi) = b;
-        *reinterpret_cast<bf16x4*>(dvrow + 8 * g + 4 * hi) = c;
-        *reinterpret_cast<bf16x4*>(dvrow + 32 + 8 * g + 4 * hi) = d;
-      }
+      store_row64(dkrow, dk0, dk1, scale, hi);
+      store_row64(dvrow, dv0, dv1, 1.0f, hi);
     }
     // ---------------- dQ : this wave owns queries [32 wid, 32 wid + 32)
     if (h + 1 < H) { load_qdo(h + 1); load_kv(h + 1); }            // both in flight during the dQ phase (fewer live registers than dK/dV)
@@ -698,23 +726,26 @@ __global__ __launch_bounds__(512, 2) void attn_bwd256_kernel(AttnArgs p, const f
         qf[ks] = ld_frag(sQ + (q0 + l31) * A_LD + ks * 16 + hi * 8);
         dof[ks] = ld_frag(sDO + (q0 + l31) * A_LD + ks * 16 + hi * 8);
       }
-      const float Dq = sD[q0 + l31], lse = sLse[q0 + l31];
+      const float Dq = sD[q0 + l31], nlse = sLse[q0 + l31];
       f32x16 dq0, dq1; zero16(dq0); zero16(dq1);
       for (int j = 0; j < ntile; ++j) {
-        f32x16 sc, dp; zero16(sc); zero16(dp);
+        f32x16 sc, dp;
         const bf16* kr = sK + (j * 32 + l31) * A_LD + hi * 8;
         const bf16* vr = sV + (j * 32 + l31) * A_LD + hi * 8;
+        sc = mfma32(ld_frag(kr), qf[0], zero);
+        dp = mfma32(ld_frag(vr), dof[0], zero);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 1; ks < 4; ++ks) {
           sc = mfma32(ld_frag(kr + ks * 16), qf[ks], sc);
           dp = mfma32(ld_frag(vr + ks * 16), dof[ks], dp);
         }
         float ds[16];
+        const unsigned mb = j == ntile - 1 ? mbits : 0u;           // only the last key tile can hold padded keys
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int kv = j * 32 + crow32(r, hi);
-          const float pr = exp2f((sc[r] * scale + (kv >= valid ? MASK_NEG : 0.f) - lse) * LOG2E);
-          ds[r] = pr * (dp[r] - Dq) * scale;
+          float pr = fast_exp2(fmaf(sc[r], c1, nlse));
+          if ((mb >> r) & 1u) pr = 0.f;
+          ds[r] = pr * (dp[r] - Dq);
         }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -724,14 +755,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd256_kernel(AttnArgs p, const f
         }
       }
       bf16* dqrow = p.dqkv + ((size_t)s * NP + q0 + l31) * ld + h * HD;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        bf16x4 a, b;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { a[e] = f2bf(dq0[4 * g + e]); b[e] = f2bf(dq1[4 * g + e]); }
-        *reinterpret_cast<bf16x4*>(dqrow + 8 * g + 4 * hi) = a;
-        *reinterpret_cast<bf16x4*>(dqrow + 32 + 8 * g + 4 * hi) = b;
-      }
+      store_row64(dqrow, dq0, dq1, scale, hi);
     }
     __syncthreads();                                               // everyone is done with this head's LDS image
   }
