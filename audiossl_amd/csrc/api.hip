@@ -102,6 +102,11 @@ int atst_transpose_bf16_2d(const uint16_t* src, int rows, int cols, uint16_t* ds
   return atst_transpose_bf16(CBF(src), rows, cols, BF(dst), ST(stream));
 }
 
+int atst_transpose_bf16_batch(const uint16_t* src_base, uint16_t* dst_base, const int32_t* table, int n, int total_tiles, void* stream) {
+  if (!src_base || !dst_base || !table) return ATST_EINVAL;
+  return atst_transpose_bf16_batch(CBF(src_base), BF(dst_base), table, n, total_tiles, ST(stream));
+}
+
 int atst_bn_stats_f32(const float* h, int R, int N, float* mean, float* m2, void* stream) {
   return atst_bn_stats(h, R, N, mean, m2, ST(stream));
 }

@@ -103,6 +103,7 @@ struct OptimArgs {
 };
 int atst_adamw_ema(const OptimArgs& a, hipStream_t st);
 int atst_transpose_bf16(const bf16* src, int rows, int cols, bf16* dst, hipStream_t st);
+int atst_transpose_bf16_batch(const bf16* src, bf16* dst, const int* table, int n, int total_tiles, hipStream_t st);
 
 // front end
 int atst_mel_frontend(const float* wave, int n_clips, int n_samples, int win_length, const float* window,

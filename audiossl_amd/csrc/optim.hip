@@ -68,7 +68,34 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16* __restrict__
     if (r0 + r < rows && c0 + c < cols) dst[(size_t)(c0 + c) * rows + r0 + r] = tile[r][c];
   }
 }
+// All 2-D parameters of the flat buffer in one launch: table[i] = {element offset, rows, cols, first tile}; a block finds
+// its matrix by scanning the (<= 128-entry) table.  Replaces one 10-us launch per weight matrix per step (58 of them).
+__global__ __launch_bounds__(256) void transpose_batch_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst,
+                                                              const int* __restrict__ table, int n) {
+  __shared__ bf16 tile[64][66];
+  int m = 0;
+  for (int i = 1; i < n; ++i) if ((int)blockIdx.x >= table[4 * i + 3]) m = i;
+  const int off = table[4 * m], rows = table[4 * m + 1], cols = table[4 * m + 2], t = blockIdx.x - table[4 * m + 3];
+  const int tc = (cols + 63) / 64;
+  const int r0 = (t / tc) * 64, c0 = (t % tc) * 64;
+  const bf16* s = src + off; bf16* d = dst + off;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    tile[r][c] = (r0 + r < rows && c0 + c < cols) ? s[(size_t)(r0 + r) * cols + c0 + c] : f2bf(0.f);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int c = i >> 6, r = i & 63;
+    if (r0 + r < rows && c0 + c < cols) d[(size_t)(c0 + c) * rows + r0 + r] = tile[r][c];
+  }
+}
 }  // namespace
+
+int atst_transpose_bf16_batch(const bf16* src, bf16* dst, const int* table, int n, int total_tiles, hipStream_t st) {
+  if (n <= 0 || total_tiles <= 0) return ATST_OK;
+  hipLaunchKernelGGL(transpose_batch_kernel, dim3(total_tiles), dim3(256), 0, st, src, dst, table, n);
+  return (int)hipGetLastError();
+}
 
 int atst_adamw_ema(const OptimArgs& a, hipStream_t st) {
   if (a.n == 0 || (a.n % 256)) return ATST_EINVAL;

@@ -377,11 +377,16 @@ class AtstEngine:
         self._synced_version = (self.p32._version, self.t32._version)
 
     def _refresh_transposes(self):
-        st = hip.stream()
-        for name, (off, shape) in self.layout.entries.items():
-            if len(shape) == 2:
-                hip.call("atst_transpose_bf16_2d", self.p16.data_ptr() + 2 * off, shape[0], shape[1],
-                         self.p16t.data_ptr() + 2 * off, st)
+        if getattr(self, "_tr_table", None) is None:
+            rows, tiles = [], 0
+            for name, (off, shape) in self.layout.entries.items():
+                if len(shape) == 2:
+                    rows.append((off, shape[0], shape[1], tiles))
+                    tiles += -(-shape[0] // 64) * -(-shape[1] // 64)
+            self._tr_table = torch.tensor(rows, dtype=torch.int32, device=self.device).contiguous()
+            self._tr_tiles = tiles
+        hip.call("atst_transpose_bf16_batch", hip.ptr(self.p16), hip.ptr(self.p16t), hip.ptr(self._tr_table),
+                 self._tr_table.shape[0], self._tr_tiles, hip.stream())
 
     # ---------------------------------------------------------------------------------------------------------------
     def _pass(self, net: str, S: int, width: int, train: bool, slot: int) -> EncoderPass:

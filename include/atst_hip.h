@@ -71,6 +71,10 @@ int atst_cast_bf16(const float* x, size_t n, uint16_t* y, void* stream);
  * 3K then yields x W^T to ~2^-16; used for the Linear in front of BatchNorm+ReLU (byol.py:13-16) */
 int atst_split3_bf16(const float* x, int R, int K, int b_layout, uint16_t* y, void* stream);
 int atst_transpose_bf16_2d(const uint16_t* src, int rows, int cols, uint16_t* dst, void* stream);
+/* Every 2-D tensor of a flat bf16 parameter buffer transposed in one launch ([out,in] -> [in,out], the dgrad operand).
+ * table (device, int32 [n][4]) = {element offset, rows, cols, first 64x64 tile index}; total_tiles = sum of tiles.     */
+int atst_transpose_bf16_batch(const uint16_t* src_base, uint16_t* dst_base, const int32_t* table, int n, int total_tiles,
+                              void* stream);
 
 /* build_mlp's BatchNorm1d(train)+ReLU: audiossl/models/atst/byol.py:13-16                                            */
 int atst_bn_stats_f32(const float* h, int R, int N, float* mean, float* m2, void* stream);
