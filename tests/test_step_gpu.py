@@ -105,6 +105,45 @@ def test_encoder_gradient_vs_reference_golden():
     assert max(abs(nerr) for _, nerr, _ in tab.values()) < 1e-2
 
 
+def test_base_arch_encoder_vs_oracle():
+    """ATST-base geometry (d = 768, 12 heads; audio_transformer.py:372-374), depth 3, ragged lengths, injected DropPath:
+    forward CLS and the gradient of the smooth objective sum(CLS * R) against the CPU oracle's autograd.  Exercises the
+    C = 768 code paths (separate LayerNorm kernels, 768 / 2304 / 3072-wide GEMM tiles, 12-head attention loop)."""
+    S, depth = 6, 3
+    W = O.recipe_weights("base", depth=depth, seed=31)
+    eng = AtstEngine("base", depth=depth)
+    eng.load_weights(W)
+    mel = O.recipe_mel(S, 1001, seed=33)
+    length = torch.tensor([1001, 1001, 777, 640, 1001, 405])
+    keep = (torch.rand(depth, 2, S, generator=torch.Generator().manual_seed(7)) > 0.3).float()
+    keep[0] = 1.0                                                       # block 0 has no DropPath (rate 0)
+    leaves = {k: v.requires_grad_(True) for k, v in W.items() if k.startswith("student.encoder.") and v.dtype == torch.float32}
+    cls_o = O.encoder_forward(W, "student.encoder.", mel, length, "base", depth, keep=keep)
+    R = torch.from_numpy(np.random.default_rng(35).standard_normal((S, 768)).astype(np.float32))
+    (cls_o * R).sum().backward()
+    ep = eng._pass("student", S, 1001, True, 0)
+    out = ep.forward(mel.cuda(), eng._valid(length, 1), None, eng.drop_path_scales(S, keep))
+    cls = out.float().reshape(S, 256, 768)[:, 0].cpu()
+    assert rel(cls.numpy(), cls_o.detach().numpy()) < 1e-2
+    eng.g32.zero_(); ep.dout.zero_()
+    rows = (torch.arange(S, dtype=torch.int32, device="cuda") * 256).contiguous()
+    hip.call("atst_scatter_rows_bf16", hip.ptr(R.cuda()), hip.ptr(rows), S, 768, hip.ptr(ep.dout), hip.stream())
+    ep.backward()
+    num = den = 0.0
+    worst = ("", 0.0)
+    for name in eng.layout.entries:
+        if not name.startswith("encoder.") or name == "encoder.mask_embed":
+            continue
+        g = eng.param_view("student", name, grad=True).double().cpu()
+        go = leaves["student." + name].grad.double()
+        r = float((g - go).norm() / (go.norm() + 1e-30))
+        num += r * g.numel(); den += g.numel()
+        if r > worst[1]:
+            worst = (name, r)
+    print(f"\n[base encoder grad] weighted mean rel-L2 {num / den:.3e}; worst {worst[0]} {worst[1]:.3e}")
+    assert num / den < 1.5e-2 and worst[1] < 3e-2
+
+
 def test_head_and_loss_backward_given_same_features():
     """Projector + predictor + loss forward/backward on fixed features vs the oracle's autograd on the same features."""
     B, Cdim = 48, 384
