@@ -51,7 +51,8 @@ def gemm_nt(A, B, epi, out_dtype, **kw):
     return Cout, C2
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 384, 256), (128, 128, 64), (1027, 1152, 384), (512, 256, 4096)])
+@pytest.mark.parametrize("M,N,K", [(300, 384, 256), (128, 128, 64), (1027, 1152, 384), (512, 256, 4096),
+                                   (8192 + 77, 1152, 384), (8192, 384, 1536)])          # last two: 256 x 384 tiles, ragged last tile
 def test_gemm_nt_plain(M, N, K):
     A, B = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2))       # asymmetric operands: catches transposed fragments
     ref = A.float() @ B.float().t()
@@ -62,8 +63,25 @@ def test_gemm_nt_plain(M, N, K):
     assert relerr(outb.float(), ref + bias) < 4e-3
 
 
-def test_gemm_nt_epilogues():
-    M, N, K, rps = 640, 384, 128, 64
+def test_gemm_nt_persistent_variant():
+    """Tuning hook 309: the persistent 256 x 384 kernel (operand stream across tile boundaries) gives the same results."""
+    M, N, K = 24576, 1152, 384
+    A, B = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2))
+    bias = rnd(N, seed=3)
+    ref, _ = gemm_nt(A, B, hip.EPI_BF16, torch.bfloat16, bias=bias)
+    hip.load().atst_tune_gemm_variant(309)
+    try:
+        out, _ = gemm_nt(A, B, hip.EPI_BF16, torch.bfloat16, bias=bias)
+        u, a = gemm_nt(A, B, hip.EPI_BIAS_GELU, torch.bfloat16, bias=bias)
+    finally:
+        hip.load().atst_tune_gemm_variant(308)
+    assert torch.equal(out, ref)
+    assert relerr(a.float(), torch.nn.functional.gelu(ref.float())) < 6e-3
+
+
+@pytest.mark.parametrize("M", [640, 8192 + 64])                     # 128-row tiles / 256-row tiles with a ragged last tile
+def test_gemm_nt_epilogues(M):
+    N, K, rps = 384, 128, 64
     A, B = bf(rnd(M, K, seed=1, scale=0.5)), bf(rnd(N, K, seed=2, scale=0.5))
     bias = rnd(N, seed=3)
     ref = A.float() @ B.float().t()
@@ -73,7 +91,7 @@ def test_gemm_nt_epilogues():
     assert relerr(a.float(), torch.nn.functional.gelu(ref + bias)) < 5e-3
     # residual with per-sequence DropPath scale
     resid = rnd(M, N, seed=4)
-    scale = torch.tensor([1.0, 0.0, 1.25, 1.0, 1.25, 0.0, 1.0, 1.0, 1.0, 1.25], device=DEV)
+    scale = torch.tensor([1.0, 0.0, 1.25, 1.0, 1.25, 0.0, 1.0, 1.0, 1.0, 1.25], device=DEV).repeat(M // (10 * rps) + 1)[:M // rps].contiguous()
     x, _ = gemm_nt(A, B, hip.EPI_RESID, torch.float32, bias=bias, resid=resid, row_scale=scale, rps=rps)
     want = resid + scale.repeat_interleave(rps)[:, None] * (ref + bias)
     assert relerr(x, want) < 2e-5
