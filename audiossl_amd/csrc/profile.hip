@@ -5,6 +5,9 @@
 namespace {
 struct Rec { hipEvent_t e0, e1; int kind; double work, bytes; };
 bool g_on = false;
+int g_stride = 1;                       // time every g_stride-th launch of each kind (event records cost ~4 us each and fence kernel overlap)
+long long g_seen[PK_COUNT] = {};
+bool g_open = false;
 std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_pool;
 hipEvent_t g_cur0; int g_kind; double g_work, g_bytes;
@@ -20,16 +23,25 @@ hipEvent_t get_event() {
 
 bool prof_on() { return g_on; }
 void prof_begin(int kind, double work, double bytes, hipStream_t st) {
+  g_open = (g_seen[kind]++ % g_stride) == 0;
+  if (!g_open) return;
   g_cur0 = get_event(); g_kind = kind; g_work = work; g_bytes = bytes;
   hipEventRecord(g_cur0, st);
 }
 void prof_end(hipStream_t st) {
+  if (!g_open) return;
+  g_open = false;
   hipEvent_t e1 = get_event();
   hipEventRecord(e1, st);
   g_recs.push_back(Rec{g_cur0, e1, g_kind, g_work, g_bytes});
 }
 
-extern "C" int atst_profile_enable(int on) { g_on = on != 0; return 0; }
+// on: 0 = off, n >= 1 = time every n-th launch of each kernel kind (1 = all)
+extern "C" int atst_profile_enable(int on) {
+  g_on = on != 0; g_stride = on > 1 ? on : 1;
+  for (int k = 0; k < PK_COUNT; ++k) g_seen[k] = 0;
+  return 0;
+}
 extern "C" int atst_profile_kinds(void) { return PK_COUNT; }
 extern "C" const char* atst_profile_name(int kind) { return kind >= 0 && kind < PK_COUNT ? NAMES[kind] : ""; }
 // Synchronises on every recorded event, accumulates per-kind milliseconds / work / launch counts, clears the records.

@@ -138,7 +138,7 @@ const float* atst_encoder_block_out(const atst_encoder_t* e, int i);
 const float* atst_encoder_tokens(const atst_encoder_t* e);
 
 /* ---- in-library kernel timing (HIP events on the launch stream); used by bench.py for the roofline object ---------- */
-int atst_profile_enable(int on);
+int atst_profile_enable(int on);      /* 0 = off ; n >= 1: HIP events around every n-th launch of each kernel kind     */
 int atst_profile_kinds(void);
 const char* atst_profile_name(int kind);
 int atst_profile_collect(double* ms, double* work, double* bytes, long long* launches);   /* arrays of atst_profile_kinds(); work = FLOPs for MFMA kinds, bytes = algorithmic HBM bytes */
