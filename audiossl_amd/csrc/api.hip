@@ -107,6 +107,16 @@ int atst_transpose_bf16_batch(const uint16_t* src_base, uint16_t* dst_base, cons
   return atst_transpose_bf16_batch(CBF(src_base), BF(dst_base), table, n, total_tiles, ST(stream));
 }
 
+int atst_rrc_bicubic_f32(const float* in, float* out, const int32_t* params, int B, int H, int W, int CH, int CW, void* stream) {
+  if (!in || !out || !params) return ATST_EINVAL;
+  return atst_rrc_bicubic(in, out, params, B, H, W, CH, CW, ST(stream));
+}
+int atst_log_mixup_exp_f32(const float* x, const float* bank, const int32_t* zidx, const int32_t* zstart, const int32_t* xstart,
+                           const float* alpha, float* out, int B, int H, int W, int Wz, void* stream) {
+  if (!x || !bank || !zidx || !zstart || !xstart || !alpha || !out) return ATST_EINVAL;
+  return atst_log_mixup_exp(x, bank, zidx, zstart, xstart, alpha, out, B, H, W, Wz, ST(stream));
+}
+
 int atst_bn_stats_f32(const float* h, int R, int N, float* mean, float* m2, void* stream) {
   return atst_bn_stats(h, R, N, mean, m2, ST(stream));
 }

@@ -109,3 +109,8 @@ int atst_transpose_bf16_batch(const bf16* src, bf16* dst, const int* table, int 
 int atst_mel_frontend(const float* wave, int n_clips, int n_samples, int win_length, const float* window,
                       const float* fb_weights, const int* fb_start, const int* fb_len, int fb_maxlen,
                       float* out, unsigned int* clipmax, hipStream_t st);
+
+// batched spectrogram augmentations (augment.hip)
+int atst_rrc_bicubic(const float* in, float* out, const int* params, int B, int H, int W, int CH, int CW, hipStream_t st);
+int atst_log_mixup_exp(const float* x, const float* bank, const int* zidx, const int* zstart, const int* xstart, const float* alpha,
+                       float* out, int B, int H, int W, int Wz, hipStream_t st);

@@ -494,7 +494,8 @@ class AtstEngine:
         for ep, rows in self._student_groups:
             n = rows.numel()
             ep.dout.zero_()
-            hip.call("atst_scatter_rows_bf16", hip.ptr(df[r0:r0 + n].contiguous()), hip.ptr(rows), n, self.cfg["embed_dim"],
+            src = df[r0:r0 + n].contiguous()                       # named: must outlive the launch call
+            hip.call("atst_scatter_rows_bf16", hip.ptr(src), hip.ptr(rows), n, self.cfg["embed_dim"],
                      hip.ptr(ep.dout), hip.stream())
             ep.backward()
             r0 += n

@@ -3,12 +3,13 @@ batches: BYOL-A ``Mixup`` (log-mix-exp against a FIFO memory bank) and ``RandomR
 crop + bicubic resize), plus ``MinMax`` / ``RandomCrop`` restated from audiossl/transforms/common.py:63-74,97-110.
 ref: audiossl/transforms/byol_a.py:7-49 (RandomResizeCrop), :61-115 (log_mixup_exp, Mixup).
 
-These are stochastic augmentations: the distributions match the reference (same parameter sampling per sample); the
-random streams do not (numpy per-worker RNG there, one torch CPU generator here).  One deliberate difference: the resize
-samples the canvas with ``grid_sample(bicubic, align_corners=True)``, which reads real canvas pixels just outside the
-crop where ``F.interpolate`` on the cropped tensor replicates the crop's border (<= 2 pixels at the crop edge)."""
+The arithmetic runs in HIP kernels (csrc/augment.hip) that take the random draws as inputs; given the same draws the
+outputs equal the reference's (goldens: tests/golden/aug_byol_a.npz).  The distributions of the draws match the
+reference (same per-sample sampling order); the random streams do not (numpy / python global RNGs per dataloader worker
+there, one RandomState per transform object here)."""
 from __future__ import annotations
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -38,37 +39,73 @@ class RandomCrop:
         return signal[..., start:start + self.size]
 
 
-class BatchMixup:
-    """Mixup(ratio=0.4, n_memory=2000, log_mixup_exp=True) over a batch; the bank holds past *un-mixed* inputs."""
+def _i32(a, device):
+    return torch.as_tensor(np.asarray(a, dtype=np.int32), device=device).contiguous()
 
-    def __init__(self, ratio=0.4, n_memory=2000, generator: torch.Generator = None):
-        self.ratio, self.n, self.gen = ratio, n_memory, generator
-        self.bank = None          # [n_filled, 1, H, T] on the batch's device
+
+class BatchMixup:
+    """Mixup(ratio=0.4, n_memory=2000, log_mixup_exp=True) over a collated batch (ref: byol_a.py:86-115), executed by
+    ``atst_log_mixup_exp_f32``.  Per sample, as in the reference: a = ratio * U(0,1); z = a uniformly drawn bank entry;
+    out = log((1-a) e^x + a e^z + eps); when x and z differ in length the shorter one is mixed into a random window of
+    the other (byol_a.py:66-77).  The bank holds past *un-mixed* inputs (FIFO).
+    Differences from the per-item reference, both deliberate: the batch is appended to the bank after it has been
+    mixed (there, item k already sees items < k of its own batch), and the bank keeps one geometry (the first width it
+    sees; the reference keeps a heterogeneous python list).  The random stream is this object's RandomState, not numpy's
+    global one."""
+
+    def __init__(self, ratio=0.4, n_memory=2000, rng: "np.random.RandomState" = None):
+        self.ratio, self.n = ratio, n_memory
+        self.rng = rng if rng is not None else np.random.RandomState()
+        self.bank = None          # [n, H, Wz] on the batch's device
         self.filled = 0
         self.head = 0
 
+    def sample_params(self, B, W):
+        """-> (alpha [B] f32, zidx, zstart, xstart [B] i32), drawn per sample in the reference's order."""
+        Wz = self.bank.shape[-1]
+        alpha = np.empty(B, np.float32); zidx = np.empty(B, np.int32)
+        zstart = np.zeros(B, np.int32); xstart = np.zeros(B, np.int32)
+        for b in range(B):
+            alpha[b] = self.ratio * self.rng.random_sample()
+            zidx[b] = self.rng.randint(self.filled)
+            if W < Wz:
+                zstart[b] = self.rng.randint(0, Wz - W)
+            elif W > Wz:
+                xstart[b] = self.rng.randint(0, W - Wz)
+        return alpha, zidx, zstart, xstart
+
+    def apply(self, x, alpha, zidx, zstart, xstart):
+        from . import hip
+        shape = x.shape
+        x3 = x.reshape(-1, shape[-2], shape[-1]).float().contiguous()
+        B, H, W = x3.shape
+        out = torch.empty_like(x3)
+        # bank slots are addressed through the ring: logical entry k (oldest first) lives at (head - filled + k) mod n
+        phys = (self.head - self.filled + np.asarray(zidx, np.int64)) % self.n
+        # keep the argument tensors alive until the launch has been enqueued (a temporary freed inside the call expression
+        # hands its memory to the next temporary)
+        d_idx, d_zs, d_xs = _i32(phys, x.device), _i32(zstart, x.device), _i32(xstart, x.device)
+        d_alpha = torch.as_tensor(np.asarray(alpha, np.float32), device=x.device).contiguous()
+        hip.call("atst_log_mixup_exp_f32", hip.ptr(x3), hip.ptr(self.bank), hip.ptr(d_idx), hip.ptr(d_zs), hip.ptr(d_xs),
+                 hip.ptr(d_alpha), hip.ptr(out), B, H, W, self.bank.shape[-1], hip.stream())
+        return out.reshape(shape)
+
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
-        B = x.shape[0]
         out = x
-        if self.filled > 0 and self.bank.shape[-1] >= x.shape[-1]:
-            alpha = (self.ratio * torch.rand(B, generator=self.gen)).to(x.device).view(B, 1, 1, 1)
-            idx = torch.randint(0, self.filled, (B,), generator=self.gen).to(x.device)
-            z = self.bank[idx]
-            if z.shape[-1] > x.shape[-1]:                     # shorter input: random window of the bank entry
-                s = int(torch.randint(0, z.shape[-1] - x.shape[-1], (1,), generator=self.gen))
-                z = z[..., s:s + x.shape[-1]]
-            mixed = (1.0 - alpha) * x.exp() + alpha * z.exp()
-            out = torch.log(mixed + torch.finfo(x.dtype).eps)
+        if self.filled > 0:
+            B = x.reshape(-1, x.shape[-2], x.shape[-1]).shape[0]
+            out = self.apply(x, *self.sample_params(B, x.shape[-1]))
         self._push(x)
         return out.float()
 
     def _push(self, x):
+        x3 = x.reshape(-1, x.shape[-2], x.shape[-1]).float()
         if self.bank is None:
-            self.bank = torch.zeros((self.n,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-        if x.shape[1:] != self.bank.shape[1:]:
+            self.bank = torch.zeros((self.n,) + tuple(x3.shape[1:]), dtype=torch.float32, device=x.device)
+        if x3.shape[1:] != self.bank.shape[1:]:
             return                                            # bank keeps one geometry (the first view length seen)
-        for i in range(0, x.shape[0], self.n):
-            chunk = x[i:i + self.n]
+        for i in range(0, x3.shape[0], self.n):
+            chunk = x3[i:i + self.n]
             k = chunk.shape[0]
             pos = (self.head + torch.arange(k, device=x.device)) % self.n
             self.bank[pos] = chunk
@@ -77,34 +114,43 @@ class BatchMixup:
 
 
 class BatchRandomResizeCrop:
-    """RandomResizeCrop(virtual_crop_scale, freq_scale, time_scale) with one parameter draw per sample."""
+    """RandomResizeCrop(virtual_crop_scale, freq_scale, time_scale) with one parameter draw per sample
+    (ref: byol_a.py:7-49), executed by ``atst_rrc_bicubic_f32``: the zero canvas is never materialised, taps are clamped
+    to the crop exactly as ``F.interpolate(crop, mode='bicubic', align_corners=True)`` does.  Given the same
+    (i, j, h, w) the output equals the reference's (tests/golden/aug_byol_a.npz); the draws come from this object's
+    RandomState instead of numpy's / python's global generators."""
 
-    def __init__(self, virtual_crop_scale=(1.0, 1.5), freq_scale=(0.6, 1.5), time_scale=(0.6, 1.5), generator=None):
+    def __init__(self, virtual_crop_scale=(1.0, 1.5), freq_scale=(0.6, 1.5), time_scale=(0.6, 1.5), rng: "np.random.RandomState" = None):
         assert time_scale[1] >= 1.0 and freq_scale[1] >= 1.0
-        self.vcs, self.fs, self.ts, self.gen = virtual_crop_scale, freq_scale, time_scale, generator
+        self.vcs, self.fs, self.ts = virtual_crop_scale, freq_scale, time_scale
+        self.rng = rng if rng is not None else np.random.RandomState()
+
+    def canvas(self, H, W):
+        return int(H * self.vcs[0]), int(W * self.vcs[1])
 
     def sample_params(self, B, H, W):
-        CH, CW = int(H * self.vcs[0]), int(W * self.vcs[1])
-        u = torch.rand(B, 4, generator=self.gen)
-        h = (((self.fs[0] + (self.fs[1] - self.fs[0]) * u[:, 0]) * H).long()).clamp(1, CH)
-        w = (((self.ts[0] + (self.ts[1] - self.ts[0]) * u[:, 1]) * W).long()).clamp(1, CW)
-        i = (u[:, 2] * (CH - h + 1).float()).long().clamp(max=CH - 1)      # randint(0, CH-h) inclusive
-        j = (u[:, 3] * (CW - w + 1).float()).long().clamp(max=CW - 1)
-        return CH, CW, i, j, h, w
+        """-> int32 [B,4] rows (i, j, h, w), drawn as get_params does (byol_a.py:24-31)."""
+        CH, CW = self.canvas(H, W)
+        out = np.empty((B, 4), np.int32)
+        for b in range(B):
+            h = int(np.clip(int(self.rng.uniform(*self.fs) * H), 1, CH))
+            w = int(np.clip(int(self.rng.uniform(*self.ts) * W), 1, CW))
+            i = self.rng.randint(0, CH - h + 1) if CH > h else 0
+            j = self.rng.randint(0, CW - w + 1) if CW > w else 0
+            out[b] = (i, j, h, w)
+        return out
+
+    def apply(self, lms: torch.Tensor, params) -> torch.Tensor:
+        from . import hip
+        shape = lms.shape
+        x3 = lms.reshape(-1, shape[-2], shape[-1]).float().contiguous()
+        B, H, W = x3.shape
+        CH, CW = self.canvas(H, W)
+        out = torch.empty_like(x3)
+        d_params = _i32(params, lms.device)
+        hip.call("atst_rrc_bicubic_f32", hip.ptr(x3), hip.ptr(out), hip.ptr(d_params), B, H, W, CH, CW, hip.stream())
+        return out.reshape(shape)
 
     def __call__(self, lms: torch.Tensor) -> torch.Tensor:
-        B, C, H, W = lms.shape
-        CH, CW, i, j, h, w = self.sample_params(B, H, W)
-        canvas = torch.zeros(B, C, CH, CW, dtype=lms.dtype, device=lms.device)
-        y0, x0 = (CH - H) // 2, (CW - W) // 2
-        canvas[:, :, y0:y0 + H, x0:x0 + W] = lms
-        dev = lms.device
-        i, j, h, w = (t.to(dev).float().view(B, 1) for t in (i, j, h, w))
-        ys = torch.linspace(0, 1, H, device=dev).view(1, H)
-        xs = torch.linspace(0, 1, W, device=dev).view(1, W)
-        sy = i + ys * (h - 1)                                  # align_corners=True mapping of the crop onto H x W
-        sx = j + xs * (w - 1)
-        gy = 2.0 * sy / max(CH - 1, 1) - 1.0
-        gx = 2.0 * sx / max(CW - 1, 1) - 1.0
-        grid = torch.stack((gx.view(B, 1, W).expand(B, H, W), gy.view(B, H, 1).expand(B, H, W)), dim=-1)
-        return F.grid_sample(canvas, grid, mode="bicubic", padding_mode="border", align_corners=True).float()
+        B = lms.reshape(-1, lms.shape[-2], lms.shape[-1]).shape[0]
+        return self.apply(lms, self.sample_params(B, lms.shape[-2], lms.shape[-1]))

@@ -137,6 +137,16 @@ int atst_encoder_bwd(const atst_encoder_t* e, void* stream);
 const float* atst_encoder_block_out(const atst_encoder_t* e, int i);
 const float* atst_encoder_tokens(const atst_encoder_t* e);
 
+/* ---- batched spectrogram augmentations, random draws supplied by the caller --------------------- */
+/* RandomResizeCrop.forward, audiossl/transforms/byol_a.py:33-49: in/out [B,H,W] fp32; params [B][4] = (i, j, h, w) of
+ * get_params (byol_a.py:24-31); CH x CW = int(H * virtual_crop_scale[0]) x int(W * virtual_crop_scale[1]).            */
+int atst_rrc_bicubic_f32(const float* in, float* out, const int32_t* params, int B, int H, int W, int CH, int CW, void* stream);
+/* log_mixup_exp(x, z, 1 - a), byol_a.py:61-83 as called by Mixup.forward :104: out = log((1-a) e^x + a e^z + eps) on
+ * the window of min(W, Wz) frames starting at xstart[b] in x and zstart[b] in z = bank[zidx[b]] (one of the two is 0);
+ * frames of x outside the window become log(e^x + eps).  x/out [B,H,W], bank [n,H,Wz], all fp32.                       */
+int atst_log_mixup_exp_f32(const float* x, const float* bank, const int32_t* zidx, const int32_t* zstart, const int32_t* xstart,
+                           const float* alpha, float* out, int B, int H, int W, int Wz, void* stream);
+
 /* ---- in-library kernel timing (HIP events on the launch stream); used by bench.py for the roofline object ---------- */
 int atst_profile_enable(int on);      /* 0 = off ; n >= 1: HIP events around every n-th launch of each kernel kind     */
 int atst_profile_kinds(void);

@@ -508,3 +508,31 @@ def recipe_wave(n_clips: int, n_samples: int = 160000, seed: int = 1234) -> Tens
     """BASELINE.md section 3 / SURVEY.md 8(d) synthetic waveform: N(0, 0.1^2) clipped to [-1,1]."""
     g = torch.Generator().manual_seed(seed)
     return torch.clamp(0.1 * torch.randn(n_clips, n_samples, generator=g), -1.0, 1.0)
+
+
+# ---- host augmentations (SURVEY 8(f) row 3) -------------------------------------------------------------------------
+def random_resize_crop(lms: Tensor, i: int, j: int, h: int, w: int, virtual_crop_scale=(1.0, 1.5)) -> Tensor:
+    """RandomResizeCrop.forward with the (i, j, h, w) of get_params given (ref: transforms/byol_a.py:33-49). lms [C,H,W]."""
+    C, H, W = lms.shape
+    CH, CW = int(H * virtual_crop_scale[0]), int(W * virtual_crop_scale[1])
+    canvas = torch.zeros(C, CH, CW, dtype=torch.float32)
+    x0, y0 = (CW - W) // 2, (CH - H) // 2
+    canvas[:, y0:y0 + H, x0:x0 + W] = lms
+    crop = canvas[:, i:i + h, j:j + w]
+    return F.interpolate(crop.unsqueeze(0), size=(H, W), mode="bicubic", align_corners=True).squeeze(0).float()
+
+
+def log_mixup_exp(x: Tensor, z: Tensor, a: float, start: int = 0) -> Tensor:
+    """Mixup.forward's mix of input x [C,H,Wx] with bank entry z [C,H,Wz] at ratio a = ratio * U (ref: byol_a.py:61-83 called
+    as log_mixup_exp(x, z, 1 - a) at :104): log((1-a) e^x + a e^z + eps); the shorter one goes into the window
+    [start, start + min(Wx, Wz)) of the longer one."""
+    ex, ez = x.exp(), z.exp()
+    Wx, Wz = x.shape[-1], z.shape[-1]
+    eps = torch.finfo(torch.float32).eps
+    if Wx < Wz:
+        return torch.log((1.0 - a) * ex + a * ez[..., start:start + Wx] + eps)
+    if Wx > Wz:
+        ex = ex.clone()
+        ex[..., start:start + Wz] = (1.0 - a) * ex[..., start:start + Wz] + a * ez
+        return torch.log(ex + eps)
+    return torch.log((1.0 - a) * ex + a * ez + eps)

@@ -271,8 +271,49 @@ def gen_sched(name="schedules"):
          n_teacher=sum(p.numel() for p in model.teacher.parameters()))
 
 
+def gen_aug(name="aug_byol_a"):
+    """RandomResizeCrop / Mixup of the reference (audiossl/transforms/byol_a.py) with seeded global RNGs; the draws are
+    recovered by replaying the same seeds, so that they can be injected into the build's kernels."""
+    import random
+    from audiossl.transforms import byol_a
+    out = {}
+    widths = [401, 101, 401, 1001, 101, 401]
+    params, outs = [], []
+    for k, W in enumerate(widths):
+        x = O.recipe_mel(1, W, seed=200 + k)[0]                                    # [1, 64, W]
+        rrc = byol_a.RandomResizeCrop(virtual_crop_scale=(1.0, 1.5), freq_scale=(0.6, 1.5), time_scale=(0.6, 1.5))
+        CH, CW = int(64 * 1.0), int(W * 1.5)
+        np.random.seed(900 + k); random.seed(900 + k)
+        params.append(byol_a.RandomResizeCrop.get_params((CH, CW), (64, W), rrc.time_scale, rrc.freq_scale))
+        np.random.seed(900 + k); random.seed(900 + k)
+        y = rrc(x)
+        assert y.shape == x.shape
+        out[f"rrc_out{k}"] = y[0, ::2, ::3].numpy()
+    out["rrc_widths"] = np.array(widths); out["rrc_params"] = np.array(params, dtype=np.int32)
+    # Mixup: equal lengths, input shorter than the bank entry, input longer than the bank entry
+    cases = [(401, 401), (101, 401), (401, 101)]
+    mix_meta = []
+    for k, (Wx, Wz) in enumerate(cases):
+        z = O.recipe_mel(1, Wz, seed=300 + k)[0]; x = O.recipe_mel(1, Wx, seed=310 + k)[0]
+        m = byol_a.Mixup(ratio=0.4, n_memory=2000)
+        np.random.seed(950 + k)
+        assert torch.equal(m(z), z)                                                # empty bank: identity, z enters the bank
+        y = m(x)
+        np.random.seed(950 + k)                                                    # replay the draws
+        np.random.random()                                                         # alpha of the first call
+        a = 0.4 * np.random.random(); idx = np.random.randint(1)
+        start = np.random.randint(0, abs(Wz - Wx)) if Wx != Wz else 0
+        mix_meta.append((Wx, Wz, idx, start))
+        out[f"mix_alpha{k}"] = np.float64(a)
+        out[f"mix_out{k}"] = y[0, ::2, ::3].numpy()
+    out["mix_meta"] = np.array(mix_meta, dtype=np.int32)
+    save(name, **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["blocks", "clip2", "clip2_nodrop", "clip6", "frame", "sched", "encgrad", "clip2_b16", "clip2_b64", "infer"]
+    which = sys.argv[1:] or ["blocks", "clip2", "clip2_nodrop", "clip6", "frame", "sched", "encgrad", "clip2_b16", "clip2_b64", "infer", "aug"]
+    if "aug" in which:
+        gen_aug()
     if "blocks" in which:
         gen_blocks()
     if "clip2" in which:

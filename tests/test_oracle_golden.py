@@ -155,3 +155,17 @@ def test_schedules_and_groups(golden_dir):
     assert list(W.keys()) == list(G["state_dict_keys"])
     n_student = sum(int(np.prod(s)) for _, s in shapes)
     assert n_student == int(G["n_student"]) == 26211328
+
+
+def test_augmentations_vs_reference_golden():
+    """RandomResizeCrop / Mixup restatements against the reference's byol_a.py run with replayed draws."""
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "aug_byol_a.npz"))
+    for k, W in enumerate(G["rrc_widths"]):
+        x = O.recipe_mel(1, int(W), seed=200 + k)[0]
+        i, j, h, w = (int(v) for v in G["rrc_params"][k])
+        y = O.random_resize_crop(x, i, j, h, w)
+        assert np.abs(y[0, ::2, ::3].numpy() - G[f"rrc_out{k}"]).max() < 1e-6
+    for k, (Wx, Wz, idx, start) in enumerate(G["mix_meta"]):
+        z = O.recipe_mel(1, int(Wz), seed=300 + k)[0]; x = O.recipe_mel(1, int(Wx), seed=310 + k)[0]
+        y = O.log_mixup_exp(x, z, float(G[f"mix_alpha{k}"]), int(start))
+        assert np.abs(y[0, ::2, ::3].numpy() - G[f"mix_out{k}"]).max() < 1e-5
