@@ -12,6 +12,8 @@ from __future__ import annotations
 
 from typing import Tuple
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -20,10 +22,18 @@ def world_size() -> int:
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def _collective() -> bool:
+    """True when the exchanges must be issued.  ATST_FORCE_COLLECTIVES=1 issues them at world size 1 as well, so that the
+    RCCL code path can be exercised on a single-GPU box (tests/test_dist_gpu.py)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("ATST_FORCE_COLLECTIVES") == "1"
+
+
 def combine_bn_stats(mean: torch.Tensor, m2: torch.Tensor, count: float) -> Tuple[torch.Tensor, torch.Tensor, float]:
     """Local per-feature (mean, M2 = sum (x-mean)^2, row count) -> global (mean, M2, count) over all ranks
     (Chan et al. parallel variance).  Identity at world size 1."""
-    if world_size() == 1:
+    if not _collective():
         return mean, m2, float(count)
     n = mean.numel()
     pack = torch.cat([mean, m2, torch.tensor([float(count)], device=mean.device, dtype=mean.dtype)])
@@ -39,7 +49,7 @@ def combine_bn_stats(mean: torch.Tensor, m2: torch.Tensor, count: float) -> Tupl
 
 def allreduce_bn_backward_sums(sum_dy: torch.Tensor, sum_dy_xhat: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """Global sums for the BatchNorm input gradient; the local sums remain the (to-be-averaged) gamma/beta gradients."""
-    if world_size() == 1:
+    if not _collective():
         return sum_dy, sum_dy_xhat
     n = sum_dy.numel()
     pack = torch.cat([sum_dy, sum_dy_xhat])
@@ -49,7 +59,7 @@ def allreduce_bn_backward_sums(sum_dy: torch.Tensor, sum_dy_xhat: torch.Tensor) 
 
 def allreduce_monitor_sums(stats: torch.Tensor, n_student: float, n_teacher: float):
     """[4, D] column sums / square sums of normalised student & teacher rows + the two row counts, one all-reduce."""
-    if world_size() == 1:
+    if not _collective():
         return stats, float(n_student), float(n_teacher)
     pack = torch.cat([stats.reshape(-1), torch.tensor([n_student, n_teacher], device=stats.device, dtype=stats.dtype)])
     dist.all_reduce(pack)
@@ -63,7 +73,7 @@ def feature_std(sums: torch.Tensor, sq_sums: torch.Tensor, n: float) -> torch.Te
 
 def allreduce_sum_(flat_grad: torch.Tensor) -> bool:
     """In-place sum of the flat gradient buffer over ranks; returns True when a reduction happened."""
-    if world_size() == 1:
+    if not _collective():
         return False
     dist.all_reduce(flat_grad)
     return True

@@ -106,10 +106,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
-    if world > 1:
+    if world > 1 or os.environ.get("ATST_FORCE_COLLECTIVES") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     dev = torch.device("cuda", local)
+    torch.manual_seed(4321 + rank)                                   # DropPath draws (device generator): reproducible runs
 
     from audiossl_amd import hip
     from audiossl_amd.engine import AtstEngine
@@ -159,8 +161,8 @@ def main():
         return loss
 
     def sync():
-        if world > 1:
-            dist.barrier()
+        if dist.is_initialized():
+            dist.barrier(device_ids=[local])
         torch.cuda.synchronize()
 
     for k in range(args.warmup):
@@ -175,7 +177,7 @@ def main():
     dt = time.perf_counter() - t0
     lib.atst_profile_enable(0)
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
+    if dist.is_initialized():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
     loss_val = float(loss)
@@ -239,7 +241,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
