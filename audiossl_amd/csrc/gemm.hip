@@ -308,22 +308,27 @@ constexpr int BNR = 384, WAVES = 8, THREADS = 512, CLD = BNR + 4;
 #define ATST_INTERLEAVE 1      // LDS-DMA issue spread between the MFMA groups (0: in front of them; experiment builds)
 #endif
 constexpr int B_BYTES = BNR * BK * 2, EPI_BYTES = 32 * CLD * 4;                                   // 24 KB ; 49,664 B
-template <int MI> struct Geo {                 // MI = 32-row accumulator blocks per wave: 2 -> 128-row tile, 4 -> 256-row tile
-  static constexpr int BMR = 64 * MI, A_BYTES = BMR * BK * 2, STAGE = A_BYTES + B_BYTES;         // 32 KB / 40 KB per stage
-  // K-tiles are ~1.8 us from issue to landing under load: the 128-row tile keeps 2 blocks x 1 tile in flight per CU, the
-  // 256-row tile (one block per CU) needs a deeper ring to cover that latency (2 stages measured latency-bound, 36 % MFMA)
-  static constexpr int NSTG = MI == 4 ? ATST_TALL_STAGES : 2;
-  static constexpr int LDS = NSTG * STAGE > EPI_BYTES + 8192 ? NSTG * STAGE : EPI_BYTES + 8192;  // 64 KB (2 blocks / CU) ; 120 KB
-  static constexpr int A_IPW = (BMR / 16) / WAVES;                                               // 1 or 2 A load instructions per wave
+// MI = 32-row accumulator blocks per wave: 2 -> 128-row tile, 4 -> 256-row tile.  BKT = K depth of one ring stage:
+// 32 (64-B LDS rows, 4 chunks) or 64 (128-B rows: every LDS-DMA lane group fetches a whole 128-B line, half as many
+// barriers per K; two stages then fill the CU's 160 KB).
+template <int MI, int BKT = BK> struct Geo {
+  static constexpr int BMR = 64 * MI, ROWB = BKT * 2, A_BYTES = BMR * ROWB, BB = BNR * ROWB, STAGE = A_BYTES + BB;   // 32 / 40 KB (BKT 32), 80 KB (256 rows, BKT 64)
+  static constexpr int NSTG = BKT == 64 ? 2 : (MI == 4 ? ATST_TALL_STAGES : 2);
+  static constexpr int LDS = NSTG * STAGE > EPI_BYTES + 8192 ? NSTG * STAGE : EPI_BYTES + 8192;  // 64 KB (2 blocks / CU) ; 120 KB ; 160 KB
+  static constexpr int RPI = 1024 / ROWB;                                                        // rows per 1-KiB load instruction
+  static constexpr int A_IPW = (BMR / RPI) / WAVES, B_IPW = (BNR / RPI) / WAVES;                 // load instructions per wave
+  static constexpr int CPR = ROWB / 16;                                                          // 16-B chunks per row
 };
+// XOR key of a row's 16-B chunks: the 16 rows of a ds_read_b128 service group must land on 16 distinct bank slots
+template <int BKT> DEVFN int swz_key(int row) { return BKT == 64 ? (row >> 1) & 7 : (row >> 2) & 3; }
 }
 
 // MI = 4 (256 x 384 tile, each wave 128 x 96 = 12 accumulators): 40 KB staged per 6 units of output = 6.7 KB / unit.
-template <int EPI, int MI, bool LN = false>
+template <int EPI, int MI, bool LN = false, int BKT = BK>
 __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(GemmArgs p) {
   using namespace row384;
-  using RG = row384::Geo<MI>;
-  constexpr int BMR = RG::BMR, A_BYTES = RG::A_BYTES, STAGE = RG::STAGE, NSTG = RG::NSTG;
+  using RG = row384::Geo<MI, BKT>;
+  constexpr int BMR = RG::BMR, A_BYTES = RG::A_BYTES, STAGE = RG::STAGE, NSTG = RG::NSTG, ROWB = RG::ROWB;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   typedef const void __attribute__((address_space(1))) * gptr_t;
   typedef void __attribute__((address_space(3))) * lptr_t;
@@ -335,27 +340,27 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
   const int m0 = (id / ntn) * BMR, n0 = (id % ntn) * BNR;
 
   char* lds = smem_raw;
-  const int lrow = lane >> 2, lchunk = lane & 3;
-  const bf16* srcA[RG::A_IPW]; const bf16* srcB[3];
+  const int lrow = lane / RG::CPR, lchunk = lane % RG::CPR;
+  const bf16* srcA[RG::A_IPW]; const bf16* srcB[RG::B_IPW];
 #pragma unroll
   for (int j = 0; j < RG::A_IPW; ++j) {
-    const int row = (wid * RG::A_IPW + j) * 16 + lrow;
+    const int row = (wid * RG::A_IPW + j) * RG::RPI + lrow;
     int ra = m0 + row; ra = ra < p.M ? ra : p.M - 1;
-    srcA[j] = p.A + (size_t)ra * p.lda + (lchunk ^ ((row >> 2) & 3)) * 8;
+    srcA[j] = p.A + (size_t)ra * p.lda + (lchunk ^ swz_key<BKT>(row)) * 8;
   }
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const int row = (wid * 3 + j) * 16 + lrow;
-    srcB[j] = p.B + (size_t)(n0 + row) * p.ldb + (lchunk ^ ((row >> 2) & 3)) * 8;
+  for (int j = 0; j < RG::B_IPW; ++j) {
+    const int row = (wid * RG::B_IPW + j) * RG::RPI + lrow;
+    srcB[j] = p.B + (size_t)(n0 + row) * p.ldb + (lchunk ^ swz_key<BKT>(row)) * 8;
   }
   auto issue = [&](int kt) {
     char* st = lds + (kt % NSTG) * STAGE;
 #pragma unroll
     for (int j = 0; j < RG::A_IPW; ++j)
-      __builtin_amdgcn_global_load_lds((gptr_t)(srcA[j] + kt * BK), (lptr_t)(st + (wid * RG::A_IPW + j) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcA[j] + kt * BKT), (lptr_t)(st + (wid * RG::A_IPW + j) * 1024), 16, 0, 0);
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
-      __builtin_amdgcn_global_load_lds((gptr_t)(srcB[j] + kt * BK), (lptr_t)(st + A_BYTES + (wid * 3 + j) * 1024), 16, 0, 0);
+    for (int j = 0; j < RG::B_IPW; ++j)
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcB[j] + kt * BKT), (lptr_t)(st + A_BYTES + (wid * RG::B_IPW + j) * 1024), 16, 0, 0);
   };
   f32x16 acc[MI][3];
 #pragma unroll
@@ -368,18 +373,18 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
 #if ATST_ABLATE == 7
   const int nk = p.K < 0 ? 1 : 0;                                // experiment builds: epilogue only
 #else
-  const int nk = p.K / BK;
+  const int nk = p.K / BKT;
 #endif
-  const int xr = (l31 >> 2) & 3;
-  const int offA = (wm * 32 * MI + l31) * 64, offB = A_BYTES + (wn * 96 + l31) * 64;
-  constexpr int LOADS_PER_TILE = RG::A_IPW + 3;                   // per wave, in issue order
-  constexpr bool ILV = ATST_INTERLEAVE && MI == 4;                // the 128-row tile has no registers to spare for the pinned order
+  const int xr = swz_key<BKT>(l31);                                // every fragment row is l31 plus a multiple of 32
+  const int offA = (wm * 32 * MI + l31) * ROWB, offB = A_BYTES + (wn * 96 + l31) * ROWB;
+  constexpr int LOADS_PER_TILE = RG::A_IPW + RG::B_IPW;           // per wave, in issue order
+  constexpr bool ILV = ATST_INTERLEAVE && MI == 4 && NSTG >= 3;   // the 128-row tile has no registers to spare for the pinned order; a 2-stage ring needs its loads early
   auto issue_one = [&](int kt, int j) {                           // j-th load instruction of tile kt
     char* st = lds + (kt % NSTG) * STAGE;
     if (j < RG::A_IPW)
-      __builtin_amdgcn_global_load_lds((gptr_t)(srcA[j < RG::A_IPW ? j : 0] + kt * BK), (lptr_t)(st + (wid * RG::A_IPW + j) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcA[j < RG::A_IPW ? j : 0] + kt * BKT), (lptr_t)(st + (wid * RG::A_IPW + j) * 1024), 16, 0, 0);
     else
-      __builtin_amdgcn_global_load_lds((gptr_t)(srcB[j >= RG::A_IPW ? j - RG::A_IPW : 0] + kt * BK), (lptr_t)(st + A_BYTES + (wid * 3 + j - RG::A_IPW) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcB[j >= RG::A_IPW ? j - RG::A_IPW : 0] + kt * BKT), (lptr_t)(st + A_BYTES + (wid * RG::B_IPW + j - RG::A_IPW) * 1024), 16, 0, 0);
   };
   // One K-tile of MFMAs.  ISSUE: the loads of tile kt + NSTG - 1 are spread BETWEEN the MFMA groups instead of in front
   // of them: every wave leaves the barrier at the same moment, and eight waves x 4-5 LDS-DMA instructions queue on the
@@ -391,7 +396,7 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
     const char* st = lds + (kt % NSTG) * STAGE;
     int slot = 0;
 #pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
+    for (int ks = 0; ks < BKT / 16; ++ks) {
       const int co = ((ks * 2 + hi) ^ xr) << 4;
       bf16x8 af[MI], bf[3];
 #if ATST_ABLATE == 5 || ATST_ABLATE == 6
@@ -402,9 +407,9 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
       (void)st; (void)co;
 #else
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const bf16x8*>(st + offA + mi * 32 * 64 + co);
+      for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const bf16x8*>(st + offA + mi * 32 * ROWB + co);
 #pragma unroll
-      for (int ni = 0; ni < 3; ++ni) bf[ni] = *reinterpret_cast<const bf16x8*>(st + offB + ni * 32 * 64 + co);
+      for (int ni = 0; ni < 3; ++ni) bf[ni] = *reinterpret_cast<const bf16x8*>(st + offB + ni * 32 * ROWB + co);
 #endif
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
@@ -1191,6 +1196,7 @@ int g_tn_wide = 0;        // wgrad: 128x384 output tiles when K % 384 == 0 (tuni
 int g_row384_tall = 2;      // 256 x 384 tiles for M >= 8192: 2 = every epilogue, 1 = plain bf16 GEMMs only, 0 = never (tuning hooks 304 / 303 / 302)
 int g_tn_rounds = 1;      // wgrad grid = this many rounds of 512 resident blocks (tuning hook 110 + r); 1 measured best (-20 %)
 int g_tn_glds = 0;        // wgrad: 1 = LDS-DMA kernel when shapes allow (tuning hook 101); measured 7 % slower than register staging
+int g_row384_bk64 = 0;      // 256-row tile with 64-deep ring stages, whole 128-B lines per LDS-DMA lane group, 2 stages (tuning hook 311 = on): measured 2-5 % slower than 3 x 32-deep
 int g_row384_persist = 0;   // persistent 256x384 kernel whose operand stream runs across tile boundaries (tuning hook 309 = on): measured no gain (qkv 167 vs 163 us, fc1+GELU 305 vs 316, residual epilogues slower) -- the cold ring per tile is not what K = 384 shapes lose
 int g_dgelu_row384 = 0;   // dGELU GEMM on the row-384 tile (tuning hook 307 = on): measured slower (LDS-atomic column sums, 78.8 vs 70.5 ms/step)
 int g_nt_variant = -1;    // -1 auto ; 0: 128x128 2-stage ; 1: 128x128 3-stage ; 2: 256x128 8 waves ; 3: 256x128 4 waves of 128x64
@@ -1223,17 +1229,17 @@ int launch_nt_cfg(const GemmArgs& a, hipStream_t st) {
   hipLaunchKernelGGL((gemm_nt_kernel<EPI, BMT, NSTG, WTM>), dim3(nblk), dim3(G::THREADS), G::LDS, st, a);
   return (int)hipGetLastError();
 }
-template <int EPI, int MI, bool LN>
+template <int EPI, int MI, bool LN, int BKT = BK>
 int launch_nt_row384_cfg(const GemmArgs& a, hipStream_t st) {
-  using RG = row384::Geo<MI>;
+  using RG = row384::Geo<MI, BKT>;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_row384_kernel<EPI, MI, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, RG::LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_row384_kernel<EPI, MI, LN, BKT>, hipFuncAttributeMaxDynamicSharedMemorySize, RG::LDS);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
   const int nblk = ((a.M + RG::BMR - 1) / RG::BMR) * (a.N / row384::BNR);
-  hipLaunchKernelGGL((gemm_nt_row384_kernel<EPI, MI, LN>), dim3(nblk), dim3(row384::THREADS), RG::LDS, st, a);
+  hipLaunchKernelGGL((gemm_nt_row384_kernel<EPI, MI, LN, BKT>), dim3(nblk), dim3(row384::THREADS), RG::LDS, st, a);
   return (int)hipGetLastError();
 }
 template <int EPI, bool LN>
@@ -1260,10 +1266,11 @@ int launch_nt_row384(const GemmArgs& a, hipStream_t st) {
   }
   // 256-row tiles: the operand ring of one block covers twice the output (6.7 vs 10.7 KB staged per 128x128 unit)
   const bool tall = a.M >= 8192 && (g_row384_tall == 2 || (g_row384_tall == 1 && EPI == EPI_BF16 && (a.K >= 768 || a.N >= 768)));
+  const bool deep = tall && g_row384_bk64 && a.K % 64 == 0;        // 64-deep ring stages
   if constexpr (EPI == EPI_RESID) {
-    if (a.ln_out) return tall ? launch_nt_row384_cfg<EPI, 4, true>(a, st) : launch_nt_row384_cfg<EPI, 2, true>(a, st);
+    if (a.ln_out) return deep ? launch_nt_row384_cfg<EPI, 4, true, 64>(a, st) : tall ? launch_nt_row384_cfg<EPI, 4, true>(a, st) : launch_nt_row384_cfg<EPI, 2, true>(a, st);
   }
-  return tall ? launch_nt_row384_cfg<EPI, 4, false>(a, st) : launch_nt_row384_cfg<EPI, 2, false>(a, st);
+  return deep ? launch_nt_row384_cfg<EPI, 4, false, 64>(a, st) : tall ? launch_nt_row384_cfg<EPI, 4, false>(a, st) : launch_nt_row384_cfg<EPI, 2, false>(a, st);
 }
 template <int EPI>
 int launch_nt(const GemmArgs& a, hipStream_t st) {
@@ -1283,7 +1290,7 @@ int launch_nt(const GemmArgs& a, hipStream_t st) {
 }  // namespace
 
 int g_stagger = 0;
-void atst_gemm_nt_set_variant(int v) { if (v >= 308) g_row384_persist = v - 308; else if (v >= 306) g_dgelu_row384 = v - 306; else if (v >= 302) g_row384_tall = v - 302; else if (v >= 300) g_row384_auto = v - 300; else if (v >= 200) g_stagger = v - 200; else if (v >= 110) g_tn_rounds = v - 110; else if (v >= 105) g_tn_tall = v - 105; else if (v >= 102 && v < 104) g_tn_wide = v - 102; else if (v >= 100) g_tn_glds = v - 100; else g_nt_variant = v; }
+void atst_gemm_nt_set_variant(int v) { if (v >= 310) g_row384_bk64 = v - 310; else if (v >= 308) g_row384_persist = v - 308; else if (v >= 306) g_dgelu_row384 = v - 306; else if (v >= 302) g_row384_tall = v - 302; else if (v >= 300) g_row384_auto = v - 300; else if (v >= 200) g_stagger = v - 200; else if (v >= 110) g_tn_rounds = v - 110; else if (v >= 105) g_tn_tall = v - 105; else if (v >= 102 && v < 104) g_tn_wide = v - 102; else if (v >= 100) g_tn_glds = v - 100; else g_nt_variant = v; }
 
 int atst_gemm_nt(const GemmArgs& a0, hipStream_t st) {
   GemmArgs a = a0; a.stagger = g_stagger;
