@@ -179,7 +179,7 @@ def attn_ref(qkv, valid, S, H, NP):
     return (att @ v).transpose(1, 2).reshape(S * NP, C)
 
 
-@pytest.mark.parametrize("NP,valid", [(256, [251, 100, 33]), (32, [26, 26, 20, 1, 7]), (64, [64, 40, 3]), (128, [128, 97])])
+@pytest.mark.parametrize("NP,valid", [(256, [251, 100, 33]), (256, [256, 1, 32, 224, 225, 2]), (32, [26, 26, 20, 1, 7]), (64, [64, 40, 3]), (128, [128, 97])])
 def test_attention(NP, valid):
     S, H = len(valid), 6
     C = H * 64
