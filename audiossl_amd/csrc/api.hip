@@ -117,8 +117,8 @@ int atst_log_mixup_exp_f32(const float* x, const float* bank, const int32_t* zid
   return atst_log_mixup_exp(x, bank, zidx, zstart, xstart, alpha, out, B, H, W, Wz, ST(stream));
 }
 
-int atst_bn_stats_f32(const float* h, int R, int N, float* mean, float* m2, void* stream) {
-  return atst_bn_stats(h, R, N, mean, m2, ST(stream));
+int atst_bn_stats_f32(const float* h, int R, int N, float* mean, float* m2, float* scratch, void* stream) {
+  return atst_bn_stats(h, R, N, mean, m2, scratch, ST(stream));
 }
 int atst_bn_apply_relu_bf16(const float* h, const float* mean, const float* rstd, const float* gamma, const float* beta,
                             int R, int N, uint16_t* y, void* stream) {
@@ -129,8 +129,8 @@ int atst_bn_apply_relu_split3_bf16(const float* h, const float* mean, const floa
   return atst_bn_apply_relu_split3(h, mean, rstd, gamma, beta, R, N, BF(y), ST(stream));
 }
 int atst_bn_relu_bwd_sums(const float* dy, const float* h, const float* mean, const float* rstd, const float* gamma,
-                          const float* beta, int R, int N, float* sum_dy, float* sum_dy_xhat, void* stream) {
-  return atst_bn_relu_bwd(dy, h, mean, rstd, gamma, beta, R, N, sum_dy, sum_dy_xhat, ST(stream));
+                          const float* beta, int R, int N, float* sum_dy, float* sum_dy_xhat, float* scratch, void* stream) {
+  return atst_bn_relu_bwd(dy, h, mean, rstd, gamma, beta, R, N, sum_dy, sum_dy_xhat, scratch, ST(stream));
 }
 int atst_bn_bwd_dx_bf16(const float* dy, const float* h, const float* mean, const float* rstd, const float* gamma,
                         const float* beta, const float* sum_dy, const float* sum_dy_xhat, float inv_count, int R, int N,

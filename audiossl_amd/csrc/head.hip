@@ -7,10 +7,13 @@
 
 namespace {
 
-// out[n] += sum_r f(h[r,n])   block = 64 columns x 4 row groups
+// part[y][n] = sum over the rows of row-block y of f(h[r,n])   block = 64 columns x 4 row groups.  The row-block partials
+// are combined in a fixed order by bn_finalize_kernel: the batch statistics -- and with them the whole forward pass -- are
+// bit-reproducible from run to run (fp32 atomics here let ~1e-7 noise flip ReLU gates behind the BatchNorm, which moved the
+// gradients of identical inputs by 0.3 % between runs at 512 rows).
 template <int MODE>  // 0: sum h ; 1: sum (h-mean)^2
 __global__ __launch_bounds__(256) void bn_col_kernel(const float* __restrict__ h, int R, int N, const float* __restrict__ mean,
-                                                     float* __restrict__ out) {
+                                                     float* __restrict__ part) {
   __shared__ float red[4][64];
   const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + c;
@@ -22,13 +25,15 @@ __global__ __launch_bounds__(256) void bn_col_kernel(const float* __restrict__ h
   }
   red[rg][c] = a;
   __syncthreads();
-  if (threadIdx.x < 64) atomicAdd(out + col, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+  if (threadIdx.x < 64) part[(size_t)blockIdx.y * N + col] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
-__global__ void scale_kernel(float* x, int n, float s) {
+__global__ void bn_finalize_kernel(const float* __restrict__ part, int gy, int N, float scale, float* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) x[i] *= s;
+  if (i >= N) return;
+  float a = 0.f;
+  for (int y = 0; y < gy; ++y) a += part[(size_t)y * N + i];
+  out[i] = a * scale;
 }
-
 __global__ void bn_apply_relu_kernel(const float* __restrict__ h, const float* __restrict__ mean, const float* __restrict__ rstd,
                                      const float* __restrict__ gamma, const float* __restrict__ beta, size_t total, int N,
                                      bf16* __restrict__ y) {
@@ -57,7 +62,7 @@ __global__ void bn_apply_relu_split3_kernel(const float* __restrict__ h, const f
 __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ h,
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          int R, int N, float* __restrict__ sum_dy, float* __restrict__ sum_dy_xhat) {
+                                                          int R, int N, float* __restrict__ part) {   // part[2][gridDim.y][N]
   __shared__ float red[2][4][64];
   const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + c;
@@ -70,9 +75,11 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const float* __restric
   }
   red[0][rg][c] = a; red[1][rg][c] = b;
   __syncthreads();
-  if (threadIdx.x < 64) {
-    atomicAdd(sum_dy + col, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
-    atomicAdd(sum_dy_xhat + col, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+  if (threadIdx.x < 64) {                                          // row-block partials, combined in fixed order (see bn_col_kernel):
+    // the BatchNorm backward subtracts these batch sums from dy with ~100x cancellation, so fp32 atomic-order noise here
+    // reached 2e-4 of the encoder's upstream gradient
+    part[(size_t)blockIdx.y * N + col] = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+    part[((size_t)gridDim.y + blockIdx.y) * N + col] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
   }
 }
 
@@ -169,14 +176,13 @@ __global__ __launch_bounds__(256) void byol_loss_kernel(const float* __restrict_
 }
 }  // namespace
 
-int atst_bn_stats(const float* h, int R, int N, float* mean, float* m2, hipStream_t st) {
-  if (N % 64 || R <= 0) return ATST_EINVAL;
-  int gy = (R + 63) / 64; if (gy > 32) gy = 32;
-  hipMemsetAsync(mean, 0, N * sizeof(float), st);
-  hipMemsetAsync(m2, 0, N * sizeof(float), st);
-  hipLaunchKernelGGL(bn_col_kernel<0>, dim3(N / 64, gy), dim3(256), 0, st, h, R, N, (const float*)nullptr, mean);
-  hipLaunchKernelGGL(scale_kernel, dim3((N + 255) / 256), dim3(256), 0, st, mean, N, 1.0f / R);
-  hipLaunchKernelGGL(bn_col_kernel<1>, dim3(N / 64, gy), dim3(256), 0, st, h, R, N, (const float*)mean, m2);
+int atst_bn_stats(const float* h, int R, int N, float* mean, float* m2, float* scratch, hipStream_t st) {
+  if (N % 64 || R <= 0 || !scratch) return ATST_EINVAL;
+  int gy = (R + 63) / 64; if (gy > ATST_BN_ROW_BLOCKS) gy = ATST_BN_ROW_BLOCKS;
+  hipLaunchKernelGGL(bn_col_kernel<0>, dim3(N / 64, gy), dim3(256), 0, st, h, R, N, (const float*)nullptr, scratch);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((N + 255) / 256), dim3(256), 0, st, (const float*)scratch, gy, N, 1.0f / R, mean);
+  hipLaunchKernelGGL(bn_col_kernel<1>, dim3(N / 64, gy), dim3(256), 0, st, h, R, N, (const float*)mean, scratch);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((N + 255) / 256), dim3(256), 0, st, (const float*)scratch, gy, N, 1.0f, m2);
   return (int)hipGetLastError();
 }
 int atst_bn_apply_relu(const float* h, const float* mean, const float* rstd, const float* gamma, const float* beta,
@@ -194,12 +200,12 @@ int atst_bn_apply_relu_split3(const float* h, const float* mean, const float* rs
   return (int)hipGetLastError();
 }
 int atst_bn_relu_bwd(const float* dy, const float* h, const float* mean, const float* rstd, const float* gamma,
-                     const float* beta, int R, int N, float* sum_dy, float* sum_dy_xhat, hipStream_t st) {
-  if (N % 64 || R <= 0) return ATST_EINVAL;
-  int gy = (R + 63) / 64; if (gy > 32) gy = 32;
-  hipMemsetAsync(sum_dy, 0, N * sizeof(float), st);
-  hipMemsetAsync(sum_dy_xhat, 0, N * sizeof(float), st);
-  hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3(N / 64, gy), dim3(256), 0, st, dy, h, mean, rstd, gamma, beta, R, N, sum_dy, sum_dy_xhat);
+                     const float* beta, int R, int N, float* sum_dy, float* sum_dy_xhat, float* scratch, hipStream_t st) {
+  if (N % 64 || R <= 0 || !scratch) return ATST_EINVAL;
+  int gy = (R + 63) / 64; if (gy > ATST_BN_ROW_BLOCKS) gy = ATST_BN_ROW_BLOCKS;
+  hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3(N / 64, gy), dim3(256), 0, st, dy, h, mean, rstd, gamma, beta, R, N, scratch);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((N + 255) / 256), dim3(256), 0, st, (const float*)scratch, gy, N, 1.0f, sum_dy);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((N + 255) / 256), dim3(256), 0, st, (const float*)(scratch + (size_t)gy * N), gy, N, 1.0f, sum_dy_xhat);
   return (int)hipGetLastError();
 }
 int atst_bn_bwd_dx(const float* dy, const float* h, const float* mean, const float* rstd, const float* gamma,

@@ -76,13 +76,14 @@ int atst_token_grad(const float* dx0, const uint8_t* rowflag, int S, int NP, int
                     float* dcls, float* dpos, float* dbias, float* dmask, bf16* g0, hipStream_t st);
 
 // heads
-int atst_bn_stats(const float* h, int R, int N, float* mean, float* m2, hipStream_t st);
+#define ATST_BN_ROW_BLOCKS 32
+int atst_bn_stats(const float* h, int R, int N, float* mean, float* m2, float* scratch /* [ATST_BN_ROW_BLOCKS * N] */, hipStream_t st);
 int atst_bn_apply_relu(const float* h, const float* mean, const float* rstd, const float* gamma, const float* beta,
                        int R, int N, bf16* y, hipStream_t st);
 int atst_bn_apply_relu_split3(const float* h, const float* mean, const float* rstd, const float* gamma, const float* beta,
                               int R, int N, bf16* y, hipStream_t st);
 int atst_bn_relu_bwd(const float* dy, const float* h, const float* mean, const float* rstd, const float* gamma,
-                     const float* beta, int R, int N, float* sum_dy, float* sum_dy_xhat, hipStream_t st);
+                     const float* beta, int R, int N, float* sum_dy, float* sum_dy_xhat, float* scratch /* [2 * ATST_BN_ROW_BLOCKS * N] */, hipStream_t st);
 int atst_bn_bwd_dx(const float* dy, const float* h, const float* mean, const float* rstd, const float* gamma,
                    const float* beta, const float* sum_dy, const float* sum_dy_xhat, float inv_count, int R, int N,
                    bf16* dh, hipStream_t st);

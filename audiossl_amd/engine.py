@@ -177,7 +177,8 @@ class HeadPass:
         _gemm(x3, w3, R, HEAD_HIDDEN, 3 * K, hip.EPI_F32, h)
         x16 = x3                                            # columns [0,K) = bf16(x): wgrad operand, ld = 3K
         mean, m2 = torch.empty(HEAD_HIDDEN, device=dev), torch.empty(HEAD_HIDDEN, device=dev)
-        hip.call("atst_bn_stats_f32", hip.ptr(h), R, HEAD_HIDDEN, hip.ptr(mean), hip.ptr(m2), st)
+        scratch = torch.empty(32 * HEAD_HIDDEN, device=dev)                          # row-block partials (fixed-order reduction)
+        hip.call("atst_bn_stats_f32", hip.ptr(h), R, HEAD_HIDDEN, hip.ptr(mean), hip.ptr(m2), hip.ptr(scratch), st)
         # SyncBatchNorm: count-weighted combine over ranks (ragged per-rank row counts of ATST-Frame are handled)
         mean, m2, count = parallel.combine_bn_stats(mean, m2, float(R))
         var = m2 / count
@@ -211,8 +212,9 @@ class HeadPass:
         _gemm(d16, self._w("3.weight", transposed=True), R, HEAD_HIDDEN, HEAD_OUT, hip.EPI_F32, dy)
         gamma, beta = self._w("1.weight", f32=True), self._w("1.bias", f32=True)
         s1, s2 = torch.empty(HEAD_HIDDEN, device=dev), torch.empty(HEAD_HIDDEN, device=dev)
+        scratch = torch.empty(2 * 32 * HEAD_HIDDEN, device=dev)                      # row-block partials (fixed-order reduction)
         hip.call("atst_bn_relu_bwd_sums", hip.ptr(dy), hip.ptr(h), hip.ptr(mean), hip.ptr(rstd), hip.ptr(gamma), hip.ptr(beta),
-                 R, HEAD_HIDDEN, hip.ptr(s1), hip.ptr(s2), st)
+                 R, HEAD_HIDDEN, hip.ptr(s1), hip.ptr(s2), hip.ptr(scratch), st)
         self._w("1.bias", grad=True).add_(s1)          # local sums: DDP averages parameter gradients afterwards
         self._w("1.weight", grad=True).add_(s2)
         s1, s2 = parallel.allreduce_bn_backward_sums(s1, s2)

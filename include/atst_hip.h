@@ -77,14 +77,15 @@ int atst_transpose_bf16_batch(const uint16_t* src_base, uint16_t* dst_base, cons
                               void* stream);
 
 /* build_mlp's BatchNorm1d(train)+ReLU: audiossl/models/atst/byol.py:13-16                                            */
-int atst_bn_stats_f32(const float* h, int R, int N, float* mean, float* m2, void* stream);
+int atst_bn_stats_f32(const float* h, int R, int N, float* mean, float* m2, float* scratch /* [32 * N] row-block partials: fixed-order (run-to-run reproducible) reduction */, void* stream);
 int atst_bn_apply_relu_bf16(const float* h, const float* mean, const float* rstd, const float* gamma, const float* beta,
                             int R, int N, uint16_t* y, void* stream);
 /* same, output as split-bf16 operand [R, 3N] = [hi | lo | hi] for the following Linear */
 int atst_bn_apply_relu_split3_bf16(const float* h, const float* mean, const float* rstd, const float* gamma,
                                    const float* beta, int R, int N, uint16_t* y, void* stream);
 int atst_bn_relu_bwd_sums(const float* dy, const float* h, const float* mean, const float* rstd, const float* gamma,
-                          const float* beta, int R, int N, float* sum_dy, float* sum_dy_xhat, void* stream);
+                          const float* beta, int R, int N, float* sum_dy, float* sum_dy_xhat,
+                          float* scratch /* [2 * 32 * N] row-block partials, fixed-order reduction */, void* stream);
 int atst_bn_bwd_dx_bf16(const float* dy, const float* h, const float* mean, const float* rstd, const float* gamma,
                         const float* beta, const float* sum_dy, const float* sum_dy_xhat, float inv_count, int R, int N,
                         uint16_t* dh, void* stream);

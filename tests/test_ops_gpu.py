@@ -251,7 +251,8 @@ def test_bn_relu_head():
     h = rnd(R, N, seed=1) * 2 + 0.5
     gamma, beta = 1 + 0.1 * rnd(N, seed=2), 0.1 * rnd(N, seed=3)
     mean, m2 = torch.empty(N, device=DEV), torch.empty(N, device=DEV)
-    hip.call("atst_bn_stats_f32", hip.ptr(h), R, N, hip.ptr(mean), hip.ptr(m2), hip.stream())
+    scratch = torch.empty(32 * N, device=DEV)
+    hip.call("atst_bn_stats_f32", hip.ptr(h), R, N, hip.ptr(mean), hip.ptr(m2), hip.ptr(scratch), hip.stream())
     assert relerr(mean, h.mean(0)) < 1e-5 and relerr(m2 / R, h.var(0, unbiased=False)) < 1e-5
     rstd = torch.rsqrt(m2 / R + 1e-5)
     y = torch.empty(R, N, dtype=torch.bfloat16, device=DEV)
@@ -262,8 +263,9 @@ def test_bn_relu_head():
     dy = rnd(R, N, seed=4)
     ref.backward(dy)
     s1, s2 = torch.empty(N, device=DEV), torch.empty(N, device=DEV)
+    scratch2 = torch.empty(2 * 32 * N, device=DEV)
     hip.call("atst_bn_relu_bwd_sums", hip.ptr(dy), hip.ptr(h), hip.ptr(mean), hip.ptr(rstd), hip.ptr(gamma), hip.ptr(beta), R, N,
-             hip.ptr(s1), hip.ptr(s2), hip.stream())
+             hip.ptr(s1), hip.ptr(s2), hip.ptr(scratch2), hip.stream())
     assert relerr(s1, br.grad) < 1e-4 and relerr(s2, gr.grad) < 1e-4
     dh = torch.empty(R, N, dtype=torch.bfloat16, device=DEV)
     hip.call("atst_bn_bwd_dx_bf16", hip.ptr(dy), hip.ptr(h), hip.ptr(mean), hip.ptr(rstd), hip.ptr(gamma), hip.ptr(beta),
