@@ -129,10 +129,6 @@ __global__ __launch_bounds__((NtGeo<BMT, NSTG, WTM>::THREADS), (NtGeo<BMT, NSTG,
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1, hi = lane >> 5, l31 = lane & 31;
 
-  if (p.stagger > 0 && blockIdx.x < 256 * G::BLOCKS_PER_CU) {     // experiment: de-phase the first round of co-resident blocks
-    const int ph = (blockIdx.x >> 3) & 3;
-    for (int i = 0; i < ph * p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-  }
   const int ntn = p.N / BN;
   const int ntm = (p.M + BMT - 1) / BMT;
   const int id = xcd_remap(blockIdx.x, ntm * ntn);
@@ -863,178 +859,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(WgradArgs p) {
     }
 }
 
-// ---- wgrad, 128 x 384 output tile: 8 waves (2 x 4), each 64 x 96 -----------------------------------------------------
-// Same register-staged / transpose-read scheme as gemm_tn_kernel, but one block covers 128 n x 384 k of dW, so the
-// operands staged per contraction row drop from 512 B per 128x128 unit to 1024 B per three units (K is 384 or 1536 on
-// this path).  32 contraction rows per stage, 2 stages, 69.6 KB LDS -> 2 blocks / CU.
-namespace tn384 {
-constexpr int RM = 32, Y_LD = 128 + 16, X_LD = 384 + 16;             // 288-B and 800-B rows: both = 8 dwords mod 64 banks
-constexpr int Y_TILE = RM * Y_LD, X_TILE = RM * X_LD, STAGE = Y_TILE + X_TILE;   // elements
-constexpr int LDS = 2 * STAGE * 2;                                    // 69,632 B
-}
-
-__global__ __launch_bounds__(512, 2) void gemm_tn_row384_kernel(WgradArgs p) {
-  using namespace tn384;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  bf16* smem = reinterpret_cast<bf16*>(smem_raw);
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wn = wid >> 2, wk = wid & 3, hi = lane >> 5, l31 = lane & 31;
-  const int ntn = p.N / 128, ntk = p.K / 384;
-  const int tile = blockIdx.x % (ntn * ntk), split = blockIdx.x / (ntn * ntk);
-  const int n0 = (tile / ntk) * 128, k0 = (tile % ntk) * 384;
-  const int m_begin = split * p.m_per_split;
-  int m_end = m_begin + p.m_per_split; if (m_end > p.M) m_end = p.M;
-  if (m_begin >= m_end) return;
-  const int nst = (m_end - m_begin + RM - 1) / RM;
-
-  // staging map: thread t moves dY chunk t and X chunks t, t+512, t+1024 (16 B each)
-  const int yr = tid >> 4, yc = (tid & 15) * 8;
-  int xr[3], xc[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) { const int c = tid + 512 * i; xr[i] = c / 48; xc[i] = (c % 48) * 8; }
-  bf16x8 ry, rx[3];
-  auto gload = [&](int st) {
-    const int mb = m_begin + st * RM;
-    bf16x8 z;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) z[e] = f2bf(0.f);
-    ry = (mb + yr < m_end) ? ld_frag(p.dY + (size_t)(mb + yr) * p.ldy + n0 + yc) : z;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) rx[i] = (mb + xr[i] < m_end) ? ld_frag(p.X + (size_t)(mb + xr[i]) * p.ldx + k0 + xc[i]) : z;
-  };
-  auto swrite = [&](int buf) {
-    bf16* sY = smem + buf * STAGE; bf16* sX = sY + Y_TILE;
-    *reinterpret_cast<bf16x8*>(sY + yr * Y_LD + yc) = ry;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) *reinterpret_cast<bf16x8*>(sX + xr[i] * X_LD + xc[i]) = rx[i];
-  };
-  f32x16 acc[2][3];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  gload(0);
-  swrite(0);
-  __syncthreads();
-  for (int st = 0; st < nst; ++st) {
-    const int buf = st & 1;
-    if (st + 1 < nst) gload(st + 1);
-    const bf16* sY = smem + buf * STAGE; const bf16* sX = sY + Y_TILE;
-#pragma unroll
-    for (int ms = 0; ms < RM / 16; ++ms) {
-      const bf16x8 a0 = ld_frag_tr(sY, Y_LD, ms * 16, wn * 64, lane), a1 = ld_frag_tr(sY, Y_LD, ms * 16, wn * 64 + 32, lane);
-#pragma unroll
-      for (int ki = 0; ki < 3; ++ki) {
-        const bf16x8 b = ld_frag_tr(sX, X_LD, ms * 16, wk * 96 + ki * 32, lane);
-        acc[0][ki] = mfma32(a0, b, acc[0][ki]);
-        acc[1][ki] = mfma32(a1, b, acc[1][ki]);
-      }
-    }
-    if (st + 1 < nst) swrite(buf ^ 1);
-    __syncthreads();
-  }
-#pragma unroll
-  for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int n = n0 + wn * 64 + ni * 32 + crow32(r, hi);
-#pragma unroll
-      for (int ki = 0; ki < 3; ++ki)
-        atomicAdd(p.dW + (size_t)n * p.ldw + k0 + wk * 96 + ki * 32 + l31, acc[ni][ki][r]);
-    }
-}
-
-// ---- wgrad, LDS-DMA pipeline -----------------------------------------------------------------------------------------
-// Same math as gemm_tn_kernel, for the common case where every split is a whole number of 32-row stages: both operand
-// tiles ([32 m][128] bf16, 256-B rows) go HBM/L2 -> LDS by global_load_lds (2-stage ring, 32 KB, 4 blocks / CU); the
-// 16-B chunk c of row r is stored at chunk c ^ (2 * (r & 3)) (applied to the per-lane source address) so that the
-// 4-row x 16-column blocks fetched by ds_read_b64_tr_b16 fall on distinct banks.
-constexpr int GM = 32;                          // contraction rows per stage
-constexpr int G_OP = GM * 256;                  // bytes per operand per stage
-constexpr int G_STAGE = 2 * G_OP;
-constexpr int WGRAD_GLDS_BYTES = 2 * G_STAGE;   // 32,768 B
-
-DEVFN bf16x8 ld_frag_tr_swz(const char* X, int r0, int c0, int lane) {
-  const int a = lane & 15, g = lane >> 4;
-  const int row = r0 + 4 * (g >> 1) + (a >> 2);
-  const int col = c0 + (g & 1) * 16 + 4 * (a & 3);                 // element column; 8 elements per 16-B chunk
-  const int pch = (col >> 3) ^ ((row & 3) << 1);
-  const bf16* ptr = reinterpret_cast<const bf16*>(X + row * 256 + pch * 16) + (col & 7);
-  s16x4 lo = lds_tr4(ptr);
-  s16x4 hi = lds_tr4(ptr + 8 * 128);                               // +8 rows: same swizzle key
-  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
-  u.s.a = lo; u.s.b = hi;
-  return u.v;
-}
-
-__global__ __launch_bounds__(256, 4) void gemm_tn_glds_kernel(WgradArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  typedef const void __attribute__((address_space(1))) * gptr_t;
-  typedef void __attribute__((address_space(3))) * lptr_t;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wn = wid >> 1, wk = wid & 1, hi = lane >> 5, l31 = lane & 31;
-  const int ntn = p.N / 128, ntk = p.K / 128;
-  const int tile = blockIdx.x % (ntn * ntk), split = blockIdx.x / (ntn * ntk);
-  const int n0 = (tile / ntk) * 128, k0 = (tile % ntk) * 128;
-  const int m_begin = split * p.m_per_split;
-  int m_end = m_begin + p.m_per_split; if (m_end > p.M) m_end = p.M;
-  if (m_begin >= m_end) return;
-  const int nst = (m_end - m_begin) / GM;
-
-  // each wave-instruction moves 4 rows x 256 B; 8 per operand tile -> 2 per wave per operand
-  const bf16* srcY[2]; const bf16* srcX[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int row = (wid * 2 + j) * 4 + (lane >> 4);
-    const int c = (lane & 15) ^ ((row & 3) << 1);
-    srcY[j] = p.dY + (size_t)(m_begin + row) * p.ldy + n0 + c * 8;
-    srcX[j] = p.X + (size_t)(m_begin + row) * p.ldx + k0 + c * 8;
-  }
-  auto issue = [&](int st) {
-    char* base = smem_raw + (st & 1) * G_STAGE + wid * 2048;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      __builtin_amdgcn_global_load_lds((gptr_t)(srcY[j] + (size_t)st * GM * p.ldy), (lptr_t)(base + j * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(srcX[j] + (size_t)st * GM * p.ldx), (lptr_t)(base + G_OP + j * 1024), 16, 0, 0);
-    }
-  };
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  issue(0);
-  for (int st = 0; st < nst; ++st) {
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // stage st landed everywhere; stage st-1 no longer read
-    if (st + 1 < nst) issue(st + 1);
-    const char* sY = smem_raw + (st & 1) * G_STAGE; const char* sX = sY + G_OP;
-#pragma unroll
-    for (int ms = 0; ms < GM / 16; ++ms) {
-      bf16x8 a0 = ld_frag_tr_swz(sY, ms * 16, wn * 64, lane), a1 = ld_frag_tr_swz(sY, ms * 16, wn * 64 + 32, lane);
-      bf16x8 b0 = ld_frag_tr_swz(sX, ms * 16, wk * 64, lane), b1 = ld_frag_tr_swz(sX, ms * 16, wk * 64 + 32, lane);
-      acc[0][0] = mfma32(a0, b0, acc[0][0]);
-      acc[0][1] = mfma32(a0, b1, acc[0][1]);
-      acc[1][0] = mfma32(a1, b0, acc[1][0]);
-      acc[1][1] = mfma32(a1, b1, acc[1][1]);
-    }
-  }
-#pragma unroll
-  for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int n = n0 + wn * 64 + ni * 32 + crow32(r, hi);
-#pragma unroll
-      for (int ki = 0; ki < 2; ++ki)
-        atomicAdd(p.dW + (size_t)n * p.ldw + k0 + wk * 64 + ki * 32 + l31, acc[ni][ki][r]);
-    }
-}
-
 // ---- wgrad, 192 x 384 output tile, LDS-DMA ring ----------------------------------------------------------------------
 // dW[n0:+192, k0:+384] += dY[m, n]^T X[m, k] over one M-split.  8 waves (2 x 4), each 96 x 96 = 9 accumulators.  A stage
 // is 64 contraction rows of both operands, row-major as they lie in HBM ([64][192] and [64][384] bf16 = 24 + 48 KB),
@@ -1192,10 +1016,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_tall_group_kernel(WgradGroup g
 
 int g_tn_tall = 1;        // wgrad: 192 x 384 LDS-DMA tile when N % 192 == 0, K % 384 == 0, M % 64 == 0 (tuning hook 105 = off, 106 = on)
 int g_row384_auto = 1;      // use the 128x384 tile whenever N % 384 == 0 (tuning hook 300 turns it off)
-int g_tn_wide = 0;        // wgrad: 128x384 output tiles when K % 384 == 0 (tuning hook 103 = on); measured no net gain over 128x128
 int g_row384_tall = 2;      // 256 x 384 tiles for M >= 8192: 2 = every epilogue, 1 = plain bf16 GEMMs only, 0 = never (tuning hooks 304 / 303 / 302)
 int g_tn_rounds = 1;      // wgrad grid = this many rounds of 512 resident blocks (tuning hook 110 + r); 1 measured best (-20 %)
-int g_tn_glds = 0;        // wgrad: 1 = LDS-DMA kernel when shapes allow (tuning hook 101); measured 7 % slower than register staging
 int g_row384_bk64 = 0;      // 256-row tile with 64-deep ring stages, whole 128-B lines per LDS-DMA lane group, 2 stages (tuning hook 311 = on): measured 2-5 % slower than 3 x 32-deep
 int g_row384_persist = 0;   // persistent 256x384 kernel whose operand stream runs across tile boundaries (tuning hook 309 = on): measured no gain (qkv 167 vs 163 us, fc1+GELU 305 vs 316, residual epilogues slower) -- the cold ring per tile is not what K = 384 shapes lose
 int g_dgelu_row384 = 0;   // dGELU GEMM on the row-384 tile (tuning hook 307 = on): measured slower (LDS-atomic column sums, 78.8 vs 70.5 ms/step)
@@ -1289,11 +1111,10 @@ int launch_nt(const GemmArgs& a, hipStream_t st) {
 
 }  // namespace
 
-int g_stagger = 0;
-void atst_gemm_nt_set_variant(int v) { if (v >= 310) g_row384_bk64 = v - 310; else if (v >= 308) g_row384_persist = v - 308; else if (v >= 306) g_dgelu_row384 = v - 306; else if (v >= 302) g_row384_tall = v - 302; else if (v >= 300) g_row384_auto = v - 300; else if (v >= 200) g_stagger = v - 200; else if (v >= 110) g_tn_rounds = v - 110; else if (v >= 105) g_tn_tall = v - 105; else if (v >= 102 && v < 104) g_tn_wide = v - 102; else if (v >= 100) g_tn_glds = v - 100; else g_nt_variant = v; }
+void atst_gemm_nt_set_variant(int v) { if (v >= 310) g_row384_bk64 = v - 310; else if (v >= 308) g_row384_persist = v - 308; else if (v >= 306) g_dgelu_row384 = v - 306; else if (v >= 302) g_row384_tall = v - 302; else if (v >= 300) g_row384_auto = v - 300; else if (v >= 110) g_tn_rounds = v - 110; else if (v >= 105) g_tn_tall = v - 105; else if (v < 100) g_nt_variant = v; }
 
 int atst_gemm_nt(const GemmArgs& a0, hipStream_t st) {
-  GemmArgs a = a0; a.stagger = g_stagger;
+  GemmArgs a = a0;
   if (a.M <= 0 || a.N % BN || a.K % BK || a.lda % 8 || a.ldb % 8) return ATST_EINVAL;
   switch (a.epi) {
     case EPI_BF16: return launch_nt<EPI_BF16>(a, st);
@@ -1328,10 +1149,8 @@ int atst_gemm_tn(const WgradArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(gemm_tn_tall_kernel, dim3(nblk), dim3(512), tnt::LDS, st, p);
     return (int)hipGetLastError();
   }
-  const bool wide = g_tn_wide && a.K % 384 == 0;                  // 128 x 384 output tiles
-  const int tiles = wide ? (a.N / 128) * (a.K / 384) : (a.N / 128) * (a.K / 128);
+  const int tiles = (a.N / 128) * (a.K / 128);
   if (p.m_per_split <= 0) {
-    // aim for a few blocks per CU; keep splits a multiple of the stage depth
     // 2 blocks / CU are resident (512 slots): pick the split count so that the grid is just under a whole number of
     // rounds (a 1044-block grid costs three rounds for two rounds of work)
     int splits = (g_tn_rounds * 512) / tiles;
@@ -1347,17 +1166,10 @@ int atst_gemm_tn(const WgradArgs& a, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WGRAD_LDS_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_tn_row384_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, tn384::LDS);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_tn_glds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WGRAD_GLDS_BYTES);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  if (wide)
-    hipLaunchKernelGGL(gemm_tn_row384_kernel, dim3(nblk), dim3(512), tn384::LDS, st, p);
-  else if (p.M % GM == 0 && p.m_per_split % GM == 0 && g_tn_glds)
-    hipLaunchKernelGGL(gemm_tn_glds_kernel, dim3(nblk), dim3(256), WGRAD_GLDS_BYTES, st, p);
-  else
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(nblk), dim3(256), WGRAD_LDS_BYTES, st, p);
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(nblk), dim3(256), WGRAD_LDS_BYTES, st, p);
   return (int)hipGetLastError();
 }
 

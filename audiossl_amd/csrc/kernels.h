@@ -18,7 +18,6 @@ struct GemmArgs {
   const float* table;                // EPI_PATCH: [rows_per_seq, N] per-token additive table
   const uint8_t* rowflag;            // EPI_PATCH: [M] 1 = replace by mask token (or null)
   const float* alt;                  // EPI_PATCH: mask_embed [N]
-  int stagger;                       // experiment knob (0 = off)
   // EPI_RESID with N == 384: optional fused LayerNorm(eps 1e-6) of the output row (the next sub-layer's pre-LN)
   const float* ln_gamma; const float* ln_beta; bf16* ln_out; float* ln_mean; float* ln_rstd;
   float* colsum;                     // EPI_DGELU: optional fp32 [N] accumulator of the column sums of the output (bias gradient)

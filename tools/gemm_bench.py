@@ -7,7 +7,6 @@ from audiossl_amd import hip
 hip.load()
 dev = "cuda"
 if os.environ.get("VARIANT"): hip.load().atst_tune_gemm_variant(int(os.environ["VARIANT"]))
-if os.environ.get("STAG"): hip.load().atst_tune_gemm_variant(200 + int(os.environ["STAG"]))
 if os.environ.get("ATTNV"): hip.load().atst_tune_gemm_variant(400 + int(os.environ["ATTNV"]))
 if os.environ.get("TNV"): hip.load().atst_tune_gemm_variant(100 + int(os.environ["TNV"]))
 M = int(os.environ.get("M", 131072))
