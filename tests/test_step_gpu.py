@@ -144,6 +144,43 @@ def test_base_arch_encoder_vs_oracle():
     assert num / den < 1.5e-2 and worst[1] < 3e-2
 
 
+@pytest.mark.parametrize("width,NP", [(401, 128), (201, 64), (101, 32), (41, 32)])
+def test_short_clip_geometries_vs_oracle(width, NP):
+    """4 s / 2 s / 1 s / 0.4 s inputs (token tiles of 128 / 64 / 32 rows; the generic attention kernels), depth 2, ragged
+    lengths: CLS and the gradient of sum(CLS * R) against the CPU oracle's autograd."""
+    S, depth = 5, 2
+    W = O.recipe_weights("small", depth=depth, seed=41)
+    eng = AtstEngine("small", depth=depth, drop_path_rate=0.0)
+    eng.load_weights(W)
+    mel = O.recipe_mel(S, width, seed=43)
+    length = torch.tensor([width, width - 4, max(width // 2, 8), width - 1, max(width // 3, 5)])
+    leaves = {k: v.requires_grad_(True) for k, v in W.items() if k.startswith("student.encoder.") and v.dtype == torch.float32}
+    cls_o = O.encoder_forward(W, "student.encoder.", mel, length, "small", depth, drop_path_rate=0.0)
+    R = torch.from_numpy(np.random.default_rng(45).standard_normal((S, 384)).astype(np.float32))
+    (cls_o * R).sum().backward()
+    ep = eng._pass("student", S, width, True, 0)
+    assert ep.NP == NP
+    out = ep.forward(mel.cuda(), eng._valid(length, 1), None, None)
+    cls = out.float().reshape(S, NP, 384)[:, 0].cpu()
+    assert rel(cls.numpy(), cls_o.detach().numpy()) < 1e-2
+    eng.g32.zero_(); ep.dout.zero_()
+    rows = (torch.arange(S, dtype=torch.int32, device="cuda") * NP).contiguous()
+    hip.call("atst_scatter_rows_bf16", hip.ptr(R.cuda()), hip.ptr(rows), S, 384, hip.ptr(ep.dout), hip.stream())
+    ep.backward()
+    num = den = 0.0
+    worst = ("", 0.0)
+    for name in eng.layout.entries:
+        if not name.startswith("encoder.") or name == "encoder.mask_embed":
+            continue
+        g = eng.param_view("student", name, grad=True).double().cpu()
+        go = leaves["student." + name].grad.double()
+        r = float((g - go).norm() / (go.norm() + 1e-30))
+        num += r * g.numel(); den += g.numel()
+        if r > worst[1]:
+            worst = (name, r)
+    assert num / den < 1.5e-2 and worst[1] < 3e-2, (num / den, worst)
+
+
 def test_head_and_loss_backward_given_same_features():
     """Projector + predictor + loss forward/backward on fixed features vs the oracle's autograd on the same features."""
     B, Cdim = 48, 384
