@@ -1102,7 +1102,8 @@ int launch_nt(const GemmArgs& a, hipStream_t st) {
   }
   int v = g_nt_variant;
   if ((v == 4 || (v < 0 && g_row384_auto)) && a.N % 384 == 0 && (EPI != EPI_DGELU || g_dgelu_row384)) return launch_nt_row384<EPI>(a, st);
-  if (v < 0) v = a.K <= 512 ? 0 : 1;
+  if (v < 0) v = (EPI == EPI_F32 && a.M >= 16384) ? 3            // ATST-Frame head Linears (83 k rows): 256x128 tile, -13 %
+               : a.K <= 512 ? 0 : 1;
   if (v == 3) return launch_nt_cfg<EPI, 256, 3, 128>(a, st);
   if (v == 2) return launch_nt_cfg<EPI, 256, 3, 64>(a, st);
   if (v == 1) return launch_nt_cfg<EPI, 128, 3, 64>(a, st);

@@ -52,7 +52,8 @@ def gemm_nt(A, B, epi, out_dtype, **kw):
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 384, 256), (128, 128, 64), (1027, 1152, 384), (512, 256, 4096),
-                                   (8192 + 77, 1152, 384), (8192, 384, 1536)])          # last two: 256 x 384 tiles, ragged last tile
+                                   (8192 + 77, 1152, 384), (8192, 384, 1536),           # 256 x 384 tiles, ragged last tile
+                                   (16384 + 40, 256, 768)])                             # fp32 output at >= 16 k rows: 256 x 128 tile (Frame heads)
 def test_gemm_nt_plain(M, N, K):
     A, B = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2))       # asymmetric operands: catches transposed fragments
     ref = A.float() @ B.float().t()
