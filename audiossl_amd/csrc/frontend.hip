@@ -67,38 +67,56 @@ __global__ __launch_bounds__(256) void stft_mel_db_kernel(const float* __restric
   const float* w = wave + (size_t)clip * n_samples;
   const int m_start = fb_start[lane], m_len = fb_len[lane];
   float vmax = -1e30f;
+  // twiddles of the two twiddled passes depend on the lane only: fetched once per block, not once per frame
+  float2 tw8[8], tw64[8];
+  f32x2 win[8];                                                    // this lane's 16 window taps
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    tw8[r] = g_tw512[(lane & 7) * r * 8]; tw64[r] = g_tw512[lane * r];
+    win[r] = *reinterpret_cast<const f32x2*>(window + 2 * (lane + 64 * r));
+  }
+  // every wave transforms its own frame in its own LDS arrays: the passes only need the wave's LDS writes to be visible
+  // to its own lanes (in-order LDS pipe + lgkmcnt(0)), not a block barrier
+  auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
   for (int fi = 0; fi < FPB / 4; ++fi) {
     const int fl = fi * 4 + wid;                       // frame within block
     int t = t0 + fl; if (t >= T) t = T - 1;             // duplicates are computed but never stored
     const int base = t * HOPS - NFFT / 2;
     float2 u[8];
+    if (base >= 0 && base + NFFT <= n_samples && ((reinterpret_cast<size_t>(w + base) & 7) == 0)) {   // interior frame, 8-B aligned: vector loads
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int j0 = 2 * (lane + 64 * r);
-      const f32x2 wn = *reinterpret_cast<const f32x2*>(window + j0);
-      u[r] = make_float2(w[reflect(base + j0, n_samples)] * wn[0], w[reflect(base + j0 + 1, n_samples)] * wn[1]);
+      for (int r = 0; r < 8; ++r) {
+        const f32x2 x2 = *reinterpret_cast<const f32x2*>(w + base + 2 * (lane + 64 * r));
+        u[r] = make_float2(x2[0] * win[r][0], x2[1] * win[r][1]);
+      }
+    } else {                                                       // frames that reach into the reflect padding
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int j0 = 2 * (lane + 64 * r);
+        u[r] = make_float2(w[reflect(base + j0, n_samples)] * win[r][0], w[reflect(base + j0 + 1, n_samples)] * win[r][1]);
+      }
     }
     dft8(u);                                            // pass p = 1 : no twiddles, out index lane*8 + r
 #pragma unroll
     for (int r = 0; r < 8; ++r) fa[wid][lane * 8 + r] = u[r];
-    __syncthreads();
+    wave_sync();
     {                                                   // pass p = 8
       const int k = lane & 7, j = (lane - k) * 8 + k;
 #pragma unroll
-      for (int r = 0; r < 8; ++r) u[r] = cmul(fa[wid][lane + 64 * r], g_tw512[k * r * 8]);
+      for (int r = 0; r < 8; ++r) u[r] = cmul(fa[wid][lane + 64 * r], tw8[r]);
       dft8(u);
 #pragma unroll
       for (int r = 0; r < 8; ++r) fb[wid][j + r * 8] = u[r];
     }
-    __syncthreads();
+    wave_sync();
     {                                                   // pass p = 64
 #pragma unroll
-      for (int r = 0; r < 8; ++r) u[r] = cmul(fb[wid][lane + 64 * r], g_tw512[lane * r]);
+      for (int r = 0; r < 8; ++r) u[r] = cmul(fb[wid][lane + 64 * r], tw64[r]);
       dft8(u);
 #pragma unroll
       for (int r = 0; r < 8; ++r) fa[wid][lane + 64 * r] = u[r];
     }
-    __syncthreads();
+    wave_sync();
     for (int k = lane; k <= 512; k += 64) {             // un-pack the real transform, power spectrum
       const float2 zk = fa[wid][k & 511];
       float2 zc = fa[wid][(512 - k) & 511]; zc.y = -zc.y;
@@ -108,7 +126,7 @@ __global__ __launch_bounds__(256) void stft_mel_db_kernel(const float* __restric
       const float2 x = cadd(e, cmul(g_tw1024[k], o));
       pw[wid][k] = x.x * x.x + x.y * x.y;
     }
-    __syncthreads();
+    wave_sync();
     float mel = 0.f;
     for (int q = 0; q < m_len; ++q) mel += fbw[lane * fb_maxlen + q] * pw[wid][m_start + q];
     const float db = 10.0f * log10f(fmaxf(mel, 1e-10f));
