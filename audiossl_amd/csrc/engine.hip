@@ -160,7 +160,23 @@ extern "C" int atst_encoder_fwd(const atst_encoder_t* e, void* stream) {
   return ATST_OK;
 }
 
+// Backward over blocks [lo, hi) (descending); head: also the final LayerNorm backward (needs hi == depth); tail: also the
+// token stage (needs lo == 0).  At every block boundary the residual gradient is back in dxA and the bf16 operand of the
+// next block's MLP branch is in w.g, so a split needs no state besides the workspace.
+static int encoder_bwd_range(const atst_encoder_t* e, int lo, int hi, bool head, bool tail, void* stream);
+
 extern "C" int atst_encoder_bwd(const atst_encoder_t* e, void* stream) {
+  if (!check(e)) return ATST_EINVAL;
+  return encoder_bwd_range(e, 0, e->depth, true, true, stream);
+}
+/* part 0: final LayerNorm + blocks [split, depth) ; part 1: blocks [0, split) + token stage.  Lets the caller start the
+ * gradient all-reduce of the upper blocks while the lower ones are still being differentiated.                          */
+extern "C" int atst_encoder_bwd_part(const atst_encoder_t* e, int part, int split, void* stream) {
+  if (!check(e) || split < 0 || split > e->depth || (part != 0 && part != 1)) return ATST_EINVAL;
+  return part == 0 ? encoder_bwd_range(e, split, e->depth, true, false, stream) : encoder_bwd_range(e, 0, split, false, true, stream);
+}
+
+static int encoder_bwd_range(const atst_encoder_t* e, int lo, int hi, bool head, bool tail, void* stream) {
   if (!check(e) || !e->train || !e->p16t || !e->g32) return ATST_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const Ws w = carve(e->ws, e->S, e->NP, e->C, e->H, e->depth, e->train);
@@ -173,31 +189,31 @@ extern "C" int atst_encoder_bwd(const atst_encoder_t* e, void* stream) {
   };
 
   float* cur = w.dxA; float* oth = w.dxB;
-  {
+  if (head) {
     LnBwdArgs a{};
     a.dy = w.dout; a.x = w.x[2 * D]; a.mean = w.meanN; a.rstd = w.rstdN; a.gamma = p + o.norm_w; a.dres = nullptr;
     a.dx = cur; a.g = w.g; a.row_scale = dps(D - 1, 1); a.rows_per_seq = NP;
     a.dgamma = G + o.norm_w; a.dbeta = G + o.norm_b; a.dbias_up = G + o.layer[D - 1].fc2_b; a.M = M; a.C = C;
     RUN(atst_ln_bwd(a, st));
   }
-  for (int i = D - 1; i >= 0; --i) {
-    const atst_layer_off_t& lo = o.layer[i];
+  for (int i = hi - 1; i >= lo; --i) {
+    const atst_layer_off_t& lo_ = o.layer[i];
     const LayerWs& l = w.L[i];
     // ---- MLP branch: x_out = x_mid + s2 * (fc2(gelu(fc1(LN2(x_mid)))) + b2) ; w.g = s2 * d(x_out)
     // The block's four weight gradients are independent of everything downstream: they are launched together after the
     // attention backward (atst_gemm_tn_group), which is why the two residual-branch gradients live in separate buffers.
-    RUN(gemm(w.g, qt + lo.fc2_w, M, 4 * C, C, EPI_DGELU, w.du, st, nullptr, nullptr, nullptr, 1, nullptr, l.u, G + lo.fc1_b));
-    RUN(gemm(w.du, qt + lo.fc1_w, M, C, 4 * C, EPI_BF16, w.dh, st));
+    RUN(gemm(w.g, qt + lo_.fc2_w, M, 4 * C, C, EPI_DGELU, w.du, st, nullptr, nullptr, nullptr, 1, nullptr, l.u, G + lo_.fc1_b));
+    RUN(gemm(w.du, qt + lo_.fc1_w, M, C, 4 * C, EPI_BF16, w.dh, st));
     {
       LnBwdArgs a{};
-      a.dy = w.dh; a.x = w.x[2 * i + 1]; a.mean = l.mean2; a.rstd = l.rstd2; a.gamma = p + lo.ln2_w; a.dres = cur;
+      a.dy = w.dh; a.x = w.x[2 * i + 1]; a.mean = l.mean2; a.rstd = l.rstd2; a.gamma = p + lo_.ln2_w; a.dres = cur;
       a.dx = oth; a.g = w.g2; a.row_scale = dps(i, 0); a.rows_per_seq = NP;
-      a.dgamma = G + lo.ln2_w; a.dbeta = G + lo.ln2_b; a.dbias_up = G + lo.proj_b; a.M = M; a.C = C;
+      a.dgamma = G + lo_.ln2_w; a.dbeta = G + lo_.ln2_b; a.dbias_up = G + lo_.proj_b; a.M = M; a.C = C;
       RUN(atst_ln_bwd(a, st));
       float* t = cur; cur = oth; oth = t;
     }
     // ---- attention branch: x_mid = x_in + s1 * (proj(attn(LN1(x_in))) + bp) ; w.g = s1 * d(x_mid)
-    RUN(gemm(w.g2, qt + lo.proj_w, M, C, C, EPI_BF16, w.d_o, st));
+    RUN(gemm(w.g2, qt + lo_.proj_w, M, C, C, EPI_BF16, w.d_o, st));
     AttnArgs at{};
     at.qkv = l.qkv; at.valid = e->valid; at.o = l.o; at.lse = l.lse; at.d_o = w.d_o; at.dqkv = w.dqkv; at.dscratch = w.dscr;
     at.S = S; at.H = e->H; at.NP = NP;
@@ -207,23 +223,24 @@ extern "C" int atst_encoder_bwd(const atst_encoder_t* e, void* stream) {
       auto set = [&](int k, const bf16* dY, const bf16* X, int N, int K, float* dW) {
         wg[k].dY = dY; wg[k].X = X; wg[k].M = M; wg[k].N = N; wg[k].K = K; wg[k].ldy = N; wg[k].ldx = K; wg[k].dW = dW; wg[k].ldw = K;
       };
-      set(0, w.du, l.h2, 4 * C, C, G + lo.fc1_w);
-      set(1, w.g, l.a, C, 4 * C, G + lo.fc2_w);
-      set(2, w.dqkv, l.h1, 3 * C, C, G + lo.qkv_w);
-      set(3, w.g2, l.o, C, C, G + lo.proj_w);
+      set(0, w.du, l.h2, 4 * C, C, G + lo_.fc1_w);
+      set(1, w.g, l.a, C, 4 * C, G + lo_.fc2_w);
+      set(2, w.dqkv, l.h1, 3 * C, C, G + lo_.qkv_w);
+      set(3, w.g2, l.o, C, C, G + lo_.proj_w);
       RUN(atst_gemm_tn_group(wg, 4, st));
     }
-    RUN(gemm(w.dqkv, qt + lo.qkv_w, M, C, 3 * C, EPI_BF16, w.dh, st));
+    RUN(gemm(w.dqkv, qt + lo_.qkv_w, M, C, 3 * C, EPI_BF16, w.dh, st));
     {
       LnBwdArgs a{};
-      a.dy = w.dh; a.x = w.x[2 * i]; a.mean = l.mean1; a.rstd = l.rstd1; a.gamma = p + lo.ln1_w; a.dres = cur;
+      a.dy = w.dh; a.x = w.x[2 * i]; a.mean = l.mean1; a.rstd = l.rstd1; a.gamma = p + lo_.ln1_w; a.dres = cur;
       a.dx = oth; a.g = i > 0 ? w.g : nullptr; a.row_scale = i > 0 ? dps(i - 1, 1) : nullptr; a.rows_per_seq = NP;
-      a.dgamma = G + lo.ln1_w; a.dbeta = G + lo.ln1_b; a.dbias_up = i > 0 ? G + o.layer[i - 1].fc2_b : nullptr;
+      a.dgamma = G + lo_.ln1_w; a.dbeta = G + lo_.ln1_b; a.dbias_up = i > 0 ? G + o.layer[i - 1].fc2_b : nullptr;
       a.M = M; a.C = C;
       RUN(atst_ln_bwd(a, st));
       float* t = cur; cur = oth; oth = t;
     }
   }
+  if (!tail) return ATST_OK;
   // ---- token stage: x0 = (1-m) (patch W^T + b) + m mask_embed + pos  (+ CLS)
   RUN(atst_token_grad(cur, e->rowflag, S, NP, e->n_tok, C, e->use_cls, e->use_cls ? G + o.cls_token : nullptr,
                       G + o.pos_embed, G + o.patch_b, e->rowflag ? G + o.mask_embed : nullptr, w.g, st));

@@ -136,6 +136,10 @@ class EncoderPass:
     def backward(self):
         hip.check(hip.load().atst_encoder_bwd(C.byref(self.e), hip.stream()), "atst_encoder_bwd")
 
+    def backward_part(self, part: int, split: int):
+        """part 0: final LayerNorm + blocks [split, depth) ; part 1: blocks [0, split) + token stage."""
+        hip.check(hip.load().atst_encoder_bwd_part(C.byref(self.e), part, split, hip.stream()), "atst_encoder_bwd_part")
+
     def tokens(self):
         return self.ws.view(hip.load().atst_encoder_tokens(C.byref(self.e)), (self.M, self.e.C), torch.float32)
 
@@ -298,6 +302,8 @@ class AtstEngine:
         self._grads_summed = False
         self.overlap_teacher = False     # side-stream teacher pass: measured no gain (full-chip kernels serialise), off by default
         self._side = torch.cuda.Stream(device=self.device)
+        self._comm = torch.cuda.Stream(device=self.device)     # gradient all-reduce underneath the backward pass
+        self.overlap_comm = True
 
     # ---------------------------------------------------------------------------------------------------------------
     def _build_offsets(self) -> hip.EncOff:
@@ -492,18 +498,49 @@ class AtstEngine:
             ds = self._ds if grad_scale == 1.0 else self._ds * float(grad_scale)
         dz = self.heads["student.predictor"].backward(ds)
         df = self.heads["student.projector"].backward(dz)
-        r0 = 0
-        for ep, rows in self._student_groups:
+        groups, offs, r0 = list(self._student_groups), [], 0
+        for ep, rows in groups:
+            offs.append(r0)
+            r0 += rows.numel()
+        # Smallest view group first: the largest one (the 10 s views) goes last so that, across ranks, the all-reduce of
+        # the upper half of the parameters (blocks depth/2.., final norm, heads -- complete once the last group's
+        # backward has passed block depth/2) runs on a second stream underneath the lower blocks' backward.
+        order = sorted(range(len(groups)), key=lambda i: groups[i][0].M)
+        self._async_reduce = False
+        overlap = self.overlap_comm and parallel._collective() and self.depth >= 2 and zero_grad
+        for k, gi in enumerate(order):
+            ep, rows = groups[gi]
             n = rows.numel()
             ep.dout.zero_()
-            src = df[r0:r0 + n].contiguous()                       # named: must outlive the launch call
+            src = df[offs[gi]:offs[gi] + n].contiguous()           # named: must outlive the launch call
             hip.call("atst_scatter_rows_bf16", hip.ptr(src), hip.ptr(rows), n, self.cfg["embed_dim"],
                      hip.ptr(ep.dout), hip.stream())
-            ep.backward()
-            r0 += n
+            if overlap and k == len(order) - 1:
+                split = self.depth // 2
+                cut = self.layout.entries[f"encoder.blocks.{split}.norm1.weight"][0]
+                ep.backward_part(0, split)
+                self._reduce_async(cut, self.layout.n_student)
+                ep.backward_part(1, split)
+                self._reduce_async(0, cut)
+                self._async_reduce = True
+            else:
+                ep.backward()
+
+    def _reduce_async(self, a: int, b: int):
+        """Sum g32[a:b] over ranks on the communication stream, ordered after everything enqueued so far."""
+        main = torch.cuda.current_stream()
+        self._comm.wait_stream(main)
+        with torch.cuda.stream(self._comm):
+            parallel.allreduce_sum_(self.g32[a:b])
 
     def allreduce_grads(self):
-        """DDP: sum student gradients over ranks (RCCL over xGMI); the 1/world mean is folded into the optimizer kernel."""
+        """DDP: sum student gradients over ranks (RCCL over xGMI); the 1/world mean is folded into the optimizer kernel.
+        When backward() already started the bucketed reduction, this only joins the communication stream."""
+        if getattr(self, "_async_reduce", False):
+            torch.cuda.current_stream().wait_stream(self._comm)
+            self._async_reduce = False
+            self._grads_summed = True
+            return
         self._grads_summed = parallel.allreduce_sum_(self.g32)
 
     def optimizer_step(self, lr: float, wd: float, ema_m: Optional[float], betas=(0.9, 0.999), eps: float = 1e-6):

@@ -80,6 +80,7 @@ _SIGS = {
     "atst_encoder_ws_bytes": (C.c_size_t, [C.c_int] * 6),
     "atst_encoder_fwd": (C.c_int, [C.POINTER(Encoder), C.c_void_p]),
     "atst_encoder_bwd": (C.c_int, [C.POINTER(Encoder), C.c_void_p]),
+    "atst_encoder_bwd_part": (C.c_int, [C.POINTER(Encoder), C.c_int, C.c_int, C.c_void_p]),
     "atst_encoder_out": (C.c_void_p, [C.POINTER(Encoder)]),
     "atst_encoder_dout": (C.c_void_p, [C.POINTER(Encoder)]),
     "atst_encoder_block_out": (C.c_void_p, [C.POINTER(Encoder), C.c_int]),

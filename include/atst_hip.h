@@ -140,6 +140,9 @@ const uint16_t* atst_encoder_out(const atst_encoder_t* e);
 /* backward: d(LN(final)) bf16 [S*NP, C] must have been written to atst_encoder_dout() (zero for unused rows) */
 uint16_t* atst_encoder_dout(const atst_encoder_t* e);
 int atst_encoder_bwd(const atst_encoder_t* e, void* stream);
+/* The same backward in two calls: part 0 = final LayerNorm + blocks [split, depth), part 1 = blocks [0, split) + token
+ * stage (the caller may start the gradient all-reduce of the upper blocks in between).                                */
+int atst_encoder_bwd_part(const atst_encoder_t* e, int part, int split, void* stream);
 /* block-level activation taps for tests: fp32 residual stream after block i (i in [0,depth)), train=1 only */
 const float* atst_encoder_block_out(const atst_encoder_t* e, int i);
 const float* atst_encoder_tokens(const atst_encoder_t* e);

@@ -181,6 +181,29 @@ def test_short_clip_geometries_vs_oracle(width, NP):
     assert num / den < 1.5e-2 and worst[1] < 3e-2, (num / den, worst)
 
 
+def test_split_backward_equals_single_call():
+    """atst_encoder_bwd_part(0, s) + (1, s) -- the form backward() uses to start the gradient all-reduce of the upper blocks
+    early -- produces the gradients of the single-call backward (up to fp32 atomic order)."""
+    S, depth = 6, 4
+    eng = AtstEngine("small", depth=depth, drop_path_rate=0.0)
+    eng.load_weights(O.recipe_weights("small", depth=depth, seed=51))
+    ep = eng._pass("student", S, 1001, True, 0)
+    ep.forward(O.recipe_mel(S, 1001, seed=53).cuda(), eng._valid(torch.tensor([1001, 900, 1001, 640, 1001, 333]), 1), None, None)
+    R = torch.from_numpy(np.random.default_rng(55).standard_normal((S, 384)).astype(np.float32)).cuda()
+    rows = (torch.arange(S, dtype=torch.int32, device="cuda") * 256).contiguous()
+    grads = []
+    for split in (None, 1, 2, 3, 0, 4):
+        eng.g32.zero_(); ep.dout.zero_()
+        hip.call("atst_scatter_rows_bf16", hip.ptr(R), hip.ptr(rows), S, 384, hip.ptr(ep.dout), hip.stream())
+        if split is None:
+            ep.backward()
+        else:
+            ep.backward_part(0, split); ep.backward_part(1, split)
+        grads.append(eng.g32.clone())
+    for g in grads[1:]:
+        assert float((g - grads[0]).norm() / grads[0].norm()) < 1e-6
+
+
 def test_head_and_loss_backward_given_same_features():
     """Projector + predictor + loss forward/backward on fixed features vs the oracle's autograd on the same features."""
     B, Cdim = 48, 384
