@@ -589,8 +589,24 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
 // LDS-resident (4 x 36 KB) so that both halves of the backward -- dK/dV (wave = 32 keys) and dQ (wave = 32 queries) --
 // read every operand on-chip after ONE staging pass (the two-kernel version stages Q,dO and K,V separately and re-reads
 // the per-wave fragments from HBM).  The next head's panels are prefetched into registers during the dQ phase.  D = rowsum(dO * O) comes from attn_rowdot_kernel.
-constexpr int B256_MAT = 256 * A_LD;                               // elements of one staged matrix
-constexpr int B256_LDS = 4 * B256_MAT * 2 + 2 * 256 * 4;           // 149,504 B
+constexpr int B256_MAT = 256 * HD;                                 // elements of one staged matrix: [256][64], 128-B rows
+constexpr int B256_LDS = 4 * B256_MAT * 2 + 2 * 256 * 4;           // 133,120 B
+// The four images are read both by rows (ds_read_b128 fragments) and transposed (ds_read_b64_tr_b16).  16-B chunk c of
+// row r is stored at chunk c ^ key(r), key = rotate-right of ((r >> 1) & 7): a bijection of (r >> 1) & 7, so the 16 rows
+// of a ds_read_b128 service group hit 16 distinct bank slots, and its top bit is bit 1 of r, so the 4 rows x 64 B of a
+// transpose-read half-wave hit 4 distinct 64-B windows (the padded 144-B pitch had 2-way conflicts there: 22 % of the
+// kernel's LDS cycles).
+DEVFN int b256_key(int row) { const int t = (row >> 1) & 7; return ((t & 1) << 2) | (t >> 1); }
+DEVFN const bf16* b256_ptr(const bf16* base, int row, int chunk) { return base + row * HD + ((chunk ^ b256_key(row)) << 3); }
+DEVFN bf16x8 b256_frag_tr(const bf16* X, int r0, int c0, int lane) {
+  const int a = lane & 15, g = lane >> 4;
+  const int row = r0 + 4 * (g >> 1) + (a >> 2);
+  const int col = c0 + (g & 1) * 16 + 4 * (a & 3);
+  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+  u.s.a = lds_tr4(b256_ptr(X, row, col >> 3) + (col & 7));
+  u.s.b = lds_tr4(b256_ptr(X, row + 8, col >> 3) + (col & 7));
+  return u.v;
+}
 
 __global__ void attn_rowdot_kernel(const bf16* __restrict__ d_o, const bf16* __restrict__ o, float* __restrict__ D,
                                    int S, int H, int NP) {
@@ -627,32 +643,69 @@ __global__ __launch_bounds__(512, 2) void attn_bwd256_kernel(AttnArgs p, const f
   const int ntile = (valid + 31) / 32 < 8 ? (valid + 31) / 32 : 8;
   const float scale = 0.125f;
 
-  // prefetch registers: {Q, dO} and {K, V} of the next head, 8 x 16 B per thread each ; lse / D one float per thread
-  bf16x8 pa[8], pb[8];
+  // next head: Q and dO go HBM -> LDS by global_load_lds during the dQ phase (their LDS images are dead once every wave
+  // has taken its own query rows into registers); K and V, which the dQ phase still reads, are prefetched into registers
+  // (8 x 16 B per thread) and written to LDS at the top of the next head ; lse / D one float per thread
+  typedef const void __attribute__((address_space(1))) * gptr_t;
+  typedef void __attribute__((address_space(3))) * lptr_t;
+  bf16x8 pb[8];
   float plse = 0.f, pd = 0.f;
-  auto load_qdo = [&](int h) {
+  // staging map: thread t moves chunk (t & 7) of rows (t >> 3) + 64 j, j = 0..3, of each of the four matrices; the
+  // permutation key of those rows is the same for every j (64 j >> 1 is a multiple of 8)
+  const int srow = tid >> 3, sk = (tid & 7) * 8;
+  const int sofs = srow * HD + (((tid & 7) ^ b256_key(srow)) << 3);
+  // LDS-DMA map: instruction i of a wave covers rows 32 wid + 8 i .. + 8 (128-B rows), lane = (row, physical chunk)
+  int dq_off[4], ddo_off[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int c = tid + 512 * i, mat = c >> 11, r = (c >> 3) & 255, k = (c & 7) * 8;
-      pa[i] = mat == 0 ? ld_frag(qkv + (size_t)r * ld + h * HD + k) : ld_frag(dob + (size_t)r * C + h * HD + k);
+  for (int i = 0; i < 4; ++i) {
+    const int row = wid * 32 + i * 8 + (lane >> 3), c = (lane & 7) ^ b256_key(row);
+    dq_off[i] = row * (int)ld + c * 8;
+    ddo_off[i] = row * C + c * 8;
+  }
+  auto dma_qdo = [&](int h) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((gptr_t)(qkv + dq_off[i] + h * HD), (lptr_t)(reinterpret_cast<char*>(sQ) + (wid * 4 + i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(dob + ddo_off[i] + h * HD), (lptr_t)(reinterpret_cast<char*>(sDO) + (wid * 4 + i) * 1024), 16, 0, 0);
     }
+  };
+  auto load_aux = [&](int h) {
     if (tid < NP) { plse = p.lse[((size_t)s * H + h) * NP + tid]; pd = Dg[((size_t)s * H + h) * NP + tid]; }
   };
   auto load_kv = [&](int h) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int c = tid + 512 * i, mat = c >> 11, r = (c >> 3) & 255, k = (c & 7) * 8;
-      pb[i] = ld_frag(qkv + (size_t)r * ld + (1 + mat) * C + h * HD + k);
+    for (int j = 0; j < 4; ++j) {
+      pb[j] = ld_frag(qkv + (size_t)(srow + 64 * j) * ld + C + h * HD + sk);
+      pb[4 + j] = ld_frag(qkv + (size_t)(srow + 64 * j) * ld + 2 * C + h * HD + sk);
     }
   };
   auto store_lds = [&]() {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int c = tid + 512 * i, mat = c >> 11, r = (c >> 3) & 255, k = (c & 7) * 8;
-      *reinterpret_cast<bf16x8*>((mat == 0 ? sQ : sDO) + r * A_LD + k) = pa[i];
-      *reinterpret_cast<bf16x8*>((mat == 0 ? sK : sV) + r * A_LD + k) = pb[i];
+    for (int j = 0; j < 4; ++j) {
+      *reinterpret_cast<bf16x8*>(sK + sofs + 64 * j * HD) = pb[j];
+      *reinterpret_cast<bf16x8*>(sV + sofs + 64 * j * HD) = pb[4 + j];
     }
     if (tid < NP) { sLse[tid] = -plse * LOG2E; sD[tid] = pd; }       // exponent offset of P = exp2(c1 s - lse log2 e)
+  };
+  // lane-only parts of the swizzled fragment addresses (row blocks are multiples of 16 rows, so the permutation key of a
+  // fragment row depends on the lane alone); the block / tile offsets are added as constants by the reads
+  int rofs[4], tofs[2][2];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) rofs[ks] = l31 * HD + (((ks * 2 + hi) ^ b256_key(l31)) << 3);
+  {
+    const int a = lane & 15, g = lane >> 4;
+    const int lrow = 4 * (g >> 1) + (a >> 2), lcol = (g & 1) * 16 + 4 * (a & 3);
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+      for (int half = 0; half < 2; ++half)
+        tofs[cc][half] = (lrow + 8 * half) * HD + (((cc * 4 + (lcol >> 3)) ^ b256_key(lrow + 8 * half)) << 3) + (lcol & 7);
+  }
+  auto rfrag = [&](const bf16* X, int row0, int ks) { return ld_frag(X + row0 * HD + rofs[ks]); };          // rows row0 + l31
+  auto tfrag = [&](const bf16* X, int r0, int cc) {                                                          // X^T fragment
+    union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+    u.s.a = lds_tr4(X + r0 * HD + tofs[cc][0]); u.s.b = lds_tr4(X + r0 * HD + tofs[cc][1]);
+    return u.v;
   };
   const float c1 = scale * LOG2E;
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -660,10 +713,12 @@ __global__ __launch_bounds__(512, 2) void attn_bwd256_kernel(AttnArgs p, const f
 #pragma unroll
   for (int r = 0; r < 16; ++r) mbits |= ((ntile - 1) * 32 + crow32(r, hi) >= valid ? 1u : 0u) << r;
   asm volatile("" : "+v"(mbits));
-  load_qdo(0);
+  dma_qdo(0);
+  load_aux(0);
   load_kv(0);
   for (int h = 0; h < H; ++h) {
-    store_lds();
+    store_lds();                                                   // K, V, lse, D of head h (waits for their loads -- and, in order, for the Q / dO DMA issued before them)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // ---------------- dK, dV : this wave owns keys [32 wid, 32 wid + 32)
     {
@@ -675,20 +730,18 @@ __global__ __launch_bounds__(512, 2) void attn_bwd256_kernel(AttnArgs p, const f
         bf16x8 kf[4], vf[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-          kf[ks] = ld_frag(sK + (k0 + l31) * A_LD + ks * 16 + hi * 8);
-          vf[ks] = ld_frag(sV + (k0 + l31) * A_LD + ks * 16 + hi * 8);
+          kf[ks] = rfrag(sK, k0, ks);
+          vf[ks] = rfrag(sV, k0, ks);
         }
         const float kbias = (k0 + l31 >= valid) ? -3.0e38f : 0.f;  // padded key: P = 0 (reference: exp(-10000 + ...) == 0 in fp32)
         for (int i = 0; i < 8; ++i) {
           f32x16 sc, dp;
-          const bf16* qr = sQ + (i * 32 + l31) * A_LD + hi * 8;
-          const bf16* dr = sDO + (i * 32 + l31) * A_LD + hi * 8;
-          sc = mfma32(ld_frag(qr), kf[0], zero);
-          dp = mfma32(ld_frag(dr), vf[0], zero);
+          sc = mfma32(rfrag(sQ, i * 32, 0), kf[0], zero);
+          dp = mfma32(rfrag(sDO, i * 32, 0), vf[0], zero);
 #pragma unroll
           for (int ks = 1; ks < 4; ++ks) {
-            sc = mfma32(ld_frag(qr + ks * 16), kf[ks], sc);
-            dp = mfma32(ld_frag(dr + ks * 16), vf[ks], dp);
+            sc = mfma32(rfrag(sQ, i * 32, ks), kf[ks], sc);
+            dp = mfma32(rfrag(sDO, i * 32, ks), vf[ks], dp);
           }
           float pv[16], ds[16];                                    // ds without the softmax scale: applied once to dK at the end
 #pragma unroll
@@ -706,10 +759,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd256_kernel(AttnArgs p, const f
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
             const bf16x8 pf = pack8(pv + 8 * t), dsf = pack8(ds + 8 * t);
-            dv0 = mfma32(ld_frag_tr(sDO, A_LD, i * 32 + 16 * t, 0, lane), pf, dv0);
-            dv1 = mfma32(ld_frag_tr(sDO, A_LD, i * 32 + 16 * t, 32, lane), pf, dv1);
-            dk0 = mfma32(ld_frag_tr(sQ, A_LD, i * 32 + 16 * t, 0, lane), dsf, dk0);
-            dk1 = mfma32(ld_frag_tr(sQ, A_LD, i * 32 + 16 * t, 32, lane), dsf, dk1);
+            dv0 = mfma32(tfrag(sDO, i * 32 + 16 * t, 0), pf, dv0);
+            dv1 = mfma32(tfrag(sDO, i * 32 + 16 * t, 1), pf, dv1);
+            dk0 = mfma32(tfrag(sQ, i * 32 + 16 * t, 0), dsf, dk0);
+            dk1 = mfma32(tfrag(sQ, i * 32 + 16 * t, 1), dsf, dk1);
           }
         }
       }
@@ -717,27 +770,30 @@ __global__ __launch_bounds__(512, 2) void attn_bwd256_kernel(AttnArgs p, const f
       store_row64(dvrow, dv0, dv1, 1.0f, hi);
     }
     // ---------------- dQ : this wave owns queries [32 wid, 32 wid + 32)
-    if (h + 1 < H) { load_qdo(h + 1); load_kv(h + 1); }            // both in flight during the dQ phase (fewer live registers than dK/dV)
     {
       const int q0 = wid * 32;
       bf16x8 qf[4], dof[4];
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        qf[ks] = ld_frag(sQ + (q0 + l31) * A_LD + ks * 16 + hi * 8);
-        dof[ks] = ld_frag(sDO + (q0 + l31) * A_LD + ks * 16 + hi * 8);
+        qf[ks] = rfrag(sQ, q0, ks);
+        dof[ks] = rfrag(sDO, q0, ks);
       }
       const float Dq = sD[q0 + l31], nlse = sLse[q0 + l31];
+      if (h + 1 < H) {                                             // every wave holds its query rows: the Q / dO images can be overwritten
+        __syncthreads();
+        dma_qdo(h + 1);
+        load_aux(h + 1);
+        load_kv(h + 1);
+      }
       f32x16 dq0, dq1; zero16(dq0); zero16(dq1);
       for (int j = 0; j < ntile; ++j) {
         f32x16 sc, dp;
-        const bf16* kr = sK + (j * 32 + l31) * A_LD + hi * 8;
-        const bf16* vr = sV + (j * 32 + l31) * A_LD + hi * 8;
-        sc = mfma32(ld_frag(kr), qf[0], zero);
-        dp = mfma32(ld_frag(vr), dof[0], zero);
+        sc = mfma32(rfrag(sK, j * 32, 0), qf[0], zero);
+        dp = mfma32(rfrag(sV, j * 32, 0), dof[0], zero);
 #pragma unroll
         for (int ks = 1; ks < 4; ++ks) {
-          sc = mfma32(ld_frag(kr + ks * 16), qf[ks], sc);
-          dp = mfma32(ld_frag(vr + ks * 16), dof[ks], dp);
+          sc = mfma32(rfrag(sK, j * 32, ks), qf[ks], sc);
+          dp = mfma32(rfrag(sV, j * 32, ks), dof[ks], dp);
         }
         float ds[16];
         const unsigned mb = j == ntile - 1 ? mbits : 0u;           // only the last key tile can hold padded keys
@@ -750,8 +806,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd256_kernel(AttnArgs p, const f
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const bf16x8 dsf = pack8(ds + 8 * t);
-          dq0 = mfma32(ld_frag_tr(sK, A_LD, j * 32 + 16 * t, 0, lane), dsf, dq0);
-          dq1 = mfma32(ld_frag_tr(sK, A_LD, j * 32 + 16 * t, 32, lane), dsf, dq1);
+          dq0 = mfma32(tfrag(sK, j * 32 + 16 * t, 0), dsf, dq0);
+          dq1 = mfma32(tfrag(sK, j * 32 + 16 * t, 1), dsf, dq1);
         }
       }
       bf16* dqrow = p.dqkv + ((size_t)s * NP + q0 + l31) * ld + h * HD;
