@@ -57,8 +57,10 @@ __global__ __launch_bounds__(256) void stft_mel_db_kernel(const float* __restric
                                                           const float* __restrict__ window, const float* __restrict__ fbw,
                                                           const int* __restrict__ fb_start, const int* __restrict__ fb_len,
                                                           int fb_maxlen, float* __restrict__ out, unsigned int* __restrict__ clipmax) {
-  __shared__ float2 fa[4][512];
-  __shared__ float2 fb[4][512];
+  // padded indices: pa(i) = i + i/8 (the radix-8 pass writes 8 consecutive points per lane: 64-B lane stride otherwise,
+  // 8-way bank conflicts), pb(i) = i + 8 (i/64) (the second pass scatters groups of 8 lanes 512 B apart)
+  __shared__ float2 fa[4][576];
+  __shared__ float2 fb[4][576];
   __shared__ float pw[4][NBIN + 7];
   __shared__ float dbb[NMEL][FPB + 1];
   __shared__ float wmax[4];
@@ -98,20 +100,20 @@ __global__ __launch_bounds__(256) void stft_mel_db_kernel(const float* __restric
     }
     dft8(u);                                            // pass p = 1 : no twiddles, out index lane*8 + r
 #pragma unroll
-    for (int r = 0; r < 8; ++r) fa[wid][lane * 8 + r] = u[r];
+    for (int r = 0; r < 8; ++r) fa[wid][lane * 9 + r] = u[r];             // pa(lane * 8 + r)
     wave_sync();
     {                                                   // pass p = 8
       const int k = lane & 7, j = (lane - k) * 8 + k;
 #pragma unroll
-      for (int r = 0; r < 8; ++r) u[r] = cmul(fa[wid][lane + 64 * r], tw8[r]);
+      for (int r = 0; r < 8; ++r) u[r] = cmul(fa[wid][lane + (lane >> 3) + 72 * r], tw8[r]);   // pa(lane + 64 r)
       dft8(u);
 #pragma unroll
-      for (int r = 0; r < 8; ++r) fb[wid][j + r * 8] = u[r];
+      for (int r = 0; r < 8; ++r) fb[wid][j + r * 8 + (lane >> 3) * 8] = u[r];                 // pb(j + 8 r), j + 8 r < 64 (lane >> 3) + 64
     }
     wave_sync();
     {                                                   // pass p = 64
 #pragma unroll
-      for (int r = 0; r < 8; ++r) u[r] = cmul(fb[wid][lane + 64 * r], tw64[r]);
+      for (int r = 0; r < 8; ++r) u[r] = cmul(fb[wid][lane + 72 * r], tw64[r]);                // pb(lane + 64 r)
       dft8(u);
 #pragma unroll
       for (int r = 0; r < 8; ++r) fa[wid][lane + 64 * r] = u[r];
