@@ -573,206 +573,6 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
   }
 }
 
-// ---- 256 x 384 tile, persistent: one block per CU walks its tiles and never drains the operand ring -------------------
-// The LDS-DMA stream runs two K-tiles ahead of the MFMAs ACROSS tile boundaries: while a tile's epilogue runs, the first
-// two K-tiles of the block's next output tile are already in flight (80 KB), so a K = 384 GEMM (12 K-tiles per output
-// tile) no longer pays a cold ring -- launch, first-load latency, two K-tiles of fill -- once per tile.  The epilogue
-// stages 16 rows at a time through the one ring stage that is idle at that point (the other two hold the prefetch).
-// Requires M % 256 == 0 and K >= 64.
-template <int EPI, bool LN>
-__global__ __launch_bounds__(512, 2) void gemm_nt_row384p_kernel(GemmArgs p) {
-  using namespace row384;
-  constexpr int MI = 4, BMR = 256, A_BYTES = BMR * BK * 2, STAGE = A_BYTES + B_BYTES, NSTG = 3, A_IPW = 2, LOADS = A_IPW + 3;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  typedef const void __attribute__((address_space(1))) * gptr_t;
-  typedef void __attribute__((address_space(3))) * lptr_t;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 2, wn = wid & 3, hi = lane >> 5, l31 = lane & 31;
-  const int ntn = p.N / BNR, ntiles = (p.M / BMR) * ntn;
-  const int nk = p.K / BK;
-  char* lds = smem_raw;
-
-  // lane-only element offsets inside a tile's operand panels; the tile origin is wave-uniform
-  int offA[A_IPW], offB[3];
-  {
-    const int lrow = lane >> 2, lchunk = lane & 3;
-#pragma unroll
-    for (int j = 0; j < A_IPW; ++j) { const int row = (wid * A_IPW + j) * 16 + lrow; offA[j] = row * p.lda + (lchunk ^ ((row >> 2) & 3)) * 8; }
-#pragma unroll
-    for (int j = 0; j < 3; ++j) { const int row = (wid * 3 + j) * 16 + lrow; offB[j] = row * p.ldb + (lchunk ^ ((row >> 2) & 3)) * 8; }
-  }
-  auto origin = [&](int t, int& m0, int& n0) { const int id = xcd_remap(t, ntiles); m0 = (id / ntn) * BMR; n0 = (id % ntn) * BNR; };
-  auto issue_one = [&](const bf16* bA, const bf16* bB, int kt, int stage, int j) {
-    char* st = lds + stage * STAGE;
-    if (j < A_IPW)
-      __builtin_amdgcn_global_load_lds((gptr_t)(bA + offA[j < A_IPW ? j : 0] + kt * BK), (lptr_t)(st + (wid * A_IPW + j) * 1024), 16, 0, 0);
-    else
-      __builtin_amdgcn_global_load_lds((gptr_t)(bB + offB[j >= A_IPW ? j - A_IPW : 0] + kt * BK), (lptr_t)(st + A_BYTES + (wid * 3 + j - A_IPW) * 1024), 16, 0, 0);
-  };
-
-  int t = blockIdx.x;
-  if (t >= ntiles) return;
-  int m0, n0, m0n = 0, n0n = 0;
-  origin(t, m0, n0);
-  int tn = t + gridDim.x;
-  bool has_next = tn < ntiles;
-  if (has_next) origin(tn, m0n, n0n);
-  const bf16* curA = p.A + (size_t)m0 * p.lda; const bf16* curB = p.B + (size_t)n0 * p.ldb;
-  const bf16* nxtA = p.A + (size_t)m0n * p.lda; const bf16* nxtB = p.B + (size_t)n0n * p.ldb;
-
-  const int xr = (l31 >> 2) & 3;
-  const int offAf = (wm * 32 * MI + l31) * 64, offBf = A_BYTES + (wn * 96 + l31) * 64;
-  int stage = 0;                                                   // ring stage of the K-tile about to be consumed
-#pragma unroll
-  for (int j = 0; j < LOADS; ++j) issue_one(curA, curB, 0, 0, j);
-#pragma unroll
-  for (int j = 0; j < LOADS; ++j) issue_one(curA, curB, 1, 1, j);
-  bool after_epilogue = false;
-
-  while (true) {
-    f32x16 acc[MI][3];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    for (int kt = 0; kt < nk; ++kt) {
-      // K-tile kt of this tile has landed (loads retire in order; the next K-tile's five loads may still be in flight)
-      const bool younger = (kt + 1 < nk) || has_next;
-      if (after_epilogue || !younger) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // also drains the epilogue's stores
-      else asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory");
-      after_epilogue = false;
-      // the stream two K-tiles ahead: this tile's kt + 2, or the first K-tiles of the block's next tile
-      const int k2 = kt + 2;
-      const bool in_tile = k2 < nk;
-      const bool do_issue = in_tile || has_next;
-      const bf16* sA = in_tile ? curA : nxtA; const bf16* sB = in_tile ? curB : nxtB;
-      const int kk = in_tile ? k2 : k2 - nk;
-      const int st2 = stage >= 1 ? stage - 1 : stage + 2;          // (stage + 2) % 3
-      const char* st = lds + stage * STAGE;
-      int slot = 0;
-#pragma unroll
-      for (int ks = 0; ks < BK / 16; ++ks) {
-        const int co = ((ks * 2 + hi) ^ xr) << 4;
-        bf16x8 af[MI], bf[3];
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const bf16x8*>(st + offAf + mi * 32 * 64 + co);
-#pragma unroll
-        for (int ni = 0; ni < 3; ++ni) bf[ni] = *reinterpret_cast<const bf16x8*>(st + offBf + ni * 32 * 64 + co);
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-#pragma unroll
-          for (int ni = 0; ni < 3; ++ni) acc[mi][ni] = mfma32(af[mi], bf[ni], acc[mi][ni]);
-          if (slot < LOADS) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (do_issue) issue_one(sA, sB, kk, st2, slot);
-            __builtin_amdgcn_sched_barrier(0);
-            ++slot;
-          }
-        }
-      }
-      stage = stage == 2 ? 0 : stage + 1;
-    }
-    asm volatile("s_barrier" ::: "memory");                         // every wave is done reading the last K-tile: its stage is the epilogue's
-    char* ep = lds + (stage >= 1 ? stage - 1 : 2) * STAGE;          // the stage just consumed; the other two hold the prefetch
-
-    float* sC = reinterpret_cast<float*>(ep);
-    float* sBias = sC + 16 * CLD;
-    float* sGamma = sBias + BNR; float* sBeta = sGamma + BNR;
-    float* sScale = sBeta + BNR;
-    constexpr bool fused_ln = LN && EPI == EPI_RESID;
-    if (tid < BNR) {
-      sBias[tid] = p.bias ? p.bias[n0 + tid] : 0.f;
-      if (fused_ln) { sGamma[tid] = p.ln_gamma[tid]; sBeta[tid] = p.ln_beta[tid]; }
-    }
-    if constexpr (EPI == EPI_RESID) {
-      if (tid < BMR) sScale[tid] = p.row_scale ? p.row_scale[(m0 + tid) / p.rows_per_seq] : 1.0f;
-    }
-#pragma unroll
-    for (int part = 0; part < 16; ++part) {
-      const int mi = part >> 2, q = part & 3;
-      auto tile_row = [&](int rl) { return (rl >> 3) * (32 * MI) + mi * 32 + q * 8 + (rl & 7); };
-#pragma unroll
-      for (int ni = 0; ni < 3; ++ni)
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          sC[(wm * 8 + e + 4 * hi) * CLD + wn * 96 + ni * 32 + l31] = acc[mi][ni][q * 4 + e];
-      EpiAux aux[fused_ln ? 1 : 2];
-      f32x2 rres[fused_ln ? 2 : 1][3];
-      if constexpr (fused_ln) {
-#pragma unroll
-        for (int q2 = 0; q2 < 2; ++q2) {
-          const int row = m0 + tile_row(wid * 2 + q2);
-#pragma unroll
-          for (int k = 0; k < 3; ++k)
-            rres[q2][k] = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p.resid + (size_t)row * p.ldc + k * 128 + lane * 2));
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int idx = tid + THREADS * i;
-          if (idx < 768) epi_fetch8<EPI, false>(p, m0 + tile_row(idx / 48), n0 + (idx % 48) * 8, aux[i]);
-        }
-      }
-      __syncthreads();
-      if constexpr (fused_ln) {
-#pragma unroll
-        for (int q2 = 0; q2 < 2; ++q2) {
-          const int rl = wid * 2 + q2, trow = tile_row(rl), row = m0 + trow;
-          const float sc = sScale[trow];
-          float v[6];
-          float sum = 0.f;
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            const int col = k * 128 + lane * 2;
-            const f32x2 a2 = *reinterpret_cast<const f32x2*>(sC + rl * CLD + col);
-            const f32x2 b2 = *reinterpret_cast<const f32x2*>(sBias + col);
-            f32x2 o = rres[q2][k] + sc * (a2 + b2);
-            __builtin_nontemporal_store(o, reinterpret_cast<f32x2*>(reinterpret_cast<float*>(p.C) + (size_t)row * p.ldc + col));
-            v[2 * k] = o[0]; v[2 * k + 1] = o[1]; sum += o[0] + o[1];
-          }
-          const float mu = wave_sum(sum) * (1.0f / 384.0f);
-          float qd = 0.f;
-#pragma unroll
-          for (int k = 0; k < 6; ++k) { const float d = v[k] - mu; qd += d * d; }
-          const float rs = rsqrtf(wave_sum(qd) * (1.0f / 384.0f) + 1e-6f);
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            const int col = k * 128 + lane * 2;
-            const f32x2 g2 = *reinterpret_cast<const f32x2*>(sGamma + col), be2 = *reinterpret_cast<const f32x2*>(sBeta + col);
-            bf16x2 hv;
-            hv[0] = f2bf((v[2 * k] - mu) * rs * g2[0] + be2[0]);
-            hv[1] = f2bf((v[2 * k + 1] - mu) * rs * g2[1] + be2[1]);
-            *reinterpret_cast<bf16x2*>(p.ln_out + (size_t)row * 384 + col) = hv;
-          }
-          if (lane == 0) { p.ln_mean[row] = mu; p.ln_rstd[row] = rs; }
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int idx = tid + THREADS * i;
-          if (idx < 768) {
-            const int rl = idx / 48, c8 = (idx % 48) * 8, trow = tile_row(rl);
-            f32x4 w0, w1;
-            if constexpr (EPI == EPI_RESID) aux[i].s = sScale[trow];
-            epilogue8<EPI>(p, m0 + trow, n0 + c8, *reinterpret_cast<const f32x4*>(sC + rl * CLD + c8), *reinterpret_cast<const f32x4*>(sC + rl * CLD + c8 + 4),
-                           *reinterpret_cast<const f32x4*>(sBias + c8), *reinterpret_cast<const f32x4*>(sBias + c8 + 4), aux[i], w0, w1);
-          }
-        }
-      }
-      if (part < 15) __syncthreads();
-    }
-    if (!has_next) break;
-    // next tile; the first K-step's barrier orders the last staging reads before the stream re-uses this stage
-    t = tn; m0 = m0n; n0 = n0n; curA = nxtA; curB = nxtB;
-    tn += gridDim.x; has_next = tn < ntiles;
-    if (has_next) { origin(tn, m0n, n0n); nxtA = p.A + (size_t)m0n * p.lda; nxtB = p.B + (size_t)n0n * p.ldb; }
-    after_epilogue = true;
-  }
-}
-
 // ---- wgrad: dW[n,k] += sum_m dY[m,n] X[m,k] -------------------------------------------------------------------------
 constexpr int WM = 64;                          // contraction rows per stage
 constexpr int W_LD = 128 + 32;                  // 160 bf16 = 320 B row stride: 4 consecutive rows x 64 B (one ds_read_b64_tr_b16 half) on 4 distinct bank windows
@@ -1019,7 +819,6 @@ int g_row384_auto = 1;      // use the 128x384 tile whenever N % 384 == 0 (tunin
 int g_row384_tall = 2;      // 256 x 384 tiles for M >= 8192: 2 = every epilogue, 1 = plain bf16 GEMMs only, 0 = never (tuning hooks 304 / 303 / 302)
 int g_tn_rounds = 1;      // wgrad grid = this many rounds of 512 resident blocks (tuning hook 110 + r); 1 measured best (-20 %)
 int g_row384_bk64 = 0;      // 256-row tile with 64-deep ring stages, whole 128-B lines per LDS-DMA lane group, 2 stages (tuning hook 311 = on): measured 2-5 % slower than 3 x 32-deep
-int g_row384_persist = 0;   // persistent 256x384 kernel whose operand stream runs across tile boundaries (tuning hook 309 = on): measured no gain (qkv 167 vs 163 us, fc1+GELU 305 vs 316, residual epilogues slower) -- the cold ring per tile is not what K = 384 shapes lose
 int g_dgelu_row384 = 0;   // dGELU GEMM on the row-384 tile (tuning hook 307 = on): measured slower (LDS-atomic column sums, 78.8 vs 70.5 ms/step)
 int g_nt_variant = -1;    // -1 auto ; 0: 128x128 2-stage ; 1: 128x128 3-stage ; 2: 256x128 8 waves ; 3: 256x128 4 waves of 128x64
 
@@ -1064,28 +863,10 @@ int launch_nt_row384_cfg(const GemmArgs& a, hipStream_t st) {
   hipLaunchKernelGGL((gemm_nt_row384_kernel<EPI, MI, LN, BKT>), dim3(nblk), dim3(row384::THREADS), RG::LDS, st, a);
   return (int)hipGetLastError();
 }
-template <int EPI, bool LN>
-int launch_nt_row384p(const GemmArgs& a, hipStream_t st) {
-  constexpr int LDSB = 3 * (256 * BK * 2 + row384::B_BYTES);      // 122,880 B
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_row384p_kernel<EPI, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
-    if (e != hipSuccess) return (int)e;
-    attr_done = true;
-  }
-  const int ntiles = (a.M / 256) * (a.N / row384::BNR);
-  hipLaunchKernelGGL((gemm_nt_row384p_kernel<EPI, LN>), dim3(ntiles < 256 ? ntiles : 256), dim3(row384::THREADS), LDSB, st, a);
-  return (int)hipGetLastError();
-}
 template <int EPI>
 int launch_nt_row384(const GemmArgs& a, hipStream_t st) {
   ProfScope ps(PK_GEMM_NT0 + EPI, 2.0 * a.M * a.N * a.K, st, nt_bytes<EPI>(a));
-  if constexpr (EPI != EPI_DGELU) {
-    if (g_row384_persist && a.M >= 8192 && a.M % 256 == 0 && a.K >= 64 && (size_t)a.M * a.lda < (1u << 31) && (a.M / 256) * (a.N / row384::BNR) > 256) {
-      if constexpr (EPI == EPI_RESID) { if (a.ln_out) return launch_nt_row384p<EPI, true>(a, st); }
-      return launch_nt_row384p<EPI, false>(a, st);
-    }
-  }
+
   // 256-row tiles: the operand ring of one block covers twice the output (6.7 vs 10.7 KB staged per 128x128 unit)
   const bool tall = a.M >= 8192 && (g_row384_tall == 2 || (g_row384_tall == 1 && EPI == EPI_BF16 && (a.K >= 768 || a.N >= 768)));
   const bool deep = tall && g_row384_bk64 && a.K % 64 == 0;        // 64-deep ring stages
@@ -1112,7 +893,7 @@ int launch_nt(const GemmArgs& a, hipStream_t st) {
 
 }  // namespace
 
-void atst_gemm_nt_set_variant(int v) { if (v >= 310) g_row384_bk64 = v - 310; else if (v >= 308) g_row384_persist = v - 308; else if (v >= 306) g_dgelu_row384 = v - 306; else if (v >= 302) g_row384_tall = v - 302; else if (v >= 300) g_row384_auto = v - 300; else if (v >= 110) g_tn_rounds = v - 110; else if (v >= 105) g_tn_tall = v - 105; else if (v < 100) g_nt_variant = v; }
+void atst_gemm_nt_set_variant(int v) { if (v >= 310) g_row384_bk64 = v - 310; else if (v >= 306) g_dgelu_row384 = v - 306; else if (v >= 302) g_row384_tall = v - 302; else if (v >= 300) g_row384_auto = v - 300; else if (v >= 110) g_tn_rounds = v - 110; else if (v >= 105) g_tn_tall = v - 105; else if (v < 100) g_nt_variant = v; }
 
 int atst_gemm_nt(const GemmArgs& a0, hipStream_t st) {
   GemmArgs a = a0;

@@ -29,7 +29,7 @@ int atst_version(void);
  *   -1 auto | 0..3 force a 128x128 / 256x128 nt tile config | 4 force the row-384 tile
  *   105/106 wgrad 192x384 LDS-DMA tile off/on        110+r wgrad grid = r rounds of resident blocks (128x128 tile)
  *   300/301 row-384 tile off/on      302/303/304 256-row tile: never / plain bf16 GEMMs / every epilogue
- *   306/307 dGELU GEMM on the row-384 tile off/on    308/309 persistent 256x384 kernel off/on
+ *   306/307 dGELU GEMM on the row-384 tile off/on
  *   310/311 64-deep ring stages off/on               400/401/404 NP=256 attention forward: per-head / online / two-pass
  *   402/403 merged NP=256 attention backward off/on                                                                      */
 int atst_tune_gemm_variant(int v);

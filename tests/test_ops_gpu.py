@@ -64,22 +64,6 @@ def test_gemm_nt_plain(M, N, K):
     assert relerr(outb.float(), ref + bias) < 4e-3
 
 
-def test_gemm_nt_persistent_variant():
-    """Tuning hook 309: the persistent 256 x 384 kernel (operand stream across tile boundaries) gives the same results."""
-    M, N, K = 24576, 1152, 384
-    A, B = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2))
-    bias = rnd(N, seed=3)
-    ref, _ = gemm_nt(A, B, hip.EPI_BF16, torch.bfloat16, bias=bias)
-    hip.load().atst_tune_gemm_variant(309)
-    try:
-        out, _ = gemm_nt(A, B, hip.EPI_BF16, torch.bfloat16, bias=bias)
-        u, a = gemm_nt(A, B, hip.EPI_BIAS_GELU, torch.bfloat16, bias=bias)
-    finally:
-        hip.load().atst_tune_gemm_variant(308)
-    assert torch.equal(out, ref)
-    assert relerr(a.float(), torch.nn.functional.gelu(ref.float())) < 6e-3
-
-
 @pytest.mark.parametrize("M", [640, 8192 + 64])                     # 128-row tiles / 256-row tiles with a ragged last tile
 def test_gemm_nt_epilogues(M):
     N, K, rps = 384, 128, 64
