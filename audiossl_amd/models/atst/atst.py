@@ -79,11 +79,18 @@ class EncoderView(_Node):
         m = (torch.arange(y.shape[1], device=y.device)[None, :] < plen[:, None]).unsqueeze(-1)
         return (y * m).sum(1) / plen[:, None]
 
-    def get_intermediate_layers(self, x, length, n=1):
-        outs, _, _ = self._blocks(x, length, n)
-        if not self.use_cls:
-            outs = [torch.cat([torch.zeros_like(o[:, :1]), o], dim=1) for o in outs]
-        return outs
+    def get_intermediate_layers(self, x, length, n=1, scene=True):
+        """Clip encoder: list of the last n normalised block outputs [S, 1 + T, C] (ref: audio_transformer.py:235-255).
+        Frame encoder: FrameAST.get_intermediate_layers (ref: methods/atstframe/audio_transformer.py:259-281) -- the last n
+        norm_frame'd block outputs concatenated on the feature axis, mean-pooled over the valid frames when ``scene``
+        ([S, n*C]) or as frame sequences ([S, T, n*C]); consumed by atstframe/embedding.py:75,121."""
+        outs, plen, _ = self._blocks(x, length, n)
+        if self.use_cls:
+            return outs
+        if not scene:
+            return torch.cat(outs, dim=-1)
+        lm = (torch.arange(outs[0].shape[1], device=outs[0].device)[None, :] < plen[:, None]).unsqueeze(-1)
+        return torch.cat([(o * lm).sum(1) / (plen[:, None] + 1e-6) for o in outs], dim=-1)
 
     def get_intermediate_layers_chunks(self, x, length, n=1, chunk_len=601, avgpool=True):
         total = x.shape[-1]

@@ -74,7 +74,7 @@ class Trainer:
                 model.global_step += 1
                 model.on_train_batch_end(loss, batch, batch_idx)
                 if self.rank == 0 and model.global_step % self.log_every == 0:
-                    rec = {k: (float(v) if torch.is_tensor(v) else v) for k, v in model.logged.items()}
+                    rec = {k: (float(v.detach()) if torch.is_tensor(v) else v) for k, v in model.logged.items()}
                     rec["it/s"] = model.global_step / (time.time() - t0)
                     self.history.append(rec)
                     print(" ".join(f"{k}={v:.5g}" if isinstance(v, float) else f"{k}={v}" for k, v in rec.items()), flush=True)

@@ -226,6 +226,28 @@ def encoder_forward(W: Weights, pre: str, mel: Tensor, length: Tensor, arch: str
 # ----------------------------------------------------------------------------------------------------------------------
 # a12-a14: head, multi-view wrapper, loss
 # ----------------------------------------------------------------------------------------------------------------------
+def frame_intermediate_layers(W: Weights, pre: str, mel: Tensor, length: Tensor, n: int = 1, scene: bool = True,
+                              arch: str = "small", depth: Optional[int] = None) -> Tensor:
+    """FrameAST.get_intermediate_layers in eval mode (ref: methods/atstframe/audio_transformer.py:259-281): norm_frame of
+    the last n block outputs; scene=True -> masked mean over the valid frames ([S, n*C]), else the frames ([S, T, n*C])."""
+    cfg = ARCH[arch]
+    depth = cfg["depth"] if depth is None else depth
+    x, plen = encoder_tokens(W, pre, mel, length, False, None, False)
+    bias = key_padding_bias(x.shape[1], plen)
+    C = x.shape[-1]
+    outs = []
+    for i in range(depth):
+        x = block_forward(W, f"{pre}blocks.{i}.", x, bias, cfg["num_heads"], None, None, 0.0)
+        if depth - i <= n:
+            y = F.layer_norm(x, (C,), W[pre + "norm_frame.weight"], W[pre + "norm_frame.bias"], LN_EPS)
+            if scene:
+                lm = (torch.arange(x.shape[1])[None, :] < plen[:, None]).unsqueeze(-1)
+                outs.append((y * lm).sum(1) / (plen.unsqueeze(-1) + 1e-6))
+            else:
+                outs.append(y)
+    return torch.cat(outs, dim=-1)
+
+
 def mlp_head(W: Weights, pre: str, x: Tensor, update_running: bool = True) -> Tensor:
     """Linear(no bias) -> BatchNorm1d(train mode, batch statistics) -> ReLU -> Linear(no bias).
     Updates running_mean / running_var / num_batches_tracked in W in place like nn.BatchNorm1d does.

@@ -256,6 +256,27 @@ def gen_infer(name="clip_inference_api"):
          layer_last=layers[-1].numpy()[:, ::10, ::4], layer_prev=layers[0].numpy()[:, ::10, ::4])
 
 
+def gen_frame_infer(name="frame_inference_api"):
+    """FrameAST.get_intermediate_layers (atstframe/audio_transformer.py:259-281) as used by atstframe/embedding.py:75,121:
+    scene=True -> masked mean over valid frames of norm_frame(block output), last n blocks concatenated; scene=False -> the
+    frame sequences themselves.  Eval mode (no DropPath)."""
+    import audio_transformer as fat
+    enc = fat.FrameAST_small(pos_type="cut", patch_embed="Linear")
+    W = O.recipe_weights("small", frame=True, seed=61)
+    enc.load_state_dict({k[len("teacher.encoder."):]: v for k, v in W.items() if k.startswith("teacher.encoder.")})
+    enc.eval()
+    x = O.recipe_mel(3, 1001, seed=63)
+    length = torch.tensor([1001, 640, 88])
+    xs = O.recipe_mel(2, 401, seed=65)
+    ls = torch.tensor([401, 401])
+    with torch.no_grad():
+        scene = enc.get_intermediate_layers(x, length, n=3, scene=True)
+        frames = enc.get_intermediate_layers(x, length, n=2, scene=False)
+        scene_short = enc.get_intermediate_layers(xs, ls, n=12, scene=True)
+    save(name, length=length.numpy(), scene=scene.numpy(), frames=frames.numpy()[:, ::5, ::4], frames_shape=np.array(frames.shape),
+         scene_short=scene_short.numpy())
+
+
 def gen_sched(name="schedules"):
     lr = ref_common.cosine_scheduler_step(5e-4 * 4 * 384 / 256, 1e-6, 39100, 1300)
     wd = ref_common.cosine_scheduler_step(0.04, 0.4, 39100, 0)
@@ -311,9 +332,11 @@ def gen_aug(name="aug_byol_a"):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["blocks", "clip2", "clip2_nodrop", "clip6", "frame", "sched", "encgrad", "clip2_b16", "clip2_b64", "infer", "aug"]
+    which = sys.argv[1:] or ["blocks", "clip2", "clip2_nodrop", "clip6", "frame", "sched", "encgrad", "clip2_b16", "clip2_b64", "infer", "aug", "frame_infer"]
     if "aug" in which:
         gen_aug()
+    if "frame_infer" in which:
+        gen_frame_infer()
     if "blocks" in which:
         gen_blocks()
     if "clip2" in which:

@@ -127,6 +127,41 @@ def test_frame_module_step():
     assert torch.isfinite(loss)
 
 
+def test_frame_inference_api_vs_reference_golden(tmp_path):
+    """FrameAST.get_intermediate_layers semantics (scene / frame outputs) against the reference golden, then the
+    embedding helpers of atstframe/embedding.py on a saved checkpoint."""
+    from audiossl_amd.models.atst import FrameATST
+    G = np.load(os.path.join(GOLD, "frame_inference_api.npz"))
+    model = FrameATST("small")
+    model.load_state_dict(O.recipe_weights("small", frame=True, seed=61))
+    enc = model.teacher.encoder
+    x, length = O.recipe_mel(3, 1001, seed=63), torch.from_numpy(G["length"])
+    scene = enc.get_intermediate_layers(x, length, n=3, scene=True)
+    assert scene.shape == (3, 3 * 384) and rel(scene.cpu().numpy(), G["scene"]) < 1.5e-2
+    frames = enc.get_intermediate_layers(x, length, n=2, scene=False)
+    assert tuple(frames.shape) == tuple(G["frames_shape"])
+    assert rel(frames.cpu().numpy()[:, ::5, ::4], G["frames"]) < 1.5e-2
+    short = enc.get_intermediate_layers(O.recipe_mel(2, 401, seed=65), torch.tensor([401, 401]), n=12)
+    assert rel(short.cpu().numpy(), G["scene_short"]) < 1.5e-2
+    # embedding helpers: 13 s of audio -> two chunks (1001 + 300 frames)
+    from audiossl_amd.methods.atstframe import embedding as E
+    from audiossl_amd.methods.atstframe.model import FrameATSTLightningModule
+    from audiossl_amd.trainer import save_checkpoint
+    module = FrameATSTLightningModule(arch="small", max_steps=10, warmup_steps=2)
+    module.model.load_state_dict(O.recipe_weights("small", frame=True, seed=61))
+    path = str(tmp_path / "frame.ckpt")
+    save_checkpoint(path, module)
+    enc2 = E.load_model(path)
+    wave = O.recipe_wave(2, 13 * 16000, seed=7).cuda()
+    emb = E.get_scene_embedding(wave, enc2)
+    assert emb.shape == (2, 12 * 384) and torch.isfinite(emb).all()
+    ts_emb, ts = E.get_timestamp_embedding(wave, enc2)
+    assert ts_emb.shape == (2, 250 + 75, 12 * 384) and ts.shape == (2, 325) and float(ts[0, 1]) == 40.0
+    mel = enc2.transform(wave[:, :160000 + 160])                   # first chunk alone == first 250 frames of the stream
+    first = enc2.get_intermediate_layers(enc2.transform(wave)[..., :1001], torch.tensor([1001, 1001]), n=12, scene=False)
+    assert rel(ts_emb[:, :250].cpu().numpy(), first.cpu().numpy()) < 1e-6 and mel.shape[-1] == 1002
+
+
 def test_batched_augmentations():
     """HIP augmentation kernels, through the host classes with the reference's draws injected, against goldens of
     audiossl/transforms/byol_a.py (tests/golden/make_golden.py gen_aug); then the classes' own sampling."""

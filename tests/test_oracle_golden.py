@@ -169,3 +169,17 @@ def test_augmentations_vs_reference_golden():
         z = O.recipe_mel(1, int(Wz), seed=300 + k)[0]; x = O.recipe_mel(1, int(Wx), seed=310 + k)[0]
         y = O.log_mixup_exp(x, z, float(G[f"mix_alpha{k}"]), int(start))
         assert np.abs(y[0, ::2, ::3].numpy() - G[f"mix_out{k}"]).max() < 1e-5
+
+
+def test_frame_inference_api_vs_reference_golden():
+    """FrameAST.get_intermediate_layers (scene / timestamp embeddings of atstframe/embedding.py) restated by the oracle."""
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "frame_inference_api.npz"))
+    W = O.recipe_weights("small", frame=True, seed=61)
+    x, length = O.recipe_mel(3, 1001, seed=63), torch.from_numpy(G["length"])
+    scene = O.frame_intermediate_layers(W, "teacher.encoder.", x, length, n=3, scene=True)
+    frames = O.frame_intermediate_layers(W, "teacher.encoder.", x, length, n=2, scene=False)
+    assert tuple(frames.shape) == tuple(G["frames_shape"])
+    assert np.abs(scene.numpy() - G["scene"]).max() < 2e-5
+    assert np.abs(frames.numpy()[:, ::5, ::4] - G["frames"]).max() < 5e-5
+    short = O.frame_intermediate_layers(W, "teacher.encoder.", O.recipe_mel(2, 401, seed=65), torch.tensor([401, 401]), n=12)
+    assert np.abs(short.numpy() - G["scene_short"]).max() < 2e-5
