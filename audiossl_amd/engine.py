@@ -546,6 +546,8 @@ class AtstEngine:
     def optimizer_step(self, lr: float, wd: float, ema_m: Optional[float], betas=(0.9, 0.999), eps: float = 1e-6):
         """HF-AdamW over the two parameter groups + EMA teacher + bf16 shadow refresh in one pass.
         ref: transformers AdamW via methods/atst/model.py:44-48 ; atst.py:29-34."""
+        if getattr(self, "_async_reduce", False):              # bucketed reduction still in flight: join it first
+            self.allreduce_grads()
         self.opt_step += 1
         t = self.opt_step
         step_size = lr * math.sqrt(1.0 - betas[1] ** t) / (1.0 - betas[0] ** t)
