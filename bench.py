@@ -91,8 +91,8 @@ def cpu_baseline(seconds_budget=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="clip6", choices=["clip6", "clip2", "frame"])
     ap.add_argument("--batch", type=int, default=256, help="clips per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
