@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="clip6", choices=["clip6", "clip2", "frame"])
     ap.add_argument("--batch", type=int, default=256, help="clips per GPU per step")
+    ap.add_argument("--arch", default="small", choices=["small", "base"],
+                    help="small = the headline model (BASELINE configs[1..3]); base (d = 768, 12 heads) is an extra data point")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--profile-stride", type=int, default=7,
@@ -123,7 +125,7 @@ def main():
 
     B, frame = args.batch, args.workload == "frame"
     ncrops = 6 if args.workload == "clip6" else 2
-    eng = AtstEngine("small", frame=frame, ncrops=ncrops)
+    eng = AtstEngine(args.arch, frame=frame, ncrops=ncrops)
     eng.init_weights(seed=0)
     eng.overlap_teacher = args.overlap
     fe = LogMelFrontend(1024 if not frame else 640)
@@ -216,7 +218,7 @@ def main():
             # HBM bytes per launch from the committed PMC passes of this same command (rocprofv3 cannot collect
             # counters while the step is being timed); tools/round_measure.sh regenerates the file.
             tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"traffic_{args.workload}.json")
-            if os.path.exists(tf) and args.batch == 256:
+            if os.path.exists(tf) and args.batch == 256 and args.arch == "small":
                 t = json.load(open(tf))["kernels"].get(d["kernel"])
                 if t:
                     roof["traffic"] = t["traffic_bytes_per_launch"]
@@ -225,13 +227,13 @@ def main():
     if rank == 0:
         clips = B * world * args.steps
         value = clips / dt
-        fpc = flops_per_clip(args.workload)
-        out = {"metric": "pretrain clips/sec (10s@16kHz, ATST-small)", "value": round(value, 2), "unit": "clips/s",
+        fpc = flops_per_clip(args.workload, d=768 if args.arch == "base" else 384)
+        out = {"metric": "pretrain clips/sec (10s@16kHz, ATST-small)" if args.arch == "small" else "pretrain clips/sec (10s@16kHz, ATST-base)", "value": round(value, 2), "unit": "clips/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": {"clip6": "ATST-small clip-level, 2 global (10 s) + 4 local (1 s) views",
                                        "clip2": "ATST-small clip-level, 2 views (10 s)",
-                                       "frame": "ATST-Frame small, masked frame objective (10 s)"}[args.workload] +
+                                       "frame": "ATST-Frame small, masked frame objective (10 s)"}[args.workload].replace("small", args.arch) +
                           ", synthetic AudioSet-shaped 10s@16kHz waveforms, mel front end inside the timed step",
                           "clips_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
                           "optimizer": "HF-AdamW + EMA teacher (fused)", "drop_path": 0.1},
