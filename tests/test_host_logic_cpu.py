@@ -75,3 +75,21 @@ def test_mask_samplers_match_oracle_restatement():
     assert m.shape == (4, 250) and m.dtype == torch.bool and int(m[0].sum()) == 163
     one = RM.get_mask_one(250, 200, 0.5)
     assert one.shape == (250,) and bool(one[200:].all()) and int(one[:200].sum()) == 100
+
+
+def test_random_resize_crop_parameter_sampling():
+    """The draws of BatchRandomResizeCrop follow get_params (transforms/byol_a.py:24-31): h, w from the scale ranges clipped
+    to the canvas, (i, j) uniform over the positions that keep the crop inside the canvas."""
+    import numpy as np
+    from audiossl_amd.transforms import BatchRandomResizeCrop
+    rrc = BatchRandomResizeCrop((1.0, 1.5), (0.6, 1.5), (0.6, 1.5), rng=np.random.RandomState(3))
+    H, W = 64, 401
+    CH, CW = rrc.canvas(H, W)
+    assert (CH, CW) == (64, 601)
+    P = rrc.sample_params(4000, H, W)
+    i, j, h, w = P[:, 0], P[:, 1], P[:, 2], P[:, 3]
+    assert h.min() >= int(0.6 * H) and h.max() == CH                       # freq scale up to 1.5 is clipped to the 64-row canvas
+    assert w.min() >= int(0.6 * W) and w.max() <= CW and w.max() > W
+    assert (i >= 0).all() and (i + h <= CH).all() and (j >= 0).all() and (j + w <= CW).all()
+    assert (i[h == CH] == 0).all()
+    assert abs(float((h == CH).mean()) - (1.5 - 1.0) / (1.5 - 0.6)) < 0.03      # P(U(0.6,1.5) * 64 >= 64)
