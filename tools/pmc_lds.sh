@@ -11,9 +11,9 @@ for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
         n = re.sub(r"\(anonymous namespace\)::|void ", "", r["Kernel_Name"]); n = re.sub(r"\(.*", "", n)[:48]
         agg[n][r["Counter_Name"]] += float(r["Counter_Value"])
 rows = sorted(agg.items(), key=lambda kv: -kv[1]["SQ_WAVE_CYCLES"])[:14]
-print(f"{'kernel':48s} {'conflict/LDSactive':>18s} {'wait/wave':>10s} {'valu/wave':>10s} {'mfma busy (per SIMD-cycle est)':>12s}")
+print(f"{'kernel':48s} {'conflict/LDSactive':>18s} {'wait/wave':>10s} {'valu/wave':>10s} {'mfma-busy/wave-cycle':>20s}")
 for n, v in rows:
     wc = v["SQ_WAVE_CYCLES"] or 1
-    print(f"{n:48s} {v['SQ_LDS_BANK_CONFLICT'] / max(v['SQ_LDS_IDX_ACTIVE'], 1):18.3f} {v['SQ_WAIT_INST_ANY'] / wc:10.3f} {v['SQ_ACTIVE_INST_VALU'] / wc:10.3f} {v['SQ_VALU_MFMA_BUSY_CYCLES'] / (4 * wc):12.3f}")
+    print(f"{n:48s} {v['SQ_LDS_BANK_CONFLICT'] / max(v['SQ_LDS_IDX_ACTIVE'], 1):18.3f} {v['SQ_WAIT_INST_ANY'] / wc:10.3f} {v['SQ_ACTIVE_INST_VALU'] / wc:10.3f} {v['SQ_VALU_MFMA_BUSY_CYCLES'] / (4 * wc):20.3f}")
 PY
 rm -rf $out
