@@ -88,6 +88,30 @@ def cpu_baseline(seconds_budget=25.0):
             "one_thread_value": round(out["one"][0], 3), "one_thread_note": "reference as shipped pins OMP/MKL to 1 thread"}
 
 
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` outside a launcher: start N ranks (one per GPU) as fresh child processes through
+    torch.distributed.run and relay rank 0's JSON line.  This parent has made no HIP / torch.cuda call, and it never
+    exec()s: the children are ordinary subprocesses (ref: Trainer(devices=nproc, strategy="ddp"), methods/atst/train.py:18-32)."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    for l in p.stdout.splitlines():
+        if not l.startswith("{"):
+            print(l, file=sys.stderr)
+    if p.returncode != 0 or not lines:
+        print(f"bench.py: the {n}-rank launch failed (exit code {p.returncode})", file=sys.stderr)
+        return p.returncode or 1
+    print(lines[-1], flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -102,16 +126,31 @@ def main():
     ap.add_argument("--profile-stride", type=int, default=7,
                     help="HIP events around every n-th launch of each kernel kind (1 = all: costs ~6 %% of the step)")
     ap.add_argument("--overlap", action="store_true", help="run the teacher pass on a second HIP stream")
+    ap.add_argument("--backend", default=os.environ.get("ATST_DIST_BACKEND", "nccl"), choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (one rank per GPU); gloo = test transport, lets several ranks share one GPU")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))                           # parent: never touches the GPU, relays rank 0's line
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
+        sys.exit(2)
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and world > ndev:
+        print(f"bench.py: {world} ranks need {world} GPUs, this node has {ndev}", file=sys.stderr)
+        sys.exit(2)
+    local = local % max(ndev, 1)                                     # gloo test transport: ranks may share a device
     torch.cuda.set_device(local)
     if world > 1 or os.environ.get("ATST_FORCE_COLLECTIVES") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda", local)
     torch.manual_seed(4321 + rank)                                   # DropPath draws (device generator): reproducible runs
 
@@ -164,7 +203,7 @@ def main():
 
     def sync():
         if dist.is_initialized():
-            dist.barrier(device_ids=[local])
+            dist.barrier(device_ids=[local]) if args.backend == "nccl" else dist.barrier()
         torch.cuda.synchronize()
 
     for k in range(args.warmup):
