@@ -58,6 +58,10 @@ int atst_layernorm_fwd(const float* x, const float* gamma, const float* beta, ui
   return atst_ln_fwd(x, gamma, beta, BF(y), mean, rstd, M, C, ST(stream));
 }
 
+int atst_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, int M, int C, void* stream) {
+  return atst_ln_fwd_f32(x, gamma, beta, y, M, C, ST(stream));
+}
+
 int atst_layernorm_bwd(const uint16_t* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                        const float* dres, float* dx, uint16_t* g, const float* row_scale, int rows_per_seq,
                        float* dgamma, float* dbeta, float* dbias_up, int M, int C, void* stream) {

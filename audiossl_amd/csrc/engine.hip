@@ -155,6 +155,11 @@ extern "C" int atst_encoder_fwd(const atst_encoder_t* e, void* stream) {
     } else {
       RUN(gemm(l.a, q + lo.fc2_w, M, C, 4 * C, EPI_RESID, w.x[2 * i + 2], st, p + lo.fc2_b, w.x[2 * i + 1], s2, NP));
     }
+    if (e->tap && i >= e->tap_first) {
+      hipError_t rc = hipMemcpyAsync(e->tap + (size_t)(i - e->tap_first) * M * C, w.x[2 * i + 2], (size_t)M * C * sizeof(float),
+                                     hipMemcpyDeviceToDevice, st);
+      if (rc != hipSuccess) return (int)rc;
+    }
   }
   if (!fuse_ln) RUN(atst_ln_fwd(w.x[2 * e->depth], p + o.norm_w, p + o.norm_b, w.hN, w.meanN, w.rstdN, M, C, st));
   return ATST_OK;
@@ -174,6 +179,11 @@ extern "C" int atst_encoder_bwd(const atst_encoder_t* e, void* stream) {
 extern "C" int atst_encoder_bwd_part(const atst_encoder_t* e, int part, int split, void* stream) {
   if (!check(e) || split < 0 || split > e->depth || (part != 0 && part != 1)) return ATST_EINVAL;
   return part == 0 ? encoder_bwd_range(e, split, e->depth, true, false, stream) : encoder_bwd_range(e, 0, split, false, true, stream);
+}
+
+extern "C" int atst_encoder_bwd_range(const atst_encoder_t* e, int lo, int hi, void* stream) {
+  if (!check(e) || lo < 0 || hi > e->depth || lo >= hi) return ATST_EINVAL;
+  return encoder_bwd_range(e, lo, hi, hi == e->depth, lo == 0, stream);
 }
 
 static int encoder_bwd_range(const atst_encoder_t* e, int lo, int hi, bool head, bool tail, void* stream) {

@@ -37,6 +37,7 @@ int atst_gemm_tn_group(const WgradArgs* items, int n, hipStream_t st);   // inde
 
 // LayerNorm (eps 1e-6), C in {384, 768}
 int atst_ln_fwd(const float* x, const float* gamma, const float* beta, bf16* y, float* mean, float* rstd, int M, int C, hipStream_t st);
+int atst_ln_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, int M, int C, hipStream_t st);   // fp32 output, no statistics (inference taps)
 struct LnBwdArgs {
   const bf16* dy;                    // [M,C] gradient wrt the LN output
   const float* x; const float* mean; const float* rstd; const float* gamma;

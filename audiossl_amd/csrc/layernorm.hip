@@ -9,9 +9,9 @@
 namespace {
 constexpr float LN_EPS = 1e-6f;
 
-template <int VPT>   // values per lane = C / 64
+template <int VPT, typename OUT = bf16>   // values per lane = C / 64 ; OUT = bf16 (GEMM operand) or float (inference taps)
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, bf16* __restrict__ y,
+                                                     const float* __restrict__ beta, OUT* __restrict__ y,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out, int M) {
   constexpr int C = VPT * 64;
   const int lane = threadIdx.x & 63;
@@ -38,15 +38,18 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 #pragma unroll
     for (int i = 0; i < VPT; ++i) { const float d = v[i] - mu; q += d * d; }
     const float rs = rsqrtf(wave_sum(q) * (1.0f / C) + LN_EPS);
-    bf16* yr = y + (size_t)row * C;
+    OUT* yr = y + (size_t)row * C;
 #pragma unroll
     for (int i = 0; i < VPT / 2; ++i) {
-      bf16x2 o;
-      o[0] = f2bf((v[2 * i] - mu) * rs * gm[2 * i] + bt[2 * i]);
-      o[1] = f2bf((v[2 * i + 1] - mu) * rs * gm[2 * i + 1] + bt[2 * i + 1]);
-      *reinterpret_cast<bf16x2*>(yr + i * 128 + lane * 2) = o;
+      const float o0 = (v[2 * i] - mu) * rs * gm[2 * i] + bt[2 * i], o1 = (v[2 * i + 1] - mu) * rs * gm[2 * i + 1] + bt[2 * i + 1];
+      if constexpr (sizeof(OUT) == 2) {
+        bf16x2 o; o[0] = f2bf(o0); o[1] = f2bf(o1);
+        *reinterpret_cast<bf16x2*>(yr + i * 128 + lane * 2) = o;
+      } else {
+        *reinterpret_cast<f32x2*>(yr + i * 128 + lane * 2) = f32x2{o0, o1};
+      }
     }
-    if (lane == 0) { mean_out[row] = mu; rstd_out[row] = rs; }
+    if (lane == 0 && mean_out) { mean_out[row] = mu; rstd_out[row] = rs; }
   }
 }
 
@@ -122,6 +125,15 @@ int atst_ln_fwd(const float* x, const float* gamma, const float* beta, bf16* y, 
   ProfScope ps(PK_LN_FWD, (double)M * C * 6.0, st);                  // read fp32, write bf16
   if (C == 384) hipLaunchKernelGGL(ln_fwd_kernel<6>, dim3(ln_grid(M)), dim3(256), 0, st, x, gamma, beta, y, mean, rstd, M);
   else if (C == 768) hipLaunchKernelGGL(ln_fwd_kernel<12>, dim3(ln_grid(M)), dim3(256), 0, st, x, gamma, beta, y, mean, rstd, M);
+  else return ATST_EINVAL;
+  return (int)hipGetLastError();
+}
+
+int atst_ln_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, int M, int C, hipStream_t st) {
+  if (M <= 0) return ATST_OK;
+  ProfScope ps(PK_LN_FWD, (double)M * C * 8.0, st);
+  if (C == 384) hipLaunchKernelGGL((ln_fwd_kernel<6, float>), dim3(ln_grid(M)), dim3(256), 0, st, x, gamma, beta, y, (float*)nullptr, (float*)nullptr, M);
+  else if (C == 768) hipLaunchKernelGGL((ln_fwd_kernel<12, float>), dim3(ln_grid(M)), dim3(256), 0, st, x, gamma, beta, y, (float*)nullptr, (float*)nullptr, M);
   else return ATST_EINVAL;
   return (int)hipGetLastError();
 }

@@ -87,6 +87,40 @@ class Workspace:
         return self.buf[off:off + n].view(dtype).view(*shape)
 
 
+class Uploader:
+    """Host -> device copies of the small per-step index / length / mask tensors WITHOUT a stream synchronisation.
+    torch's blocking copy from pageable memory ends in hipStreamSynchronize (drains the launch queue once per call);
+    here the bytes are staged in a ring of pinned slots and copied with non_blocking=True.  A slot is re-used only after
+    the event recorded behind its last copy has completed (host-side wait on that event only, never a stream drain)."""
+
+    def __init__(self, device, slot_bytes: int = 1 << 20, slots: int = 32):
+        self.device, self.slot_bytes, self.slots = device, slot_bytes, slots
+        self.buf = torch.empty(slots, slot_bytes, dtype=torch.uint8).pin_memory()
+        self.events: List[Optional[torch.cuda.Event]] = [None] * slots
+        self.k = 0
+
+    def __call__(self, t: torch.Tensor) -> torch.Tensor:
+        t = t.contiguous()
+        if t.is_cuda:
+            return t
+        n = t.numel() * t.element_size()
+        if n == 0:
+            return torch.empty(t.shape, dtype=t.dtype, device=self.device)
+        if n > self.slot_bytes:                                     # rare (large mels arrive on the device already)
+            return t.pin_memory().to(self.device, non_blocking=True)
+        i = self.k % self.slots
+        self.k += 1
+        if self.events[i] is not None:
+            self.events[i].synchronize()
+        stage = self.buf[i, :n].view(t.dtype).view(t.shape)
+        stage.copy_(t)
+        d = stage.to(self.device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[i] = ev
+        return d
+
+
 def pad_tokens(n: int) -> int:
     for np_ in (32, 64, 128, 256):
         if n <= np_:
@@ -102,8 +136,8 @@ class EncoderPass:
         cfg = eng.cfg
         self.n_tok = (width - width % 4) // 4
         self.use_cls = 0 if eng.frame else 1
-        if self.n_tok + self.use_cls > eng.n_pos:
-            raise hip.HipError(f"mel width {width} needs {self.n_tok + self.use_cls} positions; pos_embed has {eng.n_pos} "
+        if self.n_tok + 1 > eng.n_pos:                          # the table kernel reads pos row n+1 for patch n in BOTH modes
+            raise hip.HipError(f"mel width {width} needs {self.n_tok + 1} positions; pos_embed has {eng.n_pos} "
                                "(pos_type='cut', ref: audio_transformer.py:95-102)")
         self.NP = pad_tokens(self.n_tok + self.use_cls)
         self.M = S * self.NP
@@ -126,6 +160,7 @@ class EncoderPass:
 
     def forward(self, mel: torch.Tensor, valid: torch.Tensor, rowflag: Optional[torch.Tensor], dp_scale: Optional[torch.Tensor]):
         assert mel.shape == (self.S, 1, 64, self.width) and mel.dtype == torch.float32
+        valid = self.eng.upload(valid)                       # host-side lengths: pinned staging, no stream sync
         self._keep = (mel, valid, rowflag, dp_scale)        # keep inputs alive until backward
         e = self.e
         e.mel, e.valid = hip.ptr(mel), hip.ptr(valid)
@@ -139,6 +174,10 @@ class EncoderPass:
     def backward_part(self, part: int, split: int):
         """part 0: final LayerNorm + blocks [split, depth) ; part 1: blocks [0, split) + token stage."""
         hip.check(hip.load().atst_encoder_bwd_part(C.byref(self.e), part, split, hip.stream()), "atst_encoder_bwd_part")
+
+    def backward_range(self, lo: int, hi: int):
+        """blocks [lo, hi) descending (+ final LayerNorm when hi == depth, + token stage when lo == 0)."""
+        hip.check(hip.load().atst_encoder_bwd_range(C.byref(self.e), lo, hi, hip.stream()), "atst_encoder_bwd_range")
 
     def tokens(self):
         return self.ws.view(hip.load().atst_encoder_tokens(C.byref(self.e)), (self.M, self.e.C), torch.float32)
@@ -184,13 +223,15 @@ class HeadPass:
         scratch = torch.empty(32 * HEAD_HIDDEN, device=dev)                          # row-block partials (fixed-order reduction)
         hip.call("atst_bn_stats_f32", hip.ptr(h), R, HEAD_HIDDEN, hip.ptr(mean), hip.ptr(m2), hip.ptr(scratch), st)
         # SyncBatchNorm: count-weighted combine over ranks (ragged per-rank row counts of ATST-Frame are handled)
+        # count: python float at world size 1, 0-dim device tensor across ranks (ragged per-rank rows: never read back)
         mean, m2, count = parallel.combine_bn_stats(mean, m2, float(R))
         var = m2 / count
         rstd = torch.rsqrt(var + BN_EPS)
         bn = eng.bn_buffers[f"{self.net}.{self.which}"]
         with torch.no_grad():
             bn["running_mean"].mul_(1 - BN_MOMENTUM).add_(mean, alpha=BN_MOMENTUM)
-            bn["running_var"].mul_(1 - BN_MOMENTUM).add_(m2 / max(count - 1.0, 1.0), alpha=BN_MOMENTUM)
+            unb = m2 / torch.clamp(count - 1.0, min=1.0) if isinstance(count, torch.Tensor) else m2 / max(count - 1.0, 1.0)
+            bn["running_var"].mul_(1 - BN_MOMENTUM).add_(unb, alpha=BN_MOMENTUM)
             bn["num_batches_tracked"] += 1
         # second Linear also in split-bf16: its output feeds the next head's BatchNorm+ReLU gates
         y3 = torch.empty(R, 3 * HEAD_HIDDEN, dtype=torch.bfloat16, device=dev)
@@ -222,9 +263,14 @@ class HeadPass:
         self._w("1.bias", grad=True).add_(s1)          # local sums: DDP averages parameter gradients afterwards
         self._w("1.weight", grad=True).add_(s2)
         s1, s2 = parallel.allreduce_bn_backward_sums(s1, s2)
+        inv = 1.0
+        if isinstance(count, torch.Tensor):                 # global row count lives on the device: fold 1/count into the sums
+            s1, s2 = (s1 / count).contiguous(), (s2 / count).contiguous()
+        else:
+            inv = 1.0 / count
         dh16 = torch.empty(R, HEAD_HIDDEN, dtype=torch.bfloat16, device=dev)
         hip.call("atst_bn_bwd_dx_bf16", hip.ptr(dy), hip.ptr(h), hip.ptr(mean), hip.ptr(rstd), hip.ptr(gamma), hip.ptr(beta),
-                 hip.ptr(s1), hip.ptr(s2), 1.0 / count, R, HEAD_HIDDEN, hip.ptr(dh16), st)
+                 hip.ptr(s1), hip.ptr(s2), inv, R, HEAD_HIDDEN, hip.ptr(dh16), st)
         _wgrad(dh16, x16, R, HEAD_HIDDEN, self.in_dim, self._w("0.weight", grad=True), ldx=3 * self.in_dim)
         dx = torch.empty(R, self.in_dim, device=dev)
         _gemm(dh16, self._w("0.weight", transposed=True), R, self.in_dim, HEAD_HIDDEN, hip.EPI_F32, dx)
@@ -279,6 +325,8 @@ class AtstEngine:
                                         num_batches_tracked=torch.zeros((), dtype=torch.int64, device=dev))
         # drop-path rates: torch.linspace(0, rate, depth) evaluated in fp32 like the reference (audio_transformer.py:107)
         self.dpr = [float(v) for v in torch.linspace(0, drop_path_rate, self.depth)]
+        self._dpr_rates = torch.linspace(0, drop_path_rate, self.depth).to(self.device).view(-1, 1, 1)
+        self.upload = Uploader(self.device)
         self.enc_off = self._build_offsets()
         flags = torch.zeros(L.n_student // ALIGN, dtype=torch.uint8)
         for name, (off, shape) in L.entries.items():
@@ -292,6 +340,8 @@ class AtstEngine:
         self.flags_ema_only = (flags & 4).to(dev)
         self.opt_step = 0
         self._passes: Dict[Tuple, EncoderPass] = {}
+        self._cls_rows: Dict[Tuple[int, int], torch.Tensor] = {}
+        self._infer_passes: "OrderedDict[Tuple, EncoderPass]" = OrderedDict()
         self._synced_version = (-1, -1)
         self.heads = {"teacher.projector": HeadPass(self, "teacher", "projector", self.cfg["embed_dim"]),
                       "student.projector": HeadPass(self, "student", "projector", self.cfg["embed_dim"]),
@@ -304,6 +354,7 @@ class AtstEngine:
         self._side = torch.cuda.Stream(device=self.device)
         self._comm = torch.cuda.Stream(device=self.device)     # gradient all-reduce underneath the backward pass
         self.overlap_comm = True
+        self.grad_buckets = 4            # encoder slices of the overlapped all-reduce (+ one bucket for the two heads)
 
     # ---------------------------------------------------------------------------------------------------------------
     def _build_offsets(self) -> hip.EncOff:
@@ -342,6 +393,7 @@ class AtstEngine:
                     if k in W:
                         bufs[b].copy_(W[k].to(self.device))
         self.sync_shadows(force=True)
+        self.broadcast_parameters()
 
     def init_weights(self, seed: int = 0):
         """Random init with the reference's distributions, drawn on the device: encoder Linear weights, cls/pos/mask
@@ -372,6 +424,7 @@ class AtstEngine:
             for b in ("running_mean", "running_var", "num_batches_tracked"):
                 self.bn_buffers["teacher.projector"][b].copy_(self.bn_buffers["student.projector"][b])
         self.sync_shadows(force=True)
+        self.broadcast_parameters()
 
     def sync_shadows(self, force: bool = False):
         """Refresh bf16 shadows (and W^T copies) if the fp32 masters were modified through torch (version counters)."""
@@ -403,19 +456,61 @@ class AtstEngine:
             self._passes[key] = EncoderPass(self, net, S, width, train)
         return self._passes[key]
 
+    def inference_pass(self, net: str, S: int, width: int, keep: int = 4) -> EncoderPass:
+        """Forward-only EncoderPass for the inference API (no activation tape: one layer of buffers re-used by every
+        block, ~1/10 of a training workspace), least-recently-used eviction beyond `keep` geometries."""
+        key = (net, S, width)
+        lru = self._infer_passes
+        if key in lru:
+            lru.move_to_end(key)
+        else:
+            while len(lru) >= keep:
+                lru.popitem(last=False)
+            lru[key] = EncoderPass(self, net, S, width, False)
+        return lru[key]
+
     def drop_path_scales(self, S: int, keep: Optional[torch.Tensor] = None) -> torch.Tensor:
         """[depth,2,S] fp32 factors keep/keep_prob.  keep (0/1, [depth,2,S]) may be injected for parity tests; otherwise
         drawn like the reference: floor(keep_prob + U[0,1)) per sample, per branch (modules/transformer.py:48-56)."""
-        rates = torch.tensor(self.dpr, device=self.device).view(-1, 1, 1)
+        rates = self._dpr_rates
         if keep is None:
             keep = torch.floor((1.0 - rates) + torch.rand(self.depth, 2, S, device=self.device))
         else:
             keep = keep.to(self.device, torch.float32)
         return (keep / (1.0 - rates)).contiguous()
 
-    def _valid(self, lengths: torch.Tensor, use_cls: int) -> torch.Tensor:
-        l = lengths.to(self.device, torch.int64)
-        return (((l - l % 4) // 4) + use_cls).to(torch.int32).contiguous()        # ref: audio_transformer.py:70-71,194
+    def _valid(self, lengths: torch.Tensor, use_cls: int, n_max: int = 1 << 30) -> torch.Tensor:
+        """patch_length + CLS per sequence, clamped to the tokens the pass holds.  ref: audio_transformer.py:70-71,194."""
+        l = torch.as_tensor(lengths).to(torch.int64)
+        v = torch.clamp((l - l % 4) // 4, max=n_max - use_cls) + use_cls
+        return v.to(torch.int32).contiguous()                       # stays where `lengths` lives (host for DataLoader batches)
+
+    def _frame_rows(self, mk: torch.Tensor, valid: torch.Tensor, NP: int, mask_input: bool):
+        """ATST-Frame row bookkeeping for one width group.  mk [S, n_tok] bool, valid [S] (frames per sequence).
+        Returns (rows int32 [R] device: flat token indices s*NP+n of masked valid frames in (b, n) order,
+                 rowflag uint8 [S*NP] device or None).  With host-side masks (what the DataLoader delivers: the transform
+        draws them with numpy, methods/atstframe/transform.py:84-101) everything is computed on the host and uploaded
+        through pinned memory -- no device->host read-back, the row count R is known without touching the GPU."""
+        S, n_tok = mk.shape
+        if not mk.is_cuda and not valid.is_cuda:
+            sel = mk & (torch.arange(n_tok)[None, :] < valid[:, None])
+            idx = sel.reshape(-1).nonzero(as_tuple=True)[0]
+            rows = ((idx // n_tok) * NP + idx % n_tok).to(torch.int32)
+            rowflag = None
+            if mask_input:
+                rf = torch.zeros(S, NP, dtype=torch.uint8)
+                rf[:, :n_tok] = mk
+                rowflag = self.upload(rf.reshape(-1))
+            return self.upload(rows), rowflag
+        mk, valid = mk.to(self.device), valid.to(self.device)       # device-side masks: one read-back for the row count
+        rowflag = None
+        if mask_input:
+            rowflag = torch.zeros(S, NP, dtype=torch.uint8, device=self.device)
+            rowflag[:, :n_tok] = mk
+            rowflag = rowflag.reshape(-1).contiguous()
+        sel = mk & (torch.arange(n_tok, device=self.device)[None, :] < valid[:, None])
+        s_idx, n_idx = sel.nonzero(as_tuple=True)                                         # row-major (b, n) order
+        return (s_idx * NP + n_idx).to(torch.int32).contiguous(), rowflag
 
     def _run_net(self, net: str, mels, lengths, masks, mask_input: bool, keep, train: bool):
         """MultiCropWrapper.forward: encoder per width-group -> rows for the head (view-major).
@@ -423,22 +518,20 @@ class AtstEngine:
         feats, groups = [], []
         use_cls = 0 if self.frame else 1
         for gi, (a, b) in enumerate(group_views([m.shape[-1] for m in mels])):
-            mel = torch.cat([m.to(self.device, torch.float32) for m in mels[a:b]]).contiguous()
+            mel = torch.cat([m.to(self.device, torch.float32) for m in mels[a:b]]).contiguous() if b - a > 1 else \
+                mels[a].to(self.device, torch.float32).contiguous()
             S, width = mel.shape[0], mel.shape[-1]
             ep = self._pass(net, S, width, train, gi)
-            valid = self._valid(torch.cat([torch.as_tensor(l) for l in lengths[a:b]]), use_cls)
+            valid = self._valid(torch.cat([torch.as_tensor(l).reshape(-1) for l in lengths[a:b]]), use_cls, ep.n_tok + use_cls)
             rowflag = None
             if self.frame:
-                mk = torch.cat([torch.as_tensor(m) for m in masks[a:b]]).to(self.device).bool()      # [S, n_tok]
-                if mask_input:
-                    rowflag = torch.zeros(S, ep.NP, dtype=torch.uint8, device=self.device)
-                    rowflag[:, :mk.shape[1]] = mk
-                    rowflag = rowflag.reshape(-1).contiguous()
-                sel = mk & (torch.arange(mk.shape[1], device=self.device)[None, :] < valid[:, None])
-                s_idx, n_idx = sel.nonzero(as_tuple=True)                                     # row-major (b, n) order
-                rows = (s_idx * ep.NP + n_idx).to(torch.int32).contiguous()
+                mk = torch.cat([torch.as_tensor(m) for m in masks[a:b]]).bool()               # [S, n_tok]
+                rows, rowflag = self._frame_rows(mk, valid, ep.NP, mask_input)
             else:
-                rows = (torch.arange(S, device=self.device, dtype=torch.int32) * ep.NP).contiguous()
+                key = (S, ep.NP)
+                if key not in self._cls_rows:
+                    self._cls_rows[key] = (torch.arange(S, device=self.device, dtype=torch.int32) * ep.NP).contiguous()
+                rows = self._cls_rows[key]
             dp = self.drop_path_scales(S, None if keep is None else keep[gi]) if self.dpr[-1] > 0 or keep is not None else None
             out16 = ep.forward(mel, valid, rowflag, dp)
             f = torch.empty(rows.numel(), self.cfg["embed_dim"], device=self.device)
@@ -502,12 +595,18 @@ class AtstEngine:
         for ep, rows in groups:
             offs.append(r0)
             r0 += rows.numel()
-        # Smallest view group first: the largest one (the 10 s views) goes last so that, across ranks, the all-reduce of
-        # the upper half of the parameters (blocks depth/2.., final norm, heads -- complete once the last group's
-        # backward has passed block depth/2) runs on a second stream underneath the lower blocks' backward.
+        # Bucketed gradient all-reduce underneath the backward (DDP reducer semantics, methods/atst/train.py:19):
+        #   bucket 0 = projector + predictor (final right here, before any encoder backward -- its reduction hides under
+        #   the whole encoder backward); the view groups are then differentiated smallest first, and while the LAST
+        #   (largest: the 10 s views) group walks down the blocks, the encoder is reduced in `grad_buckets` slices of
+        #   blocks in reverse layer order, each as soon as that group has passed it (all other groups already have).
         order = sorted(range(len(groups)), key=lambda i: groups[i][0].M)
         self._async_reduce = False
-        overlap = self.overlap_comm and parallel._collective() and self.depth >= 2 and zero_grad
+        overlap = self.overlap_comm and parallel._collective() and zero_grad
+        L = self.layout
+        if overlap:
+            self._reduce_async(L.entries["projector.0.weight"][0], L.n_student)
+            self._async_reduce = True
         for k, gi in enumerate(order):
             ep, rows = groups[gi]
             n = rows.numel()
@@ -516,13 +615,17 @@ class AtstEngine:
             hip.call("atst_scatter_rows_bf16", hip.ptr(src), hip.ptr(rows), n, self.cfg["embed_dim"],
                      hip.ptr(ep.dout), hip.stream())
             if overlap and k == len(order) - 1:
-                split = self.depth // 2
-                cut = self.layout.entries[f"encoder.blocks.{split}.norm1.weight"][0]
-                ep.backward_part(0, split)
-                self._reduce_async(cut, self.layout.n_student)
-                ep.backward_part(1, split)
-                self._reduce_async(0, cut)
-                self._async_reduce = True
+                nb = max(1, min(self.grad_buckets, self.depth))
+                cuts = [round(self.depth * j / nb) for j in range(nb, -1, -1)]          # depth ... 0
+                top = L.entries["projector.0.weight"][0]
+                for hi, lo in zip(cuts[:-1], cuts[1:]):
+                    if hi == lo:
+                        continue
+                    ep.backward_range(lo, hi)
+                    a = 0 if lo == 0 else L.entries[f"encoder.blocks.{lo}.norm1.weight"][0]
+                    # LN1 backward of block lo adds the fc2 bias gradient of block lo-1 (below the cut: reduced later)
+                    self._reduce_async(a, top)
+                    top = a
             else:
                 ep.backward()
 
@@ -532,6 +635,19 @@ class AtstEngine:
         self._comm.wait_stream(main)
         with torch.cuda.stream(self._comm):
             parallel.allreduce_sum_(self.g32[a:b])
+
+    def broadcast_parameters(self, optimizer_state: bool = False):
+        """DDP init: every rank takes rank 0's parameters / BN buffers (and optimizer moments after a resume), so the
+        replicas start identical whatever their seeds or checkpoints were.  ref: DDP wrapper of Trainer(strategy="ddp"),
+        methods/atst/train.py:18-32.  No-op without a process group."""
+        if not parallel._collective():
+            return
+        bufs = [self.p32, self.t32] + [t for b in self.bn_buffers.values() for t in b.values()]
+        if optimizer_state:
+            bufs += [self.m32, self.v32]
+        for t in bufs:
+            dist.broadcast(t, 0)
+        self.sync_shadows(force=True)
 
     def allreduce_grads(self):
         """DDP: sum student gradients over ranks (RCCL over xGMI); the 1/world mean is folded into the optimizer kernel.

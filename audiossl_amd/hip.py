@@ -41,7 +41,7 @@ class Encoder(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("S", "NP", "n_tok", "width", "C", "H", "depth", "use_cls", "train")] + \
                [("p32", C.c_void_p), ("p16", C.c_void_p), ("p16t", C.c_void_p), ("g32", C.c_void_p), ("off", EncOff),
                 ("mel", C.c_void_p), ("valid", C.c_void_p), ("rowflag", C.c_void_p), ("dp_scale", C.c_void_p),
-                ("ws", C.c_void_p), ("ws_bytes", C.c_size_t)]
+                ("ws", C.c_void_p), ("ws_bytes", C.c_size_t), ("tap", C.c_void_p), ("tap_first", C.c_int)]
 
 
 _SIGS = {
@@ -56,6 +56,7 @@ _SIGS = {
                                     C.c_int, C.c_void_p]),
     "atst_gemm_tn_group_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "atst_layernorm_fwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p]),
+    "atst_layernorm_fwd_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p]),
     "atst_layernorm_bwd": (C.c_int, [C.c_void_p] * 9 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_void_p]),
     "atst_attention_fwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]),
     "atst_attention_bwd": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 3 + [C.c_void_p]),
@@ -81,6 +82,7 @@ _SIGS = {
     "atst_encoder_fwd": (C.c_int, [C.POINTER(Encoder), C.c_void_p]),
     "atst_encoder_bwd": (C.c_int, [C.POINTER(Encoder), C.c_void_p]),
     "atst_encoder_bwd_part": (C.c_int, [C.POINTER(Encoder), C.c_int, C.c_int, C.c_void_p]),
+    "atst_encoder_bwd_range": (C.c_int, [C.POINTER(Encoder), C.c_int, C.c_int, C.c_void_p]),
     "atst_encoder_out": (C.c_void_p, [C.POINTER(Encoder)]),
     "atst_encoder_dout": (C.c_void_p, [C.POINTER(Encoder)]),
     "atst_encoder_block_out": (C.c_void_p, [C.POINTER(Encoder), C.c_int]),

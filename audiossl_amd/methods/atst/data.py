@@ -1,6 +1,7 @@
 """``ATSTDataModule`` with the reference's constructor / argparse surface (audiossl/methods/atst/data.py:6-42).
-The LMDB store (audiossl/datasets/lmdb.py) is out of scope; any map-style dataset returning ``(waveform[1,N], label)``
-can be passed as ``dataset=``; without one a synthetic AudioSet-shaped dataset is used (N(0, 0.1^2) noise, 10 s)."""
+``data_path`` opens the reference's LMDB store through audiossl_amd.datasets.LMDBDataset (needs `lmdb` + legacy pyarrow,
+see that module); any map-style dataset returning ``(waveform[1,N], label)`` can be passed as ``dataset=``; without
+either a synthetic AudioSet-shaped dataset is used (N(0, 0.1^2) noise, 10 s)."""
 from __future__ import annotations
 
 import torch
@@ -27,6 +28,9 @@ class ATSTDataModule:
     def __init__(self, data_path=None, batch_size_per_gpu=256, num_workers=10, subset=200000, train_len=6.0, dataset=None,
                  **kwargs):
         self.transform = ATSTTrainTransform(anchor_len=(train_len, train_len), positive_len=(train_len, train_len))
+        if dataset is None and data_path is not None:        # ref: data.py:18-23 (LMDBDataset(data_path, split="train", subset=...))
+            from ...datasets import LMDBDataset
+            dataset = LMDBDataset(data_path, split="train", subset=subset, transform=self.transform)
         if dataset is None:
             dataset = SyntheticWaveDataset(min(subset, 4096), seconds=max(train_len, 10.0), transform=self.transform)
         self.dataset = dataset

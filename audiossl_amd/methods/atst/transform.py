@@ -31,18 +31,36 @@ class ATSTBatchViews:
               (lambda: BatchRandomResizeCrop((1, virtual_crop)))
         self.rrc = [rrc() if resize_crop else None for _ in range(2)]
 
+    def _view(self, k, w, n):
+        m = self.mel_feature(w[..., :n] if n > 0 else w)
+        if self.mixup[k] is not None:
+            m = self.mixup[k](m)
+        if self.rrc[k] is not None:
+            m = self.rrc[k](m)
+        return m
+
     def __call__(self, waves, lengths):
+        """Items of one view may have different crop lengths (anchor_len[0] != anchor_len[1]): the reference computes mel,
+        Mixup and RandomResizeCrop over each item's own crop (transform.py:52-73), so the batch is processed in groups
+        of equal frame count and each group is padded back to the common width.  A crop of `frames` frames is taken as
+        (frames - 1) * 160 samples: exact whenever the crop length is a multiple of the hop (the shipped 6 s / 10 s
+        recipes), up to 159 tail samples short otherwise."""
         mels = []
         t_max = max(int(w.shape[-1]) // 160 for w in waves)
         for v, (w, ln) in enumerate(zip(waves, lengths)):
-            n = (int(ln.max()) - 1) * 160 if torch.is_tensor(ln) else (int(ln) - 1) * 160
-            m = self.mel_feature(w[..., :n] if n > 0 else w)
             k = min(v, 1)
-            if self.mixup[k] is not None:
-                m = self.mixup[k](m)
-            if self.rrc[k] is not None:
-                m = self.rrc[k](m)
-            mels.append(F.pad(m, (0, max(0, t_max + 1 - m.shape[-1]))))
+            ln = torch.as_tensor(ln).reshape(-1).cpu()
+            uniq = torch.unique(ln).tolist()
+            if len(uniq) == 1:
+                m = self._view(k, w, (int(uniq[0]) - 1) * 160)
+                mels.append(F.pad(m, (0, max(0, t_max + 1 - m.shape[-1]))))
+                continue
+            out = torch.zeros(w.shape[0], 1, 64, t_max + 1, device=w.device)
+            for u in uniq:
+                idx = (ln == u).nonzero(as_tuple=True)[0].to(w.device)
+                m = self._view(k, w.index_select(0, idx), (int(u) - 1) * 160)
+                out.index_copy_(0, idx, F.pad(m, (0, max(0, t_max + 1 - m.shape[-1]))))
+            mels.append(out)
         return mels
 
 

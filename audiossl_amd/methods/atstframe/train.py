@@ -1,0 +1,40 @@
+"""CLI entry with the reference's arguments (audiossl/methods/atstframe/train.py:13-56): lr linear scaling, per-GPU batch,
+auto-resume from ``last.ckpt``.  One process per GPU: ``python -m torch.distributed.run --nproc-per-node N -m
+audiossl_amd.methods.atstframe.train ...`` (the reference lets Lightning spawn the DDP ranks, train.py:20-24)."""
+import os
+from argparse import ArgumentParser
+
+import torch
+import torch.distributed as dist
+
+from ...trainer import Trainer
+from .data import FrameATSTDataModule
+from .model import FrameATSTLightningModule
+
+
+def main(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and not dist.is_initialized():
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("nccl")
+    args.nproc = world if world > 1 else args.nproc
+    args.learning_rate = args.learning_rate * args.nproc * args.batch_size_per_gpu / 256        # ref: train.py:14
+    args.spec_h = args.n_mels                                                                     # ref: train.py:15
+    dict_args = vars(args)
+    model = FrameATSTLightningModule(**dict_args)
+    data = FrameATSTDataModule(**dict_args)
+    trainer = Trainer(max_steps=args.max_steps, default_root_dir=args.save_path, every_n_epochs=20,
+                      batch_hook=data.transform.batch_views())
+    last_ckpt = os.path.join(args.save_path, "last.ckpt") if args.save_path else None
+    trainer.fit(model, datamodule=data, ckpt_path=last_ckpt if last_ckpt and os.path.exists(last_ckpt) else None)
+
+
+if __name__ == "__main__":
+    parser = ArgumentParser("FrameATST")
+    parser.add_argument("--save_path", type=str)
+    parser.add_argument("--nproc", type=int, default=2)
+    parser.add_argument("--patch_h", type=int, default=64)
+    parser.add_argument("--patch_w", type=int, default=4)
+    parser = FrameATSTLightningModule.add_model_specific_args(parser)
+    parser = FrameATSTDataModule.add_data_specific_args(parser)
+    main(parser.parse_args())

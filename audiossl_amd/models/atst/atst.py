@@ -48,28 +48,32 @@ class EncoderView(_Node):
 
     @torch.no_grad()
     def _blocks(self, x, length, n):
-        """-> (list of LN(x_i) [S, NP, C] fp32 for the last n blocks, patch_length [S], n_tok)."""
+        """-> (list of LN(x_i) [S, n_tok(+1), C] fp32 for the last n blocks, patch_length [S] (device), n_tok).
+        Forward-only workspace (one layer of activations, re-used for every block) + fp32 taps of the last n block
+        outputs; the per-geometry passes live in a small LRU so variable-length evaluation cannot grow HBM without bound."""
         from ... import hip
         eng = self._eng[0]
         eng.sync_shadows()
         x = x.to(eng.device, torch.float32).contiguous()
         S, width = x.shape[0], x.shape[-1]
-        ep = eng._pass(self._netname, S, width, True, 1000 + width)
+        ep = eng.inference_pass(self._netname, S, width)
         if length is None:
             length = torch.full((S,), width, dtype=torch.int64)
-        valid = eng._valid(torch.as_tensor(length), ep.use_cls)             # reference patch_length (+CLS), NOT clipped to the chunk
-        ep.forward(x, torch.clamp(valid, max=ep.n_tok + ep.use_cls).contiguous(), None, None)
+        l = torch.as_tensor(length).to(torch.int64)
+        plen = (l - l % 4) // 4                                   # reference patch_length, NOT clipped to the chunk
+        valid = (torch.clamp(plen, max=ep.n_tok) + ep.use_cls).to(torch.int32)
         C = eng.cfg["embed_dim"]
+        n = min(n, eng.depth)
+        tap = torch.empty(n, ep.M, C, device=eng.device)
+        ep.e.tap, ep.e.tap_first = tap.data_ptr(), eng.depth - n
+        ep.forward(x, eng.upload(valid), None, None)
+        ep.e.tap = None
         nf = "encoder.norm_frame" if eng.frame else "encoder.norm"
         gw, gb = eng.param_view(self._netname, nf + ".weight"), eng.param_view(self._netname, nf + ".bias")
-        outs = []
-        y = torch.empty(ep.M, C, dtype=torch.bfloat16, device=eng.device)
-        mean, rstd = torch.empty(ep.M, device=eng.device), torch.empty(ep.M, device=eng.device)
-        for i in range(eng.depth - n, eng.depth):
-            hip.call("atst_layernorm_fwd", hip.ptr(ep.block_out(i)), hip.ptr(gw), hip.ptr(gb), hip.ptr(y), hip.ptr(mean), hip.ptr(rstd),
-                     ep.M, C, hip.stream())
-            outs.append(y.float().view(S, ep.NP, C)[:, :ep.n_tok + ep.use_cls].clone())
-        return outs, (valid - ep.use_cls).long(), ep.n_tok
+        y = torch.empty(n, ep.M, C, device=eng.device)
+        hip.call("atst_layernorm_fwd_f32", hip.ptr(tap), hip.ptr(gw), hip.ptr(gb), hip.ptr(y), n * ep.M, C, hip.stream())
+        outs = [y[i].view(S, ep.NP, C)[:, :ep.n_tok + ep.use_cls] for i in range(n)]
+        return outs, eng.upload(plen), ep.n_tok
 
     def forward(self, x, mask_index=None, length=None, avg=False):
         outs, plen, _ = self._blocks(x, length, 1)
@@ -94,7 +98,8 @@ class EncoderView(_Node):
 
     def get_intermediate_layers_chunks(self, x, length, n=1, chunk_len=601, avgpool=True):
         total = x.shape[-1]
-        length = torch.as_tensor(length).to(self._eng[0].device)
+        length = torch.as_tensor(length)
+        dev = self._eng[0].device
         cls_c, avg_c, marks = [], [], []
         for i in range(total // chunk_len + 1):
             start, end = i * chunk_len, min((i + 1) * chunk_len, total)
@@ -102,12 +107,12 @@ class EncoderView(_Node):
                 continue
             cur = torch.clip(length - i * chunk_len, 0)
             mark = (cur > 0) if i == 0 else (cur > chunk_len // 2)
-            outs, plen, _ = self._blocks(x[..., start:end], cur.cpu(), n)
+            outs, plen, _ = self._blocks(x[..., start:end], cur, n)
             off = 1 if self.use_cls else 0
             lm = (torch.arange(outs[0].shape[1] - off, device=outs[0].device)[None, :] < plen[:, None]).unsqueeze(-1)
             cls_c.append(torch.stack([o[:, 0] if self.use_cls else torch.zeros_like(o[:, 0]) for o in outs]))
             avg_c.append(torch.stack([(o[:, off:] * lm).sum(1) / (plen[:, None] + 1e-6) for o in outs]))
-            marks.append(mark.float())
+            marks.append(self._eng[0].upload(mark.float()) if not mark.is_cuda else mark.float())
         w = torch.stack(marks)[:, None, :, None]                        # [chunks, 1, S, 1]
         cls = (torch.stack(cls_c) * w).sum(0) / w.sum(0)                # [n, S, C]
         avg = (torch.stack(avg_c) * w).sum(0) / w.sum(0)
@@ -195,9 +200,6 @@ class ATST(nn.Module):
                 p.grad = None                       # never used in clip-level ATST (reference: grad is None)
             else:
                 p.grad = eng.param_view("student", name, grad=True)
-
-    def _load_from_state_dict(self, *args, **kwargs):
-        super()._load_from_state_dict(*args, **kwargs)
 
     def load_state_dict(self, state_dict, strict=True, **kw):
         out = super().load_state_dict(state_dict, strict=strict, **kw)

@@ -30,18 +30,22 @@ def _collective() -> bool:
     return dist.get_world_size() > 1 or os.environ.get("ATST_FORCE_COLLECTIVES") == "1"
 
 
-def combine_bn_stats(mean: torch.Tensor, m2: torch.Tensor, count: float) -> Tuple[torch.Tensor, torch.Tensor, float]:
+def combine_bn_stats(mean: torch.Tensor, m2: torch.Tensor, count: float):
     """Local per-feature (mean, M2 = sum (x-mean)^2, row count) -> global (mean, M2, count) over all ranks
-    (Chan et al. parallel variance).  Identity at world size 1."""
+    (Chan et al. parallel variance).  Identity at world size 1 (count stays a python float); across ranks the global
+    count is returned as a 0-dim tensor ON THE DEVICE OF `mean` -- per-rank row counts are ragged for ATST-Frame, and
+    reading the total back would drain the launch queue once per BatchNorm per step."""
     if not _collective():
         return mean, m2, float(count)
     n = mean.numel()
-    pack = torch.cat([mean, m2, torch.tensor([float(count)], device=mean.device, dtype=mean.dtype)])
-    gathered = [torch.empty_like(pack) for _ in range(world_size())]
-    dist.all_gather(gathered, pack)
-    allp = torch.stack(gathered)
+    pack = torch.cat([mean, m2, mean.new_full((1,), float(count))])                 # fill kernel: no host->device copy, no sync
+    # all-gather expressed as an all-reduce of a [world, 2n+1] table with only this rank's row filled: one collective
+    # that every transport supports for device tensors (8 KB x world)
+    allp = pack.new_zeros(world_size(), pack.numel())
+    allp[dist.get_rank()] = pack
+    dist.all_reduce(allp)
     means, m2s, cnts = allp[:, :n], allp[:, n:2 * n], allp[:, -1:]
-    total = float(cnts.sum())
+    total = cnts.sum()
     gmean = (means * cnts).sum(0) / total
     gm2 = (m2s + cnts * (means - gmean) ** 2).sum(0)
     return gmean, gm2, total
@@ -58,12 +62,13 @@ def allreduce_bn_backward_sums(sum_dy: torch.Tensor, sum_dy_xhat: torch.Tensor) 
 
 
 def allreduce_monitor_sums(stats: torch.Tensor, n_student: float, n_teacher: float):
-    """[4, D] column sums / square sums of normalised student & teacher rows + the two row counts, one all-reduce."""
+    """[4, D] column sums / square sums of normalised student & teacher rows + the two row counts, one all-reduce.
+    Across ranks the counts come back as 0-dim tensors on the device of `stats` (no read-back)."""
     if not _collective():
         return stats, float(n_student), float(n_teacher)
-    pack = torch.cat([stats.reshape(-1), torch.tensor([n_student, n_teacher], device=stats.device, dtype=stats.dtype)])
+    pack = torch.cat([stats.reshape(-1), stats.new_full((1,), float(n_student)), stats.new_full((1,), float(n_teacher))])
     dist.all_reduce(pack)
-    return pack[:-2].view_as(stats), float(pack[-2]), float(pack[-1])
+    return pack[:-2].view_as(stats), pack[-2], pack[-1]
 
 
 def feature_std(sums: torch.Tensor, sq_sums: torch.Tensor, n: float) -> torch.Tensor:

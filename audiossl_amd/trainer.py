@@ -55,18 +55,26 @@ class Trainer:
         model.trainer = self
         self.optimizers = model.configure_optimizers()
         opt = self.optimizers[0]
+        epoch = 0
         if ckpt_path and os.path.exists(ckpt_path):
-            load_checkpoint(ckpt_path, model)
+            ckpt = load_checkpoint(ckpt_path, model)
+            epoch = int(ckpt.get("epoch", -1)) + 1          # Lightning stores the zero-based index of the finished epoch
+            model.model.engine.broadcast_parameters(optimizer_state=True)
         loader = train_dataloaders if train_dataloaders is not None else datamodule.train_dataloader(self.rank, self.world)
         dev = model.model.engine.device
-        epoch, t0 = 0, time.time()
+        t0, step0 = time.time(), model.global_step
         while True:
+            if hasattr(getattr(loader, "sampler", None), "set_epoch"):
+                loader.sampler.set_epoch(epoch)
             for batch_idx, batch in enumerate(loader):
-                (views, lengths), labels = batch[0], batch[1]
+                inputs, labels = batch[0], batch[1]
+                # clip ATST: (views, lengths) (methods/atst/model.py:26) ; ATST-Frame: (views, lengths, masks) (atstframe/model.py:120)
+                views, lengths, masks = (inputs[0], inputs[1], inputs[2] if len(inputs) > 2 else None)
                 views = [v.to(dev, non_blocking=True) for v in views]
                 if self.batch_hook is not None and views[0].dim() == 3:            # [B,1,n] waveforms -> mel views
                     views = self.batch_hook(views, lengths)
-                loss = model.training_step(((views, lengths), labels), batch_idx)
+                step_in = (views, lengths) if masks is None else (views, lengths, masks)
+                loss = model.training_step((step_in, labels), batch_idx)
                 opt.zero_grad()
                 loss.backward()
                 model.on_after_backward()
@@ -75,7 +83,7 @@ class Trainer:
                 model.on_train_batch_end(loss, batch, batch_idx)
                 if self.rank == 0 and model.global_step % self.log_every == 0:
                     rec = {k: (float(v.detach()) if torch.is_tensor(v) else v) for k, v in model.logged.items()}
-                    rec["it/s"] = model.global_step / (time.time() - t0)
+                    rec["it/s"] = (model.global_step - step0) / (time.time() - t0)
                     self.history.append(rec)
                     print(" ".join(f"{k}={v:.5g}" if isinstance(v, float) else f"{k}={v}" for k, v in rec.items()), flush=True)
                 if 0 < self.max_steps <= model.global_step:
@@ -84,9 +92,9 @@ class Trainer:
             done = (0 < self.max_steps <= model.global_step) or (self.max_epochs and epoch >= self.max_epochs)
             if self.root and self.rank == 0:
                 if epoch % self.every_n_epochs == 0:
-                    save_checkpoint(os.path.join(self.root, f"checkpoint-epoch={epoch - 1:05d}.ckpt"), model, opt, epoch)
+                    save_checkpoint(os.path.join(self.root, f"checkpoint-epoch={epoch - 1:05d}.ckpt"), model, opt, epoch - 1)
                 if done or epoch % self.every_n_epochs == 0:
-                    save_checkpoint(os.path.join(self.root, "last.ckpt"), model, opt, epoch)
+                    save_checkpoint(os.path.join(self.root, "last.ckpt"), model, opt, epoch - 1)
             if done:
                 break
         return model

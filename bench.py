@@ -181,10 +181,12 @@ def main():
         import numpy as np
         rs = np.random.RandomState(1234 + rank)
         from audiossl_amd.methods.atstframe.random_mask import block_mask
-        m = torch.from_numpy(np.stack([block_mask(250, 0.65, 5, rng=rs) for _ in range(B)])).to(dev)
-        masks = [m, m]
+        # host-side masks, one draw per clip per step, as the DataLoader would deliver them (the transform draws them
+        # with numpy on the workers: methods/atstframe/transform.py:84-101); generated before the timed region
+        mask_sets = [torch.from_numpy(np.stack([block_mask(250, 0.65, 5, rng=rs) for _ in range(B)])) for _ in range(total)]
 
     def step(k):
+        nonlocal masks
         o = offs[k]
         if frame:
             mel = fe(buf[:, o[0]:o[0] + 160000])
@@ -195,6 +197,8 @@ def main():
             if ncrops == 6:                                  # 4 local views of 1 s -> 101 frames -> 25 patches + CLS
                 mels += [fe(buf[:, o[2 + v]:o[2 + v] + 16000]) for v in range(4)]
                 lens += [torch.full((B,), 101)] * 4
+        if frame:
+            masks = [mask_sets[k], mask_sets[k]]              # ONE mask shared by both views (transform.py:99)
         loss, _, _ = eng.forward(mels, lens, masks)
         eng.backward()
         eng.allreduce_grads()

@@ -59,6 +59,9 @@ int atst_gemm_tn_group_bf16(const atst_wgrad_t* items, int n, void* stream);
 /* nn.LayerNorm(eps=1e-6): audiossl/modules/transformer.py:128,132 ; audio_transformer.py:113                         */
 int atst_layernorm_fwd(const float* x, const float* gamma, const float* beta, uint16_t* y, float* mean, float* rstd,
                        int M, int C, void* stream);
+/* same LayerNorm with an fp32 output and no saved statistics: the inference API's norm(x_i) of the block taps
+ * (audio_transformer.py:235-255, 277-286 ; atstframe/audio_transformer.py:259-281)                                    */
+int atst_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, int M, int C, void* stream);
 int atst_layernorm_bwd(const uint16_t* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                        const float* dres, float* dx, uint16_t* g, const float* row_scale, int rows_per_seq,
                        float* dgamma, float* dbeta, float* dbias_up, int M, int C, void* stream);
@@ -131,6 +134,9 @@ typedef struct {
   const uint8_t* rowflag;             /* [S*NP] 1 = substitute mask token (ATST-Frame student) or NULL */
   const float* dp_scale;              /* [depth,2,S] DropPath keep/keep_prob factors or NULL */
   void* ws; size_t ws_bytes;          /* activation workspace, atst_encoder_ws_bytes() */
+  /* optional block taps (inference API, get_intermediate_layers): when tap != NULL the fp32 residual stream after
+   * block i is copied to tap[(i - tap_first) * S*NP*C] for every i >= tap_first; works with train = 0 workspaces */
+  float* tap; int tap_first;
 } atst_encoder_t;
 
 size_t atst_encoder_ws_bytes(int S, int NP, int C, int H, int depth, int train);
@@ -143,6 +149,10 @@ int atst_encoder_bwd(const atst_encoder_t* e, void* stream);
 /* The same backward in two calls: part 0 = final LayerNorm + blocks [split, depth), part 1 = blocks [0, split) + token
  * stage (the caller may start the gradient all-reduce of the upper blocks in between).                                */
 int atst_encoder_bwd_part(const atst_encoder_t* e, int part, int split, void* stream);
+/* General form: backward over blocks [lo, hi) (descending).  hi == depth also runs the final LayerNorm backward, lo == 0
+ * also the token stage.  Consecutive calls hi..lo must tile [0, depth) from the top; between two calls the parameter
+ * gradients of the blocks already walked are final, so the caller can reduce them across ranks bucket by bucket.      */
+int atst_encoder_bwd_range(const atst_encoder_t* e, int lo, int hi, void* stream);
 /* block-level activation taps for tests: fp32 residual stream after block i (i in [0,depth)), train=1 only */
 const float* atst_encoder_block_out(const atst_encoder_t* e, int i);
 const float* atst_encoder_tokens(const atst_encoder_t* e);

@@ -191,3 +191,46 @@ def test_batched_augmentations():
     assert z.shape == x.shape and torch.isfinite(z).all()
     ident = BatchRandomResizeCrop((1, 1.0), freq_scale=(1.0, 1.0), time_scale=(1.0, 1.0))(x)
     assert rel(ident.cpu().numpy(), x.cpu().numpy()) < 1e-6                              # full-size crop == identity
+
+
+def test_frame_trainer_end_to_end(tmp_path):
+    """FrameATSTDataModule -> Trainer (batch carries (crops, lengths, masks), ref: atstframe/model.py:120) -> GPU stage of the
+    transform (mel win 640, clean view + Mixup / frequency-only RandomResizeCrop view, ONE shared mask) -> HIP step,
+    checkpoint, resume with the epoch counter restored."""
+    from audiossl_amd.methods.atstframe.data import FrameATSTDataModule
+    from audiossl_amd.methods.atstframe.model import FrameATSTLightningModule
+    from audiossl_amd.trainer import Trainer
+    torch.manual_seed(0)
+    module = FrameATSTLightningModule(arch="small", learning_rate=1e-3, warmup_steps=2, max_steps=4, ema=0.997)
+    dm = FrameATSTDataModule(batch_size_per_gpu=2, num_workers=0, subset=4, win_length=640, aug_tea=False, aug_stu=True,
+                             mask_ratio=0.65, mask_type="block", anchor_len=10, mask_len=5)
+    hook = dm.transform.batch_views()
+    (crops, lengths, masks), _ = next(iter(dm.train_dataloader()))
+    views = hook([crops[0].cuda()], lengths)
+    assert len(views) == 2 and views[0].shape == (2, 1, 64, 1001) and views[1].shape == (2, 1, 64, 1001)
+    again = hook([crops[0].cuda()], lengths)
+    assert torch.equal(views[0], again[0])                                     # aug_tea=False: view 0 is the clean mel
+    assert not torch.equal(again[0], again[1])                                 # view 1: Mixup (bank now filled) + freq RRC
+    trainer = Trainer(max_steps=4, default_root_dir=str(tmp_path), every_n_epochs=1, log_every_n_steps=1, batch_hook=hook)
+    trainer.fit(module, datamodule=dm)
+    assert module.global_step == 4 and {"loss", "loss_frm", "std_frm_tea", "std_frm_stu"} <= set(module.logged)
+    assert module.model.student.encoder.mask_embed.grad is not None and torch.isfinite(module.logged["loss"])
+    raw = torch.load(os.path.join(str(tmp_path), "last.ckpt"), map_location="cpu", weights_only=False)
+    assert raw["epoch"] == 1 and raw["global_step"] == 4                       # two epochs of two batches; zero-based index of the last
+    resumed = FrameATSTLightningModule(arch="small", learning_rate=1e-3, warmup_steps=2, max_steps=6, ema=0.997)
+    t2 = Trainer(max_steps=6, default_root_dir=str(tmp_path), every_n_epochs=1, log_every_n_steps=1, batch_hook=hook)
+    t2.fit(resumed, datamodule=dm, ckpt_path=os.path.join(str(tmp_path), "last.ckpt"))
+    assert resumed.global_step == 6 and resumed.model.engine.opt_step == 6
+    assert os.path.exists(os.path.join(str(tmp_path), "checkpoint-epoch=00002.ckpt"))     # epoch numbering continued, nothing overwritten
+
+
+def test_inference_workspaces_are_bounded():
+    """Variable-width evaluation re-uses a small LRU of forward-only workspaces (no activation tape)."""
+    model = ATST("small", depth=2)
+    enc = model.teacher.encoder
+    for w in (401, 405, 409, 413, 417, 421, 425):
+        y = enc(O.recipe_mel(2, w, seed=w), length=torch.tensor([w, w - 100]))
+        assert y.shape == (2, 384) and torch.isfinite(y).all()
+    eng = model.engine
+    assert len(eng._infer_passes) <= 4 and not any(k[3] for k in eng._passes)     # no training-sized pass was created
+    assert all(not p.train for p in eng._infer_passes.values())

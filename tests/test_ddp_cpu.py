@@ -27,7 +27,7 @@ def _worker(rank, world, port, q):
     # ---- forward statistics
     mean_l = hl.mean(0); m2_l = ((hl - mean_l) ** 2).sum(0)
     mean, m2, count = P.combine_bn_stats(mean_l, m2_l, hl.shape[0])
-    ok = torch.allclose(mean, h.mean(0)) and torch.allclose(m2 / count, h.var(0, unbiased=False)) and count == R
+    ok = torch.allclose(mean, h.mean(0)) and torch.allclose(m2 / count, h.var(0, unbiased=False)) and float(count) == R
     # ---- backward: loss = mean over ALL rows of relu(bn(h)) . w_out ; each rank holds d(loss)/dy for its rows
     rstd = torch.rsqrt(m2 / count + 1e-5)
     hr = h.clone().requires_grad_(True); gr = gamma.clone().requires_grad_(True); br = beta.clone().requires_grad_(True)
@@ -51,7 +51,7 @@ def _worker(rank, world, port, q):
     # ---- fused monitor all-reduce
     stats = torch.arange(8, dtype=torch.float64).view(4, 2) * (rank + 1)
     st, ns, nt = P.allreduce_monitor_sums(stats, 4.0 + rank, 2.0)
-    ok = ok and torch.equal(st, torch.arange(8, dtype=torch.float64).view(4, 2) * 3) and ns == 9.0 and nt == 4.0
+    ok = ok and torch.equal(st, torch.arange(8, dtype=torch.float64).view(4, 2) * 3) and float(ns) == 9.0 and float(nt) == 4.0
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 

@@ -1,7 +1,12 @@
-"""The one-process-per-GPU launch path of bench.py on the single-GPU box: `torch.distributed.run` with one rank, RCCL process
+"""(1) The one-process-per-GPU launch path of bench.py on the single-GPU box: `torch.distributed.run` with one rank, RCCL process
 group, and ATST_FORCE_COLLECTIVES=1 so that every exchange of the data-parallel step (SyncBN all-gather / all-reduce, the
 flat-gradient all-reduce, the fused monitor all-reduce, barrier, max-over-ranks timing) is actually issued through RCCL.
-With one rank the collectives are identities, so the loss must equal the non-distributed run's."""
+With one rank the collectives are identities, so the loss must equal the non-distributed run's.
+(2) The product path at world size 2: two ranks on shards of a batch == one process on the concatenated batch (loss, flat
+gradient, BatchNorm running statistics, parameters after one fused optimizer step), with the bucketed all-reduce overlap
+on and off, clip-level and ATST-Frame.  Transport: RCCL when the node has >= 2 GPUs, otherwise gloo with both ranks on
+cuda:0 (tests/dist_worker.py) -- so the property is checked on the single-GPU box too.
+(3) `python bench.py --gpus 2` launches its own ranks and reports n_gpus 2."""
 import json
 import os
 import subprocess
@@ -31,3 +36,67 @@ def test_torchrun_single_rank_rccl(workload):
                 "--master-port", "29541"] + common, {"ATST_FORCE_COLLECTIVES": "1"})
     assert dist["n_gpus"] == 1 and dist["scaling"] == "weak"
     assert abs(dist["loss"] - plain["loss"]) < 2e-3, (dist["loss"], plain["loss"])      # wgrad atomics: not bit-reproducible
+
+
+def _worker(tmp_path, tag, world, mode, overlap=1, batch=16):
+    out = os.path.join(str(tmp_path), f"{tag}.npz")
+    base = [os.path.join(ROOT, "tests", "dist_worker.py"), "--mode", mode, "--out", out, "--overlap", str(overlap), "--batch", str(batch)]
+    if world == 1:
+        cmd = [sys.executable] + base
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+               "127.0.0.1", "--master-port", str(29560 + overlap + (7 if mode != "clip" else 0))] + base
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    import numpy as np
+    return np.load(out)
+
+
+def _rel(a, b):
+    import numpy as np
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+@pytest.mark.parametrize("mode,overlap", [("clip", 1), ("clip", 0), ("frame", 1)])
+def test_two_ranks_equal_one_rank_on_the_concatenated_batch(tmp_path, mode, overlap):
+    """16 clips per rank.  The two runs differ only in fp32 summation order (Chan-combined vs one-pass BatchNorm statistics,
+    wgrad M-splits); each BatchNorm backward amplifies that ~100x through the cancellation dy - mean(dy) - xhat mean(dy xhat)
+    (DESIGN.md section 4), more with fewer rows.  Measured (tools/dist_diag.py, profiles/r02_dist_diag.txt): run-to-run
+    5e-8; 2 ranks vs 1: whole buffer 1.7e-3, predictor 2.6e-5, projector 8.5e-4 at 16 clips/rank (9.7e-3 / 1.7e-3 /
+    1.4e-2 at 4 clips/rank); overlap on == overlap off to the last digit."""
+    one = _worker(tmp_path, f"one_{mode}", 1, mode)
+    two = _worker(tmp_path, f"two_{mode}_{overlap}", 2, mode, overlap)
+    assert int(two["world"]) == 2 and float(two["same"][0]) == 1.0          # ranks hold identical parameters after the step
+    assert abs(float(two["loss"][0]) - float(one["loss"][0])) < 2e-4, (two["loss"], one["loss"])
+    assert abs(float(two["std_s"]) - float(one["std_s"])) < 1e-4 and abs(float(two["std_t"]) - float(one["std_t"])) < 1e-4
+    assert _rel(two["grads"], one["grads"]) < 5e-3, _rel(two["grads"], one["grads"])
+    n_pred = 2 * 4096 * 256 + 2 * 4096                                       # predictor = tail of the flat buffer
+    assert _rel(two["grads"][-n_pred:], one["grads"][-n_pred:]) < 5e-4
+    for k in one.files:
+        if k.startswith("bn/") and not k.endswith("num_batches_tracked"):
+            assert _rel(two[k], one[k]) < 1e-4, k
+    # the first Adam step is lr * g / (|g| + eps): gradient entries near zero turn fp32 noise into +-lr (1e-3 on 2e-2 weights)
+    assert _rel(two["params"], one["params"]) < 2e-3 and _rel(two["teacher"], one["teacher"]) < 2e-5
+
+
+def test_two_ranks_ragged_frame_rows(tmp_path):
+    """Per-rank masked-row counts differ (SyncBN count-weighted combine with a device-side total, ragged gather): DDP then
+    averages per-rank mean-loss gradients, which is not the concatenated-batch gradient -- checked here: the step runs,
+    every rank ends with identical parameters, and the loss is close to the concatenated run's."""
+    one = _worker(tmp_path, "one_fr", 1, "frame_ragged", batch=4)
+    two = _worker(tmp_path, "two_fr", 2, "frame_ragged", 1, batch=4)
+    assert float(two["same"][0]) == 1.0
+    assert abs(float(two["loss"][0]) - float(one["loss"][0])) < 2e-2
+    for k in one.files:
+        if k.startswith("bn/") and not k.endswith("num_batches_tracked"):
+            assert _rel(two[k], one[k]) < 1e-4, k                           # SyncBN statistics ARE the concatenated batch's
+
+
+def test_bench_launches_its_own_ranks():
+    import torch
+    extra = [] if torch.cuda.device_count() >= 2 else ["--backend", "gloo"]
+    out = run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8", "--workload", "clip2",
+               "--no-cpu-baseline", "--no-profile"] + extra)
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 16 and out["config"]["parallelism"] == "dp2"

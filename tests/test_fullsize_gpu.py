@@ -70,3 +70,34 @@ def test_backward_linearity_loss_range_and_ema_endpoints(ncrops):
     for name in eng.layout.entries:
         if not name.startswith("predictor."):
             assert torch.equal(eng.param_view("teacher", name), eng.param_view("student", name)), name
+
+
+def test_frame_full_size_properties():
+    """ATST-Frame at the benchmark size (256 clips x 2 views, 250 frames, block masks 0.65 / 5): the head sees exactly the
+    masked valid frames; permuting the clips (with their masks) leaves the loss unchanged; masks on the host and masks
+    on the device give the same rows; backward is linear in the upstream scale; gradients reach mask_embed."""
+    from audiossl_amd.methods.atstframe.random_mask import block_mask
+    eng = AtstEngine("small", frame=True, drop_path_rate=0.0)
+    eng.init_weights(seed=6)
+    g = torch.Generator().manual_seed(17)
+    mels = [torch.randn(B, 1, 64, 1001, generator=g).clamp_(-1, 1) for _ in range(2)]
+    lens = [torch.randint(400, 1002, (B,), generator=g)] * 2
+    rs = np.random.RandomState(3)
+    m = torch.from_numpy(np.stack([block_mask(250, 0.65, 5, rng=rs) for _ in range(B)]))
+    loss, std_s, std_t = eng.forward(mels, lens, [m, m])
+    plen = (lens[0] - lens[0] % 4) // 4
+    want_rows = int((m & (torch.arange(250)[None, :] < plen[:, None])).sum()) * 2
+    assert sum(r.numel() for _, r in eng._student_groups) == want_rows            # bit-exact ragged row count
+    rows_host = eng._student_groups[0][1].clone()
+    assert torch.isfinite(loss) and 0.0 <= float(loss) <= 4.0
+    eng.backward()
+    g1 = eng.g32.clone()
+    assert torch.isfinite(g1).all() and float(eng.param_view("student", "encoder.mask_embed", grad=True).abs().max()) > 0
+    loss_dev, _, _ = eng.forward(mels, lens, [m.cuda(), m.cuda()])                 # device-side masks: same rows, same loss
+    assert torch.equal(eng._student_groups[0][1], rows_host) and abs(float(loss_dev) - float(loss)) < 1e-6
+    eng.backward(grad_scale=2.0)
+    rel = float((eng.g32 - 2.0 * g1).norm() / (2.0 * g1.norm()))
+    assert rel < 2e-3, rel
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(9))
+    loss_p, _, _ = eng.forward([x[perm] for x in mels], [l[perm] for l in lens], [m[perm], m[perm]])
+    assert abs(float(loss_p) - float(loss)) < 2e-4, (float(loss_p), float(loss))   # BatchNorm sums reorder: fp32 noise only

@@ -93,3 +93,84 @@ def test_random_resize_crop_parameter_sampling():
     assert (i >= 0).all() and (i + h <= CH).all() and (j >= 0).all() and (j + w <= CW).all()
     assert (i[h == CH] == 0).all()
     assert abs(float((h == CH).mean()) - (1.5 - 1.0) / (1.5 - 0.6)) < 0.03      # P(U(0.6,1.5) * 64 >= 64)
+
+
+# ---- ATST-Frame host surface (methods/atstframe/transform.py:14-101, data.py:20-111) ----------------------------------
+def test_frame_transform_batch_contract():
+    from audiossl_amd.methods.atstframe.transform import FrameATSTTrainTransform, get_num_patches
+    from audiossl_amd.methods.atstframe.data import FrameATSTDataModule
+    assert get_num_patches(64, 1001, 64, 4) == 250 and get_num_patches(64, 601, 64, 4) == 150
+    t = FrameATSTTrainTransform(win_length=640, aug_tea=False, aug_stu=True, mask_ratio=0.65, mask_type="block", anchor_len=10, mask_len=5)
+    wave = 0.1 * torch.randn(1, 170000)
+    crops, lengths, masks = t(wave)
+    assert len(crops) == 1 and crops[0].shape == (1, 160000)               # ONE crop feeds both views (transform.py:78-82)
+    assert lengths == [1001, 1001]
+    assert len(masks) == 2 and masks[0] is masks[1] and masks[0].shape == (250,) and masks[0].dtype == torch.bool
+    assert 60 <= int(masks[0].sum()) <= 163                                # overlapping spans: realised ratio < 0.65
+    short = t(0.1 * torch.randn(1, 100000))[0][0]                          # shorter than the crop: zero-padded (RandomCrop)
+    assert short.shape == (1, 160000) and float(short[0, 100000:].abs().max()) == 0.0
+    r = FrameATSTTrainTransform(mask_type="random", mask_ratio=0.75, anchor_len=6.)
+    _, ln, mk = r(wave)
+    assert ln == [601, 601] and mk[0].shape == (150,) and int(mk[0].sum()) == 113       # randperm < 150*0.75 -> 113 exactly
+    u = FrameATSTTrainTransform(mask_type="uniform", mask_ratio=0.65, anchor_len=10, min_mask_len=2)
+    assert u(wave)[2][0].shape == (250,)
+    with pytest.raises(NotImplementedError):
+        FrameATSTTrainTransform(n_mels=128)
+    # collate: what training_step receives -- ((crops, lengths, masks), label), ref: atstframe/model.py:120
+    dm = FrameATSTDataModule(batch_size_per_gpu=4, num_workers=0, subset=8, win_length=640, aug_tea=False, mask_ratio=0.65,
+                             anchor_len=10, mix_up=False)
+    assert dm.transform.mix_up is True                                     # reference quirk: mix_up is not forwarded (data.py:46-57)
+    (crops, lengths, masks), label = next(iter(dm.train_dataloader()))
+    assert crops[0].shape == (4, 1, 160000) and [tuple(l.shape) for l in lengths] == [(4,), (4,)] and int(lengths[0][0]) == 1001
+    assert masks[0].shape == (4, 250) and torch.equal(masks[0], masks[1]) and not masks[0].is_cuda
+    assert label.shape == (4, 1, 527)
+    bv = dm.transform.batch_views.__self__                                 # the GPU stage is configured from the transform
+    assert bv.win_length == 640 and bv.aug_tea is False and bv.aug_stu is True
+
+
+def test_block_mask_uniform_type_follows_fairseq_draw_order():
+    """uniform: rand() (span count), randint(other, 2L+1, num) (lengths), choice(S - min_len, num) (starts)."""
+    S, p, L, other = 250, 0.65, 5, 2
+    rs = np.random.RandomState(9)
+    got = RM.block_mask(S, p, L, rng=rs, mask_type="uniform", mask_other=other)
+    rs = np.random.RandomState(9)
+    num = max(2, int(p * S / float(L) + rs.rand()))
+    lengths = rs.randint(other, 2 * L + 1, size=num)
+    starts = rs.choice(S - int(lengths.min()), num, replace=False)
+    want = np.zeros(S, bool)
+    for s0, ln in zip(starts, lengths):
+        want[s0:min(S, s0 + ln)] = True
+    assert np.array_equal(got, want)
+
+
+def test_lmdb_dataset_semantics_on_a_dict_store():
+    """Subset shuffle / cycle window / item contract of audiossl/datasets/lmdb.py:12-98, key-value layer replaced."""
+    import random
+    from audiossl_amd.datasets import DictStore, LMDBDataset
+    items = {f"clip{i:03d}".encode("ascii"): (np.full((1, 1, 1600), i, np.float32), np.eye(527, dtype=np.float32)[None, i % 527])
+             for i in range(10)}
+    random.seed(1234)
+    ds = LMDBDataset("unused", "train", subset=4, store=DictStore(items), return_key=True)
+    random.seed(1234)
+    keys = list(items)
+    random.shuffle(keys)
+    assert ds.keys == keys[:4] and len(ds) == 4 and ds.num_classes == 527 and ds.start == 4
+    wave, label, key = ds[0]
+    assert wave.shape == (1, 1600) and label.shape == (527,) and key == keys[0] and float(wave[0, 0]) == int(keys[0][4:])
+    ds.cycle()
+    assert ds.keys == keys[4:8] and ds.start == 8
+    ds.cycle()                                                             # wraps: tail + head, then reshuffles the pool
+    assert ds.keys == keys[8:] + keys[:2] and ds.start == 0
+    full = LMDBDataset("unused", "train", subset=None, store=DictStore(items), transform=lambda w: (w * 2, 7))
+    (w2, seven), lab = full[3]
+    assert len(full) == 10 and seven == 7 and float(w2[0, 0]) == 6.0
+    with pytest.raises(RuntimeError):
+        LMDBDataset("/nonexistent", "train")                               # no lmdb / legacy pyarrow in this image: loud failure
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "4"], cwd=root, env=dict(os.environ, WORLD_SIZE="2", RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "WORLD_SIZE=2" in r.stderr
