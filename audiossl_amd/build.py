@@ -21,6 +21,8 @@ if os.environ.get("ATST_TALL_STAGES"):
     FLAGS.append("-DATST_TALL_STAGES=" + os.environ["ATST_TALL_STAGES"])
 if os.environ.get("ATST_ABLATE"):          # experiment builds only (tools/gemm_bench.py)
     FLAGS.append("-DATST_ABLATE=" + os.environ["ATST_ABLATE"])
+if os.environ.get("ATST_TRACE"):           # experiment builds only (tools/trace_gemm.py)
+    FLAGS.append("-DATST_TRACE=" + os.environ["ATST_TRACE"])
 if os.environ.get("ATST_NT_STORES"):
     FLAGS.append("-DATST_NT_STORES=" + os.environ["ATST_NT_STORES"])
 

@@ -20,6 +20,9 @@
 #endif
 
 #include <type_traits>
+#ifndef ATST_TRACE
+#define ATST_TRACE 0       // experiment builds (tools/trace_gemm.py): block ATST_TRACE-1 of the row-384 kernel stamps s_memtime at its phase boundaries into p.colsum
+#endif
 
 namespace {
 
@@ -320,7 +323,7 @@ template <int BKT> DEVFN int swz_key(int row) { return BKT == 64 ? (row >> 1) & 
 }
 
 // MI = 4 (256 x 384 tile, each wave 128 x 96 = 12 accumulators): 40 KB staged per 6 units of output = 6.7 KB / unit.
-template <int EPI, int MI, bool LN = false, int BKT = BK>
+template <int EPI, int MI, bool LN = false, int BKT = BK, bool PP = false>
 __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(GemmArgs p) {
   using namespace row384;
   using RG = row384::Geo<MI, BKT>;
@@ -426,6 +429,52 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
       }
     }
   };
+  if constexpr (PP) {
+    // Ping-pong schedule.  The two waves that share a SIMD (wid and wid + 4: wave row 0 and wave row 1 of the tile)
+    // alternate roles every half k-tile: while one runs its 24 MFMAs of tile t, the other issues its LDS-DMA share of
+    // tile t + 2 -- so the block never has all eight waves queueing on the CU's one vector-memory address path while
+    // the matrix pipes idle, nor all eight contending for the matrix pipes while the address path idles (the
+    // lock-step schedule below does exactly that: loads-only 104 us + MFMA-only 91 us = 147 us together).
+    //   phase 2t  : row 0 computes tile t        | row 1 issues tile t+2, waits for its share of tile t+1
+    //   phase 2t+1: row 0 issues tile t+2, waits | row 1 computes tile t
+    // Every wave executes two barriers per k-tile.  Stage (t+2) % 3 == (t-1) % 3 was last read in phases 2t-2 / 2t-1.
+    static_assert(!PP || (NSTG == 3 && LOADS_PER_TILE == 5), "ping-pong schedule is written for the 3-stage, 5-loads-per-wave ring");
+#if ATST_TRACE
+    unsigned long long* trc = reinterpret_cast<unsigned long long*>(p.colsum) + (size_t)wid * 64 * 8;
+    const bool trace = EPI == EPI_BF16 && p.colsum && (int)blockIdx.x == ATST_TRACE - 1 && lane == 0;
+#define STAMP(k, i) do { if (trace && (k) < 64) trc[(k) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(k, i) do { } while (0)
+#endif
+    STAMP(0, 6);
+    issue(0);
+    if (nk > 1) { issue(1); asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int kt = 0; kt < nk; ++kt) {
+      const bool more = kt + 2 < nk;
+      STAMP(kt, 0);
+      if (wm == 0) {
+        tile(kt, std::false_type{});
+        STAMP(kt, 1);
+        asm volatile("s_barrier" ::: "memory");
+        STAMP(kt, 2);
+        if (more) { issue(kt + 2); STAMP(kt, 3); asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(kt, 4);
+        asm volatile("s_barrier" ::: "memory");
+      } else {
+        if (more) { issue(kt + 2); STAMP(kt, 3); asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(kt, 4);
+        asm volatile("s_barrier" ::: "memory");
+        STAMP(kt, 2);
+        tile(kt, std::false_type{});
+        STAMP(kt, 1);
+        asm volatile("s_barrier" ::: "memory");
+      }
+      STAMP(kt, 5);
+    }
+  } else {
 #pragma unroll
   for (int t = 0; t < NSTG - 1; ++t)
     if (t < nk) issue(t);
@@ -442,13 +491,22 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
 #if ATST_ABLATE != 4 && ATST_ABLATE != 6
     if (!ILV) issue(kt + NSTG - 1);
 #endif
+#if ATST_TRACE
+    { unsigned long long* trc = reinterpret_cast<unsigned long long*>(p.colsum) + (size_t)wid * 64 * 8;
+      if (EPI == EPI_BF16 && p.colsum && (int)blockIdx.x == ATST_TRACE - 1 && lane == 0 && kt < 64) trc[kt * 8 + 0] = __builtin_amdgcn_s_memtime(); }
+#endif
     tile(kt, std::true_type{});
+#if ATST_TRACE
+    { unsigned long long* trc = reinterpret_cast<unsigned long long*>(p.colsum) + (size_t)wid * 64 * 8;
+      if (EPI == EPI_BF16 && p.colsum && (int)blockIdx.x == ATST_TRACE - 1 && lane == 0 && kt < 64) trc[kt * 8 + 1] = __builtin_amdgcn_s_memtime(); }
+#endif
   }
   for (int kt = nfull; kt < nk; ++kt) {                           // drain: nothing left to fetch
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     tile(kt, std::false_type{});
   }
   asm volatile("s_barrier" ::: "memory");
+  }
 
   // Epilogue: the fp32 tile goes through LDS 32 rows at a time so that every global access is a 16-B piece of a full
   // 384-column row.  Part (mi, h) takes 16 rows of accumulator block mi from EVERY wave (two 16-row groups, one per
@@ -818,6 +876,7 @@ int g_tn_tall = 1;        // wgrad: 192 x 384 LDS-DMA tile when N % 192 == 0, K 
 int g_row384_auto = 1;      // use the 128x384 tile whenever N % 384 == 0 (tuning hook 300 turns it off)
 int g_row384_tall = 2;      // 256 x 384 tiles for M >= 8192: 2 = every epilogue, 1 = plain bf16 GEMMs only, 0 = never (tuning hooks 304 / 303 / 302)
 int g_tn_rounds = 1;      // wgrad grid = this many rounds of 512 resident blocks (tuning hook 110 + r); 1 measured best (-20 %)
+int g_row384_pp = 0;        // ping-pong main loop of the 256-row tile (tuning hook 321 = on)
 int g_row384_bk64 = 0;      // 256-row tile with 64-deep ring stages, whole 128-B lines per LDS-DMA lane group, 2 stages (tuning hook 311 = on): measured 2-5 % slower than 3 x 32-deep
 int g_dgelu_row384 = 0;   // dGELU GEMM on the row-384 tile (tuning hook 307 = on): measured slower (LDS-atomic column sums, 78.8 vs 70.5 ms/step)
 int g_nt_variant = -1;    // -1 auto ; 0: 128x128 2-stage ; 1: 128x128 3-stage ; 2: 256x128 8 waves ; 3: 256x128 4 waves of 128x64
@@ -850,17 +909,17 @@ int launch_nt_cfg(const GemmArgs& a, hipStream_t st) {
   hipLaunchKernelGGL((gemm_nt_kernel<EPI, BMT, NSTG, WTM>), dim3(nblk), dim3(G::THREADS), G::LDS, st, a);
   return (int)hipGetLastError();
 }
-template <int EPI, int MI, bool LN, int BKT = BK>
+template <int EPI, int MI, bool LN, int BKT = BK, bool PP = false>
 int launch_nt_row384_cfg(const GemmArgs& a, hipStream_t st) {
   using RG = row384::Geo<MI, BKT>;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_row384_kernel<EPI, MI, LN, BKT>, hipFuncAttributeMaxDynamicSharedMemorySize, RG::LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_row384_kernel<EPI, MI, LN, BKT, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, RG::LDS);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
   const int nblk = ((a.M + RG::BMR - 1) / RG::BMR) * (a.N / row384::BNR);
-  hipLaunchKernelGGL((gemm_nt_row384_kernel<EPI, MI, LN, BKT>), dim3(nblk), dim3(row384::THREADS), RG::LDS, st, a);
+  hipLaunchKernelGGL((gemm_nt_row384_kernel<EPI, MI, LN, BKT, PP>), dim3(nblk), dim3(row384::THREADS), RG::LDS, st, a);
   return (int)hipGetLastError();
 }
 template <int EPI>
@@ -870,6 +929,12 @@ int launch_nt_row384(const GemmArgs& a, hipStream_t st) {
   // 256-row tiles: the operand ring of one block covers twice the output (6.7 vs 10.7 KB staged per 128x128 unit)
   const bool tall = a.M >= 8192 && (g_row384_tall == 2 || (g_row384_tall == 1 && EPI == EPI_BF16 && (a.K >= 768 || a.N >= 768)));
   const bool deep = tall && g_row384_bk64 && a.K % 64 == 0;        // 64-deep ring stages
+  if (tall && g_row384_pp && ATST_TALL_STAGES == 3) {               // ping-pong main loop (tuning hook 320 / 321)
+    if constexpr (EPI == EPI_RESID) {
+      if (a.ln_out) return launch_nt_row384_cfg<EPI, 4, true, BK, true>(a, st);
+    }
+    return launch_nt_row384_cfg<EPI, 4, false, BK, true>(a, st);
+  }
   if constexpr (EPI == EPI_RESID) {
     if (a.ln_out) return deep ? launch_nt_row384_cfg<EPI, 4, true, 64>(a, st) : tall ? launch_nt_row384_cfg<EPI, 4, true>(a, st) : launch_nt_row384_cfg<EPI, 2, true>(a, st);
   }
@@ -893,7 +958,7 @@ int launch_nt(const GemmArgs& a, hipStream_t st) {
 
 }  // namespace
 
-void atst_gemm_nt_set_variant(int v) { if (v >= 310) g_row384_bk64 = v - 310; else if (v >= 306) g_dgelu_row384 = v - 306; else if (v >= 302) g_row384_tall = v - 302; else if (v >= 300) g_row384_auto = v - 300; else if (v >= 110) g_tn_rounds = v - 110; else if (v >= 105) g_tn_tall = v - 105; else if (v < 100) g_nt_variant = v; }
+void atst_gemm_nt_set_variant(int v) { if (v >= 320) g_row384_pp = v - 320; else if (v >= 310) g_row384_bk64 = v - 310; else if (v >= 306) g_dgelu_row384 = v - 306; else if (v >= 302) g_row384_tall = v - 302; else if (v >= 300) g_row384_auto = v - 300; else if (v >= 110) g_tn_rounds = v - 110; else if (v >= 105) g_tn_tall = v - 105; else if (v < 100) g_nt_variant = v; }
 
 int atst_gemm_nt(const GemmArgs& a0, hipStream_t st) {
   GemmArgs a = a0;

@@ -118,6 +118,8 @@ def load(path: Optional[str] = None):
         fn.restype, fn.argtypes = res, args
     if path is None:
         _lib = lib
+        for v in filter(None, os.environ.get("ATST_TUNE", "").split(",")):      # tuning hooks for A/B runs (include/atst_hip.h)
+            lib.atst_tune_gemm_variant(int(v))
     return lib
 
 

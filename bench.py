@@ -159,8 +159,6 @@ def main():
     from audiossl_amd.frontend import LogMelFrontend
     from audiossl_amd.utils.common import cosine_scheduler_step
     lib = hip.load()
-    for v in filter(None, os.environ.get("ATST_TUNE", "").split(",")):      # tuning hooks for A/B runs (tools/bench_kernels.py)
-        lib.atst_tune_gemm_variant(int(v))
 
     B, frame = args.batch, args.workload == "frame"
     ncrops = 6 if args.workload == "clip6" else 2
