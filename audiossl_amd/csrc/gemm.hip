@@ -20,6 +20,9 @@
 #endif
 
 #include <type_traits>
+#ifndef ATST_TRACE_FINE
+#define ATST_TRACE_FINE 0   // 1: also stamp every k-tile of the main loop (tools/trace_gemm.py; perturbs the loop)
+#endif
 #ifndef ATST_TRACE
 #define ATST_TRACE 0       // experiment builds (tools/trace_gemm.py): block ATST_TRACE-1 of the row-384 kernel stamps s_memtime at its phase boundaries into p.colsum
 #endif
@@ -36,6 +39,16 @@ constexpr int C_LD = BN + 4;                   // fp32 epilogue staging tile [12
 // waited on without also waiting for that store to be acknowledged by L2, so a load -> store -> load -> store sequence
 // costs one full memory round trip per store (measured: that was ~half of every GEMM's time).
 struct EpiAux { f32x4 a0, a1; float s; };
+
+// Blocks of one launch start together and every tile costs the same, so all CUs (and both blocks of a CU) run their
+// main loops -- HBM reads only -- and then their epilogues -- HBM writes only -- in lock step.  Delaying every other
+// first-round block by about half a tile time puts half of the chip in each phase at any moment.
+DEVFN void phase_skew(int cycles) {
+  if (cycles > 0) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)cycles) __builtin_amdgcn_s_sleep(16);
+  }
+}
 
 template <int EPI, bool SCALE = true>
 DEVFN void epi_fetch8(const GemmArgs& p, int row, int col, EpiAux& x) {
@@ -323,7 +336,9 @@ template <int BKT> DEVFN int swz_key(int row) { return BKT == 64 ? (row >> 1) & 
 }
 
 // MI = 4 (256 x 384 tile, each wave 128 x 96 = 12 accumulators): 40 KB staged per 6 units of output = 6.7 KB / unit.
-template <int EPI, int MI, bool LN = false, int BKT = BK, bool PP = false>
+// DIR: epilogue straight from the accumulator registers (below).  The MFMA operands are then swapped (C^T = B A^T), so
+// that a lane owns ONE output row (m = lane & 31) and its registers run along n.
+template <int EPI, int MI, bool LN = false, int BKT = BK, bool PP = false, bool DIR = false>
 __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(GemmArgs p) {
   using namespace row384;
   using RG = row384::Geo<MI, BKT>;
@@ -337,7 +352,12 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
   const int ntm = (p.M + BMR - 1) / BMR;
   const int id = xcd_remap(blockIdx.x, ntm * ntn);
   const int m0 = (id / ntn) * BMR, n0 = (id % ntn) * BNR;
+  if (MI == 4 && blockIdx.x < 256 && ((blockIdx.x >> 3) & 1)) phase_skew(p.skew);     // one block per CU: every other CU of each XCD
 
+#if ATST_TRACE
+  if (EPI != EPI_DGELU && p.colsum && (int)blockIdx.x == ATST_TRACE - 1 && lane == 0)
+    (reinterpret_cast<unsigned long long*>(p.colsum) + (size_t)wid * 64 * 8)[7] = __builtin_amdgcn_s_memtime();
+#endif
   char* lds = smem_raw;
   const int lrow = lane / RG::CPR, lchunk = lane % RG::CPR;
   const bf16* srcA[RG::A_IPW]; const bf16* srcB[RG::B_IPW];
@@ -416,7 +436,7 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
         asm volatile("" :: "v"(af[mi]), "v"(bf[0]), "v"(bf[1]), "v"(bf[2]));
 #else
 #pragma unroll
-        for (int ni = 0; ni < 3; ++ni) acc[mi][ni] = mfma32(af[mi], bf[ni], acc[mi][ni]);
+        for (int ni = 0; ni < 3; ++ni) acc[mi][ni] = DIR ? mfma32(bf[ni], af[mi], acc[mi][ni]) : mfma32(af[mi], bf[ni], acc[mi][ni]);
 #endif
 #if ATST_ABLATE != 4 && ATST_ABLATE != 6
         if (ILV && ISSUE && slot < LOADS_PER_TILE) {
@@ -441,7 +461,7 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
     static_assert(!PP || (NSTG == 3 && LOADS_PER_TILE == 5), "ping-pong schedule is written for the 3-stage, 5-loads-per-wave ring");
 #if ATST_TRACE
     unsigned long long* trc = reinterpret_cast<unsigned long long*>(p.colsum) + (size_t)wid * 64 * 8;
-    const bool trace = EPI == EPI_BF16 && p.colsum && (int)blockIdx.x == ATST_TRACE - 1 && lane == 0;
+    const bool trace = ATST_TRACE_FINE && EPI == EPI_BF16 && p.colsum && (int)blockIdx.x == ATST_TRACE - 1 && lane == 0;
 #define STAMP(k, i) do { if (trace && (k) < 64) trc[(k) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define STAMP(k, i) do { } while (0)
@@ -493,12 +513,12 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
 #endif
 #if ATST_TRACE
     { unsigned long long* trc = reinterpret_cast<unsigned long long*>(p.colsum) + (size_t)wid * 64 * 8;
-      if (EPI == EPI_BF16 && p.colsum && (int)blockIdx.x == ATST_TRACE - 1 && lane == 0 && kt < 64) trc[kt * 8 + 0] = __builtin_amdgcn_s_memtime(); }
+      if (ATST_TRACE_FINE && EPI == EPI_BF16 && p.colsum && (int)blockIdx.x == ATST_TRACE - 1 && lane == 0 && kt < 64) trc[kt * 8 + 0] = __builtin_amdgcn_s_memtime(); }
 #endif
     tile(kt, std::true_type{});
 #if ATST_TRACE
     { unsigned long long* trc = reinterpret_cast<unsigned long long*>(p.colsum) + (size_t)wid * 64 * 8;
-      if (EPI == EPI_BF16 && p.colsum && (int)blockIdx.x == ATST_TRACE - 1 && lane == 0 && kt < 64) trc[kt * 8 + 1] = __builtin_amdgcn_s_memtime(); }
+      if (ATST_TRACE_FINE && EPI == EPI_BF16 && p.colsum && (int)blockIdx.x == ATST_TRACE - 1 && lane == 0 && kt < 64) trc[kt * 8 + 1] = __builtin_amdgcn_s_memtime(); }
 #endif
   }
   for (int kt = nfull; kt < nk; ++kt) {                           // drain: nothing left to fetch
@@ -508,6 +528,155 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
   asm volatile("s_barrier" ::: "memory");
   }
 
+#if ATST_TRACE
+  unsigned long long* trc2 = reinterpret_cast<unsigned long long*>(p.colsum) + (size_t)wid * 64 * 8;
+  const bool trace2 = EPI != EPI_DGELU && p.colsum && (int)blockIdx.x == ATST_TRACE - 1 && lane == 0;
+#define STAMP2(i) do { if (trace2) trc2[(i) * 8 + 7] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP2(i) do { } while (0)
+#endif
+  STAMP2(1);
+  if constexpr (DIR) {
+    // ---- epilogue straight from the accumulator registers --------------------------------------------------------------
+    // Measured (tools/trace_epi.py, profiles/r02_trace_epi.txt): staging the tile through LDS costs ~1.9 k cycles for each
+    // of its 8 parts whatever the epilogue does (24 ds_write_b32 per lane, two block barriers, conflicted read-back) =
+    // 15 k cycles per tile against a 29 k main loop at K = 384; and an epilogue that loads (residual) pays one exposed HBM
+    // round trip per part (8.8 k cycles each).  With the swapped MFMA orientation a lane owns row m = lane & 31 of each
+    // 32 x 32 accumulator block and 4-column groups {8 g + 4 hi .. + 3}; one v_permlane32_swap per register pair trades
+    // groups between the half-waves so that every lane holds two runs of 8 consecutive columns (16 hi + 8 k .. + 7).  Those
+    // runs are exactly what epi_fetch8 / epilogue8 work on: 16-B (bf16) / 2 x 16-B (fp32) global accesses per run, no LDS
+    // round trip, no barrier (the fused LayerNorm needs one per 32-row block for the cross-wave row statistics), and the
+    // residual loads of a whole accumulator row block are in flight at once (12 KB per wave).
+    float* sBias = reinterpret_cast<float*>(smem_raw);
+    float* sGamma = sBias + BNR; float* sBeta = sGamma + BNR;
+    float* sScale = sBeta + BNR;                                  // [BMR]
+    float* sStat = sScale + BMR;                                  // [4 wave columns][BMR rows][2]: (mean, M2) of 96 columns
+    constexpr bool fused_ln = LN && EPI == EPI_RESID;
+    if (tid < BNR) {
+      sBias[tid] = p.bias ? p.bias[n0 + tid] : 0.f;
+      if (fused_ln) { sGamma[tid] = p.ln_gamma[tid]; sBeta[tid] = p.ln_beta[tid]; }
+    }
+    if constexpr (EPI == EPI_RESID) {
+      if (tid < BMR) { const int row = m0 + tid; sScale[tid] = (p.row_scale && row < p.M) ? p.row_scale[row / p.rows_per_seq] : 1.0f; }
+    }
+    __syncthreads();
+    auto swap_runs = [&](f32x16& v) {                             // afterwards run k = {v[4k..4k+3], v[4k+8..4k+11]}: columns 16 hi + 8 k .. + 7
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float fa = v[4 * k + e], fb = v[4 * k + 8 + e];    // (bit_cast straight on a vector-element lvalue reads element 0: clang quirk)
+          auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, fa), __builtin_bit_cast(unsigned, fb), false, false);
+          const unsigned r0 = r[0], r1 = r[1];
+          v[4 * k + e] = __builtin_bit_cast(float, r0); v[4 * k + 8 + e] = __builtin_bit_cast(float, r1);
+        }
+    };
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int trow = wm * 32 * MI + mi * 32 + l31, row = m0 + trow;
+      const bool live = row < p.M;
+      const int cbase = wn * 96 + 16 * hi;                        // + ni * 32 + 8 * k
+      if constexpr (!fused_ln) {
+        EpiAux aux[3][2];
+#pragma unroll
+        for (int ni = 0; ni < 3; ++ni)
+#pragma unroll
+          for (int k = 0; k < 2; ++k)
+            if (live) epi_fetch8<EPI, false>(p, row, n0 + cbase + ni * 32 + 8 * k, aux[ni][k]);
+#pragma unroll
+        for (int ni = 0; ni < 3; ++ni) {
+          swap_runs(acc[mi][ni]);
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int c = cbase + ni * 32 + 8 * k;
+            const f32x16& v = acc[mi][ni];
+            f32x4 v0 = {v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]}, v1 = {v[4 * k + 8], v[4 * k + 9], v[4 * k + 10], v[4 * k + 11]};
+            if (live) {
+              f32x4 w0, w1;
+              if constexpr (EPI == EPI_RESID) aux[ni][k].s = sScale[trow];
+              epilogue8<EPI>(p, row, n0 + c, v0, v1, *reinterpret_cast<const f32x4*>(sBias + c), *reinterpret_cast<const f32x4*>(sBias + c + 4), aux[ni][k], w0, w1);
+            }
+          }
+        }
+      } else {
+        // residual + LayerNorm of the next sub-layer.  Row statistics: the lane pair (hi = 0, 1) of every wave column holds
+        // 96 of the row's 384 values -> (mean, M2) of those 96, exchanged through LDS, combined exactly (equal counts).
+        f32x4 rr[3][2][2];
+#pragma unroll
+        for (int ni = 0; ni < 3; ++ni)
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const float* src = p.resid + (size_t)row * p.ldc + cbase + ni * 32 + 8 * k;
+            if (live) { rr[ni][k][0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src)); rr[ni][k][1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + 4)); }
+          }
+        const float sc = sScale[trow];
+        float s1 = 0.f;
+#pragma unroll
+        for (int ni = 0; ni < 3; ++ni) {
+          swap_runs(acc[mi][ni]);
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int c = cbase + ni * 32 + 8 * k;
+            f32x16& v = acc[mi][ni];
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(sBias + c), b1 = *reinterpret_cast<const f32x4*>(sBias + c + 4);
+            f32x4 o0, o1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              o0[e] = rr[ni][k][0][e] + sc * (v[4 * k + e] + b0[e]);
+              o1[e] = rr[ni][k][1][e] + sc * (v[4 * k + 8 + e] + b1[e]);
+              v[4 * k + e] = o0[e]; v[4 * k + 8 + e] = o1[e];
+              s1 += o0[e] + o1[e];
+            }
+            if (live) {
+              float* dst = reinterpret_cast<float*>(p.C) + (size_t)row * p.ldc + c;
+              __builtin_nontemporal_store(o0, reinterpret_cast<f32x4*>(dst));
+              __builtin_nontemporal_store(o1, reinterpret_cast<f32x4*>(dst + 4));
+            }
+          }
+        }
+        s1 += __shfl_xor(s1, 32, 64);
+        const float mw = s1 * (1.0f / 96.0f);
+        float q = 0.f;
+#pragma unroll
+        for (int ni = 0; ni < 3; ++ni)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { const float d = acc[mi][ni][r] - mw; q += d * d; }
+        q += __shfl_xor(q, 32, 64);
+        if (hi == 0) { sStat[(wn * BMR + trow) * 2] = mw; sStat[(wn * BMR + trow) * 2 + 1] = q; }
+        __syncthreads();
+        float mu = 0.f, m2 = 0.f, mws[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { mws[w] = sStat[(w * BMR + trow) * 2]; mu += mws[w]; m2 += sStat[(w * BMR + trow) * 2 + 1]; }
+        mu *= 0.25f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const float d = mws[w] - mu; m2 += 96.0f * d * d; }
+        const float rs = rsqrtf(m2 * (1.0f / 384.0f) + 1e-6f);
+#pragma unroll
+        for (int ni = 0; ni < 3; ++ni)
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int c = cbase + ni * 32 + 8 * k;
+            const f32x16& v = acc[mi][ni];
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(sGamma + c), g1 = *reinterpret_cast<const f32x4*>(sGamma + c + 4);
+            const f32x4 e0 = *reinterpret_cast<const f32x4*>(sBeta + c), e1 = *reinterpret_cast<const f32x4*>(sBeta + c + 4);
+            float t[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              t[e] = (v[4 * k + e] - mu) * rs * g0[e] + e0[e];
+              t[4 + e] = (v[4 * k + 8 + e] - mu) * rs * g1[e] + e1[e];
+            }
+            if (live) *reinterpret_cast<bf16x8*>(p.ln_out + (size_t)row * 384 + c) = pack8(t);
+          }
+        if (live && wn == 0 && hi == 0) { p.ln_mean[row] = mu; p.ln_rstd[row] = rs; }
+      }
+    }
+#if ATST_TRACE
+    STAMP2(9);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP2(10);
+#endif
+    return;
+  }
   // Epilogue: the fp32 tile goes through LDS 32 rows at a time so that every global access is a 16-B piece of a full
   // 384-column row.  Part (mi, h) takes 16 rows of accumulator block mi from EVERY wave (two 16-row groups, one per
   // wave row), so all waves retire the same 24 accumulator registers per part and the registers freed by the dump hold
@@ -528,6 +697,30 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
   if constexpr (EPI == EPI_RESID) {
     if (tid < BMR) { const int row = m0 + tid; sScale[tid] = (p.row_scale && row < p.M) ? p.row_scale[row / p.rows_per_seq] : 1.0f; }
   }
+  EpiAux auxb[2][fused_ln ? 1 : 3];
+  f32x2 rresb[2][fused_ln ? 4 : 1][3];
+  auto epi_prefetch = [&](int part, EpiAux (&aux)[fused_ln ? 1 : 3], f32x2 (&rres)[fused_ln ? 4 : 1][3]) {
+    const int mi = part >> 1, h = part & 1;
+    auto tile_row = [&](int rl) { return (rl >> 4) * (32 * MI) + mi * 32 + h * 16 + (rl & 15); };
+    if constexpr (fused_ln) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = m0 + tile_row(wid * 4 + q);
+        if (row < p.M) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+            rres[q][k] = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p.resid + (size_t)row * p.ldc + k * 128 + lane * 2));
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int idx = tid + THREADS * i, row = m0 + tile_row(idx / 48);
+        if (row < p.M) epi_fetch8<EPI, false>(p, row, n0 + (idx % 48) * 8, aux[i]);
+      }
+    }
+  };
+  epi_prefetch(0, auxb[0], rresb[0]);
 #pragma unroll
   for (int part = 0; part < NPART; ++part) {
     const int mi = part >> 1, h = part & 1;
@@ -539,28 +732,20 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
         const int lrow = wm * 16 + (r8 & 3) + 8 * (r8 >> 2) + 4 * hi;
         sC[lrow * CLD + wn * 96 + ni * 32 + l31] = acc[mi][ni][h * 8 + r8];
       }
-    EpiAux aux[fused_ln ? 1 : 3];
-    f32x2 rres[fused_ln ? 4 : 1][3];
-    if constexpr (fused_ln) {
-      {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int row = m0 + tile_row(wid * 4 + q);
-          if (row < p.M) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-              rres[q][k] = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p.resid + (size_t)row * p.ldc + k * 128 + lane * 2));
-          }
-        }
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const int idx = tid + THREADS * i, row = m0 + tile_row(idx / 48);
-        if (row < p.M) epi_fetch8<EPI, false>(p, row, n0 + (idx % 48) * 8, aux[i]);
-      }
+    if (part == 3) STAMP2(20);
+    // global loads of the epilogue (residual / saved pre-activation / token table) run ONE PART AHEAD: part p's were
+    // issued before part p-1's staging barrier, part p+1's go out here.  Issued at the top of their own part they left a
+    // full HBM round trip exposed in every part (tools/trace_epi.py: 5.6 k of the 8.8 k cycles of a residual part were
+    // that wait, with every CU of the chip in the same phase).
+    EpiAux (&aux)[fused_ln ? 1 : 3] = auxb[part & 1];
+    f32x2 (&rres)[fused_ln ? 4 : 1][3] = rresb[part & 1];
+    if (part + 1 < NPART) {
+      __builtin_amdgcn_sched_barrier(0);                          // keep these loads BEHIND the accumulator dump above: issued earlier they cost 17 spilled registers
+      epi_prefetch(part + 1, auxb[(part + 1) & 1], rresb[(part + 1) & 1]);
     }
+    if (part == 3) STAMP2(21);
     __syncthreads();
+    if (part == 3) STAMP2(22);
     if constexpr (fused_ln) {
       {
         // Fused residual + LayerNorm of the NEXT sub-layer (N == 384: the block owns whole rows): one wave per row,
@@ -621,12 +806,260 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
         }
       }
     }
+    if (part == 3) STAMP2(23);
     if (part < NPART - 1) __syncthreads();
+    STAMP2(2 + part);
   }
   if constexpr (EPI == EPI_DGELU) {
     if (p.colsum) {
       __syncthreads();
       if (tid < BNR) atomicAdd(p.colsum + n0 + tid, sCol[tid]);
+    }
+  }
+#if ATST_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  STAMP2(10);
+#endif
+}
+
+// ---- 4-wave blocks, two per CU -----------------------------------------------------------------------------------------
+// Same wave tile as the 256 x 384 kernel (128 x 96 = 12 accumulators, 256 registers), but FOUR waves per block so that two
+// independent blocks share a CU (one wave of each per SIMD): while one block is in its epilogue (VALU + stores) or
+// blocked on LDS-DMA issue, the other runs its MFMAs -- the phases that the one-block-per-CU kernel serialises
+// (profiles/r02_trace_gemm.txt: 2608 cycles per k-tile against 1536 of MFMA time, then an epilogue with idle matrix pipes).
+//   WM = 2: waves 2 x 2, block tile 256 x 192.  A row panel is staged by the blocks of both column halves (the second read
+//           is an L2 hit), B half as often per row: the best operand mix measured (tools/probes/mix_probe: A 6.1 TB/s).
+//   WM = 1: waves 1 x 4, block tile 128 x 384: whole rows, for the residual + LayerNorm epilogue.
+// Operand rings are split: A (the HBM stream) NA stages deep, B (L2-resident weights) two.  vmcnt retires in order per
+// wave, so the operands are issued by DIFFERENT waves (A: wave 0 [and 1]; B: the others): the A loaders keep NA - 2 tiles
+// in flight behind the one being waited for, which a wave that also issued B could not (waiting for B(t+1) would retire
+// every older A load first).  ~48 KB of HBM reads in flight per CU is what the memory system needs to stream at full rate
+// (tools/probes/l2lds_probe: 10 B/clk/CU x ~4800 clk).
+namespace w4 {
+template <int WM> struct Geo {
+  static constexpr int WN = 4 / WM, BM = 128 * WM, BNB = 96 * WN, THREADS = 256;
+  static constexpr int A_STAGE = BM * 64, B_STAGE = BNB * 64;                 // 64-B rows (BK = 32): 8 / 16 KB ; 24 / 12 KB
+  static constexpr int NA = WM == 1 ? 4 : 3, NB = 2;
+  static constexpr int A_BYTES = NA * A_STAGE, RING = A_BYTES + NB * B_STAGE;  // 32 + 48 = 80 KB ; 48 + 24 = 72 KB
+  static constexpr int CLD = BNB + 4, RP = 16 * WM;                           // staged rows per epilogue part
+  static constexpr int EPI_BYTES = RP * CLD * 4 + 3 * BNB * 4 + BM * 4;
+  static constexpr int LDS = RING > EPI_BYTES ? RING : EPI_BYTES;
+  static constexpr int A_WAVES = WM == 1 ? 1 : 2, B_WAVES = 4 - A_WAVES;
+  static constexpr int PA = (BM / 16) / A_WAVES, PB = (BNB / 16) / B_WAVES;   // 1-KiB pieces per loader wave per k-tile: 8, 8 ; 8, 6
+  static constexpr int SPR = BNB / 8;                                        // 8-column slots per row
+};
+}
+
+template <int EPI, int WM, bool LN = false>
+__global__ __launch_bounds__(256, 2) void gemm_nt_w4_kernel(GemmArgs p) {
+  using G = w4::Geo<WM>;
+  constexpr int WN = G::WN, BM = G::BM, BNB = G::BNB, CLD = G::CLD, NA = G::NA, NB = G::NB, MI = 4;
+  static_assert(!LN || WM == 1, "the fused LayerNorm needs whole rows");
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  typedef const void __attribute__((address_space(1))) * gptr_t;
+  typedef void __attribute__((address_space(3))) * lptr_t;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WN, wn = wid % WN, hi = lane >> 5, l31 = lane & 31;
+  const int ntn = p.N / BNB;
+  const int ntm = (p.M + BM - 1) / BM;
+  const int id = xcd_remap(blockIdx.x, ntm * ntn);
+  const int m0 = (id / ntn) * BM, n0 = (id % ntn) * BNB;
+  if (blockIdx.x >= 256 && blockIdx.x < 512) phase_skew(p.skew);                      // two blocks per CU: the second of each pair
+
+  char* ldsA = smem_raw; char* ldsB = smem_raw + G::A_BYTES;
+  const bool a_loader = wid < G::A_WAVES;
+  const int lrow = lane >> 2, lchunk = lane & 3;
+  // per-lane source of piece 0 of this wave's share; piece j is 16 rows further down
+  const bf16* src;
+  int piece0;
+  if (a_loader) {
+    piece0 = wid * G::PA;
+    const int row = piece0 * 16 + lrow;
+    int ra = m0 + row; ra = ra < p.M ? ra : p.M - 1;               // clamp: rows >= M are never stored
+    src = p.A + (size_t)ra * p.lda + (lchunk ^ ((row >> 2) & 3)) * 8;
+  } else {
+    piece0 = (wid - G::A_WAVES) * G::PB;
+    const int row = piece0 * 16 + lrow;
+    src = p.B + (size_t)(n0 + row) * p.ldb + (lchunk ^ ((row >> 2) & 3)) * 8;
+  }
+  // rows >= M inside a piece: only the last M-tile can be ragged; clamp per piece there
+  const bool ragged = m0 + BM > p.M;
+  auto issue = [&](int kt) {
+    if (a_loader) {
+      char* st = ldsA + (kt % NA) * G::A_STAGE + piece0 * 1024;
+#pragma unroll
+      for (int j = 0; j < G::PA; ++j) {
+        const bf16* s_ = src + (size_t)j * 16 * p.lda;
+        if (ragged) {
+          const int row = (piece0 + j) * 16 + lrow;
+          int ra = m0 + row; ra = ra < p.M ? ra : p.M - 1;
+          s_ = p.A + (size_t)ra * p.lda + (lchunk ^ ((row >> 2) & 3)) * 8;
+        }
+        __builtin_amdgcn_global_load_lds((gptr_t)(s_ + kt * BK), (lptr_t)(st + j * 1024), 16, 0, 0);
+      }
+    } else {
+      char* st = ldsB + (kt % NB) * G::B_STAGE + piece0 * 1024;
+#pragma unroll
+      for (int j = 0; j < G::PB; ++j)
+        __builtin_amdgcn_global_load_lds((gptr_t)(src + (size_t)j * 16 * p.ldb + kt * BK), (lptr_t)(st + j * 1024), 16, 0, 0);
+    }
+  };
+  f32x16 acc[MI][3];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = p.K / BK;
+  const int xr = (l31 >> 2) & 3;
+  const int offA = (wm * 128 + l31) * 64, offB = (wn * 96 + l31) * 64;
+  // prologue: A loaders NA - 1 tiles ahead, B loaders NB - 1
+  if (a_loader) {
+#pragma unroll
+    for (int t = 0; t < NA - 1; ++t) if (t < nk) issue(t);
+  } else {
+#pragma unroll
+    for (int t = 0; t < NB - 1; ++t) if (t < nk) issue(t);
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    // my share of tile kt has landed (my younger tiles may still be in flight); barrier => everyone's has, and everyone
+    // is done reading tile kt - 1, whose stages the next issue overwrites
+    if (a_loader) {
+      const int younger = nk - 1 - kt < NA - 2 ? nk - 1 - kt : NA - 2;
+      if (younger >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");       // PA == 8 in both geometries
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // NB == 2: nothing younger
+    }
+    asm volatile("s_barrier" ::: "memory");
+    if (a_loader) { if (kt + NA - 1 < nk) issue(kt + NA - 1); }
+    else { if (kt + NB - 1 < nk) issue(kt + NB - 1); }
+    const char* sa = ldsA + (kt % NA) * G::A_STAGE; const char* sb = ldsB + (kt % NB) * G::B_STAGE;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      const int co = ((ks * 2 + hi) ^ xr) << 4;
+      bf16x8 af[MI], bf[3];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const bf16x8*>(sa + offA + mi * 32 * 64 + co);
+#pragma unroll
+      for (int ni = 0; ni < 3; ++ni) bf[ni] = *reinterpret_cast<const bf16x8*>(sb + offB + ni * 32 * 64 + co);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 3; ++ni) acc[mi][ni] = mfma32(af[mi], bf[ni], acc[mi][ni]);
+    }
+  }
+  asm volatile("s_barrier" ::: "memory");
+
+  // Epilogue: as in the 8-wave kernel, the fp32 tile goes through LDS so that every global access is a 16-B piece of a
+  // contiguous row segment.  Part (mi, h) stages 16 rows of accumulator block mi from every wave: 16 * WM rows x BNB columns.
+  float* sC = reinterpret_cast<float*>(smem_raw);
+  float* sBias = sC + G::RP * CLD;
+  float* sGamma = sBias + BNB; float* sBeta = sGamma + BNB;
+  float* sScale = sBeta + BNB;
+  float* sCol = sGamma;                                           // EPI_DGELU column sums (no LN there)
+  constexpr int NPART = 2 * MI;
+  constexpr bool fused_ln = LN && EPI == EPI_RESID;
+  for (int c = tid; c < BNB; c += 256) {
+    sBias[c] = p.bias ? p.bias[n0 + c] : 0.f;
+    if (fused_ln) { sGamma[c] = p.ln_gamma[c]; sBeta[c] = p.ln_beta[c]; }
+    if (EPI == EPI_DGELU) sCol[c] = 0.f;
+  }
+  if constexpr (EPI == EPI_RESID) {
+    if (tid < BM) { const int row = m0 + tid; sScale[tid] = (p.row_scale && row < p.M) ? p.row_scale[row / p.rows_per_seq] : 1.0f; }
+  }
+#pragma unroll
+  for (int part = 0; part < NPART; ++part) {
+    const int mi = part >> 1, h = part & 1;
+    auto tile_row = [&](int rl) { return (rl >> 4) * 128 + mi * 32 + h * 16 + (rl & 15); };   // staged row -> row of the block tile
+#pragma unroll
+    for (int ni = 0; ni < 3; ++ni)
+#pragma unroll
+      for (int r8 = 0; r8 < 8; ++r8) {
+        const int lr = wm * 16 + (r8 & 3) + 8 * (r8 >> 2) + 4 * hi;
+        sC[lr * CLD + wn * 96 + ni * 32 + l31] = acc[mi][ni][h * 8 + r8];
+      }
+    EpiAux aux[fused_ln ? 1 : 3];
+    f32x2 rres[fused_ln ? 4 : 1][3];
+    if constexpr (fused_ln) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = m0 + tile_row(wid * 4 + q);
+        if (row < p.M) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+            rres[q][k] = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p.resid + (size_t)row * p.ldc + k * 128 + lane * 2));
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int idx = tid + 256 * i, row = m0 + tile_row(idx / G::SPR);
+        if (row < p.M) epi_fetch8<EPI, false>(p, row, n0 + (idx % G::SPR) * 8, aux[i]);
+      }
+    }
+    __syncthreads();
+    if constexpr (fused_ln) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int rl = wid * 4 + q, trow = tile_row(rl), row = m0 + trow;
+        if (row >= p.M) continue;
+        const float sc = sScale[trow];
+        float v[6];
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int col = k * 128 + lane * 2;
+          const f32x2 a2 = *reinterpret_cast<const f32x2*>(sC + rl * CLD + col);
+          const f32x2 b2 = *reinterpret_cast<const f32x2*>(sBias + col);
+          f32x2 o = rres[q][k] + sc * (a2 + b2);
+          __builtin_nontemporal_store(o, reinterpret_cast<f32x2*>(reinterpret_cast<float*>(p.C) + (size_t)row * p.ldc + col));
+          v[2 * k] = o[0]; v[2 * k + 1] = o[1]; sum += o[0] + o[1];
+        }
+        const float mu = wave_sum(sum) * (1.0f / 384.0f);
+        float qd = 0.f;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { const float d = v[k] - mu; qd += d * d; }
+        const float rs = rsqrtf(wave_sum(qd) * (1.0f / 384.0f) + 1e-6f);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int col = k * 128 + lane * 2;
+          const f32x2 g2 = *reinterpret_cast<const f32x2*>(sGamma + col), be2 = *reinterpret_cast<const f32x2*>(sBeta + col);
+          bf16x2 hv;
+          hv[0] = f2bf((v[2 * k] - mu) * rs * g2[0] + be2[0]);
+          hv[1] = f2bf((v[2 * k + 1] - mu) * rs * g2[1] + be2[1]);
+          *reinterpret_cast<bf16x2*>(p.ln_out + (size_t)row * 384 + col) = hv;
+        }
+        if (lane == 0) { p.ln_mean[row] = mu; p.ln_rstd[row] = rs; }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int idx = tid + 256 * i, rl = idx / G::SPR, c8 = (idx % G::SPR) * 8;
+        const int trow = tile_row(rl), row = m0 + trow;
+        if (row < p.M) {
+          f32x4 w0, w1;
+          if constexpr (EPI == EPI_RESID) aux[i].s = sScale[trow];
+          epilogue8<EPI>(p, row, n0 + c8, *reinterpret_cast<const f32x4*>(sC + rl * CLD + c8), *reinterpret_cast<const f32x4*>(sC + rl * CLD + c8 + 4),
+                         *reinterpret_cast<const f32x4*>(sBias + c8), *reinterpret_cast<const f32x4*>(sBias + c8 + 4), aux[i], w0, w1);
+          if constexpr (EPI == EPI_DGELU) {
+            if (p.colsum) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { atomicAdd(sCol + c8 + e, w0[e]); atomicAdd(sCol + c8 + 4 + e, w1[e]); }
+            }
+          }
+        }
+      }
+    }
+    if (part < NPART - 1) __syncthreads();
+  }
+  if constexpr (EPI == EPI_DGELU) {
+    if (p.colsum) {
+      __syncthreads();
+      for (int c = tid; c < BNB; c += 256) atomicAdd(p.colsum + n0 + c, sCol[c]);
     }
   }
 }
@@ -876,6 +1309,7 @@ int g_tn_tall = 1;        // wgrad: 192 x 384 LDS-DMA tile when N % 192 == 0, K 
 int g_row384_auto = 1;      // use the 128x384 tile whenever N % 384 == 0 (tuning hook 300 turns it off)
 int g_row384_tall = 2;      // 256 x 384 tiles for M >= 8192: 2 = every epilogue, 1 = plain bf16 GEMMs only, 0 = never (tuning hooks 304 / 303 / 302)
 int g_tn_rounds = 1;      // wgrad grid = this many rounds of 512 resident blocks (tuning hook 110 + r); 1 measured best (-20 %)
+int g_row384_dir = 0;       // 256-row tile: epilogue straight from the accumulator registers (tuning hook 341 = on)
 int g_row384_pp = 0;        // ping-pong main loop of the 256-row tile (tuning hook 321 = on)
 int g_row384_bk64 = 0;      // 256-row tile with 64-deep ring stages, whole 128-B lines per LDS-DMA lane group, 2 stages (tuning hook 311 = on): measured 2-5 % slower than 3 x 32-deep
 int g_dgelu_row384 = 0;   // dGELU GEMM on the row-384 tile (tuning hook 307 = on): measured slower (LDS-atomic column sums, 78.8 vs 70.5 ms/step)
@@ -909,26 +1343,68 @@ int launch_nt_cfg(const GemmArgs& a, hipStream_t st) {
   hipLaunchKernelGGL((gemm_nt_kernel<EPI, BMT, NSTG, WTM>), dim3(nblk), dim3(G::THREADS), G::LDS, st, a);
   return (int)hipGetLastError();
 }
-template <int EPI, int MI, bool LN, int BKT = BK, bool PP = false>
+template <int EPI, int MI, bool LN, int BKT = BK, bool PP = false, bool DIR = false>
 int launch_nt_row384_cfg(const GemmArgs& a, hipStream_t st) {
   using RG = row384::Geo<MI, BKT>;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_row384_kernel<EPI, MI, LN, BKT, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, RG::LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_row384_kernel<EPI, MI, LN, BKT, PP, DIR>, hipFuncAttributeMaxDynamicSharedMemorySize, RG::LDS);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
   const int nblk = ((a.M + RG::BMR - 1) / RG::BMR) * (a.N / row384::BNR);
-  hipLaunchKernelGGL((gemm_nt_row384_kernel<EPI, MI, LN, BKT, PP>), dim3(nblk), dim3(row384::THREADS), RG::LDS, st, a);
+  hipLaunchKernelGGL((gemm_nt_row384_kernel<EPI, MI, LN, BKT, PP, DIR>), dim3(nblk), dim3(row384::THREADS), RG::LDS, st, a);
+  return (int)hipGetLastError();
+}
+int g_w4_auto = 1;          // hook 360 / 361: 4-wave kernels for launches of fewer than 1.5 rounds of 256 x 384 tiles
+int g_skew = 0;             // hook 100000 + c: phase skew in shader cycles per k-tile of the main loop (0 = off)
+int g_w4_min_m = 8192;     // hook 351: use the 4-wave kernels for every M (parity tests run small shapes)
+int g_w4_mode = 0;          // 4-wave two-blocks-per-CU kernels (tuning hook 330 + m): 0 off ; 1 = 128x384 for everything ; 2 = 256x192 (plain epilogues) + 128x384 (fused LayerNorm) ; 3 = 256x192 for the plain epilogues only
+template <int EPI, int WM, bool LN>
+int launch_nt_w4_cfg(const GemmArgs& a, hipStream_t st) {
+  using G = w4::Geo<WM>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<EPI, WM, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  const int nblk = ((a.M + G::BM - 1) / G::BM) * (a.N / G::BNB);
+  hipLaunchKernelGGL((gemm_nt_w4_kernel<EPI, WM, LN>), dim3(nblk), dim3(256), G::LDS, st, a);
   return (int)hipGetLastError();
 }
 template <int EPI>
-int launch_nt_row384(const GemmArgs& a, hipStream_t st) {
+int launch_nt_row384(const GemmArgs& a0, hipStream_t st) {
+  GemmArgs a = a0;
+  a.skew = g_skew * (a.K / BK);
   ProfScope ps(PK_GEMM_NT0 + EPI, 2.0 * a.M * a.N * a.K, st, nt_bytes<EPI>(a));
 
+  // Fewer than 1.5 rounds of 256 x 384 tiles (the 1 s local views: M = 32768, N = 384 -> 128 blocks on 256 CUs): the 4-wave
+  // kernels launch twice as many, half as large blocks, two per CU.  Measured at M = 32768 (profiles/r02_gemm_bench.txt):
+  // proj+resid 49 -> 36 us, fc2+resid 96 -> 75, fc1 dgrad 67 -> 53, qkv dgrad 48 -> 39, qkv fwd 47 -> 43; at M = 131072 the
+  // 8-wave tile is 10-25 % faster (B is staged once per 256 rows), and fc1+GELU (N = 1536) is never better on 4 waves.
+  const long tiles8 = (long)((a.M + 255) / 256) * (a.N / 384);
+  const bool small_grid = g_w4_auto && a.M >= 2048 && tiles8 <= 384 && EPI != EPI_BIAS_GELU && EPI != EPI_DGELU && EPI != EPI_PATCH;
+  if ((g_w4_mode && a.M >= g_w4_min_m) || small_grid) {
+    const int w4m = g_w4_mode ? g_w4_mode : 2;
+    if constexpr (EPI == EPI_RESID) {
+      if (a.ln_out) { if (w4m != 3) return launch_nt_w4_cfg<EPI, 1, true>(a, st); }
+      else return w4m == 1 ? launch_nt_w4_cfg<EPI, 1, false>(a, st) : launch_nt_w4_cfg<EPI, 2, false>(a, st);
+    } else {
+      return w4m == 1 ? launch_nt_w4_cfg<EPI, 1, false>(a, st) : launch_nt_w4_cfg<EPI, 2, false>(a, st);
+    }
+  }
   // 256-row tiles: the operand ring of one block covers twice the output (6.7 vs 10.7 KB staged per 128x128 unit)
-  const bool tall = a.M >= 8192 && (g_row384_tall == 2 || (g_row384_tall == 1 && EPI == EPI_BF16 && (a.K >= 768 || a.N >= 768)));
+  const bool tall = a.M >= (g_w4_min_m < 8192 ? g_w4_min_m : 8192) && (g_row384_tall == 2 || (g_row384_tall == 1 && EPI == EPI_BF16 && (a.K >= 768 || a.N >= 768)));
   const bool deep = tall && g_row384_bk64 && a.K % 64 == 0;        // 64-deep ring stages
+  if constexpr (EPI == EPI_BF16 || EPI == EPI_F32 || EPI == EPI_BIAS_GELU || EPI == EPI_RESID) {
+    if (tall && g_row384_dir && ATST_TALL_STAGES == 3) {            // epilogue straight from the registers (tuning hook 340 = off / 341 = on)
+      if constexpr (EPI == EPI_RESID) {
+        if (a.ln_out) return launch_nt_row384_cfg<EPI, 4, true, BK, false, true>(a, st);
+      }
+      return launch_nt_row384_cfg<EPI, 4, false, BK, false, true>(a, st);
+    }
+  }
   if (tall && g_row384_pp && ATST_TALL_STAGES == 3) {               // ping-pong main loop (tuning hook 320 / 321)
     if constexpr (EPI == EPI_RESID) {
       if (a.ln_out) return launch_nt_row384_cfg<EPI, 4, true, BK, true>(a, st);
@@ -958,7 +1434,7 @@ int launch_nt(const GemmArgs& a, hipStream_t st) {
 
 }  // namespace
 
-void atst_gemm_nt_set_variant(int v) { if (v >= 320) g_row384_pp = v - 320; else if (v >= 310) g_row384_bk64 = v - 310; else if (v >= 306) g_dgelu_row384 = v - 306; else if (v >= 302) g_row384_tall = v - 302; else if (v >= 300) g_row384_auto = v - 300; else if (v >= 110) g_tn_rounds = v - 110; else if (v >= 105) g_tn_tall = v - 105; else if (v < 100) g_nt_variant = v; }
+void atst_gemm_nt_set_variant(int v) { if (v >= 100000) g_skew = v - 100000; else if (v >= 360) g_w4_auto = v - 360; else if (v >= 350) g_w4_min_m = v == 351 ? 1 : 8192; else if (v >= 340) g_row384_dir = v - 340; else if (v >= 330) g_w4_mode = v - 330; else if (v >= 320) g_row384_pp = v - 320; else if (v >= 310) g_row384_bk64 = v - 310; else if (v >= 306) g_dgelu_row384 = v - 306; else if (v >= 302) g_row384_tall = v - 302; else if (v >= 300) g_row384_auto = v - 300; else if (v >= 110) g_tn_rounds = v - 110; else if (v >= 105) g_tn_tall = v - 105; else if (v < 100) g_nt_variant = v; }
 
 int atst_gemm_nt(const GemmArgs& a0, hipStream_t st) {
   GemmArgs a = a0;

@@ -21,6 +21,7 @@ struct GemmArgs {
   // EPI_RESID with N == 384: optional fused LayerNorm(eps 1e-6) of the output row (the next sub-layer's pre-LN)
   const float* ln_gamma; const float* ln_beta; bf16* ln_out; float* ln_mean; float* ln_rstd;
   float* colsum;                     // EPI_DGELU: optional fp32 [N] accumulator of the column sums of the output (bias gradient)
+  int skew;                          // start-up delay (shader cycles) of every other first-round block: de-phases main loops and epilogues
 };
 int atst_gemm_nt(const GemmArgs& a, hipStream_t st);
 void atst_gemm_nt_set_variant(int v);     // tuning hook: -1 auto, 0/1/2 fixed tile configuration
