@@ -697,11 +697,22 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
   if constexpr (EPI == EPI_RESID) {
     if (tid < BMR) { const int row = m0 + tid; sScale[tid] = (p.row_scale && row < p.M) ? p.row_scale[row / p.rows_per_seq] : 1.0f; }
   }
-  EpiAux auxb[2][fused_ln ? 1 : 3];
-  f32x2 rresb[2][fused_ln ? 4 : 1][3];
-  auto epi_prefetch = [&](int part, EpiAux (&aux)[fused_ln ? 1 : 3], f32x2 (&rres)[fused_ln ? 4 : 1][3]) {
+#pragma unroll
+  for (int part = 0; part < NPART; ++part) {
     const int mi = part >> 1, h = part & 1;
-    auto tile_row = [&](int rl) { return (rl >> 4) * (32 * MI) + mi * 32 + h * 16 + (rl & 15); };
+    auto tile_row = [&](int rl) { return (rl >> 4) * (32 * MI) + mi * 32 + h * 16 + (rl & 15); };   // staged row -> row of the block tile
+#pragma unroll
+    for (int ni = 0; ni < 3; ++ni)
+#pragma unroll
+      for (int r8 = 0; r8 < 8; ++r8) {
+        const int lrow = wm * 16 + (r8 & 3) + 8 * (r8 >> 2) + 4 * hi;
+        sC[lrow * CLD + wn * 96 + ni * 32 + l31] = acc[mi][ni][h * 8 + r8];
+      }
+    if (part == 3) STAMP2(20);
+    // (Issuing these loads one part ahead was measured: no gain -- 219 vs 218 us on fc2+residual -- and 17 spilled
+    // registers; a part's time is set by the CU's memory throughput, not by the exposed round trip.)
+    EpiAux aux[fused_ln ? 1 : 3];
+    f32x2 rres[fused_ln ? 4 : 1][3];
     if constexpr (fused_ln) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -718,30 +729,6 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
         const int idx = tid + THREADS * i, row = m0 + tile_row(idx / 48);
         if (row < p.M) epi_fetch8<EPI, false>(p, row, n0 + (idx % 48) * 8, aux[i]);
       }
-    }
-  };
-  epi_prefetch(0, auxb[0], rresb[0]);
-#pragma unroll
-  for (int part = 0; part < NPART; ++part) {
-    const int mi = part >> 1, h = part & 1;
-    auto tile_row = [&](int rl) { return (rl >> 4) * (32 * MI) + mi * 32 + h * 16 + (rl & 15); };   // staged row -> row of the block tile
-#pragma unroll
-    for (int ni = 0; ni < 3; ++ni)
-#pragma unroll
-      for (int r8 = 0; r8 < 8; ++r8) {
-        const int lrow = wm * 16 + (r8 & 3) + 8 * (r8 >> 2) + 4 * hi;
-        sC[lrow * CLD + wn * 96 + ni * 32 + l31] = acc[mi][ni][h * 8 + r8];
-      }
-    if (part == 3) STAMP2(20);
-    // global loads of the epilogue (residual / saved pre-activation / token table) run ONE PART AHEAD: part p's were
-    // issued before part p-1's staging barrier, part p+1's go out here.  Issued at the top of their own part they left a
-    // full HBM round trip exposed in every part (tools/trace_epi.py: 5.6 k of the 8.8 k cycles of a residual part were
-    // that wait, with every CU of the chip in the same phase).
-    EpiAux (&aux)[fused_ln ? 1 : 3] = auxb[part & 1];
-    f32x2 (&rres)[fused_ln ? 4 : 1][3] = rresb[part & 1];
-    if (part + 1 < NPART) {
-      __builtin_amdgcn_sched_barrier(0);                          // keep these loads BEHIND the accumulator dump above: issued earlier they cost 17 spilled registers
-      epi_prefetch(part + 1, auxb[(part + 1) & 1], rresb[(part + 1) & 1]);
     }
     if (part == 3) STAMP2(21);
     __syncthreads();
