@@ -5,13 +5,16 @@ the C ABI.  The reference is fp32; the HIP path rounds GEMM operands and saved a
 Tolerances (each justified by a measurement recorded in DESIGN.md "Precision"):
   * integer / index work (patch gather, valid lengths, ragged row order, untouched mask_embed): bit-exact
   * forward quantities: tokens 5e-3, block outputs / CLS 1e-2 rel-L2, head outputs 2.5e-2, loss |d| 5e-3, std 2e-3
-  * gradients on a smooth objective (encoder-only golden, 12 layers, ragged lengths, DropPath): per tensor 3e-2,
-    parameter-weighted mean 1.5e-2                                   (measured: mean 6.8e-3, max 9.7e-3)
+  * gradients on a smooth objective (encoder-only golden, 12 layers, ragged lengths, DropPath): per tensor 2.4e-2,
+    parameter-weighted mean 1e-2                                     (measured: mean 6.9e-3, max 1.57e-2; x1.5)
   * head + loss backward given identical input features (oracle run on the HIP features): 1.5e-2
   * full step vs the fp32 reference: gradients pass through two BatchNorm+ReLU heads whose gates are discontinuous; a
     1 % forward perturbation flips ~1 % of the gates and moves every upstream gradient by ~sqrt(1 %) = 10 %
     (the fp32 reference itself moves by 10-27 % when its inputs are merely rounded to bf16).  Checked: last-layer
-    gradients (no gate behind them) 3e-2, every tensor's norm within 5 % (B >= 16), per tensor rel-L2 <= 0.3.
+    gradients (no gate behind them) 3e-2, every tensor's norm within 5 % (B >= 16), per tensor rel-L2 <= 0.19 (B >= 16).
+    test_gradient_gap_is_the_relu_gates pins that gap: with the HIP run's gate patterns injected into the fp32 oracle the
+    difference drops to 1.3-1.7 % (0.4-1.1 % against the bf16-emulating oracle), and the gate patterns alone move the
+    fp32 oracle by the whole gap (profiles/r02_parity_emu.txt, profiles/r02_bf16_floor.txt).
   north_star's "student grads within 1e-3 rel" is therefore NOT met by the bf16 path (nor could any bf16 path meet it).
 """
 import os
@@ -103,7 +106,7 @@ def test_encoder_gradient_vs_reference_golden():
     mean = sum(r * n for r, _, n in tab.values()) / sum(n for _, _, n in tab.values())
     worst = max(tab.items(), key=lambda kv: kv[1][0])
     print(f"\n[encoder grad] weighted mean rel-L2 {mean:.3e}; worst {worst[0]} {worst[1][0]:.3e}")
-    assert mean < 1.5e-2 and worst[1][0] < 3e-2
+    assert mean < 1.0e-2 and worst[1][0] < 2.4e-2            # measured 6.9e-3 / 1.57e-2 (pos_embed) (x1.5)
     assert max(abs(nerr) for _, nerr, _ in tab.values()) < 1e-2
 
 
@@ -143,7 +146,7 @@ def test_base_arch_encoder_vs_oracle():
         if r > worst[1]:
             worst = (name, r)
     print(f"\n[base encoder grad] weighted mean rel-L2 {num / den:.3e}; worst {worst[0]} {worst[1]:.3e}")
-    assert num / den < 1.5e-2 and worst[1] < 3e-2
+    assert num / den < 1.0e-2 and worst[1] < 2.4e-2             # measured 6.9e-3 / 1.6e-2 (x1.5)
 
 
 @pytest.mark.parametrize("width,NP", [(401, 128), (201, 64), (101, 32), (41, 32)])
@@ -274,8 +277,9 @@ def test_clip_step_vs_reference_golden(name):
         if k in CANCELLING:
             continue
         assert abs(nerr) < (5e-2 if big else 0.4), (k, nerr)
-        if big:
-            assert r < 0.3, (k, r)
+        # per-tensor rel-L2 vs the fp32 reference: ALL of it is ReLU-gate flips (test_gradient_gap_is_the_relu_gates);
+        # measured worst tensor 0.125 (B=16), 0.19 (6 crops, B=2), 0.8 (2 views, B=2: four BatchNorm rows) -> x1.5
+        assert r < (0.19 if big else (0.28 if ncrops == 6 else 1.2)), (k, r)
     for k in ("student.projector.1.running_mean", "student.projector.1.running_var", "teacher.projector.1.running_var"):
         net, which, _, buf = k.split(".")
         got = eng.bn_buffers[f"{net}.{which}"][buf].cpu()[sample_idx(4096)].numpy()
@@ -309,7 +313,7 @@ def test_frame_step_vs_reference_golden():
     assert tab["predictor.3.weight"][0] < 3e-2
     for k, (r, nerr, n) in tab.items():                                    # ~650 head rows: well inside the B>=16 regime
         if k not in CANCELLING:
-            assert abs(nerr) < 5e-2 and r < 0.3, (k, r, nerr)
+            assert abs(nerr) < 5e-2 and r < 7.5e-2, (k, r, nerr)          # measured worst 4.8e-2 (x1.5)
 
 
 @pytest.mark.parametrize("name,tol", [("clip_small_2views_b16", dict(g32=(1.9e-2, 2.7e-2), emu=(1.7e-2, 2.8e-2), flip=5e-2)),
