@@ -34,6 +34,21 @@ int atst_gemm_nt_bf16(const uint16_t* A, const uint16_t* B, int M, int N, int K,
   return atst_gemm_nt(a, ST(stream));
 }
 
+int atst_gemm_nt_fp8(const uint8_t* A8, const uint8_t* B8, int M, int N, int K, int lda, int ldb, int epi, void* C, int ldc,
+                     void* C2, const float* bias, const float* resid, const float* row_scale, int rows_per_seq,
+                     const float* dq, float dq_mul, void* stream) {
+  GemmArgs a{};
+  a.A = CBF(A8); a.B = CBF(B8); a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.epi = epi; a.C = C; a.ldc = ldc; a.C2 = C2;
+  a.bias = bias; a.resid = resid; a.row_scale = row_scale; a.rows_per_seq = rows_per_seq > 0 ? rows_per_seq : 1;
+  a.fp8 = 1; a.dq = dq; a.dq_mul = dq_mul;
+  if ((epi == EPI_BIAS_GELU && (!bias || !C2)) || (epi == EPI_RESID && (!bias || !resid)) || epi == EPI_DGELU || epi == EPI_PATCH) return ATST_EINVAL;
+  return atst_gemm_nt(a, ST(stream));
+}
+int atst_quant_fp8_bf16(const uint16_t* x, size_t n, float scale, uint8_t* y, void* stream) { return atst_quant_fp8(CBF(x), n, scale, y, ST(stream)); }
+int atst_quant_weights_fp8(const float* p32, const int32_t* table, int n, uint8_t* p8, float* dq, float* amax, void* stream) {
+  return ::atst_quant_weights_fp8(p32, table, n, p8, dq, amax, ST(stream));
+}
+
 int atst_gemm_tn_bf16(const uint16_t* dY, const uint16_t* X, int M, int N, int K, int ldy, int ldx, float* dW, int ldw,
                       int m_per_split, void* stream) {
   WgradArgs a{};

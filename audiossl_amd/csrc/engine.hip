@@ -17,6 +17,7 @@ struct Ws {
   float* x[2 * ATST_MAX_DEPTH + 1];
   LayerWs L[ATST_MAX_DEPTH];
   bf16* hN; float *meanN, *rstdN;
+  uint8_t *q8a, *q8b;                 // fp8 forward: e4m3 copies of the current GEMM's A operand ([M,C] and [M,4C])
   // backward scratch
   float *dxA, *dxB;
   bf16 *g, *g2, *dh, *du, *dqkv, *d_o, *dout;
@@ -53,6 +54,7 @@ Ws carve(void* ws, int S, int NP, int C, int H, int depth, int train) {
   }
   for (int i = nl; i < depth; ++i) w.L[i] = w.L[0];
   w.hN = c.take<bf16>(M * C); w.meanN = c.take<float>(M); w.rstdN = c.take<float>(M);
+  w.q8a = c.take<uint8_t>(M * C); w.q8b = c.take<uint8_t>(M * 4 * C);
   if (train) {
     w.dxA = c.take<float>(M * C); w.dxB = c.take<float>(M * C);
     w.g = c.take<bf16>(M * C); w.g2 = c.take<bf16>(M * C); w.dh = c.take<bf16>(M * C); w.du = c.take<bf16>(M * 4 * C);
@@ -75,6 +77,16 @@ int gemm(const bf16* A, const bf16* B, int M, int N, int K, int epi, void* C, hi
   a.A = A; a.B = B; a.M = M; a.N = N; a.K = K; a.lda = K; a.ldb = K; a.epi = epi; a.C = C; a.ldc = N; a.C2 = C2;
   a.bias = bias; a.resid = resid; a.row_scale = row_scale; a.rows_per_seq = rps; a.U = U; a.colsum = colsum;
   a.ln_gamma = ln_g; a.ln_beta = ln_b; a.ln_out = ln_out; a.ln_mean = ln_mean; a.ln_rstd = ln_rstd;
+  return atst_gemm_nt(a, st);
+}
+// e4m3 forward GEMM: A8 [M,K] (activation copy, scale act_scale), B8 [N,K] (weight shadow, per-tensor scale in *w_dq)
+constexpr float ACT_SCALE = 8.0f, ACT_SCALE_GELU = 4.0f;   // LayerNorm / attention outputs stay within +-56, GELU outputs within +-112
+int gemm8(const uint8_t* A8, const uint8_t* B8, int M, int N, int K, int epi, void* C, hipStream_t st, const float* w_dq, float act_scale,
+          const float* bias = nullptr, const float* resid = nullptr, const float* row_scale = nullptr, int rps = 1, void* C2 = nullptr) {
+  GemmArgs a{};
+  a.A = reinterpret_cast<const bf16*>(A8); a.B = reinterpret_cast<const bf16*>(B8); a.M = M; a.N = N; a.K = K; a.lda = K; a.ldb = K;
+  a.epi = epi; a.C = C; a.ldc = N; a.C2 = C2; a.bias = bias; a.resid = resid; a.row_scale = row_scale; a.rows_per_seq = rps;
+  a.fp8 = 1; a.dq = w_dq; a.dq_mul = 1.0f / act_scale;
   return atst_gemm_nt(a, st);
 }
 int wgrad(const bf16* dY, const bf16* X, int M, int N, int K, float* dW, hipStream_t st) {
@@ -118,7 +130,9 @@ extern "C" int atst_encoder_fwd(const atst_encoder_t* e, void* stream) {
   const float* p = e->p32; const bf16* q = B16(e->p16);
   const atst_enc_off_t& o = e->off;
 
-  const bool fuse_ln = C == 384;                    // N == 384: the residual GEMM blocks own whole rows
+  const bool f8 = e->fp8 != 0;                      // forward GEMMs on e4m3 copies of the operands (ATST-base recipe, configs[4])
+  if (f8 && (!e->p8 || !e->w_dq || C % 384)) return ATST_EINVAL;
+  const bool fuse_ln = C == 384 && !f8;             // N == 384: the residual GEMM blocks own whole rows
   RUN(atst_patchify(e->mel, S, e->width, NP, e->use_cls, w.patches, st));
   RUN(atst_token_table(e->use_cls ? p + o.cls_token : nullptr, p + o.pos_embed, p + o.patch_b, NP, e->n_tok, C, e->use_cls, w.table, st));
   {
@@ -133,27 +147,45 @@ extern "C" int atst_encoder_fwd(const atst_encoder_t* e, void* stream) {
     const LayerWs& l = w.L[i];
     const float* s1 = e->dp_scale ? e->dp_scale + (size_t)(2 * i) * S : nullptr;
     const float* s2 = e->dp_scale ? e->dp_scale + (size_t)(2 * i + 1) * S : nullptr;
-    if (i == 0 || !fuse_ln) RUN(atst_ln_fwd(w.x[2 * i], p + lo.ln1_w, p + lo.ln1_b, l.h1, l.mean1, l.rstd1, M, C, st));
-    RUN(gemm(l.h1, q + lo.qkv_w, M, 3 * C, C, EPI_BF16, l.qkv, st));
-    AttnArgs at{};
-    at.qkv = l.qkv; at.valid = e->valid; at.o = l.o; at.lse = l.lse; at.S = S; at.H = e->H; at.NP = NP;
-    RUN(atst_attn_fwd(at, st));
-    if (fuse_ln) {                                  // proj + residual + LN2 in one kernel
-      RUN(gemm(l.o, q + lo.proj_w, M, C, C, EPI_RESID, w.x[2 * i + 1], st, p + lo.proj_b, w.x[2 * i], s1, NP, nullptr, nullptr,
-               nullptr, p + lo.ln2_w, p + lo.ln2_b, l.h2, l.mean2, l.rstd2));
-    } else {
-      RUN(gemm(l.o, q + lo.proj_w, M, C, C, EPI_RESID, w.x[2 * i + 1], st, p + lo.proj_b, w.x[2 * i], s1, NP));
+    if (f8) {
+      const uint8_t* q8 = e->p8; const float* dq = e->w_dq + 4 * i;
+      const size_t MC = (size_t)M * C;
+      RUN(atst_ln_fwd(w.x[2 * i], p + lo.ln1_w, p + lo.ln1_b, l.h1, l.mean1, l.rstd1, M, C, st));
+      RUN(atst_quant_fp8(l.h1, MC, ACT_SCALE, w.q8a, st));
+      RUN(gemm8(w.q8a, q8 + lo.qkv_w, M, 3 * C, C, EPI_BF16, l.qkv, st, dq + 0, ACT_SCALE));
+      AttnArgs at{};
+      at.qkv = l.qkv; at.valid = e->valid; at.o = l.o; at.lse = l.lse; at.S = S; at.H = e->H; at.NP = NP;
+      RUN(atst_attn_fwd(at, st));
+      RUN(atst_quant_fp8(l.o, MC, ACT_SCALE, w.q8a, st));
+      RUN(gemm8(w.q8a, q8 + lo.proj_w, M, C, C, EPI_RESID, w.x[2 * i + 1], st, dq + 1, ACT_SCALE, p + lo.proj_b, w.x[2 * i], s1, NP));
       RUN(atst_ln_fwd(w.x[2 * i + 1], p + lo.ln2_w, p + lo.ln2_b, l.h2, l.mean2, l.rstd2, M, C, st));
-    }
-    RUN(gemm(l.h2, q + lo.fc1_w, M, 4 * C, C, EPI_BIAS_GELU, e->train ? l.u : nullptr, st, p + lo.fc1_b, nullptr, nullptr, 1, l.a));
-    if (fuse_ln) {                                  // fc2 + residual + (LN1 of the next block | final norm)
-      const bool last = i + 1 == e->depth;
-      const LayerWs& nl = w.L[last ? i : i + 1];
-      RUN(gemm(l.a, q + lo.fc2_w, M, C, 4 * C, EPI_RESID, w.x[2 * i + 2], st, p + lo.fc2_b, w.x[2 * i + 1], s2, NP, nullptr, nullptr,
-               nullptr, p + (last ? o.norm_w : o.layer[i + 1].ln1_w), p + (last ? o.norm_b : o.layer[i + 1].ln1_b),
-               last ? w.hN : nl.h1, last ? w.meanN : nl.mean1, last ? w.rstdN : nl.rstd1));
+      RUN(atst_quant_fp8(l.h2, MC, ACT_SCALE, w.q8a, st));
+      RUN(gemm8(w.q8a, q8 + lo.fc1_w, M, 4 * C, C, EPI_BIAS_GELU, e->train ? l.u : nullptr, st, dq + 2, ACT_SCALE, p + lo.fc1_b, nullptr, nullptr, 1, l.a));
+      RUN(atst_quant_fp8(l.a, 4 * MC, ACT_SCALE_GELU, w.q8b, st));
+      RUN(gemm8(w.q8b, q8 + lo.fc2_w, M, C, 4 * C, EPI_RESID, w.x[2 * i + 2], st, dq + 3, ACT_SCALE_GELU, p + lo.fc2_b, w.x[2 * i + 1], s2, NP));
     } else {
-      RUN(gemm(l.a, q + lo.fc2_w, M, C, 4 * C, EPI_RESID, w.x[2 * i + 2], st, p + lo.fc2_b, w.x[2 * i + 1], s2, NP));
+      if (i == 0 || !fuse_ln) RUN(atst_ln_fwd(w.x[2 * i], p + lo.ln1_w, p + lo.ln1_b, l.h1, l.mean1, l.rstd1, M, C, st));
+      RUN(gemm(l.h1, q + lo.qkv_w, M, 3 * C, C, EPI_BF16, l.qkv, st));
+      AttnArgs at{};
+      at.qkv = l.qkv; at.valid = e->valid; at.o = l.o; at.lse = l.lse; at.S = S; at.H = e->H; at.NP = NP;
+      RUN(atst_attn_fwd(at, st));
+      if (fuse_ln) {                                  // proj + residual + LN2 in one kernel
+        RUN(gemm(l.o, q + lo.proj_w, M, C, C, EPI_RESID, w.x[2 * i + 1], st, p + lo.proj_b, w.x[2 * i], s1, NP, nullptr, nullptr,
+                 nullptr, p + lo.ln2_w, p + lo.ln2_b, l.h2, l.mean2, l.rstd2));
+      } else {
+        RUN(gemm(l.o, q + lo.proj_w, M, C, C, EPI_RESID, w.x[2 * i + 1], st, p + lo.proj_b, w.x[2 * i], s1, NP));
+        RUN(atst_ln_fwd(w.x[2 * i + 1], p + lo.ln2_w, p + lo.ln2_b, l.h2, l.mean2, l.rstd2, M, C, st));
+      }
+      RUN(gemm(l.h2, q + lo.fc1_w, M, 4 * C, C, EPI_BIAS_GELU, e->train ? l.u : nullptr, st, p + lo.fc1_b, nullptr, nullptr, 1, l.a));
+      if (fuse_ln) {                                  // fc2 + residual + (LN1 of the next block | final norm)
+        const bool last = i + 1 == e->depth;
+        const LayerWs& nl = w.L[last ? i : i + 1];
+        RUN(gemm(l.a, q + lo.fc2_w, M, C, 4 * C, EPI_RESID, w.x[2 * i + 2], st, p + lo.fc2_b, w.x[2 * i + 1], s2, NP, nullptr, nullptr,
+                 nullptr, p + (last ? o.norm_w : o.layer[i + 1].ln1_w), p + (last ? o.norm_b : o.layer[i + 1].ln1_b),
+                 last ? w.hN : nl.h1, last ? w.meanN : nl.mean1, last ? w.rstdN : nl.rstd1));
+      } else {
+        RUN(gemm(l.a, q + lo.fc2_w, M, C, 4 * C, EPI_RESID, w.x[2 * i + 2], st, p + lo.fc2_b, w.x[2 * i + 1], s2, NP));
+      }
     }
     if (e->tap && i >= e->tap_first) {
       hipError_t rc = hipMemcpyAsync(e->tap + (size_t)(i - e->tap_first) * M * C, w.x[2 * i + 2], (size_t)M * C * sizeof(float),

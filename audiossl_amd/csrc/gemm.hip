@@ -338,7 +338,11 @@ template <int BKT> DEVFN int swz_key(int row) { return BKT == 64 ? (row >> 1) & 
 // MI = 4 (256 x 384 tile, each wave 128 x 96 = 12 accumulators): 40 KB staged per 6 units of output = 6.7 KB / unit.
 // DIR: epilogue straight from the accumulator registers (below).  The MFMA operands are then swapped (C^T = B A^T), so
 // that a lane owns ONE output row (m = lane & 31) and its registers run along n.
-template <int EPI, int MI, bool LN = false, int BKT = BK, bool PP = false, bool DIR = false>
+// F8: the operands are OCP e4m3 bytes.  The host passes them as pairs ("bf16" elements: K, lda, ldb halved), so the whole
+// LDS-DMA ring -- 64-byte rows, XOR swizzle, stage geometry -- is byte-identical; a k-tile then covers K = 64 and feeds ONE
+// v_mfma_scale_f32_32x32x64_f8f6f4 per accumulator (unit block scales; twice the bf16 MFMA rate) instead of two
+// 32x32x16 bf16 MFMAs: half the matrix-pipe time AND half the operand bytes per FLOP.  p.dq undoes the per-tensor scales.
+template <int EPI, int MI, bool LN = false, int BKT = BK, bool PP = false, bool DIR = false, bool F8 = false>
 __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(GemmArgs p) {
   using namespace row384;
   using RG = row384::Geo<MI, BKT>;
@@ -414,6 +418,34 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
     constexpr bool ISSUE = decltype(issue_tag)::value;
     const char* st = lds + (kt % NSTG) * STAGE;
     int slot = 0;
+    if constexpr (F8) {
+      // lane (row l31, half hi) owns bytes [32 hi, 32 hi + 32) of its 64-byte row: chunks 2 hi and 2 hi + 1 (swizzled); A and B
+      // use the same (half, byte) -> k map, which is all the contraction needs
+      typedef int v4i_ __attribute__((ext_vector_type(4)));
+      typedef int v8i_ __attribute__((ext_vector_type(8)));
+      const int c0 = ((2 * hi) ^ xr) << 4, c1 = ((2 * hi + 1) ^ xr) << 4;
+      auto frag = [&](const char* rowp) {
+        const v4i_ lo = *reinterpret_cast<const v4i_*>(rowp + c0), hi4 = *reinterpret_cast<const v4i_*>(rowp + c1);
+        return v8i_{lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+      };
+      v8i_ b8[3];
+#pragma unroll
+      for (int ni = 0; ni < 3; ++ni) b8[ni] = frag(st + offB + ni * 32 * ROWB);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const v8i_ a8 = frag(st + offA + mi * 32 * ROWB);
+#pragma unroll
+        for (int ni = 0; ni < 3; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8[ni], acc[mi][ni], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+        if (ILV && ISSUE) {                                      // 5 loads over 4 slots
+          __builtin_amdgcn_sched_barrier(0);
+          issue_one(kt + NSTG - 1, slot); ++slot;
+          if (mi == 0) { issue_one(kt + NSTG - 1, slot); ++slot; }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int ks = 0; ks < BKT / 16; ++ks) {
       const int co = ((ks * 2 + hi) ^ xr) << 4;
@@ -689,6 +721,7 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
   float* sCol = sGamma;                                           // EPI_DGELU: column sums of du (fc1 bias gradient); no LN there
   constexpr int NPART = 2 * MI;
   constexpr bool fused_ln = LN && EPI == EPI_RESID;
+  const float dqv = F8 ? (p.dq ? *p.dq : 1.0f) * (p.dq_mul != 0.f ? p.dq_mul : 1.0f) : 1.0f;
   if (tid < BNR) {                                                // visible after the first staging barrier
     sBias[tid] = p.bias ? p.bias[n0 + tid] : 0.f;
     if (fused_ln) { sGamma[tid] = p.ln_gamma[tid]; sBeta[tid] = p.ln_beta[tid]; }
@@ -706,7 +739,7 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
 #pragma unroll
       for (int r8 = 0; r8 < 8; ++r8) {
         const int lrow = wm * 16 + (r8 & 3) + 8 * (r8 >> 2) + 4 * hi;
-        sC[lrow * CLD + wn * 96 + ni * 32 + l31] = acc[mi][ni][h * 8 + r8];
+        sC[lrow * CLD + wn * 96 + ni * 32 + l31] = F8 ? acc[mi][ni][h * 8 + r8] * dqv : acc[mi][ni][h * 8 + r8];
       }
     if (part == 3) STAMP2(20);
     // (Issuing these loads one part ahead was measured: no gain -- 219 vs 218 us on fc2+residual -- and 17 spilled
@@ -1330,17 +1363,17 @@ int launch_nt_cfg(const GemmArgs& a, hipStream_t st) {
   hipLaunchKernelGGL((gemm_nt_kernel<EPI, BMT, NSTG, WTM>), dim3(nblk), dim3(G::THREADS), G::LDS, st, a);
   return (int)hipGetLastError();
 }
-template <int EPI, int MI, bool LN, int BKT = BK, bool PP = false, bool DIR = false>
+template <int EPI, int MI, bool LN, int BKT = BK, bool PP = false, bool DIR = false, bool F8 = false>
 int launch_nt_row384_cfg(const GemmArgs& a, hipStream_t st) {
   using RG = row384::Geo<MI, BKT>;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_row384_kernel<EPI, MI, LN, BKT, PP, DIR>, hipFuncAttributeMaxDynamicSharedMemorySize, RG::LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_row384_kernel<EPI, MI, LN, BKT, PP, DIR, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, RG::LDS);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
   const int nblk = ((a.M + RG::BMR - 1) / RG::BMR) * (a.N / row384::BNR);
-  hipLaunchKernelGGL((gemm_nt_row384_kernel<EPI, MI, LN, BKT, PP, DIR>), dim3(nblk), dim3(row384::THREADS), RG::LDS, st, a);
+  hipLaunchKernelGGL((gemm_nt_row384_kernel<EPI, MI, LN, BKT, PP, DIR, F8>), dim3(nblk), dim3(row384::THREADS), RG::LDS, st, a);
   return (int)hipGetLastError();
 }
 int g_w4_auto = 1;          // hook 360 / 361: 4-wave kernels for launches of fewer than 1.5 rounds of 256 x 384 tiles
@@ -1364,6 +1397,14 @@ template <int EPI>
 int launch_nt_row384(const GemmArgs& a0, hipStream_t st) {
   GemmArgs a = a0;
   a.skew = g_skew * (a.K / BK);
+  if (a.fp8) {                                                    // e4m3 operands seen as byte pairs: K, lda, ldb are already halved
+    if constexpr (EPI == EPI_BF16 || EPI == EPI_BIAS_GELU || EPI == EPI_RESID || EPI == EPI_F32) {
+      ProfScope ps(PK_GEMM_NT0 + EPI, 4.0 * a.M * a.N * a.K, st, nt_bytes<EPI>(a));
+      return launch_nt_row384_cfg<EPI, 4, false, BK, false, false, true>(a, st);
+    } else {
+      return ATST_EINVAL;
+    }
+  }
   ProfScope ps(PK_GEMM_NT0 + EPI, 2.0 * a.M * a.N * a.K, st, nt_bytes<EPI>(a));
 
   // Fewer than 1.5 rounds of 256 x 384 tiles (the 1 s local views: M = 32768, N = 384 -> 128 blocks on 256 CUs): the 4-wave
@@ -1425,6 +1466,17 @@ void atst_gemm_nt_set_variant(int v) { if (v >= 100000) g_skew = v - 100000; els
 
 int atst_gemm_nt(const GemmArgs& a0, hipStream_t st) {
   GemmArgs a = a0;
+  if (a.fp8) {                                                    // e4m3: K a multiple of 64 bytes, row-384 tile only, no fused LayerNorm
+    if (a.M <= 0 || a.N % 384 || a.K % 64 || a.lda % 16 || a.ldb % 16 || a.ln_out) return ATST_EINVAL;
+    a.K /= 2; a.lda /= 2; a.ldb /= 2;
+    switch (a.epi) {
+      case EPI_BF16: return launch_nt_row384<EPI_BF16>(a, st);
+      case EPI_F32: return launch_nt_row384<EPI_F32>(a, st);
+      case EPI_BIAS_GELU: return launch_nt_row384<EPI_BIAS_GELU>(a, st);
+      case EPI_RESID: return launch_nt_row384<EPI_RESID>(a, st);
+    }
+    return ATST_EINVAL;
+  }
   if (a.M <= 0 || a.N % BN || a.K % BK || a.lda % 8 || a.ldb % 8) return ATST_EINVAL;
   switch (a.epi) {
     case EPI_BF16: return launch_nt<EPI_BF16>(a, st);

@@ -21,6 +21,9 @@ struct GemmArgs {
   // EPI_RESID with N == 384: optional fused LayerNorm(eps 1e-6) of the output row (the next sub-layer's pre-LN)
   const float* ln_gamma; const float* ln_beta; bf16* ln_out; float* ln_mean; float* ln_rstd;
   float* colsum;                     // EPI_DGELU: optional fp32 [N] accumulator of the column sums of the output (bias gradient)
+  float dq_mul;                      // fp8 GEMMs: host factor on top of *dq (1 / activation scale); 0 is read as 1
+  const float* dq;                   // fp8 GEMMs: device scalar multiplied into the accumulators (1 / (scale_A * scale_B)); null = 1
+  int fp8;                           // operands are OCP e4m3 bytes (K, lda, ldb in elements = bytes); MX-scaled MFMA, unit block scales
   int skew;                          // start-up delay (shader cycles) of every other first-round block: de-phases main loops and epilogues
 };
 int atst_gemm_nt(const GemmArgs& a, hipStream_t st);
@@ -92,6 +95,12 @@ int atst_cast_f32_bf16(const float* x, size_t n, bf16* y, hipStream_t st);
 int atst_split3(const float* x, int R, int K, int b_layout, bf16* y, hipStream_t st);
 int atst_byol_loss(const float* student, const float* teacher, int B, int ncrops, int D, float* loss, float* dstudent,
                    float* stats, hipStream_t st);
+
+// fp8 (OCP e4m3) operand preparation for the ATST-base forward GEMMs (BASELINE.json configs[4])
+int atst_quant_fp8(const bf16* x, size_t n, float scale, uint8_t* y, hipStream_t st);               // y = e4m3(clamp(x * scale, +-448))
+// every tensor of `table` (device int32 [n][2] = {element offset, numel}, 256-aligned) of a flat fp32 buffer -> e4m3 at the same
+// offsets with a per-tensor scale 448 / amax; dq[t] = amax / 448 (the factor that undoes it).  amax: device scratch [n].
+int atst_quant_weights_fp8(const float* p32, const int* table, int n, uint8_t* p8, float* dq, float* amax, hipStream_t st);
 
 // optimizer
 struct OptimArgs {

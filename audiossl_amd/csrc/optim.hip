@@ -109,3 +109,59 @@ int atst_transpose_bf16(const bf16* src, int rows, int cols, bf16* dst, hipStrea
   hipLaunchKernelGGL(transpose_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, st, src, rows, cols, dst);
   return (int)hipGetLastError();
 }
+
+
+// ---- fp8 (OCP e4m3) operand preparation ----------------------------------------------------------------------------------
+namespace {
+__global__ void quant_fp8_kernel(const bf16* __restrict__ x, size_t n8, float scale, unsigned* __restrict__ y) {
+  // 8 bf16 in (16 B), 8 e4m3 out (8 B) per thread per iteration
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + i * 8);
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = __builtin_amdgcn_fmed3f(bf2f(v[e]) * scale, -448.f, 448.f);
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false); lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false); hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+    y[i * 2] = (unsigned)lo; y[i * 2 + 1] = (unsigned)hi;
+  }
+}
+__global__ void amax_batch_kernel(const float* __restrict__ p, const int* __restrict__ table, float* __restrict__ amax) {
+  const int t = blockIdx.y;
+  const size_t off = (size_t)table[2 * t], n = (size_t)table[2 * t + 1];
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(p[off + i]));
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(amax + t), __float_as_uint(m));   // non-negative floats order like their bits
+}
+__global__ void quant_weights_kernel(const float* __restrict__ p, const int* __restrict__ table, const float* __restrict__ amax,
+                                     unsigned* __restrict__ p8, float* __restrict__ dq) {
+  const int t = blockIdx.y;
+  const size_t off = (size_t)table[2 * t], n4 = (size_t)table[2 * t + 1] / 4;
+  const float a = fmaxf(amax[t], 1e-30f), s = 448.f / a;
+  if (blockIdx.x == 0 && threadIdx.x == 0) dq[t] = a / 448.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p + off + i * 4);
+    int r = 0;
+    r = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(v[0] * s, -448.f, 448.f), __builtin_amdgcn_fmed3f(v[1] * s, -448.f, 448.f), r, false);
+    r = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(v[2] * s, -448.f, 448.f), __builtin_amdgcn_fmed3f(v[3] * s, -448.f, 448.f), r, true);
+    p8[(off + i * 4) / 4] = (unsigned)r;
+  }
+}
+}  // namespace
+
+int atst_quant_fp8(const bf16* x, size_t n, float scale, uint8_t* y, hipStream_t st) {
+  if (n == 0) return ATST_OK;
+  if (n % 8) return ATST_EINVAL;
+  int grid = (int)((n / 8 + 255) / 256); if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(quant_fp8_kernel, dim3(grid), dim3(256), 0, st, x, n / 8, scale, reinterpret_cast<unsigned*>(y));
+  return (int)hipGetLastError();
+}
+int atst_quant_weights_fp8(const float* p32, const int* table, int n, uint8_t* p8, float* dq, float* amax, hipStream_t st) {
+  if (n <= 0) return ATST_OK;
+  hipError_t e = hipMemsetAsync(amax, 0, sizeof(float) * n, st);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(amax_batch_kernel, dim3(32, n), dim3(256), 0, st, p32, table, amax);
+  hipLaunchKernelGGL(quant_weights_kernel, dim3(32, n), dim3(256), 0, st, p32, table, amax, reinterpret_cast<unsigned*>(p8), dq);
+  return (int)hipGetLastError();
+}

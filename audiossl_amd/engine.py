@@ -152,6 +152,9 @@ class EncoderPass:
         else:
             e.p32, e.p16, e.p16t, e.g32 = eng.t32.data_ptr(), eng.t16.data_ptr(), None, None
         e.off = eng.enc_off
+        if eng.fp8:
+            e.fp8 = 1
+            e.p8, e.w_dq = (eng.p8.data_ptr(), eng.dq_s.data_ptr()) if net == "student" else (eng.t8.data_ptr(), eng.dq_t.data_ptr())
         e.ws, e.ws_bytes = self.ws.buf.data_ptr(), nbytes
         self.e = e
         self.out = self.ws.view(lib.atst_encoder_out(C.byref(e)), (self.M, e.C), torch.bfloat16)
@@ -301,7 +304,7 @@ class AtstEngine:
     """Owns the flat parameter / gradient / optimizer-state buffers of student and teacher and runs the training step."""
 
     def __init__(self, arch: str = "small", frame: bool = False, depth: Optional[int] = None, ncrops: int = 2,
-                 device: Optional[torch.device] = None, drop_path_rate: float = 0.1, n_pos: int = 251):
+                 device: Optional[torch.device] = None, drop_path_rate: float = 0.1, n_pos: int = 251, fp8: bool = False):
         if arch not in ARCH:
             raise RuntimeError("arch {} is not implemented".format(arch))      # ref: models/atst/atst.py:17
         hip.load()                                                               # fail loudly when the .so is missing
@@ -319,6 +322,18 @@ class AtstEngine:
         self.p32, self.g32, self.m32, self.v32 = z(L.n_student), z(L.n_student), z(L.n_student), z(L.n_student)
         self.t32 = z(L.n_teacher)
         self.p16, self.p16t, self.t16 = z(L.n_student, torch.bfloat16), z(L.n_student, torch.bfloat16), z(L.n_teacher, torch.bfloat16)
+        # fp8 forward (BASELINE.json configs[4], ATST-base recipe): e4m3 shadows of the four Linear weights of every block,
+        # per-tensor scaled, refreshed with the bf16 shadows; the backward and everything saved for it stay bf16
+        self.fp8 = bool(fp8)
+        if self.fp8:
+            rows = []
+            for i in range(self.depth):
+                for nm in ("attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight"):
+                    off, shape = L.entries[f"encoder.blocks.{i}.{nm}"]
+                    rows.append((off, math.prod(shape)))
+            self._f8_table = torch.tensor(rows, dtype=torch.int32, device=dev).contiguous()
+            self.p8, self.t8 = z(L.n_student, torch.uint8), z(L.n_teacher, torch.uint8)
+            self.dq_s, self.dq_t, self._f8_amax = z(len(rows)), z(len(rows)), z(len(rows))
         self.bn_buffers: Dict[str, Dict[str, torch.Tensor]] = {}
         for key in ("student.projector", "student.predictor", "teacher.projector"):
             self.bn_buffers[key] = dict(running_mean=z(HEAD_HIDDEN), running_var=torch.ones(HEAD_HIDDEN, device=dev),
@@ -437,7 +452,16 @@ class AtstEngine:
         self._refresh_transposes()
         self._synced_version = (self.p32._version, self.t32._version)
 
+    def _refresh_fp8(self):
+        if not self.fp8:
+            return
+        n = self._f8_table.shape[0]
+        for p32, p8, dq in ((self.p32, self.p8, self.dq_s), (self.t32, self.t8, self.dq_t)):
+            hip.call("atst_quant_weights_fp8", hip.ptr(p32), hip.ptr(self._f8_table), n, hip.ptr(p8), hip.ptr(dq), hip.ptr(self._f8_amax),
+                     hip.stream())
+
     def _refresh_transposes(self):
+        self._refresh_fp8()
         if getattr(self, "_tr_table", None) is None:
             rows, tiles = [], 0
             for name, (off, shape) in self.layout.entries.items():
@@ -681,3 +705,4 @@ class AtstEngine:
         hip.call("atst_adamw_ema_step", hip.ptr(self.p32), hip.ptr(self.g32), hip.ptr(self.m32), hip.ptr(self.v32), hip.ptr(self.t32),
                  hip.ptr(self.p16), hip.ptr(self.t16), hip.ptr(self.flags_ema_only), self.layout.n_student, self.layout.n_teacher,
                  0.0, 0.0, 0.9, 0.999, 1e-6, 0.0, m, 1.0, hip.stream())
+        self._refresh_fp8()

@@ -121,6 +121,9 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="clips per GPU per step")
     ap.add_argument("--arch", default="small", choices=["small", "base"],
                     help="small = the headline model (BASELINE configs[1..3]); base (d = 768, 12 heads) is an extra data point")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"],
+                    help="fp8: the four Linear layers of every block run their FORWARD on OCP e4m3 operands (MX-scaled MFMA); "
+                         "backward and saved activations stay bf16 (BASELINE.json configs[4]: use with --arch base)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--profile-stride", type=int, default=7,
@@ -162,7 +165,7 @@ def main():
 
     B, frame = args.batch, args.workload == "frame"
     ncrops = 6 if args.workload == "clip6" else 2
-    eng = AtstEngine(args.arch, frame=frame, ncrops=ncrops)
+    eng = AtstEngine(args.arch, frame=frame, ncrops=ncrops, fp8=args.dtype == "fp8")
     eng.init_weights(seed=0)
     eng.overlap_teacher = args.overlap
     fe = LogMelFrontend(1024 if not frame else 640)
@@ -271,7 +274,8 @@ def main():
         fpc = flops_per_clip(args.workload, d=768 if args.arch == "base" else 384)
         out = {"metric": "pretrain clips/sec (10s@16kHz, ATST-small)" if args.arch == "small" else "pretrain clips/sec (10s@16kHz, ATST-base)", "value": round(value, 2), "unit": "clips/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "bf16" if args.dtype == "bf16" else "fp8 (e4m3 forward GEMMs) + bf16", "data": "synthetic",
                "config": {"workload": {"clip6": "ATST-small clip-level, 2 global (10 s) + 4 local (1 s) views",
                                        "clip2": "ATST-small clip-level, 2 views (10 s)",
                                        "frame": "ATST-Frame small, masked frame objective (10 s)"}[args.workload].replace("small", args.arch) +

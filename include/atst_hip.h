@@ -49,6 +49,16 @@ int atst_gemm_nt_bf16(const uint16_t* A, const uint16_t* B, int M, int N, int K,
                       void* C, int ldc, void* C2, const float* bias, const float* resid, const float* row_scale,
                       int rows_per_seq, const uint16_t* U, const float* table, const uint8_t* rowflag, const float* alt,
                       float* colsum /* EPI_DGELU: optional [N] += column sums of the output */, void* stream);
+/* The same GEMM on OCP e4m3 operands (A8 [M,K], B8 [N,K] bytes; N % 384 == 0, K % 64 == 0) with v_mfma_scale_f32_32x32x64_f8f6f4:
+ * C = epilogue(dq_mul * (*dq) * A8 B8^T); epilogues BF16 / F32 / BIAS_GELU / RESID.  north_star "fp8 MFMA QKV/MLP GEMMs".      */
+int atst_gemm_nt_fp8(const uint8_t* A8, const uint8_t* B8, int M, int N, int K, int lda, int ldb, int epi, void* C, int ldc,
+                     void* C2, const float* bias, const float* resid, const float* row_scale, int rows_per_seq,
+                     const float* dq, float dq_mul, void* stream);
+/* y = e4m3(clamp(scale * x, +-448)) for a bf16 tensor of n elements (n % 8 == 0)                                           */
+int atst_quant_fp8_bf16(const uint16_t* x, size_t n, float scale, uint8_t* y, void* stream);
+/* per-tensor-scaled e4m3 shadows of n tensors of a flat fp32 buffer: table int32 [n][2] = {element offset, numel};
+ * dq[t] = amax_t / 448; amax = device scratch [n]                                                                             */
+int atst_quant_weights_fp8(const float* p32, const int32_t* table, int n, uint8_t* p8, float* dq, float* amax, void* stream);
 /* dW[N,K] += dY[M,N]^T X[M,K]  (fp32 accumulate); autograd of the same nn.Linear calls.                              */
 int atst_gemm_tn_bf16(const uint16_t* dY, const uint16_t* X, int M, int N, int K, int ldy, int ldx, float* dW, int ldw,
                       int m_per_split, void* stream);
@@ -137,6 +147,11 @@ typedef struct {
   /* optional block taps (inference API, get_intermediate_layers): when tap != NULL the fp32 residual stream after
    * block i is copied to tap[(i - tap_first) * S*NP*C] for every i >= tap_first; works with train = 0 workspaces */
   float* tap; int tap_first;
+  /* fp8 forward (ATST-base recipe, BASELINE.json configs[4]): when fp8 != 0 the four Linear layers of every block run on OCP
+   * e4m3 operands (MX-scaled MFMA, unit block scales): p8 = e4m3 weight shadow at the SAME element offsets as p32
+   * (atst_quant_weights_fp8), w_dq = [depth][4] per-tensor factors (qkv, proj, fc1, fc2) that undo the weight scales.
+   * Activations are re-quantised per GEMM with fixed scales; saved tensors and the whole backward stay bf16.              */
+  const uint8_t* p8; const float* w_dq; int fp8;
 } atst_encoder_t;
 
 size_t atst_encoder_ws_bytes(int S, int NP, int C, int H, int depth, int train);

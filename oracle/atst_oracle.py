@@ -148,6 +148,53 @@ class _HeadLinear(torch.autograd.Function):         # forward ~exact (split-bf16
         return g @ w, g.t() @ x
 
 
+_FP8 = False
+FP8_ACT_SCALE, FP8_ACT_SCALE_GELU = 8.0, 4.0        # csrc/engine.hip ACT_SCALE / ACT_SCALE_GELU
+
+
+class emulate_fp8:
+    """On top of emulate_bf16: the four Linear layers of every block evaluate their FORWARD on OCP e4m3 copies of their
+    operands -- activations x fixed scale, weights x 448 / amax per tensor, both saturated at +-448 -- exactly like the HIP
+    fp8 path (csrc/engine.hip gemm8, csrc/optim.hip quant kernels); gradients flow as if the bf16 operands had been used."""
+
+    def __init__(self, on: bool = True):
+        self.on = on
+
+    def __enter__(self):
+        global _FP8
+        self.prev, _FP8 = _FP8, self.on
+        return self
+
+    def __exit__(self, *a):
+        global _FP8
+        _FP8 = self.prev
+
+
+def _q8(x: Tensor, scale) -> Tensor:
+    return (x * scale).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32) / scale
+
+
+class _Fp8Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, w_master, act_scale):
+        ctx.save_for_backward(x, w)
+        ws = 448.0 / w_master.abs().max().clamp_min(1e-30)          # the e4m3 shadow is cut from the fp32 master
+        return _q8(x, act_scale) @ _q8(w_master, ws).t()
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors                                     # gradients as if the bf16 operands had been used
+        return g @ w, g.reshape(-1, g.shape[-1]).t() @ x.reshape(-1, x.shape[-1]), None, None
+
+
+def _linear(x: Tensor, W: Weights, key: str, b: Optional[Tensor], act_scale: float = FP8_ACT_SCALE) -> Tensor:
+    """F.linear on the (bf16-shadow when emulating) weight W[key], or its e4m3-forward version inside emulate_fp8()."""
+    if not _FP8:
+        return F.linear(x, _w(W, key), b)
+    y = _Fp8Linear.apply(x, _w(W, key), W[key].detach(), act_scale)
+    return y if b is None else y + b
+
+
 def _r(x):
     return _RoundFwd.apply(x) if _EMU else x
 
@@ -269,7 +316,7 @@ def block_forward(W: Weights, pre: str, x: Tensor, bias: Optional[Tensor], num_h
     S, N, C = x.shape
     hd = C // num_heads
     h = _rb(F.layer_norm(x, (C,), W[pre + "norm1.weight"], W[pre + "norm1.bias"], LN_EPS))
-    qkv = _rb(F.linear(h, _w(W, pre + "attn.qkv.weight"), W.get(pre + "attn.qkv.bias")))
+    qkv = _rb(_linear(h, W, pre + "attn.qkv.weight", W.get(pre + "attn.qkv.bias")))
     qkv = qkv.reshape(S, N, 3, num_heads, hd).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0], qkv[1], qkv[2]
     att = torch.matmul(q, k.transpose(-2, -1)) * (hd ** -0.5)
@@ -277,14 +324,14 @@ def block_forward(W: Weights, pre: str, x: Tensor, bias: Optional[Tensor], num_h
         att = att + bias
     att = _r(_rg(att).softmax(dim=-1))
     y = _rb(torch.matmul(att, v).transpose(1, 2).reshape(S, N, C))
-    y = _rg(F.linear(y, _w(W, pre + "attn.proj.weight"), W[pre + "attn.proj.bias"]))
+    y = _rg(_linear(y, W, pre + "attn.proj.weight", W[pre + "attn.proj.bias"]))
     if keep_attn is not None and drop_prob > 0.0:
         y = y / (1.0 - drop_prob) * keep_attn.to(y.dtype)[:, None, None]
     x = x + y
     h = _rb(F.layer_norm(x, (C,), W[pre + "norm2.weight"], W[pre + "norm2.bias"], LN_EPS))
-    h = _rg(F.linear(h, _w(W, pre + "mlp.fc1.weight"), W[pre + "mlp.fc1.bias"]))
+    h = _rg(_linear(h, W, pre + "mlp.fc1.weight", W[pre + "mlp.fc1.bias"]))
     h = _r(_GeluSavedBf16.apply(h)) if _EMU else F.gelu(h)      # exact erf GELU (nn.GELU default)
-    h = _rg(F.linear(h, _w(W, pre + "mlp.fc2.weight"), W[pre + "mlp.fc2.bias"]))
+    h = _rg(_linear(h, W, pre + "mlp.fc2.weight", W[pre + "mlp.fc2.bias"], FP8_ACT_SCALE_GELU))
     if keep_mlp is not None and drop_prob > 0.0:
         h = h / (1.0 - drop_prob) * keep_mlp.to(h.dtype)[:, None, None]
     return x + h
