@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """HBM traffic per launch from two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950).
 
-    python tools/traffic_from_pmc.py <fetch_dir> <write_dir> <out.json> [workload]
+    python tools/traffic_from_pmc.py <fetch_dir> <write_dir> <out.json> [workload] [HEAD the counters were taken at]
 
 Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md "HBM": both counters are in KB; FETCH_SIZE counts
 128-B fabric requests at 64 B, so it is doubled (checked here on the optimizer kernel, whose algorithmic read volume is
@@ -42,6 +42,7 @@ def load(d, counter):
 def main():
     fd, wd, out = sys.argv[1:4]
     workload = sys.argv[4] if len(sys.argv) > 4 else "clip6"
+    head = sys.argv[5] if len(sys.argv) > 5 else "unknown HEAD"
     ft, fc = load(fd, "FETCH_SIZE")
     wt, wc = load(wd, "WRITE_SIZE")
     rows = {}
@@ -52,7 +53,7 @@ def main():
         w = wt[k] / max(wc[k], 1) * 1024.0
         rows[k] = {"launches_fetch_pass": fc[k], "launches_write_pass": wc[k], "fetch_bytes_per_launch": round(f),
                    "write_bytes_per_launch": round(w), "traffic_bytes_per_launch": round(f + w)}
-    json.dump({"workload": workload, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes",
+    json.dump({"workload": workload, "head": head, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes",
                "corrections": "KB -> bytes; FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B)", "kernels": rows},
               open(out, "w"), indent=1)
     for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["traffic_bytes_per_launch"] * max(kv[1]["launches_fetch_pass"], 1))[:14]:
