@@ -159,15 +159,18 @@ __global__ void db_finalize_kernel(float* __restrict__ x, const unsigned int* __
   }
 }
 
-int init_twiddles() {
-  static bool done = false;
+// Twiddle tables are filled by a kernel on the caller's stream the first time the front end runs (double-precision
+// sincos, rounded to fp32 exactly like the host tables used to be): no hipMemcpyToSymbol, so no entry point synchronises.
+__global__ void twiddle_init_kernel() {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 512) { const double a = -2.0 * M_PI * i / 512.0; g_tw512[i] = make_float2((float)cos(a), (float)sin(a)); }
+  if (i < NBIN) { const double a = -2.0 * M_PI * i / 1024.0; g_tw1024[i] = make_float2((float)cos(a), (float)sin(a)); }
+}
+int init_twiddles(hipStream_t st) {
+  static bool done = false;                           // later launches on other streams: the caller's streams are ordered after the first step
   if (done) return 0;
-  static float2 h512[512], h1024[NBIN];
-  for (int j = 0; j < 512; ++j) { const double a = -2.0 * M_PI * j / 512.0; h512[j] = make_float2((float)std::cos(a), (float)std::sin(a)); }
-  for (int k = 0; k < NBIN; ++k) { const double a = -2.0 * M_PI * k / 1024.0; h1024[k] = make_float2((float)std::cos(a), (float)std::sin(a)); }
-  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_tw512), h512, sizeof(h512));
-  if (e != hipSuccess) return (int)e;
-  e = hipMemcpyToSymbol(HIP_SYMBOL(g_tw1024), h1024, sizeof(h1024));
+  hipLaunchKernelGGL(twiddle_init_kernel, dim3((NBIN + 255) / 256), dim3(256), 0, st);
+  const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   done = true;
   return 0;
@@ -179,7 +182,7 @@ int atst_mel_frontend(const float* wave, int n_clips, int n_samples, int win_len
                       float* out, unsigned int* clipmax, hipStream_t st) {
   (void)win_length;                                   // the zero-padded 1024-tap window is supplied by the caller
   if (n_clips <= 0 || n_samples < NFFT / 2 + 1) return ATST_EINVAL;
-  int rc = init_twiddles();
+  int rc = init_twiddles(st);
   if (rc) return rc;
   const int T = 1 + n_samples / HOPS;
   hipMemsetAsync(clipmax, 0, n_clips * sizeof(unsigned int), st);
