@@ -15,7 +15,7 @@ KIND = {"0": "gemm_nt_kernel<0:bf16>", "1": "gemm_nt_kernel<1:f32>", "2": "gemm_
 
 def kind_of(name: str) -> str:
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
-    m = re.match(r"gemm_nt(?:_row384)?_kernel<\(?(?:Epi\))?(\d)", name)
+    m = re.match(r"gemm_nt(?:_row384|_w4)?_kernel<\(?(?:Epi\))?(\d)", name)
     if m:
         return KIND[m.group(1)]
     m = re.match(r"(gemm_tn)(?:_\w+)?_kernel", name)
