@@ -21,6 +21,10 @@ if os.environ.get("ATST_TALL_STAGES"):
     FLAGS.append("-DATST_TALL_STAGES=" + os.environ["ATST_TALL_STAGES"])
 if os.environ.get("ATST_ABLATE"):          # experiment builds only (tools/gemm_bench.py)
     FLAGS.append("-DATST_ABLATE=" + os.environ["ATST_ABLATE"])
+if os.environ.get("ATST_EXPERIMENTS"):     # also compile the measured-and-rejected GEMM variants (tuning hooks 311 / 321 / 331 / 341)
+    FLAGS.append("-DATST_EXPERIMENTS=" + os.environ["ATST_EXPERIMENTS"])
+if os.environ.get("ATST_TRACE_FINE"):
+    FLAGS.append("-DATST_TRACE_FINE=" + os.environ["ATST_TRACE_FINE"])
 if os.environ.get("ATST_TRACE"):           # experiment builds only (tools/trace_gemm.py)
     FLAGS.append("-DATST_TRACE=" + os.environ["ATST_TRACE"])
 if os.environ.get("ATST_NT_STORES"):

@@ -20,6 +20,10 @@
 #endif
 
 #include <type_traits>
+#ifndef ATST_EXPERIMENTS
+#define ATST_EXPERIMENTS 0  // 1: also compile the measured-and-rejected variants behind the tuning hooks (ping-pong main loop 321,
+                            // register epilogue 341, 64-deep ring 311, 128x384 4-wave tile for every epilogue 331): profiles/r02_trace_epi.txt
+#endif
 #ifndef ATST_TRACE_FINE
 #define ATST_TRACE_FINE 0   // 1: also stamp every k-tile of the main loop (tools/trace_gemm.py; perturbs the loop)
 #endif
@@ -1417,15 +1421,16 @@ int launch_nt_row384(const GemmArgs& a0, hipStream_t st) {
     const int w4m = g_w4_mode ? g_w4_mode : 2;
     if constexpr (EPI == EPI_RESID) {
       if (a.ln_out) { if (w4m != 3) return launch_nt_w4_cfg<EPI, 1, true>(a, st); }
-      else return w4m == 1 ? launch_nt_w4_cfg<EPI, 1, false>(a, st) : launch_nt_w4_cfg<EPI, 2, false>(a, st);
-    } else {
-      return w4m == 1 ? launch_nt_w4_cfg<EPI, 1, false>(a, st) : launch_nt_w4_cfg<EPI, 2, false>(a, st);
     }
+    if constexpr (ATST_EXPERIMENTS) {
+      if (w4m == 1 && !a.ln_out) return launch_nt_w4_cfg<EPI, 1, false>(a, st);
+    }
+    if (!a.ln_out) return launch_nt_w4_cfg<EPI, 2, false>(a, st);
   }
   // 256-row tiles: the operand ring of one block covers twice the output (6.7 vs 10.7 KB staged per 128x128 unit)
   const bool tall = a.M >= (g_w4_min_m < 8192 ? g_w4_min_m : 8192) && (g_row384_tall == 2 || (g_row384_tall == 1 && EPI == EPI_BF16 && (a.K >= 768 || a.N >= 768)));
   const bool deep = tall && g_row384_bk64 && a.K % 64 == 0;        // 64-deep ring stages
-  if constexpr (EPI == EPI_BF16 || EPI == EPI_F32 || EPI == EPI_BIAS_GELU || EPI == EPI_RESID) {
+  if constexpr (ATST_EXPERIMENTS && (EPI == EPI_BF16 || EPI == EPI_F32 || EPI == EPI_BIAS_GELU || EPI == EPI_RESID)) {
     if (tall && g_row384_dir && ATST_TALL_STAGES == 3) {            // epilogue straight from the registers (tuning hook 340 = off / 341 = on)
       if constexpr (EPI == EPI_RESID) {
         if (a.ln_out) return launch_nt_row384_cfg<EPI, 4, true, BK, false, true>(a, st);
@@ -1433,16 +1438,24 @@ int launch_nt_row384(const GemmArgs& a0, hipStream_t st) {
       return launch_nt_row384_cfg<EPI, 4, false, BK, false, true>(a, st);
     }
   }
-  if (tall && g_row384_pp && ATST_TALL_STAGES == 3) {               // ping-pong main loop (tuning hook 320 / 321)
-    if constexpr (EPI == EPI_RESID) {
-      if (a.ln_out) return launch_nt_row384_cfg<EPI, 4, true, BK, true>(a, st);
+  if constexpr (ATST_EXPERIMENTS) {
+    if (tall && g_row384_pp && ATST_TALL_STAGES == 3) {             // ping-pong main loop (tuning hook 320 / 321)
+      if constexpr (EPI == EPI_RESID) {
+        if (a.ln_out) return launch_nt_row384_cfg<EPI, 4, true, BK, true>(a, st);
+      }
+      return launch_nt_row384_cfg<EPI, 4, false, BK, true>(a, st);
     }
-    return launch_nt_row384_cfg<EPI, 4, false, BK, true>(a, st);
+    if (deep) {
+      if constexpr (EPI == EPI_RESID) {
+        if (a.ln_out) return launch_nt_row384_cfg<EPI, 4, true, 64>(a, st);
+      }
+      return launch_nt_row384_cfg<EPI, 4, false, 64>(a, st);
+    }
   }
   if constexpr (EPI == EPI_RESID) {
-    if (a.ln_out) return deep ? launch_nt_row384_cfg<EPI, 4, true, 64>(a, st) : tall ? launch_nt_row384_cfg<EPI, 4, true>(a, st) : launch_nt_row384_cfg<EPI, 2, true>(a, st);
+    if (a.ln_out) return tall ? launch_nt_row384_cfg<EPI, 4, true>(a, st) : launch_nt_row384_cfg<EPI, 2, true>(a, st);
   }
-  return deep ? launch_nt_row384_cfg<EPI, 4, false, 64>(a, st) : tall ? launch_nt_row384_cfg<EPI, 4, false>(a, st) : launch_nt_row384_cfg<EPI, 2, false>(a, st);
+  return tall ? launch_nt_row384_cfg<EPI, 4, false>(a, st) : launch_nt_row384_cfg<EPI, 2, false>(a, st);
 }
 template <int EPI>
 int launch_nt(const GemmArgs& a, hipStream_t st) {
@@ -1455,7 +1468,9 @@ int launch_nt(const GemmArgs& a, hipStream_t st) {
   if (v < 0) v = (EPI == EPI_F32 && a.M >= 16384) ? 3            // ATST-Frame head Linears (83 k rows): 256x128 tile, -13 %
                : a.K <= 512 ? 0 : 1;
   if (v == 3) return launch_nt_cfg<EPI, 256, 3, 128>(a, st);
-  if (v == 2) return launch_nt_cfg<EPI, 256, 3, 64>(a, st);
+  if constexpr (ATST_EXPERIMENTS) {
+    if (v == 2) return launch_nt_cfg<EPI, 256, 3, 64>(a, st);
+  }
   if (v == 1) return launch_nt_cfg<EPI, 128, 3, 64>(a, st);
   return launch_nt_cfg<EPI, 128, 2, 64>(a, st);
 }
