@@ -101,3 +101,24 @@ def test_frame_full_size_properties():
     perm = torch.randperm(B, generator=torch.Generator().manual_seed(9))
     loss_p, _, _ = eng.forward([x[perm] for x in mels], [l[perm] for l in lens], [m[perm], m[perm]])
     assert abs(float(loss_p) - float(loss)) < 2e-4, (float(loss_p), float(loss))   # BatchNorm sums reorder: fp32 noise only
+
+
+def test_training_reduces_the_loss_end_to_end():
+    """30 optimizer steps on one fixed batch (12 layers, 16 clips x 2 views, DropPath on, HF-AdamW + EMA teacher through the
+    fused kernels): the BYOL loss must fall -- forward, backward, optimizer, bf16 shadow refresh and EMA are consistent."""
+    eng = AtstEngine("small", drop_path_rate=0.1)
+    eng.init_weights(seed=8)
+    g = torch.Generator().manual_seed(21)
+    base = torch.randn(16, 1, 64, 1001, generator=g).clamp_(-1, 1)
+    mels = [(base + 0.05 * torch.randn(16, 1, 64, 1001, generator=g)).clamp_(-1, 1).cuda() for _ in range(2)]
+    lens = [torch.full((16,), 1001)] * 2
+    torch.manual_seed(0)
+    losses = []
+    for k in range(30):
+        loss, _, _ = eng.forward(mels, lens)
+        eng.backward()
+        eng.optimizer_step(5e-4, 0.04, 0.99)
+        losses.append(loss)
+    losses = [float(l) for l in losses]
+    assert all(np.isfinite(losses)) and np.mean(losses[-5:]) < np.mean(losses[:5]) - 0.05, losses
+    assert torch.isfinite(eng.p32).all() and torch.isfinite(eng.t32).all()
