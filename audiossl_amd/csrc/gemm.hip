@@ -1181,11 +1181,21 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(WgradArgs p) {
 // row are XOR-permuted (tr_swz, applied to the per-lane source address) so that the 4-row x 32-column blocks fetched by
 // ds_read_b64_tr_b16 -- the hardware transpose that turns the m-major image into MFMA fragments -- fall on distinct banks.  36.9 KB staged per 64 rows of a 192x384 tile = 8.2 KB per 128x128 unit, against
 // 16 KB for the square tile: the wgrad GEMMs are bound by that L2 -> LDS traffic.
+#ifndef ATST_TN_RM
+#define ATST_TN_RM 64          // contraction rows per ring stage: 64 (2-stage ring) | 32 (4-stage ring: measured SLOWER, 268 vs 225 us on fc2 wgrad)
+#endif
 namespace tnt {
-constexpr int TN = 192, TK = 384, RM = 64;
+constexpr int TN = 192, TK = 384, RM = ATST_TN_RM;
 constexpr int PY = TN * 2, PX = TK * 2;                               // row pitches in bytes
-constexpr int Y_BYTES = RM * PY, X_BYTES = RM * PX, STAGE = Y_BYTES + X_BYTES;   // 24,576 + 49,152
-constexpr int LDS = 2 * STAGE;                                        // 147,456 B
+constexpr int Y_BYTES = RM * PY, X_BYTES = RM * PX, STAGE = Y_BYTES + X_BYTES;   // RM 64: 24,576 + 49,152 ; RM 32: half
+// Both operands of a weight gradient are streamed from HBM; with 64-row stages only two fit (144 KB), i.e. one stage of
+// prefetch.  Tried (round 2): 32-row stages in a 4-deep ring (three stages = 108 KB in flight, same LDS): SLOWER -- fc2 wgrad
+// 225 -> 268 us, the grouped launch 320 -> 376 us: twice the barriers and 4-5 instead of 9 LDS-DMA pieces per wave per stage
+// cost more than the deeper prefetch returns.  Kept selectable (ATST_TN_RM=32).
+constexpr int NST = RM == 64 ? 2 : 4;
+constexpr int LDS = NST * STAGE;                                      // 147,456 B either way
+constexpr int Y_PIECES = Y_BYTES / 1024, PIECES = STAGE / 1024;       // 1-KiB LDS-DMA pieces per stage: 12 + 24 (RM 32) ; 24 + 48
+constexpr int PPW = (PIECES + 7) / 8;                                 // per wave: 5 (waves 0-3) / 4 (RM 32) ; 9 (RM 64)
 }
 
 // ds_read_b64_tr_b16 is serviced 32 lanes at a time = 4 rows x 64 B of the image, over 64 banks (256 B): the four rows
@@ -1220,26 +1230,32 @@ DEVFN void tn_tall_body(const WgradArgs& p, int tile, int split, char* smem_raw)
   if (m_begin >= m_end) return;
   const int nst = (m_end - m_begin) / RM;
 
-  // lane -> (row, chunk) of the linear stage image; element offsets from the split's first row
-  int offY[3], offX[6];
+  // lane -> (row, chunk) of the linear stage image.  Piece q (1 KiB) of a stage: q < Y_PIECES -> dY image, else X image;
+  // wave w issues pieces w, w + 8, w + 16, ...
+  int off[PPW]; bool isx[PPW]; bool have[PPW]; int ldsoff[PPW];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const int q = (wid * 3 + j) * 64 + lane, row = q / 24, c = (q % 24) ^ tr_swz<PY>(row);
-    offY[j] = row * p.ldy + n0 + c * 8;
-  }
-#pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    const int q = (wid * 6 + j) * 64 + lane, row = q / 48, c = (q % 48) ^ tr_swz<PX>(row);
-    offX[j] = row * p.ldx + k0 + c * 8;
+  for (int j = 0; j < PPW; ++j) {
+    const int q = wid + 8 * j;
+    have[j] = q < PIECES;
+    isx[j] = q >= Y_PIECES;
+    if (!isx[j]) {
+      const int c_ = q * 64 + lane, row = c_ / 24, c = (c_ % 24) ^ tr_swz<PY>(row);
+      off[j] = row * p.ldy + n0 + c * 8; ldsoff[j] = q * 1024;
+    } else {
+      const int c_ = (q - Y_PIECES) * 64 + lane, row = c_ / 48, c = (c_ % 48) ^ tr_swz<PX>(row);
+      off[j] = row * p.ldx + k0 + c * 8; ldsoff[j] = Y_BYTES + (q - Y_PIECES) * 1024;
+    }
   }
   const bf16* baseY = p.dY + (size_t)m_begin * p.ldy;
   const bf16* baseX = p.X + (size_t)m_begin * p.ldx;
-  auto issue_one = [&](int st, int j) {
-    char* buf = smem_raw + (st & 1) * STAGE;
-    if (j < 3)
-      __builtin_amdgcn_global_load_lds((gptr_t)(baseY + (size_t)st * RM * p.ldy + offY[j < 3 ? j : 0]), (lptr_t)(buf + (wid * 3 + j) * 1024), 16, 0, 0);
-    else
-      __builtin_amdgcn_global_load_lds((gptr_t)(baseX + (size_t)st * RM * p.ldx + offX[j >= 3 ? j - 3 : 0]), (lptr_t)(buf + Y_BYTES + (wid * 6 + j - 3) * 1024), 16, 0, 0);
+  auto issue_stage = [&](int st) {
+    char* buf = smem_raw + (st % NST) * STAGE;
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      if (!have[j]) continue;
+      const bf16* src = isx[j] ? baseX + (size_t)st * RM * p.ldx + off[j] : baseY + (size_t)st * RM * p.ldy + off[j];
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + ldsoff[j]), 16, 0, 0);
+    }
   };
   f32x16 acc[3][3];
 #pragma unroll
@@ -1250,18 +1266,23 @@ DEVFN void tn_tall_body(const WgradArgs& p, int tile, int split, char* smem_raw)
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
 #pragma unroll
-  for (int j = 0; j < 9; ++j) issue_one(0, j);
+  for (int s_ = 0; s_ < NST - 1; ++s_)
+    if (s_ < nst) issue_stage(s_);
+  constexpr int MINPW = PIECES / 8;                               // loads per stage of the waves that issue the fewest
   for (int st = 0; st < nst; ++st) {
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // stage st landed everywhere; the other buffer is free
-    const char* sY = smem_raw + (st & 1) * STAGE; const char* sX = sY + Y_BYTES;
-    const bool more = st + 1 < nst;
-    int slot = 0;
-#if ATST_TN_ISSUE == 1
-    if (more) {
-#pragma unroll
-      for (int j = 0; j < 9; ++j) issue_one(st + 1, j);
+    // stage st has landed (my loads retire in order; up to NST - 2 younger stages stay in flight; waves that issue one piece
+    // more per stage simply wait for a little of stage st + 1 as well); barrier => for everyone, and stage st - 1's buffer is free
+    const int younger = nst - 1 - st < NST - 2 ? nst - 1 - st : NST - 2;
+    if (younger >= 2) {
+      if constexpr (MINPW * 2 == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (younger == 1) {
+      if constexpr (MINPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-#endif
+    asm volatile("s_barrier" ::: "memory");
+    if (st + NST - 1 < nst) issue_stage(st + NST - 1);
+    const char* sY = smem_raw + (st % NST) * STAGE; const char* sX = sY + Y_BYTES;
 #pragma unroll
     for (int ms = 0; ms < RM / 16; ++ms) {
       bf16x8 a[3], b[3];
@@ -1270,25 +1291,9 @@ DEVFN void tn_tall_body(const WgradArgs& p, int tile, int split, char* smem_raw)
 #pragma unroll
       for (int i = 0; i < 3; ++i) b[i] = ld_frag_tr_p<PX>(sX, ms * 16, wk * 96 + i * 32, lane);
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
+      for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
-#if ATST_TN_ISSUE == 0
-        if (slot < 9) {                                           // next stage's loads go between the MFMA groups
-          __builtin_amdgcn_sched_barrier(0);
-          if (more) issue_one(st + 1, slot);
-          __builtin_amdgcn_sched_barrier(0);
-          ++slot;
-        }
-#elif ATST_TN_ISSUE == 2
-        if (slot < 9) {                                           // two per group: all issued within the first 40 % of the stage
-          __builtin_amdgcn_sched_barrier(0);
-          if (more) { issue_one(st + 1, slot); if (slot + 1 < 9) issue_one(st + 1, slot + 1); }
-          __builtin_amdgcn_sched_barrier(0);
-          slot += 2;
-        }
-#endif
-      }
     }
   }
 #pragma unroll
