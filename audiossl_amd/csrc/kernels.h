@@ -21,6 +21,7 @@ struct GemmArgs {
   // EPI_RESID with N == 384: optional fused LayerNorm(eps 1e-6) of the output row (the next sub-layer's pre-LN)
   const float* ln_gamma; const float* ln_beta; bf16* ln_out; float* ln_mean; float* ln_rstd;
   float* colsum;                     // EPI_DGELU: optional fp32 [N] accumulator of the column sums of the output (bias gradient)
+  uint8_t* q8; float q8_scale;       // EPI_BIAS_GELU: optional e4m3 copy of the activation * q8_scale (A operand of the fp8 fc2 GEMM)
   float dq_mul;                      // fp8 GEMMs: host factor on top of *dq (1 / activation scale); 0 is read as 1
   const float* dq;                   // fp8 GEMMs: device scalar multiplied into the accumulators (1 / (scale_A * scale_B)); null = 1
   int fp8;                           // operands are OCP e4m3 bytes (K, lda, ldb in elements = bytes); MX-scaled MFMA, unit block scales
@@ -40,7 +41,8 @@ int atst_gemm_tn(const WgradArgs& a, hipStream_t st);
 int atst_gemm_tn_group(const WgradArgs* items, int n, hipStream_t st);   // independent weight gradients sharing one launch
 
 // LayerNorm (eps 1e-6), C in {384, 768}
-int atst_ln_fwd(const float* x, const float* gamma, const float* beta, bf16* y, float* mean, float* rstd, int M, int C, hipStream_t st);
+int atst_ln_fwd(const float* x, const float* gamma, const float* beta, bf16* y, float* mean, float* rstd, int M, int C, hipStream_t st,
+                uint8_t* y8 = nullptr, float s8 = 1.0f);   // y8: optional e4m3 copy of y * s8 (fp8 forward)
 int atst_ln_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, int M, int C, hipStream_t st);   // fp32 output, no statistics (inference taps)
 struct LnBwdArgs {
   const bf16* dy;                    // [M,C] gradient wrt the LN output

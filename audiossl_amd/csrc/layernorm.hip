@@ -12,7 +12,8 @@ constexpr float LN_EPS = 1e-6f;
 template <int VPT, typename OUT = bf16>   // values per lane = C / 64 ; OUT = bf16 (GEMM operand) or float (inference taps)
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, OUT* __restrict__ y,
-                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out, int M) {
+                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out, int M,
+                                                     uint8_t* __restrict__ y8 = nullptr, float s8 = 1.0f) {
   constexpr int C = VPT * 64;
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -45,6 +46,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
       if constexpr (sizeof(OUT) == 2) {
         bf16x2 o; o[0] = f2bf(o0); o[1] = f2bf(o1);
         *reinterpret_cast<bf16x2*>(yr + i * 128 + lane * 2) = o;
+        if (y8) {                                                  // fp8 forward: e4m3 copy of the SAME bf16 values (the next GEMM's A operand)
+          const int q = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(bf2f(o[0]) * s8, -448.f, 448.f),
+                                                        __builtin_amdgcn_fmed3f(bf2f(o[1]) * s8, -448.f, 448.f), 0, false);
+          *reinterpret_cast<unsigned short*>(y8 + (size_t)row * C + i * 128 + lane * 2) = (unsigned short)q;
+        }
       } else {
         *reinterpret_cast<f32x2*>(yr + i * 128 + lane * 2) = f32x2{o0, o1};
       }
@@ -120,11 +126,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs p) {
 int ln_grid(int M) { int b = (M + 3) / 4; return b < 2048 ? b : 2048; }
 }  // namespace
 
-int atst_ln_fwd(const float* x, const float* gamma, const float* beta, bf16* y, float* mean, float* rstd, int M, int C, hipStream_t st) {
+int atst_ln_fwd(const float* x, const float* gamma, const float* beta, bf16* y, float* mean, float* rstd, int M, int C, hipStream_t st,
+                uint8_t* y8, float s8) {
   if (M <= 0) return ATST_OK;
-  ProfScope ps(PK_LN_FWD, (double)M * C * 6.0, st);                  // read fp32, write bf16
-  if (C == 384) hipLaunchKernelGGL(ln_fwd_kernel<6>, dim3(ln_grid(M)), dim3(256), 0, st, x, gamma, beta, y, mean, rstd, M);
-  else if (C == 768) hipLaunchKernelGGL(ln_fwd_kernel<12>, dim3(ln_grid(M)), dim3(256), 0, st, x, gamma, beta, y, mean, rstd, M);
+  ProfScope ps(PK_LN_FWD, (double)M * C * (y8 ? 7.0 : 6.0), st);      // read fp32, write bf16 (+ e4m3)
+  if (C == 384) hipLaunchKernelGGL(ln_fwd_kernel<6>, dim3(ln_grid(M)), dim3(256), 0, st, x, gamma, beta, y, mean, rstd, M, y8, s8);
+  else if (C == 768) hipLaunchKernelGGL(ln_fwd_kernel<12>, dim3(ln_grid(M)), dim3(256), 0, st, x, gamma, beta, y, mean, rstd, M, y8, s8);
   else return ATST_EINVAL;
   return (int)hipGetLastError();
 }
