@@ -331,7 +331,8 @@ constexpr int BNR = 384, WAVES = 8, THREADS = 512, CLD = BNR + 4;
 #ifndef ATST_INTERLEAVE
 #define ATST_INTERLEAVE 1      // LDS-DMA issue spread between the MFMA groups (0: in front of them; experiment builds)
 #endif
-constexpr int B_BYTES = BNR * BK * 2, EPI_BYTES = 32 * CLD * 4;                                   // 24 KB ; 49,664 B
+constexpr int CLD2 = 448, PLANE1 = 208;       // staging layout of the epilogues WITHOUT the fused LayerNorm (see the staging loop)
+constexpr int B_BYTES = BNR * BK * 2, EPI_BYTES = 32 * CLD2 * 4;                                  // 24 KB ; 57,344 B
 // MI = 32-row accumulator blocks per wave: 2 -> 128-row tile, 4 -> 256-row tile.  BKT = K depth of one ring stage:
 // 32 (64-B LDS rows, 4 chunks) or 64 (128-B rows: every LDS-DMA lane group fetches a whole 128-B line, half as many
 // barriers per K; two stages then fill the CU's 160 KB).
@@ -727,15 +728,15 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
   // that part's global loads (residual / saved activations), which are issued as one batch before the staging barrier
   // while the stores follow it (see epi_fetch8).
   float* sC = reinterpret_cast<float*>(smem_raw);
-  float* sBias = sC + 32 * CLD;                                   // bias of this block's 384 columns (zeros when absent)
-  float* sGamma = sBias + BNR; float* sBeta = sGamma + BNR;       // fused LayerNorm affine parameters
+  float* sBias = sC + 32 * CLD2;                                  // bias of this block's 384 columns (zeros when absent)
+  float* sGamma = sBias + CLD2; float* sBeta = sGamma + BNR;      // fused LayerNorm affine parameters
   float* sScale = sBeta + BNR;                                    // per-row DropPath scale of this block's rows
   float* sCol = sGamma;                                           // EPI_DGELU: column sums of du (fc1 bias gradient); no LN there
   constexpr int NPART = 2 * MI;
   constexpr bool fused_ln = LN && EPI == EPI_RESID;
   const float dqv = F8 ? (p.dq ? *p.dq : 1.0f) * (p.dq_mul != 0.f ? p.dq_mul : 1.0f) : 1.0f;
-  if (tid < BNR) {                                                // visible after the first staging barrier
-    sBias[tid] = p.bias ? p.bias[n0 + tid] : 0.f;
+  if (tid < BNR) {                                                // visible after the first staging barrier; bias in the same two-plane layout as the tile
+    sBias[fused_ln ? tid : ((tid >> 3) << 2) + (tid & 3) + ((tid & 4) ? PLANE1 : 0)] = p.bias ? p.bias[n0 + tid] : 0.f;
     if (fused_ln) { sGamma[tid] = p.ln_gamma[tid]; sBeta[tid] = p.ln_beta[tid]; }
     if (EPI == EPI_DGELU) sCol[tid] = 0.f;
   }
@@ -751,7 +752,14 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
 #pragma unroll
       for (int r8 = 0; r8 < 8; ++r8) {
         const int lrow = wm * 16 + (r8 & 3) + 8 * (r8 >> 2) + 4 * hi;
-        sC[lrow * CLD + wn * 96 + ni * 32 + l31] = F8 ? acc[mi][ni][h * 8 + r8] * dqv : acc[mi][ni][h * 8 + r8];
+        // Staging layout.  Fused LayerNorm: plain rows (pitch CLD), read back as f32x2 per lane -- conflict-free.  Other
+        // epilogues read 8 consecutive columns per thread as two f32x4; in plain rows the 16-lane service groups of
+        // ds_read_b128 then stride 32 B and hit every bank twice (SQ counters, round 1: 15-18 % of the LDS cycles of the bf16 /
+        // GELU epilogues were bank conflicts).  There the low and the high four columns of every 8-column slot live in two
+        // planes (columns 0-191 / 208-399 of a 448-float row): a service group reads 16 consecutive 16-B pieces of one plane.
+        const int ccol = wn * 96 + ni * 32 + l31;
+        const int pos = fused_ln ? lrow * CLD + ccol : lrow * CLD2 + ((ccol >> 3) << 2) + (ccol & 3) + ((ccol & 4) ? PLANE1 : 0);
+        sC[pos] = F8 ? acc[mi][ni][h * 8 + r8] * dqv : acc[mi][ni][h * 8 + r8];
       }
     if (part == 3) STAMP2(20);
     // (Issuing these loads one part ahead was measured: no gain -- 219 vs 218 us on fc2+residual -- and 17 spilled
@@ -822,13 +830,13 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
         const int idx = tid + THREADS * i, rl = idx / 48, c8 = (idx % 48) * 8;
         const int trow = tile_row(rl), row = m0 + trow;
 #if ATST_ABLATE != 0 && ATST_ABLATE != 7
-        if (sC[rl * CLD + c8] != 12345.678f) continue;               // experiment builds: no epilogue stores
+        if (sC[rl * CLD2 + (c8 >> 1)] != 12345.678f) continue;        // experiment builds: no epilogue stores
 #endif
         if (row < p.M) {
           f32x4 w0, w1;
           if constexpr (EPI == EPI_RESID) aux[i].s = sScale[trow];
-          epilogue8<EPI>(p, row, n0 + c8, *reinterpret_cast<const f32x4*>(sC + rl * CLD + c8), *reinterpret_cast<const f32x4*>(sC + rl * CLD + c8 + 4),
-                         *reinterpret_cast<const f32x4*>(sBias + c8), *reinterpret_cast<const f32x4*>(sBias + c8 + 4), aux[i], w0, w1);
+          epilogue8<EPI>(p, row, n0 + c8, *reinterpret_cast<const f32x4*>(sC + rl * CLD2 + (c8 >> 1)), *reinterpret_cast<const f32x4*>(sC + rl * CLD2 + PLANE1 + (c8 >> 1)),
+                         *reinterpret_cast<const f32x4*>(sBias + (c8 >> 1)), *reinterpret_cast<const f32x4*>(sBias + PLANE1 + (c8 >> 1)), aux[i], w0, w1);
           if constexpr (EPI == EPI_DGELU) {
             if (p.colsum) {
 #pragma unroll
@@ -874,7 +882,8 @@ template <int WM> struct Geo {
   static constexpr int NA = WM == 1 ? 4 : 3, NB = 2;
   static constexpr int A_BYTES = NA * A_STAGE, RING = A_BYTES + NB * B_STAGE;  // 32 + 48 = 80 KB ; 48 + 24 = 72 KB
   static constexpr int CLD = BNB + 4, RP = 16 * WM;                           // staged rows per epilogue part
-  static constexpr int EPI_BYTES = RP * CLD * 4 + 3 * BNB * 4 + BM * 4;
+  static constexpr int PL1 = BNB / 2 + 16, CLD2 = BNB == 192 ? 224 : 448;     // two-plane staging of the epilogues without LayerNorm (conflict-free f32x4 read-back)
+  static constexpr int EPI_BYTES = RP * CLD2 * 4 + (CLD2 + 2 * BNB) * 4 + BM * 4;
   static constexpr int LDS = RING > EPI_BYTES ? RING : EPI_BYTES;
   static constexpr int A_WAVES = WM == 1 ? 1 : 2, B_WAVES = 4 - A_WAVES;
   static constexpr int PA = (BM / 16) / A_WAVES, PB = (BNB / 16) / B_WAVES;   // 1-KiB pieces per loader wave per k-tile: 8, 8 ; 8, 6
@@ -989,14 +998,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_w4_kernel(GemmArgs p) {
   // Epilogue: as in the 8-wave kernel, the fp32 tile goes through LDS so that every global access is a 16-B piece of a
   // contiguous row segment.  Part (mi, h) stages 16 rows of accumulator block mi from every wave: 16 * WM rows x BNB columns.
   float* sC = reinterpret_cast<float*>(smem_raw);
-  float* sBias = sC + G::RP * CLD;
-  float* sGamma = sBias + BNB; float* sBeta = sGamma + BNB;
+  float* sBias = sC + G::RP * G::CLD2;
+  float* sGamma = sBias + G::CLD2; float* sBeta = sGamma + BNB;
   float* sScale = sBeta + BNB;
   float* sCol = sGamma;                                           // EPI_DGELU column sums (no LN there)
   constexpr int NPART = 2 * MI;
   constexpr bool fused_ln = LN && EPI == EPI_RESID;
   for (int c = tid; c < BNB; c += 256) {
-    sBias[c] = p.bias ? p.bias[n0 + c] : 0.f;
+    sBias[fused_ln ? c : ((c >> 3) << 2) + (c & 3) + ((c & 4) ? G::PL1 : 0)] = p.bias ? p.bias[n0 + c] : 0.f;
     if (fused_ln) { sGamma[c] = p.ln_gamma[c]; sBeta[c] = p.ln_beta[c]; }
     if (EPI == EPI_DGELU) sCol[c] = 0.f;
   }
@@ -1012,7 +1021,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_w4_kernel(GemmArgs p) {
 #pragma unroll
       for (int r8 = 0; r8 < 8; ++r8) {
         const int lr = wm * 16 + (r8 & 3) + 8 * (r8 >> 2) + 4 * hi;
-        sC[lr * CLD + wn * 96 + ni * 32 + l31] = acc[mi][ni][h * 8 + r8];
+        const int ccol = wn * 96 + ni * 32 + l31;
+        sC[fused_ln ? lr * CLD + ccol : lr * G::CLD2 + ((ccol >> 3) << 2) + (ccol & 3) + ((ccol & 4) ? G::PL1 : 0)] = acc[mi][ni][h * 8 + r8];
       }
     EpiAux aux[fused_ln ? 1 : 3];
     f32x2 rres[fused_ln ? 4 : 1][3];
@@ -1075,8 +1085,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_w4_kernel(GemmArgs p) {
         if (row < p.M) {
           f32x4 w0, w1;
           if constexpr (EPI == EPI_RESID) aux[i].s = sScale[trow];
-          epilogue8<EPI>(p, row, n0 + c8, *reinterpret_cast<const f32x4*>(sC + rl * CLD + c8), *reinterpret_cast<const f32x4*>(sC + rl * CLD + c8 + 4),
-                         *reinterpret_cast<const f32x4*>(sBias + c8), *reinterpret_cast<const f32x4*>(sBias + c8 + 4), aux[i], w0, w1);
+          epilogue8<EPI>(p, row, n0 + c8, *reinterpret_cast<const f32x4*>(sC + rl * G::CLD2 + (c8 >> 1)), *reinterpret_cast<const f32x4*>(sC + rl * G::CLD2 + G::PL1 + (c8 >> 1)),
+                         *reinterpret_cast<const f32x4*>(sBias + (c8 >> 1)), *reinterpret_cast<const f32x4*>(sBias + G::PL1 + (c8 >> 1)), aux[i], w0, w1);
           if constexpr (EPI == EPI_DGELU) {
             if (p.colsum) {
 #pragma unroll
