@@ -728,11 +728,14 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
   // that part's global loads (residual / saved activations), which are issued as one batch before the staging barrier
   // while the stores follow it (see epi_fetch8).
   float* sC = reinterpret_cast<float*>(smem_raw);
-  float* sBias = sC + 32 * CLD2;                                  // bias of this block's 384 columns (zeros when absent)
+  // rows staged per part: 32 (16 from each wave row).  64 (HPP = 2; the 256-row tile's 120 KB ring holds them: half as many
+  // staging barriers) was measured: qkv 166 -> 160 us but proj/fc2+residual 127 -> 130 / 215 -> 220, step 57.98 -> 58.89 ms.
+  constexpr int HPP = 1, RP = 32 * HPP, SLOTS = RP * 48 / THREADS, LNROWS = RP / WAVES;
+  float* sBias = sC + RP * CLD2;                                  // bias of this block's 384 columns (zeros when absent)
   float* sGamma = sBias + CLD2; float* sBeta = sGamma + BNR;      // fused LayerNorm affine parameters
   float* sScale = sBeta + BNR;                                    // per-row DropPath scale of this block's rows
   float* sCol = sGamma;                                           // EPI_DGELU: column sums of du (fc1 bias gradient); no LN there
-  constexpr int NPART = 2 * MI;
+  constexpr int NPART = 2 * MI / HPP;
   constexpr bool fused_ln = LN && EPI == EPI_RESID;
   const float dqv = F8 ? (p.dq ? *p.dq : 1.0f) * (p.dq_mul != 0.f ? p.dq_mul : 1.0f) : 1.0f;
   if (tid < BNR) {                                                // visible after the first staging barrier; bias in the same two-plane layout as the tile
@@ -745,13 +748,15 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
   }
 #pragma unroll
   for (int part = 0; part < NPART; ++part) {
-    const int mi = part >> 1, h = part & 1;
-    auto tile_row = [&](int rl) { return (rl >> 4) * (32 * MI) + mi * 32 + h * 16 + (rl & 15); };   // staged row -> row of the block tile
+    const int mi = HPP == 2 ? part : part >> 1, h = HPP == 2 ? 0 : part & 1;
+    auto tile_row = [&](int rl) {                                 // staged row -> row of the block tile
+      return HPP == 2 ? (rl >> 5) * (32 * MI) + mi * 32 + (rl & 31) : (rl >> 4) * (32 * MI) + mi * 32 + h * 16 + (rl & 15);
+    };
 #pragma unroll
     for (int ni = 0; ni < 3; ++ni)
 #pragma unroll
-      for (int r8 = 0; r8 < 8; ++r8) {
-        const int lrow = wm * 16 + (r8 & 3) + 8 * (r8 >> 2) + 4 * hi;
+      for (int r8 = 0; r8 < 8 * HPP; ++r8) {
+        const int lrow = wm * (16 * HPP) + (r8 & 3) + 8 * (r8 >> 2) + 4 * hi;
         // Staging layout.  Fused LayerNorm: plain rows (pitch CLD), read back as f32x2 per lane -- conflict-free.  Other
         // epilogues read 8 consecutive columns per thread as two f32x4; in plain rows the 16-lane service groups of
         // ds_read_b128 then stride 32 B and hit every bank twice (SQ counters, round 1: 15-18 % of the LDS cycles of the bf16 /
@@ -761,15 +766,15 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
         const int pos = fused_ln ? lrow * CLD + ccol : lrow * CLD2 + ((ccol >> 3) << 2) + (ccol & 3) + ((ccol & 4) ? PLANE1 : 0);
         sC[pos] = F8 ? acc[mi][ni][h * 8 + r8] * dqv : acc[mi][ni][h * 8 + r8];
       }
-    if (part == 3) STAMP2(20);
+    if (part == NPART / 2 - 1) STAMP2(20);
     // (Issuing these loads one part ahead was measured: no gain -- 219 vs 218 us on fc2+residual -- and 17 spilled
     // registers; a part's time is set by the CU's memory throughput, not by the exposed round trip.)
-    EpiAux aux[fused_ln ? 1 : 3];
-    f32x2 rres[fused_ln ? 4 : 1][3];
+    EpiAux aux[fused_ln ? 1 : SLOTS];
+    f32x2 rres[fused_ln ? LNROWS : 1][3];
     if constexpr (fused_ln) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int row = m0 + tile_row(wid * 4 + q);
+      for (int q = 0; q < LNROWS; ++q) {
+        const int row = m0 + tile_row(wid * LNROWS + q);
         if (row < p.M) {
 #pragma unroll
           for (int k = 0; k < 3; ++k)
@@ -778,22 +783,22 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
+      for (int i = 0; i < SLOTS; ++i) {
         const int idx = tid + THREADS * i, row = m0 + tile_row(idx / 48);
         if (row < p.M) epi_fetch8<EPI, false>(p, row, n0 + (idx % 48) * 8, aux[i]);
       }
     }
-    if (part == 3) STAMP2(21);
+    if (part == NPART / 2 - 1) STAMP2(21);
     __syncthreads();
-    if (part == 3) STAMP2(22);
+    if (part == NPART / 2 - 1) STAMP2(22);
     if constexpr (fused_ln) {
       {
         // Fused residual + LayerNorm of the NEXT sub-layer (N == 384: the block owns whole rows): one wave per row,
         // x_new = resid + s (acc + bias) -> fp32 stream ; h = LN(x_new) -> bf16 operand of the next GEMM ; row statistics
         // saved for the LayerNorm backward.  Replaces a separate HBM pass (ln_fwd_kernel) over x.
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int rl = wid * 4 + q, trow = tile_row(rl), row = m0 + trow;
+        for (int q = 0; q < LNROWS; ++q) {
+          const int rl = wid * LNROWS + q, trow = tile_row(rl), row = m0 + trow;
           if (row >= p.M) continue;
           const float sc = sScale[trow];
           float v[6];
@@ -826,7 +831,7 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
+      for (int i = 0; i < SLOTS; ++i) {
         const int idx = tid + THREADS * i, rl = idx / 48, c8 = (idx % 48) * 8;
         const int trow = tile_row(rl), row = m0 + trow;
 #if ATST_ABLATE != 0 && ATST_ABLATE != 7
@@ -846,7 +851,7 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
         }
       }
     }
-    if (part == 3) STAMP2(23);
+    if (part == NPART / 2 - 1) STAMP2(23);
     if (part < NPART - 1) __syncthreads();
     STAMP2(2 + part);
   }
