@@ -120,14 +120,15 @@ __global__ void cast_kernel(const float* __restrict__ x, size_t n, bf16* __restr
 // [2D..4D) teacher.  Monitor sums are kept in registers across the rows a wave visits and reduced once per block
 // (ATST-Frame has ~170 k rows: one atomic per row-element serialised the whole kernel).
 __global__ __launch_bounds__(256) void byol_loss_kernel(const float* __restrict__ student, const float* __restrict__ teacher,
-                                                        int B, int ncrops, float coef, float* __restrict__ acc,
+                                                        int B, int ncrops, int nteach, float coef, float* __restrict__ acc,
                                                         float* __restrict__ dstudent, float* __restrict__ stats) {
   constexpr int D = 256;
   __shared__ float red[4][4 * D];
   __shared__ float racc[4];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
-  const int ns = ncrops * B, total = ns + 2 * B;
+  // nteach == 2: cross-view pairs (iq != iv) ; nteach == 1: the asymmetric ATST-Frame loss, teacher view 0 vs student view 0
+  const int ns = ncrops * B, total = ns + nteach * B;
   float st[4][4];                                          // [student sum, student sq, teacher sum, teacher sq][4 columns of this lane]
 #pragma unroll
   for (int a = 0; a < 4; ++a)
@@ -148,8 +149,8 @@ __global__ __launch_bounds__(256) void byol_loss_kernel(const float* __restrict_
     float sh[4], T[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int e = 0; e < 4; ++e) sh[e] = s[e] / ns_;
-    for (int iq = 0; iq < 2; ++iq) {
-      if (iq == iv) continue;
+    for (int iq = 0; iq < nteach; ++iq) {
+      if (nteach == 2 && iq == iv) continue;
       const f32x4 t = *reinterpret_cast<const f32x4*>(teacher + (size_t)(iq * B + b) * D + lane * 4);
       const float n = fmaxf(sqrtf(wave_sum(t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3])), 1e-12f);
 #pragma unroll
@@ -232,13 +233,16 @@ int atst_cast_f32_bf16(const float* x, size_t n, bf16* y, hipStream_t st) {
 }
 int atst_byol_loss(const float* student, const float* teacher, int B, int ncrops, int D, float* loss, float* dstudent,
                    float* stats, hipStream_t st) {
-  if (D != 256 || B <= 0 || ncrops < 2) return ATST_EINVAL;
-  const int npairs = 2 * ncrops - 2;
+  // ncrops == -1: asymmetric ATST-Frame loss (methods/atstframe/byol.py:83-84): one teacher view against one student view
+  const bool asym = ncrops == -1;
+  if (D != 256 || B <= 0 || (!asym && ncrops < 2)) return ATST_EINVAL;
+  const int nstu = asym ? 1 : ncrops, nteach = asym ? 1 : 2;
+  const int npairs = asym ? 1 : 2 * ncrops - 2;
   const float coef = 2.0f / ((float)npairs * (float)B);
   hipMemsetAsync(loss, 0, sizeof(float), st);
   hipMemsetAsync(stats, 0, 4 * D * sizeof(float), st);
-  const int rows = (ncrops + 2) * B;
+  const int rows = (nstu + nteach) * B;
   int grid = (rows + 3) / 4; if (grid > 512) grid = 512;
-  hipLaunchKernelGGL(byol_loss_kernel, dim3(grid), dim3(256), 0, st, student, teacher, B, ncrops, coef, loss, dstudent, stats);
+  hipLaunchKernelGGL(byol_loss_kernel, dim3(grid), dim3(256), 0, st, student, teacher, B, nstu, nteach, coef, loss, dstudent, stats);
   return (int)hipGetLastError();
 }

@@ -304,13 +304,17 @@ class AtstEngine:
     """Owns the flat parameter / gradient / optimizer-state buffers of student and teacher and runs the training step."""
 
     def __init__(self, arch: str = "small", frame: bool = False, depth: Optional[int] = None, ncrops: int = 2,
-                 device: Optional[torch.device] = None, drop_path_rate: float = 0.1, n_pos: int = 251, fp8: bool = False):
+                 device: Optional[torch.device] = None, drop_path_rate: float = 0.1, n_pos: int = 251, fp8: bool = False,
+                 symmetric: bool = True):
         if arch not in ARCH:
             raise RuntimeError("arch {} is not implemented".format(arch))      # ref: models/atst/atst.py:17
         hip.load()                                                               # fail loudly when the .so is missing
         if not torch.cuda.is_available():
             raise hip.HipError("AtstEngine needs a HIP device (MI355X); there is no CPU product path")
         self.arch, self.frame, self.ncrops = arch, frame, ncrops
+        if not symmetric and not frame:
+            raise hip.HipError("symmetric=False is the ATST-Frame option (methods/atstframe/model.py:68-76)")
+        self.symmetric = bool(symmetric)
         self.cfg = ARCH[arch]
         self.depth = self.cfg["depth"] if depth is None else depth
         self.n_pos = n_pos
@@ -569,33 +573,43 @@ class AtstEngine:
         """teacher(first 2 views / unmasked) -> student(all views / masked) -> loss.  Returns (loss, std_s, std_t) as
         0-dim device tensors; saves what backward() needs.  ref: models/atst/atst.py:24-28, atstframe/model.py:68-72."""
         self.sync_shadows()
-        nt = len(mels) if self.frame else 2
         mels = [m.to(self.device, torch.float32) for m in mels]
-        # The teacher pass has no data dependence on the student pass: it runs on a second HIP stream so that kernels of
-        # the two passes interleave on the chip (one kernel's epilogue-store phase overlaps the other's load phase).
+        asym = self.frame and not self.symmetric
+        if asym:                                   # ref: atstframe/model.py:73-76 -- teacher: view 0 unmasked ; student: views 1.. masked
+            t_sl, s_sl = slice(0, 1), slice(1, None)
+        else:
+            t_sl, s_sl = slice(0, len(mels) if self.frame else 2), slice(0, None)
+        sub = lambda seq, sl: None if seq is None else list(seq)[sl]
+        # The teacher pass has no data dependence on the student pass: it can run on a second HIP stream (measured: no gain,
+        # full-chip kernels serialise; off by default).
         main = torch.cuda.current_stream()
         if self.overlap_teacher:
             self._side.wait_stream(main)
             with torch.cuda.stream(self._side):
-                tf, _ = self._run_net("teacher", mels[:nt], lengths[:nt], None if masks is None else masks[:nt], False, keep_teacher, False)
+                tf, _ = self._run_net("teacher", mels[t_sl], lengths[t_sl], sub(masks, t_sl), False, keep_teacher, False)
                 t_out = self.heads["teacher.projector"].forward(tf, False)
         else:
-            tf, _ = self._run_net("teacher", mels[:nt], lengths[:nt], None if masks is None else masks[:nt], False, keep_teacher, False)
+            tf, _ = self._run_net("teacher", mels[t_sl], lengths[t_sl], sub(masks, t_sl), False, keep_teacher, False)
             t_out = self.heads["teacher.projector"].forward(tf, False)
-        sf, groups = self._run_net("student", mels, lengths, masks, True, keep_student, train)
+        sf, groups = self._run_net("student", mels[s_sl], lengths[s_sl], sub(masks, s_sl), True, keep_student, train)
         z = self.heads["student.projector"].forward(sf, train)
         s_out = self.heads["student.predictor"].forward(z, train)
         if self.overlap_teacher:
             main.wait_stream(self._side)
         self._teacher_keep = (tf, t_out)
-        ncrops = 2 if self.frame else self.ncrops
-        if s_out.shape[0] % ncrops or t_out.shape[0] % 2 or s_out.shape[0] // ncrops != t_out.shape[0] // 2:
-            raise hip.HipError("views must contribute equal row counts (chunk() semantics of ByolLoss)")
-        B = t_out.shape[0] // 2
         self._ds = torch.empty_like(s_out)
+        if asym:
+            if s_out.shape[0] != t_out.shape[0]:
+                raise hip.HipError("asymmetric ATST-Frame loss: teacher view 0 and student view 1 must select the same rows "
+                                   "(one shared mask, equal lengths: methods/atstframe/transform.py:93-99)")
+            B, ncrops, npairs = s_out.shape[0], -1, 1
+        else:
+            ncrops = 2 if self.frame else self.ncrops
+            if s_out.shape[0] % ncrops or t_out.shape[0] % 2 or s_out.shape[0] // ncrops != t_out.shape[0] // 2:
+                raise hip.HipError("views must contribute equal row counts (chunk() semantics of ByolLoss)")
+            B, npairs = t_out.shape[0] // 2, 2 * ncrops - 2
         hip.call("atst_byol_loss_f32", hip.ptr(s_out), hip.ptr(t_out), B, ncrops, HEAD_OUT, hip.ptr(self._acc), hip.ptr(self._ds),
                  hip.ptr(self._stats), hip.stream())
-        npairs = 2 * ncrops - 2
         loss = 2.0 - 2.0 * self._acc[0] / (npairs * B)
         # one fused all-reduce instead of the reference's six (byol.py:48-50, twice)
         stats, ns, ntc = parallel.allreduce_monitor_sums(self._stats, float(s_out.shape[0]), float(t_out.shape[0]))

@@ -172,7 +172,7 @@ class ATST(nn.Module):
         depth = kwargs.pop("depth", None)
         spec_w = kwargs.pop("spec_w", 1001)
         self.engine = AtstEngine(arch, frame=frame, depth=depth, ncrops=ncrops, drop_path_rate=drop,
-                                 n_pos=spec_w // 4 + 1)
+                                 n_pos=spec_w // 4 + 1, symmetric=kwargs.pop("symmetric", True))
         self.ncrops, self.frame = ncrops, frame
         self.engine.init_weights()
         self.student = _Net(self.engine, "student")
@@ -208,14 +208,16 @@ class ATST(nn.Module):
 
 
 class FrameATST(ATST):
-    """ref: audiossl/methods/atstframe/model.py:24-85 (ATST-Frame branch: avg_blocks=0, symmetric, Linear patch embed)."""
+    """ref: audiossl/methods/atstframe/model.py:24-85 (ATST-Frame branch: avg_blocks=0, Linear patch embed; symmetric=True: both
+    views through both networks, cross-view loss; symmetric=False: teacher sees view 0, student the masked view 1, one pair)."""
 
     def __init__(self, arch="small", symmetric=True, pos_type="cut", avg_blocks=0, patch_embed="Linear", **kwargs):
-        if not symmetric or pos_type != "cut" or avg_blocks != 0 or patch_embed != "Linear":
-            raise NotImplementedError("HIP path implements the shipped ATST-Frame recipe: symmetric, pos_type='cut', "
-                                      "avg_blocks=0, patch_embed='Linear' (methods/atstframe/train_small.sh)")
-        super().__init__(arch=arch, ncrops=2, frame=True, **kwargs)
-        self.symmetric = True
+        if pos_type != "cut" or avg_blocks != 0 or patch_embed != "Linear":
+            raise NotImplementedError("HIP path implements the ATST-Frame branch of the reference: pos_type='cut', avg_blocks=0 "
+                                      "(not the data2vec-style variant), patch_embed='Linear' (methods/atstframe/train_small.sh); "
+                                      "symmetric and asymmetric losses are both available")
+        super().__init__(arch=arch, ncrops=2, frame=True, symmetric=symmetric, **kwargs)
+        self.symmetric = bool(symmetric)
 
     def forward(self, x, length, mask, keep_teacher=None, keep_student=None):
         return super().forward(x, length, mask, keep_teacher, keep_student)

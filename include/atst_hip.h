@@ -109,7 +109,9 @@ int atst_bn_bwd_dx_bf16(const float* dy, const float* h, const float* mean, cons
                         const float* beta, const float* sum_dy, const float* sum_dy_xhat, float inv_count, int R, int N,
                         uint16_t* dh, void* stream);
 /* ByolLoss.forward + its backward: audiossl/models/atst/byol.py:24-78.  acc[0] = sum of pair cosines,
- * loss = 2 - 2*acc/((2*ncrops-2)*B); stats [4,256] = student/teacher column sums and square sums of normalised rows. */
+ * loss = 2 - 2*acc/((2*ncrops-2)*B); stats [4,256] = student/teacher column sums and square sums of normalised rows.
+ * ncrops == -1: the asymmetric ATST-Frame loss (methods/atstframe/byol.py:83-84, model.py:73-76): student [B,256] (view 1)
+ * against teacher [B,256] (view 0), loss = 2 - 2*acc/B.                                                                   */
 int atst_byol_loss_f32(const float* student, const float* teacher, int B, int ncrops, int D, float* acc, float* dstudent,
                        float* stats, void* stream);
 

@@ -528,13 +528,20 @@ def frame_byol_loss(student: Tensor, teacher: Tensor):
 
 
 def frame_atst_forward(W: Weights, mels, lengths, masks, arch: str = "small", keep_teacher=None, keep_student=None,
-                       depth=None, drop_path_rate: float = 0.1):
-    """FrameATST.forward, symmetric: teacher sees the unmasked input, student the mask-token-substituted one.
-    ref: methods/atstframe/model.py:68-72."""
+                       depth=None, drop_path_rate: float = 0.1, symmetric: bool = True):
+    """FrameATST.forward: teacher sees the unmasked input, student the mask-token-substituted one.  symmetric: both views
+    through both networks (model.py:68-72); otherwise teacher on view 0, student on view 1, one pair scored with
+    2 - 2 cosine_similarity (model.py:73-76, byol.py:23-36,83-84)."""
+    if symmetric:
+        with torch.no_grad():
+            t = frame_net_forward(W, "teacher.", mels, lengths, masks, False, arch, False, keep_teacher, depth, drop_path_rate)
+        s = frame_net_forward(W, "student.", mels, lengths, masks, True, arch, True, keep_student, depth, drop_path_rate)
+        return frame_byol_loss(s, t)
     with torch.no_grad():
-        t = frame_net_forward(W, "teacher.", mels, lengths, masks, False, arch, False, keep_teacher, depth, drop_path_rate)
-    s = frame_net_forward(W, "student.", mels, lengths, masks, True, arch, True, keep_student, depth, drop_path_rate)
-    return frame_byol_loss(s, t)
+        t = frame_net_forward(W, "teacher.", mels[:1], lengths[:1], masks[:1], False, arch, False, keep_teacher, depth, drop_path_rate)
+    s = frame_net_forward(W, "student.", mels[1:], lengths[1:], masks[1:], True, arch, True, keep_student, depth, drop_path_rate)
+    loss = 2 - 2 * F.cosine_similarity(s, t, dim=-1).mean()
+    return loss, feature_std(s), feature_std(t)
 
 
 # ----------------------------------------------------------------------------------------------------------------------

@@ -215,6 +215,44 @@ def gen_frame(name="frame_small"):
     save(name, **arrs)
 
 
+def gen_frame_asym(name="frame_small_asym"):
+    """FrameATST(symmetric=False): teacher on view 0 (unmasked), student on view 1 (masked), ByolLoss(symmetric=False)
+    (methods/atstframe/model.py:73-76, byol.py:83-84); assembled from its parts like gen_frame."""
+    import audio_transformer as fat
+    import byol as fbyol
+    torch.manual_seed(5)
+    student = fbyol.MultiCropWrapper(fat.FrameAST_small(pos_type="cut", patch_embed="Linear"), 384, predictor=True)
+    teacher = fbyol.MultiCropWrapper(fat.FrameAST_small(pos_type="cut", patch_embed="Linear"), 384, predictor=False)
+    loss_fn = fbyol.ByolLoss(symmetric=False)
+    W = O.recipe_weights("small", frame=True, seed=13)
+    student.load_state_dict({k[len("student."):]: v for k, v in W.items() if k.startswith("student.")})
+    teacher.load_state_dict({k[len("teacher."):]: v for k, v in W.items() if k.startswith("teacher.")})
+    for p in teacher.parameters():
+        p.requires_grad = False
+    student.train(); teacher.train()
+    B = 4
+    mels = [O.recipe_mel(B, 1001, seed=31), O.recipe_mel(B, 1001, seed=32)]
+    lens = [torch.tensor([1001, 702, 1001, 850])] * 2
+    rs = np.random.RandomState(77)
+    m = torch.from_numpy(np.stack([O.block_mask(250, 0.65, 5, rng=rs) for _ in range(B)]))
+    masks = [m, m]
+    torch.manual_seed(19)
+    with RandRecorder() as rr:
+        tea = teacher(mels[:1], lens[:1], masks[:1], False)
+        n_t = len(rr.draws)
+        stu = student(mels[1:], lens[1:], masks[1:], True)
+        loss, std_s, std_t = loss_fn(stu, tea)
+    loss.backward()
+    rates = O.drop_path_rates(12)
+    arrs = dict(B=B, lengths=np.stack([l.numpy() for l in lens]), mask=m.numpy(), M=stu.shape[0],
+                loss=loss.item(), std_s=std_s.item(), std_t=std_t.item(),
+                teacher_out=tea.detach().numpy()[::7], student_out=stu.detach().numpy()[::7],
+                keep_t0=keep_from_draws(rr.draws[:n_t], 12, rates).numpy(),
+                keep_s0=keep_from_draws(rr.draws[n_t:], 12, rates).numpy())
+    arrs.update(grad_digest(student.named_parameters()))
+    save(name, **arrs)
+
+
 def gen_encoder_grad(name="clip_encoder_grad"):
     """Encoder-only gradient pin that does not pass through the tiny-batch BatchNorm (which is ill-conditioned at B=2,
     see DESIGN.md "Precision"): L = sum(CLS * R) for a fixed R, full-depth AST_small, ragged lengths, DropPath on."""
@@ -332,7 +370,7 @@ def gen_aug(name="aug_byol_a"):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["blocks", "clip2", "clip2_nodrop", "clip6", "frame", "sched", "encgrad", "clip2_b16", "clip2_b64", "infer", "aug", "frame_infer"]
+    which = sys.argv[1:] or ["blocks", "clip2", "clip2_nodrop", "clip6", "frame", "sched", "encgrad", "clip2_b16", "clip2_b64", "infer", "aug", "frame_infer", "frame_asym"]
     if "aug" in which:
         gen_aug()
     if "frame_infer" in which:
@@ -360,5 +398,7 @@ if __name__ == "__main__":
         gen_clip("clip_small_2views_b64", 2, [1001, 1001], [L, L2], B=64, seed_x=71)
     if "frame" in which:
         gen_frame()
+    if "frame_asym" in which:
+        gen_frame_asym()
     if "sched" in which:
         gen_sched()

@@ -138,6 +138,23 @@ def test_frame_step(golden_dir):
     grad_check(G, [(n, p) for n, p in leaves])
 
 
+def test_frame_step_asymmetric(golden_dir):
+    """FrameATST(symmetric=False): teacher on view 0, student on the masked view 1, one cosine pair (model.py:73-76)."""
+    G = load(golden_dir, "frame_small_asym")
+    B = int(G["B"])
+    W = O.recipe_weights("small", frame=True, seed=13)
+    leaves = student_leaves(W)
+    mels = [O.recipe_mel(B, 1001, seed=31), O.recipe_mel(B, 1001, seed=32)]
+    lens = [torch.from_numpy(l) for l in G["lengths"]]
+    masks = [torch.from_numpy(G["mask"])] * 2
+    loss, std_s, std_t = O.frame_atst_forward(W, mels, lens, masks, "small", [torch.from_numpy(G["keep_t0"])],
+                                              [torch.from_numpy(G["keep_s0"])], symmetric=False)
+    loss.backward()
+    assert abs(loss.item() - float(G["loss"])) < 1e-5
+    assert abs(std_s.item() - float(G["std_s"])) < 1e-5 and abs(std_t.item() - float(G["std_t"])) < 1e-5
+    grad_check(G, [(n, p) for n, p in leaves])
+
+
 def test_schedules_and_groups(golden_dir):
     G = load(golden_dir, "schedules")
     idx = G["idx"]

@@ -316,6 +316,33 @@ def test_frame_step_vs_reference_golden():
             assert abs(nerr) < 5e-2 and r < 7.5e-2, (k, r, nerr)          # measured worst 4.8e-2 (x1.5)
 
 
+def test_frame_asymmetric_step_vs_reference_golden():
+    """FrameATST(symmetric=False) (methods/atstframe/model.py:73-76): teacher on the clean view 0, student on the masked view 1."""
+    from audiossl_amd.models.atst import FrameATST
+    G = load("frame_small_asym")
+    B = int(G["B"])
+    model = FrameATST("small", symmetric=False)
+    eng = model.engine
+    eng.load_weights(O.recipe_weights("small", frame=True, seed=13))
+    mels = [O.recipe_mel(B, 1001, seed=31), O.recipe_mel(B, 1001, seed=32)]
+    lens = [torch.from_numpy(l) for l in G["lengths"]]
+    masks = [torch.from_numpy(G["mask"])] * 2
+    loss, std_s, std_t = eng.forward(mels, lens, masks, [torch.from_numpy(G["keep_t0"])], [torch.from_numpy(G["keep_s0"])])
+    eng.backward()
+    s_out, t_out = eng.last_outputs
+    assert s_out.shape[0] == int(G["M"]) == t_out.shape[0]                 # same masked & valid rows for both networks
+    rs, rt = rel(s_out.cpu().numpy()[::7], G["student_out"]), rel(t_out.cpu().numpy()[::7], G["teacher_out"])
+    print(f"\n[frame asym] loss {loss.item():.6f} (ref {float(G['loss']):.6f}) out rel {rs:.2e} {rt:.2e}")
+    assert abs(loss.item() - float(G["loss"])) < 5e-3
+    assert abs(std_s.item() - float(G["std_s"])) < 2e-3 and abs(std_t.item() - float(G["std_t"])) < 2e-3
+    assert rs < 2.5e-2 and rt < 2.5e-2
+    tab = grad_table(eng, G)
+    assert len(tab) == 146 and tab["predictor.3.weight"][0] < 3e-2
+    for k, (r, nerr, n) in tab.items():
+        if k not in CANCELLING:
+            assert abs(nerr) < 5e-2 and r < 0.12, (k, r, nerr)            # ReLU-gate flips behind ~650 BatchNorm rows (cf. symmetric: 4.8e-2)
+
+
 @pytest.mark.parametrize("name,tol", [("clip_small_2views_b16", dict(g32=(1.9e-2, 2.7e-2), emu=(1.7e-2, 2.8e-2), flip=5e-2)),
                                       ("frame_small", dict(g32=(2.6e-2, 3.2e-2), emu=(6.5e-3, 9e-3), flip=2e-2))])
 def test_gradient_gap_is_the_relu_gates(name, tol):
