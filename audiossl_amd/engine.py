@@ -27,7 +27,7 @@ def _round_up(n, a=ALIGN):
     return (n + a - 1) // a * a
 
 
-def encoder_param_shapes(arch: str, depth: Optional[int] = None, frame: bool = False, n_pos: int = 251):
+def encoder_param_shapes(arch: str, depth: Optional[int] = None, frame: bool = False, n_pos: int = 251, patch_embed: str = "Linear"):
     """Parameter names/shapes in the reference's registration order (= state_dict order).
     ref: audiossl/models/atst/audio_transformer.py:80-120 ; audiossl/methods/atstframe/audio_transformer.py:101-149."""
     cfg = ARCH[arch]
@@ -35,7 +35,11 @@ def encoder_param_shapes(arch: str, depth: Optional[int] = None, frame: bool = F
     out = [("mask_embed", (1, 1, d))]
     if not frame:
         out.append(("cls_token", (1, 1, d)))
-    out += [("pos_embed", (1, n_pos, d)), ("patch_embed.patch_embed.weight", (d, 256)), ("patch_embed.patch_embed.bias", (d,))]
+    # patch_embed="CNN" (ATST-Frame option, atstframe/audio_transformer.py:57-74,117-118): Conv2d(1, d, (64, 4), stride (64, 4)) -- the
+    # same contraction over k = f * 4 + t, stored as [d, 1, 64, 4] under `patch_embed.proj.*`
+    pe = [("patch_embed.proj.weight", (d, 1, 64, 4)), ("patch_embed.proj.bias", (d,))] if patch_embed == "CNN" else \
+         [("patch_embed.patch_embed.weight", (d, 256)), ("patch_embed.patch_embed.bias", (d,))]
+    out += [("pos_embed", (1, n_pos, d))] + pe
     for i in range(depth):
         b = f"blocks.{i}."
         out += [(b + "norm1.weight", (d,)), (b + "norm1.bias", (d,)), (b + "attn.qkv.weight", (3 * d, d)),
@@ -56,11 +60,11 @@ def head_param_shapes(in_dim: int):
 class FlatLayout:
     """name -> (offset, shape) for 'encoder.*', 'projector.*', 'predictor.*' in one flat buffer."""
 
-    def __init__(self, arch: str, depth: Optional[int], frame: bool):
+    def __init__(self, arch: str, depth: Optional[int], frame: bool, patch_embed: str = "Linear"):
         d = ARCH[arch]["embed_dim"]
         self.entries: "OrderedDict[str, Tuple[int, Tuple[int, ...]]]" = OrderedDict()
         off = 0
-        groups = [("encoder.", encoder_param_shapes(arch, depth, frame)), ("projector.", head_param_shapes(d)),
+        groups = [("encoder.", encoder_param_shapes(arch, depth, frame, patch_embed=patch_embed)), ("projector.", head_param_shapes(d)),
                   ("predictor.", head_param_shapes(HEAD_OUT))]
         for prefix, shapes in groups:
             for name, shape in shapes:
@@ -305,7 +309,7 @@ class AtstEngine:
 
     def __init__(self, arch: str = "small", frame: bool = False, depth: Optional[int] = None, ncrops: int = 2,
                  device: Optional[torch.device] = None, drop_path_rate: float = 0.1, n_pos: int = 251, fp8: bool = False,
-                 symmetric: bool = True):
+                 symmetric: bool = True, patch_embed: str = "Linear"):
         if arch not in ARCH:
             raise RuntimeError("arch {} is not implemented".format(arch))      # ref: models/atst/atst.py:17
         hip.load()                                                               # fail loudly when the .so is missing
@@ -315,12 +319,15 @@ class AtstEngine:
         if not symmetric and not frame:
             raise hip.HipError("symmetric=False is the ATST-Frame option (methods/atstframe/model.py:68-76)")
         self.symmetric = bool(symmetric)
+        if patch_embed not in ("Linear", "CNN") or (patch_embed == "CNN" and not frame):
+            raise NotImplementedError("patch_embed={} not implemted".format(patch_embed))      # ref: atstframe/audio_transformer.py:119-120
+        self.patch_embed = patch_embed
         self.cfg = ARCH[arch]
         self.depth = self.cfg["depth"] if depth is None else depth
         self.n_pos = n_pos
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        self.layout = L = FlatLayout(arch, self.depth, frame)
+        self.layout = L = FlatLayout(arch, self.depth, frame, patch_embed)
         dev = self.device
         z = lambda n, dt=torch.float32: torch.zeros(n, dtype=dt, device=dev)
         self.p32, self.g32, self.m32, self.v32 = z(L.n_student), z(L.n_student), z(L.n_student), z(L.n_student)
@@ -381,7 +388,8 @@ class AtstEngine:
         g = lambda n: E["encoder." + n][0]
         o.mask_embed, o.pos_embed = g("mask_embed"), g("pos_embed")
         o.cls_token = g("cls_token") if not self.frame else 0
-        o.patch_w, o.patch_b = g("patch_embed.patch_embed.weight"), g("patch_embed.patch_embed.bias")
+        pe = "patch_embed.proj." if self.patch_embed == "CNN" else "patch_embed.patch_embed."
+        o.patch_w, o.patch_b = g(pe + "weight"), g(pe + "bias")
         nf = "norm_frame" if self.frame else "norm"
         o.norm_w, o.norm_b = g(nf + ".weight"), g(nf + ".bias")
         for i in range(self.depth):
@@ -424,7 +432,9 @@ class AtstEngine:
         with torch.no_grad():
             for name, (off, shape) in self.layout.entries.items():
                 v = self.param_view("student", name)
-                if name.startswith("encoder."):
+                if name.startswith("encoder.patch_embed.proj."):        # nn.Conv2d keeps torch's default init (_init_weights skips it)
+                    v.uniform_(-1.0 / 16.0, 1.0 / 16.0, generator=g)      # kaiming_uniform(a=sqrt 5): bound 1/sqrt(fan_in = 256), bias alike
+                elif name.startswith("encoder."):
                     if name.endswith(".bias"):
                         v.zero_()
                     elif len(shape) == 1:

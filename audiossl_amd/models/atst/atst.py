@@ -172,7 +172,8 @@ class ATST(nn.Module):
         depth = kwargs.pop("depth", None)
         spec_w = kwargs.pop("spec_w", 1001)
         self.engine = AtstEngine(arch, frame=frame, depth=depth, ncrops=ncrops, drop_path_rate=drop,
-                                 n_pos=spec_w // 4 + 1, symmetric=kwargs.pop("symmetric", True))
+                                 n_pos=spec_w // 4 + 1, symmetric=kwargs.pop("symmetric", True),
+                                 patch_embed=kwargs.pop("patch_embed", "Linear"))
         self.ncrops, self.frame = ncrops, frame
         self.engine.init_weights()
         self.student = _Net(self.engine, "student")
@@ -212,11 +213,11 @@ class FrameATST(ATST):
     views through both networks, cross-view loss; symmetric=False: teacher sees view 0, student the masked view 1, one pair)."""
 
     def __init__(self, arch="small", symmetric=True, pos_type="cut", avg_blocks=0, patch_embed="Linear", **kwargs):
-        if pos_type != "cut" or avg_blocks != 0 or patch_embed != "Linear":
+        if pos_type != "cut" or avg_blocks != 0 or patch_embed not in ("Linear", "CNN"):
             raise NotImplementedError("HIP path implements the ATST-Frame branch of the reference: pos_type='cut', avg_blocks=0 "
-                                      "(not the data2vec-style variant), patch_embed='Linear' (methods/atstframe/train_small.sh); "
-                                      "symmetric and asymmetric losses are both available")
-        super().__init__(arch=arch, ncrops=2, frame=True, symmetric=symmetric, **kwargs)
+                                      "(not the data2vec-style variant), patch_embed 'Linear' or 'CNN'; symmetric and asymmetric "
+                                      "losses are both available")
+        super().__init__(arch=arch, ncrops=2, frame=True, symmetric=symmetric, patch_embed=patch_embed, **kwargs)
         self.symmetric = bool(symmetric)
 
     def forward(self, x, length, mask, keep_teacher=None, keep_student=None):

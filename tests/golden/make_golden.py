@@ -253,6 +253,35 @@ def gen_frame_asym(name="frame_small_asym"):
     save(name, **arrs)
 
 
+def gen_frame_cnn(name="frame_cnn_patch_embed"):
+    """FrameAST_small(patch_embed="CNN") (atstframe/audio_transformer.py:57-74): Conv2d(1, d, (64, 4), stride (64, 4)) patch
+    embedding.  Parameter names / shapes of the reference module and its eval-mode frame features on recipe weights whose
+    conv kernel is the recipe's Linear weight viewed as [d, 1, 64, 4]."""
+    import audio_transformer as fat
+    enc = fat.FrameAST_small(pos_type="cut", patch_embed="CNN")
+    W = O.recipe_weights("small", frame=True, seed=81)
+    sd = {}
+    for k, v in W.items():
+        if not k.startswith("teacher.encoder."):
+            continue
+        k = k[len("teacher.encoder."):]
+        if k == "patch_embed.patch_embed.weight":
+            sd["patch_embed.proj.weight"] = v.reshape(v.shape[0], 1, 64, 4).clone()
+        elif k == "patch_embed.patch_embed.bias":
+            sd["patch_embed.proj.bias"] = v.clone()
+        else:
+            sd[k] = v
+    enc.load_state_dict(sd)
+    enc.eval()
+    x, length = O.recipe_mel(2, 1001, seed=83), torch.tensor([1001, 650])
+    with torch.no_grad():
+        scene = enc.get_intermediate_layers(x, length, 2, scene=True)
+        frames = enc.get_intermediate_layers(x, length, 1, scene=False)
+    names = np.array([n for n, _ in enc.named_parameters()])
+    shapes = np.array([" ".join(str(d) for d in p.shape) for _, p in enc.named_parameters()])
+    save(name, length=length.numpy(), scene=scene.numpy(), frames=frames.numpy()[:, ::5, ::4], param_names=names, param_shapes=shapes)
+
+
 def gen_encoder_grad(name="clip_encoder_grad"):
     """Encoder-only gradient pin that does not pass through the tiny-batch BatchNorm (which is ill-conditioned at B=2,
     see DESIGN.md "Precision"): L = sum(CLS * R) for a fixed R, full-depth AST_small, ragged lengths, DropPath on."""
@@ -370,7 +399,7 @@ def gen_aug(name="aug_byol_a"):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["blocks", "clip2", "clip2_nodrop", "clip6", "frame", "sched", "encgrad", "clip2_b16", "clip2_b64", "infer", "aug", "frame_infer", "frame_asym"]
+    which = sys.argv[1:] or ["blocks", "clip2", "clip2_nodrop", "clip6", "frame", "sched", "encgrad", "clip2_b16", "clip2_b64", "infer", "aug", "frame_infer", "frame_asym", "frame_cnn"]
     if "aug" in which:
         gen_aug()
     if "frame_infer" in which:
@@ -400,5 +429,7 @@ if __name__ == "__main__":
         gen_frame()
     if "frame_asym" in which:
         gen_frame_asym()
+    if "frame_cnn" in which:
+        gen_frame_cnn()
     if "sched" in which:
         gen_sched()

@@ -234,3 +234,30 @@ def test_inference_workspaces_are_bounded():
     eng = model.engine
     assert len(eng._infer_passes) <= 4 and not any(k[3] for k in eng._passes)     # no training-sized pass was created
     assert all(not p.train for p in eng._infer_passes.values())
+
+
+def test_frame_cnn_patch_embed_vs_reference_golden():
+    """FrameATST(patch_embed="CNN"): the Conv2d(1, d, (64, 4), stride (64, 4)) patch embedding of the reference
+    (atstframe/audio_transformer.py:57-74) is the same contraction as the Linear one; state_dict keys / shapes are the conv's."""
+    from audiossl_amd.models.atst import FrameATST
+    G = np.load(os.path.join(GOLD, "frame_cnn_patch_embed.npz"))
+    model = FrameATST("small", patch_embed="CNN")
+    sd = model.state_dict()
+    assert sd["teacher.encoder.patch_embed.proj.weight"].shape == (384, 1, 64, 4) and "teacher.encoder.patch_embed.patch_embed.weight" not in sd
+    W = O.recipe_weights("small", frame=True, seed=81)
+    W2 = {}
+    for k, v in W.items():
+        if k.endswith("patch_embed.patch_embed.weight"):
+            W2[k.replace("patch_embed.patch_embed.weight", "patch_embed.proj.weight")] = v.reshape(v.shape[0], 1, 64, 4)
+        elif k.endswith("patch_embed.patch_embed.bias"):
+            W2[k.replace("patch_embed.patch_embed.bias", "patch_embed.proj.bias")] = v
+        else:
+            W2[k] = v
+    model.load_state_dict(W2)
+    enc = model.teacher.encoder
+    x, length = O.recipe_mel(2, 1001, seed=83), torch.from_numpy(G["length"])
+    scene = enc.get_intermediate_layers(x, length, n=2, scene=True)
+    frames = enc.get_intermediate_layers(x, length, n=1, scene=False)
+    assert rel(scene.cpu().numpy(), G["scene"]) < 1.0e-2 and rel(frames.cpu().numpy()[:, ::5, ::4], G["frames"]) < 1.0e-2
+    with pytest.raises(NotImplementedError):
+        FrameATST("small", patch_embed="MLP")

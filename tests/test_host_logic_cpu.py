@@ -174,3 +174,15 @@ def test_bench_refuses_a_world_size_that_is_not_gpus():
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "4"], cwd=root, env=dict(os.environ, WORLD_SIZE="2", RANK="0"),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 2 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_cnn_patch_embed_layout_matches_reference_names():
+    """patch_embed="CNN" (atstframe/audio_transformer.py:57-74,117-118): same flat layout, Conv2d names / shapes."""
+    G = np.load(os.path.join(GOLD, "frame_cnn_patch_embed.npz"))
+    shapes = E.encoder_param_shapes("small", None, True, patch_embed="CNN")
+    assert [n for n, _ in shapes] == list(G["param_names"])
+    assert [" ".join(str(d) for d in s) for _, s in shapes] == list(G["param_shapes"])
+    L = E.FlatLayout("small", None, True, "CNN")
+    Ll = E.FlatLayout("small", None, True, "Linear")
+    assert L.entries["encoder.patch_embed.proj.weight"][0] == Ll.entries["encoder.patch_embed.patch_embed.weight"][0]
+    assert L.n_student == Ll.n_student
