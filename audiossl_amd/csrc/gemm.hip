@@ -1218,7 +1218,11 @@ constexpr int Y_BYTES = RM * PY, X_BYTES = RM * PX, STAGE = Y_BYTES + X_BYTES;  
 constexpr int NST = RM == 64 ? 2 : 4;
 constexpr int LDS = NST * STAGE;                                      // 147,456 B either way
 constexpr int Y_PIECES = Y_BYTES / 1024, PIECES = STAGE / 1024;       // 1-KiB LDS-DMA pieces per stage: 12 + 24 (RM 32) ; 24 + 48
-constexpr int PPW = (PIECES + 7) / 8;                                 // per wave: 5 (waves 0-3) / 4 (RM 32) ; 9 (RM 64)
+#ifndef ATST_TN_SPLIT
+#define ATST_TN_SPLIT 0        // 1: only waves 4-7 issue the LDS-DMA of the next stage while waves 0-3 already run the stage's MFMAs (measured: no gain, see below)
+#endif
+constexpr int LOADERS = ATST_TN_SPLIT ? 4 : 8, LOADER0 = ATST_TN_SPLIT ? 4 : 0;
+constexpr int PPW = (PIECES + LOADERS - 1) / LOADERS;                 // pieces per loader wave per stage: 18 (split) / 9 (RM 64)
 }
 
 // ds_read_b64_tr_b16 is serviced 32 lanes at a time = 4 rows x 64 B of the image, over 64 banks (256 B): the four rows
@@ -1239,6 +1243,12 @@ DEVFN bf16x8 ld_frag_tr_p(const char* X, int r0, int c0, int lane) {
   return u.v;
 }
 
+#if ATST_TRACE
+__device__ unsigned long long g_tn_trc[8 * 260 * 4];            // [wave][stage][0: loop top, 1: after wait, 2: after barrier + issue, 3: after MFMAs]
+#define TSTAMP(i) do { if (ttrace && st < 260) g_tn_trc[(wid * 260 + st) * 4 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TSTAMP(i) do { } while (0)
+#endif
 // one (tile, split) of one problem
 DEVFN void tn_tall_body(const WgradArgs& p, int tile, int split, char* smem_raw) {
   using namespace tnt;
@@ -1254,12 +1264,16 @@ DEVFN void tn_tall_body(const WgradArgs& p, int tile, int split, char* smem_raw)
   const int nst = (m_end - m_begin) / RM;
 
   // lane -> (row, chunk) of the linear stage image.  Piece q (1 KiB) of a stage: q < Y_PIECES -> dY image, else X image;
-  // wave w issues pieces w, w + 8, w + 16, ...
+  // loader wave w issues pieces w', w' + LOADERS, ...
+  // Stage timeline measured with every wave issuing its 9 pieces right after the barrier (tools/trace_tn.py): 1.5-2.0 k cycles
+  // of LDS-DMA issue with idle matrix pipes, then 2.6-3.3 k cycles for the 2 x 36 MFMAs of a SIMD: 5.3 k per 64 rows.  With the
+  // issue moved to waves 4-7 alone, waves 0-3 compute meanwhile and the two waves of a SIMD no longer contend for its pipe.
+  const bool loader = wid >= LOADER0;
   int off[PPW]; bool isx[PPW]; bool have[PPW]; int ldsoff[PPW];
 #pragma unroll
   for (int j = 0; j < PPW; ++j) {
-    const int q = wid + 8 * j;
-    have[j] = q < PIECES;
+    const int q = (wid - LOADER0) + LOADERS * j;
+    have[j] = loader && q < PIECES;
     isx[j] = q >= Y_PIECES;
     if (!isx[j]) {
       const int c_ = q * 64 + lane, row = c_ / 24, c = (c_ % 24) ^ tr_swz<PY>(row);
@@ -1291,8 +1305,12 @@ DEVFN void tn_tall_body(const WgradArgs& p, int tile, int split, char* smem_raw)
 #pragma unroll
   for (int s_ = 0; s_ < NST - 1; ++s_)
     if (s_ < nst) issue_stage(s_);
-  constexpr int MINPW = PIECES / 8;                               // loads per stage of the waves that issue the fewest
+  constexpr int MINPW = PIECES / LOADERS;                         // loads per stage of the loader waves that issue the fewest
+#if ATST_TRACE
+  const bool ttrace = (int)blockIdx.x == 100 && lane == 0;
+#endif
   for (int st = 0; st < nst; ++st) {
+    TSTAMP(0);
     // stage st has landed (my loads retire in order; up to NST - 2 younger stages stay in flight; waves that issue one piece
     // more per stage simply wait for a little of stage st + 1 as well); barrier => for everyone, and stage st - 1's buffer is free
     const int younger = nst - 1 - st < NST - 2 ? nst - 1 - st : NST - 2;
@@ -1303,8 +1321,10 @@ DEVFN void tn_tall_body(const WgradArgs& p, int tile, int split, char* smem_raw)
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    TSTAMP(1);
     asm volatile("s_barrier" ::: "memory");
     if (st + NST - 1 < nst) issue_stage(st + NST - 1);
+    TSTAMP(2);
     const char* sY = smem_raw + (st % NST) * STAGE; const char* sX = sY + Y_BYTES;
 #pragma unroll
     for (int ms = 0; ms < RM / 16; ++ms) {
@@ -1318,7 +1338,11 @@ DEVFN void tn_tall_body(const WgradArgs& p, int tile, int split, char* smem_raw)
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
     }
+    TSTAMP(3);
   }
+#if ATST_TRACE
+  { const int st = 259; TSTAMP(0); }
+#endif
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -1582,6 +1606,11 @@ bool tn_tall_ok(const WgradArgs& a) {
   return g_tn_tall && a.N % tnt::TN == 0 && a.K % tnt::TK == 0 && a.M % tnt::RM == 0 && a.M >= 8192 && a.ldy % 8 == 0 && a.ldx % 8 == 0;
 }
 
+#if ATST_TRACE
+extern "C" int atst_debug_tn_trace(unsigned long long* host, int n) {   // trace builds only (tools/trace_tn.py)
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tn_trc), sizeof(unsigned long long) * (size_t)n);
+}
+#endif
 int atst_gemm_tn_group(const WgradArgs* items, int n, hipStream_t st) {
   if (n < 1 || n > ATST_WGRAD_GROUP_MAX) return ATST_EINVAL;
   bool tall = true;
