@@ -13,8 +13,9 @@ SOURCES = ["api.hip", "engine.hip", "gemm.hip", "layernorm.hip", "attention.hip"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
 if os.environ.get("ATST_EXTRA_FLAGS"):      # experiment builds: e.g. ATST_EXTRA_FLAGS="-DATST_ABLATE_ATTN_STORE"
     FLAGS += os.environ["ATST_EXTRA_FLAGS"].split()
-if os.environ.get("ATST_TN_ISSUE"):
-    FLAGS.append("-DATST_TN_ISSUE=" + os.environ["ATST_TN_ISSUE"])
+for _k in ("ATST_TN_ILV", "ATST_TN_SPLIT", "ATST_TN_RM"):
+    if os.environ.get(_k):
+        FLAGS.append(f"-D{_k}=" + os.environ[_k])
 if os.environ.get("ATST_INTERLEAVE"):
     FLAGS.append("-DATST_INTERLEAVE=" + os.environ["ATST_INTERLEAVE"])
 if os.environ.get("ATST_TALL_STAGES"):

@@ -1218,6 +1218,9 @@ constexpr int Y_BYTES = RM * PY, X_BYTES = RM * PX, STAGE = Y_BYTES + X_BYTES;  
 constexpr int NST = RM == 64 ? 2 : 4;
 constexpr int LDS = NST * STAGE;                                      // 147,456 B either way
 constexpr int Y_PIECES = Y_BYTES / 1024, PIECES = STAGE / 1024;       // 1-KiB LDS-DMA pieces per stage: 12 + 24 (RM 32) ; 24 + 48
+#ifndef ATST_TN_ILV
+#define ATST_TN_ILV 0          // 1: the next stage's LDS-DMA pieces are issued one per MFMA group instead of all after the barrier
+#endif
 #ifndef ATST_TN_SPLIT
 #define ATST_TN_SPLIT 0        // 1: only waves 4-7 issue the LDS-DMA of the next stage while waves 0-3 already run the stage's MFMAs (measured: no gain, see below)
 #endif
@@ -1285,14 +1288,15 @@ DEVFN void tn_tall_body(const WgradArgs& p, int tile, int split, char* smem_raw)
   }
   const bf16* baseY = p.dY + (size_t)m_begin * p.ldy;
   const bf16* baseX = p.X + (size_t)m_begin * p.ldx;
-  auto issue_stage = [&](int st) {
+  auto issue_piece = [&](int st, int j) {
     char* buf = smem_raw + (st % NST) * STAGE;
+    if (!have[j]) return;
+    const bf16* src = isx[j] ? baseX + (size_t)st * RM * p.ldx + off[j] : baseY + (size_t)st * RM * p.ldy + off[j];
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + ldsoff[j]), 16, 0, 0);
+  };
+  auto issue_stage = [&](int st) {
 #pragma unroll
-    for (int j = 0; j < PPW; ++j) {
-      if (!have[j]) continue;
-      const bf16* src = isx[j] ? baseX + (size_t)st * RM * p.ldx + off[j] : baseY + (size_t)st * RM * p.ldy + off[j];
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + ldsoff[j]), 16, 0, 0);
-    }
+    for (int j = 0; j < PPW; ++j) issue_piece(st, j);
   };
   f32x16 acc[3][3];
 #pragma unroll
@@ -1323,9 +1327,13 @@ DEVFN void tn_tall_body(const WgradArgs& p, int tile, int split, char* smem_raw)
     }
     TSTAMP(1);
     asm volatile("s_barrier" ::: "memory");
-    if (st + NST - 1 < nst) issue_stage(st + NST - 1);
+    const bool more = st + NST - 1 < nst;
+#if !ATST_TN_ILV
+    if (more) issue_stage(st + NST - 1);
+#endif
     TSTAMP(2);
     const char* sY = smem_raw + (st % NST) * STAGE; const char* sX = sY + Y_BYTES;
+    int slot = 0;
 #pragma unroll
     for (int ms = 0; ms < RM / 16; ++ms) {
       bf16x8 a[3], b[3];
@@ -1334,9 +1342,18 @@ DEVFN void tn_tall_body(const WgradArgs& p, int tile, int split, char* smem_raw)
 #pragma unroll
       for (int i = 0; i < 3; ++i) b[i] = ld_frag_tr_p<PX>(sX, ms * 16, wk * 96 + i * 32, lane);
 #pragma unroll
-      for (int i = 0; i < 3; ++i)
+      for (int i = 0; i < 3; ++i) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+#if ATST_TN_ILV
+        if (slot < PPW) {                                         // next stage's LDS-DMA pieces spread between the MFMA groups
+          __builtin_amdgcn_sched_barrier(0);
+          if (more) issue_piece(st + NST - 1, slot);
+          __builtin_amdgcn_sched_barrier(0);
+          ++slot;
+        }
+#endif
+      }
     }
     TSTAMP(3);
   }
