@@ -746,6 +746,7 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
   if constexpr (EPI == EPI_RESID) {
     if (tid < BMR) { const int row = m0 + tid; sScale[tid] = (p.row_scale && row < p.M) ? p.row_scale[row / p.rows_per_seq] : 1.0f; }
   }
+  float dg_col = 0.f;                                             // EPI_DGELU: this thread's column of the fc1 bias gradient
 #pragma unroll
   for (int part = 0; part < NPART; ++part) {
     const int mi = HPP == 2 ? part : part >> 1, h = HPP == 2 ? 0 : part & 1;
@@ -837,16 +838,30 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
 #if ATST_ABLATE != 0 && ATST_ABLATE != 7
         if (sC[rl * CLD2 + (c8 >> 1)] != 12345.678f) continue;        // experiment builds: no epilogue stores
 #endif
+        f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = w0;
         if (row < p.M) {
-          f32x4 w0, w1;
           if constexpr (EPI == EPI_RESID) aux[i].s = sScale[trow];
           epilogue8<EPI>(p, row, n0 + c8, *reinterpret_cast<const f32x4*>(sC + rl * CLD2 + (c8 >> 1)), *reinterpret_cast<const f32x4*>(sC + rl * CLD2 + PLANE1 + (c8 >> 1)),
                          *reinterpret_cast<const f32x4*>(sBias + (c8 >> 1)), *reinterpret_cast<const f32x4*>(sBias + PLANE1 + (c8 >> 1)), aux[i], w0, w1);
-          if constexpr (EPI == EPI_DGELU) {
-            if (p.colsum) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) { atomicAdd(sCol + c8 + e, w0[e]); atomicAdd(sCol + c8 + 4 + e, w1[e]); }
-            }
+        }
+        if constexpr (EPI == EPI_DGELU) {
+          // fc1 bias gradient = column sums of du.  The products go back into this thread's own staging slot (zeros for rows
+          // beyond M); after a barrier 384 threads add up one column each over the 32 staged rows -- conflict-free in the
+          // two-plane layout -- and keep the running sum in a register.  (One LDS atomic per element made this tile 2.7x
+          // slower than the 128x128 kernel: 2624 vs 950 us at the base geometry.)
+          if (p.colsum) {
+            *reinterpret_cast<f32x4*>(sC + rl * CLD2 + (c8 >> 1)) = w0;
+            *reinterpret_cast<f32x4*>(sC + rl * CLD2 + PLANE1 + (c8 >> 1)) = w1;
+          }
+        }
+      }
+      if constexpr (EPI == EPI_DGELU) {
+        if (p.colsum) {
+          __syncthreads();
+          if (tid < BNR) {
+            const int ph = ((tid >> 3) << 2) + (tid & 3) + ((tid & 4) ? PLANE1 : 0);
+#pragma unroll 8
+            for (int r = 0; r < RP; ++r) dg_col += sC[r * CLD2 + ph];
           }
         }
       }
@@ -856,10 +871,7 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
     STAMP2(2 + part);
   }
   if constexpr (EPI == EPI_DGELU) {
-    if (p.colsum) {
-      __syncthreads();
-      if (tid < BNR) atomicAdd(p.colsum + n0 + tid, sCol[tid]);
-    }
+    if (p.colsum && tid < BNR) atomicAdd(p.colsum + n0 + tid, dg_col);
   }
 #if ATST_TRACE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1405,7 +1417,7 @@ int g_tn_rounds = 1;      // wgrad grid = this many rounds of 512 resident block
 int g_row384_dir = 0;       // 256-row tile: epilogue straight from the accumulator registers (tuning hook 341 = on)
 int g_row384_pp = 0;        // ping-pong main loop of the 256-row tile (tuning hook 321 = on)
 int g_row384_bk64 = 0;      // 256-row tile with 64-deep ring stages, whole 128-B lines per LDS-DMA lane group, 2 stages (tuning hook 311 = on): measured 2-5 % slower than 3 x 32-deep
-int g_dgelu_row384 = 0;   // dGELU GEMM on the row-384 tile (tuning hook 307 = on): measured slower (LDS-atomic column sums, 78.8 vs 70.5 ms/step)
+int g_dgelu_row384 = 2;   // dGELU GEMM on the 256x384 tile: 0 never / 1 always / 2 when K >= 768 (hooks 306 / 307 / 308).  Measured with the staged column sums: base (K = 768) 968 -> 935 us, small (K = 384) 206 -> 227 us; with per-element LDS atomics it was 2.7x slower
 int g_nt_variant = -1;    // -1 auto ; 0: 128x128 2-stage ; 1: 128x128 3-stage ; 2: 256x128 8 waves ; 3: 256x128 4 waves of 128x64
 
 // Algorithmic HBM bytes of one nt GEMM: both operands once, every epilogue input once, every output once.
@@ -1533,7 +1545,7 @@ int launch_nt(const GemmArgs& a, hipStream_t st) {
     if constexpr (EPI == EPI_RESID) return launch_nt_row384<EPI>(a, st);
   }
   int v = g_nt_variant;
-  if ((v == 4 || (v < 0 && g_row384_auto)) && a.N % 384 == 0 && (EPI != EPI_DGELU || g_dgelu_row384)) return launch_nt_row384<EPI>(a, st);
+  if ((v == 4 || (v < 0 && g_row384_auto)) && a.N % 384 == 0 && (EPI != EPI_DGELU || g_dgelu_row384 == 1 || (g_dgelu_row384 == 2 && a.K >= 768))) return launch_nt_row384<EPI>(a, st);
   if (v < 0) v = (EPI == EPI_F32 && a.M >= 16384) ? 3            // ATST-Frame head Linears (83 k rows): 256x128 tile, -13 %
                : a.K <= 512 ? 0 : 1;
   if (v == 3) return launch_nt_cfg<EPI, 256, 3, 128>(a, st);

@@ -25,13 +25,19 @@ extern "C" {
 enum { ATST_EPI_BF16 = 0, ATST_EPI_F32 = 1, ATST_EPI_BIAS_GELU = 2, ATST_EPI_RESID = 3, ATST_EPI_DGELU = 4, ATST_EPI_PATCH = 5 };
 
 int atst_version(void);
-/* Tuning hooks for A/B measurements (tools/gemm_bench.py, bench.py ATST_TUNE=...); defaults are the measured best.
+/* Tuning hooks for A/B measurements (tools/gemm_bench.py, env ATST_TUNE=a,b,... read by audiossl_amd/hip.py); defaults are the
+ * measured best.
  *   -1 auto | 0..3 force a 128x128 / 256x128 nt tile config | 4 force the row-384 tile
  *   105/106 wgrad 192x384 LDS-DMA tile off/on        110+r wgrad grid = r rounds of resident blocks (128x128 tile)
  *   300/301 row-384 tile off/on      302/303/304 256-row tile: never / plain bf16 GEMMs / every epilogue
- *   306/307 dGELU GEMM on the row-384 tile off/on
- *   310/311 64-deep ring stages off/on               400/401/404 NP=256 attention forward: per-head / online / two-pass
- *   402/403 merged NP=256 attention backward off/on                                                                      */
+ *   306/307/308 dGELU GEMM on the 256x384 tile: never / always / when K >= 768 (default)
+ *   330+m 4-wave two-blocks-per-CU kernels: 0 only for small grids (default, see 360/361) ; 2 everywhere (256x192 + 128x384/LN)
+ *   350/351 apply the tall / 4-wave kernels from M = 8192 (default) / from any M (parity tests of those kernels at small M)
+ *   360/361 4-wave kernels for launches of <= 1.5 rounds of 256x384 tiles off/on
+ *   400/401/404 NP=256 attention forward: per-head / online / two-pass      402/403 merged NP=256 attention backward off/on
+ * Only in builds with ATST_EXPERIMENTS=1 (measured and rejected, profiles/r02_trace_epi.txt): 310/311 64-deep ring stages,
+ *   320/321 ping-pong main loop, 331 128x384 4-wave tile for every epilogue, 340/341 epilogue straight from the registers.
+ * 100000+c: start-up skew of every other first-round block by c cycles per k-tile (measured: no effect).                  */
 int atst_tune_gemm_variant(int v);
 
 /* ---- front end: torchaudio MelSpectrogram -> AmplitudeToDB(top_db=80) -> MinMax ---------------------------------
