@@ -13,23 +13,15 @@ SOURCES = ["api.hip", "engine.hip", "gemm.hip", "layernorm.hip", "attention.hip"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
 if os.environ.get("ATST_EXTRA_FLAGS"):      # experiment builds: e.g. ATST_EXTRA_FLAGS="-DATST_ABLATE_ATTN_STORE"
     FLAGS += os.environ["ATST_EXTRA_FLAGS"].split()
-for _k in ("ATST_TN_ILV", "ATST_TN_SPLIT", "ATST_TN_RM"):
-    if os.environ.get(_k):
-        FLAGS.append(f"-D{_k}=" + os.environ[_k])
-if os.environ.get("ATST_INTERLEAVE"):
-    FLAGS.append("-DATST_INTERLEAVE=" + os.environ["ATST_INTERLEAVE"])
-if os.environ.get("ATST_TALL_STAGES"):
-    FLAGS.append("-DATST_TALL_STAGES=" + os.environ["ATST_TALL_STAGES"])
-if os.environ.get("ATST_ABLATE"):          # experiment builds only (tools/gemm_bench.py)
-    FLAGS.append("-DATST_ABLATE=" + os.environ["ATST_ABLATE"])
-if os.environ.get("ATST_EXPERIMENTS"):     # also compile the measured-and-rejected GEMM variants (tuning hooks 311 / 321 / 331 / 341)
-    FLAGS.append("-DATST_EXPERIMENTS=" + os.environ["ATST_EXPERIMENTS"])
-if os.environ.get("ATST_TRACE_FINE"):
-    FLAGS.append("-DATST_TRACE_FINE=" + os.environ["ATST_TRACE_FINE"])
-if os.environ.get("ATST_TRACE"):           # experiment builds only (tools/trace_gemm.py)
-    FLAGS.append("-DATST_TRACE=" + os.environ["ATST_TRACE"])
-if os.environ.get("ATST_NT_STORES"):
-    FLAGS.append("-DATST_NT_STORES=" + os.environ["ATST_NT_STORES"])
+# Experiment builds for the stand-alone GEMM tools (tools/gemm_bench.py, trace_*.py, ablate*.sh): the measured-and-rejected
+# round-2 GEMM variants live in tools/experiments/gemm_r02_variants.hip, which replaces csrc/gemm.hip when ATST_GEMM_VARIANTS=1
+# or any of its switches is set.  That translation unit predates EPI_LNBWD: the encoder backward does not run on such a build.
+_VARIANT_SWITCHES = ("ATST_TN_ILV", "ATST_TN_SPLIT", "ATST_TN_RM", "ATST_INTERLEAVE", "ATST_TALL_STAGES", "ATST_ABLATE", "ATST_EXPERIMENTS",
+                     "ATST_TRACE_FINE", "ATST_TRACE", "ATST_NT_STORES", "ATST_TN_ISSUE")
+GEMM_VARIANTS = os.environ.get("ATST_GEMM_VARIANTS") == "1" or any(os.environ.get(k) for k in _VARIANT_SWITCHES)
+VARIANT_SRC = os.path.join(os.path.dirname(HERE), "tools", "experiments", "gemm_r02_variants.hip")
+if GEMM_VARIANTS:
+    FLAGS += ["-I", CSRC] + [f"-D{k}=" + os.environ[k] for k in _VARIANT_SWITCHES if os.environ.get(k)]
 
 
 
@@ -46,6 +38,8 @@ def _digest():
         p = os.path.join(CSRC, f)
         if os.path.isfile(p):
             h.update(open(p, "rb").read())
+    if GEMM_VARIANTS:
+        h.update(open(VARIANT_SRC, "rb").read())
     h.update(" ".join(FLAGS).encode())
     return h.hexdigest()
 
@@ -61,7 +55,8 @@ def build(force=False, verbose=True):
     for s in SOURCES:
         o = os.path.join(LIBDIR, s.replace(".hip", ".o"))
         objs.append(o)
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, s), "-o", o]
+        src = VARIANT_SRC if (GEMM_VARIANTS and s == "gemm.hip") else os.path.join(CSRC, s)
+        cmd = [hipcc, *FLAGS, "-c", src, "-o", o]
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     for s, p in procs:
         out, _ = p.communicate()

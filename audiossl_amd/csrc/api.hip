@@ -34,6 +34,29 @@ int atst_gemm_nt_bf16(const uint16_t* A, const uint16_t* B, int M, int N, int K,
   return atst_gemm_nt(a, ST(stream));
 }
 
+int atst_gemm_nt_resid_ln_bf16(const uint16_t* A, const uint16_t* B, int M, int K, const float* bias, const float* resid, const float* row_scale,
+                               int rows_per_seq, float* x_out, const float* ln_gamma, const float* ln_beta, uint16_t* ln_out, float* ln_mean,
+                               float* ln_rstd, void* stream) {
+  if (!A || !B || !bias || !resid || !x_out || !ln_gamma || !ln_beta || !ln_out || !ln_mean || !ln_rstd) return ATST_EINVAL;
+  GemmArgs a{};
+  a.A = CBF(A); a.B = CBF(B); a.M = M; a.N = 384; a.K = K; a.lda = K; a.ldb = K; a.epi = EPI_RESID; a.C = x_out; a.ldc = 384;
+  a.bias = bias; a.resid = resid; a.row_scale = row_scale; a.rows_per_seq = rows_per_seq > 0 ? rows_per_seq : 1;
+  a.ln_gamma = ln_gamma; a.ln_beta = ln_beta; a.ln_out = BF(ln_out); a.ln_mean = ln_mean; a.ln_rstd = ln_rstd;
+  return atst_gemm_nt(a, ST(stream));
+}
+
+int atst_gemm_nt_lnbwd_bf16(const uint16_t* dY, const uint16_t* Wt, int M, int K, const float* x, const float* mean, const float* rstd,
+                            const float* gamma, const float* dres, float* dx, uint16_t* g, const float* row_scale, int rows_per_seq,
+                            float* dgamma, float* dbeta, float* dbias_up, void* stream) {
+  if (!dY || !Wt || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta) return ATST_EINVAL;
+  GemmArgs a{};
+  a.A = CBF(dY); a.B = CBF(Wt); a.M = M; a.N = 384; a.K = K; a.lda = K; a.ldb = K; a.epi = EPI_LNBWD; a.C = dx; a.ldc = 384;
+  a.resid = dres; a.row_scale = row_scale; a.rows_per_seq = rows_per_seq > 0 ? rows_per_seq : 1; a.ln_gamma = gamma;
+  a.ln_mean = const_cast<float*>(mean); a.ln_rstd = const_cast<float*>(rstd); a.lnb_x = x; a.lnb_g = BF(g);
+  a.lnb_dgamma = dgamma; a.lnb_dbeta = dbeta; a.lnb_dbias_up = dbias_up;
+  return atst_gemm_nt(a, ST(stream));
+}
+
 int atst_gemm_nt_fp8(const uint8_t* A8, const uint8_t* B8, int M, int N, int K, int lda, int ldb, int epi, void* C, int ldc,
                      void* C2, const float* bias, const float* resid, const float* row_scale, int rows_per_seq,
                      const float* dq, float dq_mul, void* stream) {

@@ -90,6 +90,17 @@ int gemm8(const uint8_t* A8, const uint8_t* B8, int M, int N, int K, int epi, vo
   a.fp8 = 1; a.dq = w_dq; a.dq_mul = 1.0f / act_scale; a.q8 = q8; a.q8_scale = q8_scale;
   return atst_gemm_nt(a, st);
 }
+// dgrad GEMM (N == 384) whose epilogue is the backward of the LayerNorm in front of the differentiated Linear:
+// dx = dres + LN'(dY W) ; g = bf16(row_scale dx) ; dgamma, dbeta, dbias_up += column sums (EPI_LNBWD, gemm.hip)
+int gemm_lnbwd(const bf16* dY, const bf16* Wt, int M, int K, const float* x, const float* mean, const float* rstd, const float* gamma,
+               const float* dres, float* dx, bf16* g, const float* row_scale, int rps, float* dgamma, float* dbeta, float* dbias_up,
+               hipStream_t st) {
+  GemmArgs a{};
+  a.A = dY; a.B = Wt; a.M = M; a.N = 384; a.K = K; a.lda = K; a.ldb = K; a.epi = EPI_LNBWD; a.C = dx; a.ldc = 384;
+  a.resid = dres; a.row_scale = row_scale; a.rows_per_seq = rps; a.ln_gamma = gamma; a.ln_mean = const_cast<float*>(mean);
+  a.ln_rstd = const_cast<float*>(rstd); a.lnb_x = x; a.lnb_g = g; a.lnb_dgamma = dgamma; a.lnb_dbeta = dbeta; a.lnb_dbias_up = dbias_up;
+  return atst_gemm_nt(a, st);
+}
 int wgrad(const bf16* dY, const bf16* X, int M, int N, int K, float* dW, hipStream_t st) {
   WgradArgs a{};
   a.dY = dY; a.X = X; a.M = M; a.N = N; a.K = K; a.ldy = N; a.ldx = K; a.dW = dW; a.ldw = K; a.m_per_split = 0;
@@ -231,6 +242,9 @@ static int encoder_bwd_range(const atst_encoder_t* e, int lo, int hi, bool head,
     return e->dp_scale ? e->dp_scale + (size_t)(2 * layer + which) * S : nullptr;
   };
 
+  // C == 384: the two N = 384 dgrad GEMMs of a block own whole rows, so their epilogue runs the LayerNorm backward itself
+  // (no dh round trip through HBM, no separate pass over x and the residual gradient)
+  const bool fuse_lnb = C == 384;
   float* cur = w.dxA; float* oth = w.dxB;
   if (head) {
     LnBwdArgs a{};
@@ -246,8 +260,12 @@ static int encoder_bwd_range(const atst_encoder_t* e, int lo, int hi, bool head,
     // The block's four weight gradients are independent of everything downstream: they are launched together after the
     // attention backward (atst_gemm_tn_group), which is why the two residual-branch gradients live in separate buffers.
     RUN(gemm(w.g, qt + lo_.fc2_w, M, 4 * C, C, EPI_DGELU, w.du, st, nullptr, nullptr, nullptr, 1, nullptr, l.u, G + lo_.fc1_b));
-    RUN(gemm(w.du, qt + lo_.fc1_w, M, C, 4 * C, EPI_BF16, w.dh, st));
-    {
+    if (fuse_lnb) {
+      RUN(gemm_lnbwd(w.du, qt + lo_.fc1_w, M, 4 * C, w.x[2 * i + 1], l.mean2, l.rstd2, p + lo_.ln2_w, cur, oth, w.g2, dps(i, 0), NP,
+                     G + lo_.ln2_w, G + lo_.ln2_b, G + lo_.proj_b, st));
+      float* t = cur; cur = oth; oth = t;
+    } else {
+      RUN(gemm(w.du, qt + lo_.fc1_w, M, C, 4 * C, EPI_BF16, w.dh, st));
       LnBwdArgs a{};
       a.dy = w.dh; a.x = w.x[2 * i + 1]; a.mean = l.mean2; a.rstd = l.rstd2; a.gamma = p + lo_.ln2_w; a.dres = cur;
       a.dx = oth; a.g = w.g2; a.row_scale = dps(i, 0); a.rows_per_seq = NP;
@@ -272,8 +290,12 @@ static int encoder_bwd_range(const atst_encoder_t* e, int lo, int hi, bool head,
       set(3, w.g2, l.o, C, C, G + lo_.proj_w);
       RUN(atst_gemm_tn_group(wg, 4, st));
     }
-    RUN(gemm(w.dqkv, qt + lo_.qkv_w, M, C, 3 * C, EPI_BF16, w.dh, st));
-    {
+    if (fuse_lnb) {
+      RUN(gemm_lnbwd(w.dqkv, qt + lo_.qkv_w, M, 3 * C, w.x[2 * i], l.mean1, l.rstd1, p + lo_.ln1_w, cur, oth, i > 0 ? w.g : nullptr,
+                     i > 0 ? dps(i - 1, 1) : nullptr, NP, G + lo_.ln1_w, G + lo_.ln1_b, i > 0 ? G + o.layer[i - 1].fc2_b : nullptr, st));
+      float* t = cur; cur = oth; oth = t;
+    } else {
+      RUN(gemm(w.dqkv, qt + lo_.qkv_w, M, C, 3 * C, EPI_BF16, w.dh, st));
       LnBwdArgs a{};
       a.dy = w.dh; a.x = w.x[2 * i]; a.mean = l.mean1; a.rstd = l.rstd1; a.gamma = p + lo_.ln1_w; a.dres = cur;
       a.dx = oth; a.g = i > 0 ? w.g : nullptr; a.row_scale = i > 0 ? dps(i - 1, 1) : nullptr; a.rows_per_seq = NP;

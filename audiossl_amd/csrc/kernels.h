@@ -2,7 +2,7 @@
 #pragma once
 #include "common.h"
 
-enum GemmEpilogue { EPI_BF16 = 0, EPI_F32 = 1, EPI_BIAS_GELU = 2, EPI_RESID = 3, EPI_DGELU = 4, EPI_PATCH = 5 };
+enum GemmEpilogue { EPI_BF16 = 0, EPI_F32 = 1, EPI_BIAS_GELU = 2, EPI_RESID = 3, EPI_DGELU = 4, EPI_PATCH = 5, EPI_LNBWD = 6 };
 
 struct GemmArgs {
   const bf16* A; const bf16* B;      // A [M,K] lda ; B [N,K] ldb   (C = A * B^T)
@@ -21,11 +21,16 @@ struct GemmArgs {
   // EPI_RESID with N == 384: optional fused LayerNorm(eps 1e-6) of the output row (the next sub-layer's pre-LN)
   const float* ln_gamma; const float* ln_beta; bf16* ln_out; float* ln_mean; float* ln_rstd;
   float* colsum;                     // EPI_DGELU: optional fp32 [N] accumulator of the column sums of the output (bias gradient)
+  // EPI_LNBWD (N == 384, dgrad GEMMs in front of a LayerNorm): the accumulator row is dy of LayerNorm(x) and the epilogue is
+  // that LayerNorm's backward (LnBwdArgs semantics): C = dx fp32 [M,384] = resid (residual gradient, or null) + LN backward;
+  // lnb_g = bf16(row_scale * dx) or null; column sums into lnb_dgamma / lnb_dbeta / lnb_dbias_up (null = skip);
+  // statistics of the forward in ln_mean / ln_rstd, affine weight in ln_gamma.
+  const float* lnb_x; bf16* lnb_g; float* lnb_dgamma; float* lnb_dbeta; float* lnb_dbias_up;
   uint8_t* q8; float q8_scale;       // EPI_BIAS_GELU: optional e4m3 copy of the activation * q8_scale (A operand of the fp8 fc2 GEMM)
   float dq_mul;                      // fp8 GEMMs: host factor on top of *dq (1 / activation scale); 0 is read as 1
   const float* dq;                   // fp8 GEMMs: device scalar multiplied into the accumulators (1 / (scale_A * scale_B)); null = 1
   int fp8;                           // operands are OCP e4m3 bytes (K, lda, ldb in elements = bytes); MX-scaled MFMA, unit block scales
-  int skew;                          // start-up delay (shader cycles) of every other first-round block: de-phases main loops and epilogues
+  int skew;                          // only read by tools/experiments/gemm_r02_variants.hip (start-up skew experiment)
 };
 int atst_gemm_nt(const GemmArgs& a, hipStream_t st);
 void atst_gemm_nt_set_variant(int v);     // tuning hook: -1 auto, 0/1/2 fixed tile configuration

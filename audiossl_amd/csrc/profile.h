@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 enum ProfKind {
   PK_GEMM_NT0 = 0, PK_GEMM_NT1, PK_GEMM_NT2, PK_GEMM_NT3, PK_GEMM_NT4, PK_GEMM_NT5, PK_GEMM_TN,
-  PK_ATTN_FWD, PK_ATTN_BWD_DKV, PK_ATTN_BWD_DQ, PK_LN_FWD, PK_LN_BWD, PK_MEL, PK_OPTIM, PK_COUNT
+  PK_ATTN_FWD, PK_ATTN_BWD_DKV, PK_ATTN_BWD_DQ, PK_LN_FWD, PK_LN_BWD, PK_MEL, PK_OPTIM, PK_GEMM_NT6, PK_COUNT
 };
 bool prof_on();
 void prof_begin(int kind, double work, double bytes, hipStream_t st);   // work = algorithmic FLOPs (MFMA kinds) or bytes (HBM kinds); bytes = algorithmic HBM bytes

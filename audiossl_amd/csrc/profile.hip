@@ -14,7 +14,7 @@ hipEvent_t g_cur0; int g_kind; double g_work, g_bytes;
 const char* const NAMES[PK_COUNT] = {
   "gemm_nt_kernel<0:bf16>", "gemm_nt_kernel<1:f32>", "gemm_nt_kernel<2:bias_gelu>", "gemm_nt_kernel<3:resid>",
   "gemm_nt_kernel<4:dgelu>", "gemm_nt_kernel<5:patch>", "gemm_tn_kernel", "attn_fwd_kernel", "attn_bwd_dkv_kernel",
-  "attn_bwd_dq_kernel", "ln_fwd_kernel", "ln_bwd_kernel", "stft_mel_db_kernel", "adamw_ema_kernel"};
+  "attn_bwd_dq_kernel", "ln_fwd_kernel", "ln_bwd_kernel", "stft_mel_db_kernel", "adamw_ema_kernel", "gemm_nt_kernel<6:lnbwd>"};
 hipEvent_t get_event() {
   if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
   hipEvent_t e; hipEventCreate(&e); return e;

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libatst_hip.so")
 ATST_MAX_DEPTH = 24
 
-EPI_BF16, EPI_F32, EPI_BIAS_GELU, EPI_RESID, EPI_DGELU, EPI_PATCH = range(6)
+EPI_BF16, EPI_F32, EPI_BIAS_GELU, EPI_RESID, EPI_DGELU, EPI_PATCH, EPI_LNBWD = range(7)
 
 
 class HipError(RuntimeError):
@@ -53,6 +53,8 @@ _SIGS = {
     "atst_gemm_nt_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                     C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "atst_gemm_nt_resid_ln_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 7),
+    "atst_gemm_nt_lnbwd_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 8 + [C.c_int] + [C.c_void_p] * 4),
     "atst_gemm_nt_fp8": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_void_p,
                                    C.c_float, C.c_void_p]),
     "atst_quant_fp8_bf16": (C.c_int, [C.c_void_p, C.c_size_t, C.c_float, C.c_void_p, C.c_void_p]),

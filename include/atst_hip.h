@@ -22,7 +22,8 @@ extern "C" {
 #define ATST_MAX_DEPTH 24
 
 /* GEMM epilogues (gemm_nt) */
-enum { ATST_EPI_BF16 = 0, ATST_EPI_F32 = 1, ATST_EPI_BIAS_GELU = 2, ATST_EPI_RESID = 3, ATST_EPI_DGELU = 4, ATST_EPI_PATCH = 5 };
+enum { ATST_EPI_BF16 = 0, ATST_EPI_F32 = 1, ATST_EPI_BIAS_GELU = 2, ATST_EPI_RESID = 3, ATST_EPI_DGELU = 4, ATST_EPI_PATCH = 5,
+       ATST_EPI_LNBWD = 6 /* only through atst_gemm_nt_lnbwd_bf16 */ };
 
 int atst_version(void);
 /* Tuning hooks for A/B measurements (tools/gemm_bench.py, env ATST_TUNE=a,b,... read by audiossl_amd/hip.py); defaults are the
@@ -35,9 +36,8 @@ int atst_version(void);
  *   350/351 apply the tall / 4-wave kernels from M = 8192 (default) / from any M (parity tests of those kernels at small M)
  *   360/361 4-wave kernels for launches of <= 1.5 rounds of 256x384 tiles off/on
  *   400/401/404 NP=256 attention forward: per-head / online / two-pass      402/403 merged NP=256 attention backward off/on
- * Only in builds with ATST_EXPERIMENTS=1 (measured and rejected, profiles/r02_trace_epi.txt): 310/311 64-deep ring stages,
- *   320/321 ping-pong main loop, 331 128x384 4-wave tile for every epilogue, 340/341 epilogue straight from the registers.
- * 100000+c: start-up skew of every other first-round block by c cycles per k-tile (measured: no effect).                  */
+ * The measured-and-rejected GEMM variants of round 2 (64-deep ring stages, ping-pong main loop, register epilogue, start-up
+ * skew, phase tracers) are not part of this library: tools/experiments/gemm_r02_variants.hip (ATST_GEMM_VARIANTS=1 build).          */
 int atst_tune_gemm_variant(int v);
 
 /* ---- front end: torchaudio MelSpectrogram -> AmplitudeToDB(top_db=80) -> MinMax ---------------------------------
@@ -55,6 +55,21 @@ int atst_gemm_nt_bf16(const uint16_t* A, const uint16_t* B, int M, int N, int K,
                       void* C, int ldc, void* C2, const float* bias, const float* resid, const float* row_scale,
                       int rows_per_seq, const uint16_t* U, const float* table, const uint8_t* rowflag, const float* alt,
                       float* colsum /* EPI_DGELU: optional [N] += column sums of the output */, void* stream);
+/* Residual GEMM (N = 384 = the whole row) that also produces the LayerNorm of the new residual row:
+ *   x_out = resid + row_scale[row / rows_per_seq] * (A B^T + bias) fp32 [M,384] ; ln_out = bf16(LayerNorm(x_out; gamma, beta, eps 1e-6)) ;
+ *   ln_mean / ln_rstd = the row statistics (saved for the backward).  `x = x + drop_path(attn(norm1(x)))` followed by `norm2(x)`,
+ *   audiossl/modules/transformer.py:136-150 ; what atst_encoder_fwd launches for proj and fc2 when C = 384.                   */
+int atst_gemm_nt_resid_ln_bf16(const uint16_t* A, const uint16_t* B, int M, int K, const float* bias, const float* resid, const float* row_scale,
+                               int rows_per_seq, float* x_out, const float* ln_gamma, const float* ln_beta, uint16_t* ln_out, float* ln_mean,
+                               float* ln_rstd, void* stream);
+/* dgrad GEMM in front of a LayerNorm with that LayerNorm's backward as its epilogue (N = 384 = the whole row):
+ *   dy = dY[M,K] Wt[384,K]^T (never written) ; dx = dres + LayerNorm'(dy | x, mean, rstd, gamma) fp32 [M,384] ;
+ *   g = bf16(row_scale[row / rows_per_seq] * dx) (or null) ; dgamma += sum_rows dy xhat ; dbeta += sum_rows dy ;
+ *   dbias_up += sum_rows g (or null).  Replaces atst_gemm_nt_bf16(EPI_BF16) + atst_layernorm_bwd: autograd of
+ *   `x + drop_path(f(norm(x)))`, audiossl/modules/transformer.py:136-150 (Block.forward).                                     */
+int atst_gemm_nt_lnbwd_bf16(const uint16_t* dY, const uint16_t* Wt, int M, int K, const float* x, const float* mean, const float* rstd,
+                            const float* gamma, const float* dres, float* dx, uint16_t* g, const float* row_scale, int rows_per_seq,
+                            float* dgamma, float* dbeta, float* dbias_up, void* stream);
 /* The same GEMM on OCP e4m3 operands (A8 [M,K], B8 [N,K] bytes; N % 384 == 0, K % 64 == 0) with v_mfma_scale_f32_32x32x64_f8f6f4:
  * C = epilogue(dq_mul * (*dq) * A8 B8^T); epilogues BF16 / F32 / BIAS_GELU / RESID.  north_star "fp8 MFMA QKV/MLP GEMMs".      */
 int atst_gemm_nt_fp8(const uint8_t* A8, const uint8_t* B8, int M, int N, int K, int lda, int ldb, int epi, void* C, int ldc,

@@ -155,6 +155,74 @@ def test_layernorm(C):
     assert relerr(dbu, want_g.sum(0)) < 2e-3
 
 
+@pytest.mark.parametrize("M,K,hook,with_up", [(640, 128, None, True),          # 128-row tile, 8 waves
+                                              (2048 + 40, 1152, None, True),  # <= 1.5 rounds: 128x384 tile on 4 waves, ragged
+                                              (8192 + 64, 1536, 360, True),   # 256-row tile, 8 waves (4-wave auto-selection off)
+                                              (700, 384, None, False)])       # block 0: no upstream operand / bias gradient
+def test_gemm_lnbwd_epilogue(M, K, hook, with_up):
+    """dgrad GEMM whose epilogue is the LayerNorm backward (EPI_LNBWD) vs autograd of layer_norm on the fp32 product."""
+    C, rps = 384, 32
+    lib = hip.load()
+    dY, Wt = bf(rnd(M, K, seed=1, scale=0.5)), bf(rnd(C, K, seed=2, scale=0.5))
+    x = rnd(M, C, seed=3) * 2 + 0.3
+    gamma, beta = 1 + 0.1 * rnd(C, seed=4), 0.1 * rnd(C, seed=5)
+    mean, var = x.mean(1), x.var(1, unbiased=False)
+    rstd = torch.rsqrt(var + 1e-6)
+    dres = rnd(M, C, seed=6)
+    scale = ((torch.arange((M + rps - 1) // rps, device=DEV) % 3).float() * 0.625).contiguous()
+    dx = torch.empty(M, C, device=DEV)
+    g = torch.empty(M, C, dtype=torch.bfloat16, device=DEV) if with_up else None
+    dgamma, dbeta, dbu = (torch.full((C,), 0.125, device=DEV) for _ in range(3))
+    if hook is not None:
+        lib.atst_tune_gemm_variant(hook)
+    try:
+        hip.call("atst_gemm_nt_lnbwd_bf16", hip.ptr(dY), hip.ptr(Wt), M, K, hip.ptr(x), hip.ptr(mean.contiguous()), hip.ptr(rstd.contiguous()),
+                 hip.ptr(gamma), hip.ptr(dres), hip.ptr(dx), hip.ptr(g), hip.ptr(scale), rps, hip.ptr(dgamma), hip.ptr(dbeta),
+                 hip.ptr(dbu) if with_up else None, hip.stream())
+    finally:
+        if hook is not None:
+            lib.atst_tune_gemm_variant(361)
+    dy = dY.float() @ Wt.float().t()
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    torch.nn.functional.layer_norm(xr, (C,), gr, br, 1e-6).backward(dy)
+    want_dx = dres + xr.grad
+    assert relerr(dx, want_dx) < 3e-5
+    assert relerr(dgamma, gr.grad + 0.125) < 3e-5 and relerr(dbeta, br.grad + 0.125) < 3e-5
+    if with_up:
+        want_g = want_dx * scale.repeat_interleave(rps)[:M, None]
+        assert relerr(g.float(), want_g) < 4e-3
+        assert relerr(dbu, want_g.sum(0) + 0.125) < 3e-5
+    else:
+        assert float((dbu - 0.125).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("M,K,hook", [(640, 128, None), (2048 + 40, 384, None), (8192 + 64, 1536, 360)])   # 128-row tile / 4-wave 128x384 / 256-row tile
+def test_gemm_resid_layernorm_epilogue(M, K, hook):
+    """residual GEMM whose epilogue also emits LayerNorm(new row) + its statistics vs the fp32 formulation."""
+    C, rps = 384, 32
+    lib = hip.load()
+    A, B = bf(rnd(M, K, seed=1, scale=0.5)), bf(rnd(C, K, seed=2, scale=0.5))
+    bias, resid = rnd(C, seed=3), rnd(M, C, seed=4) * 2 + 0.2
+    gamma, beta = 1 + 0.1 * rnd(C, seed=5), 0.1 * rnd(C, seed=6)
+    scale = ((torch.arange((M + rps - 1) // rps, device=DEV) % 3).float() * 0.625).contiguous()
+    x = torch.empty(M, C, device=DEV)
+    h = torch.empty(M, C, dtype=torch.bfloat16, device=DEV)
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    if hook is not None:
+        lib.atst_tune_gemm_variant(hook)
+    try:
+        hip.call("atst_gemm_nt_resid_ln_bf16", hip.ptr(A), hip.ptr(B), M, K, hip.ptr(bias), hip.ptr(resid), hip.ptr(scale), rps, hip.ptr(x),
+                 hip.ptr(gamma), hip.ptr(beta), hip.ptr(h), hip.ptr(mean), hip.ptr(rstd), hip.stream())
+    finally:
+        if hook is not None:
+            lib.atst_tune_gemm_variant(361)
+    want = resid + scale.repeat_interleave(rps)[:M, None] * (A.float() @ B.float().t() + bias)
+    assert relerr(x, want) < 2e-5
+    assert relerr(mean, want.mean(1)) < 2e-5
+    assert relerr(rstd, torch.rsqrt(want.var(1, unbiased=False) + 1e-6)) < 2e-5
+    assert relerr(h.float(), torch.nn.functional.layer_norm(want, (C,), gamma, beta, 1e-6)) < 4e-3
+
+
 def attn_ref(qkv, valid, S, H, NP):
     C = H * 64
     q, k, v = qkv.float().reshape(S, NP, 3, H, 64).permute(2, 0, 3, 1, 4)

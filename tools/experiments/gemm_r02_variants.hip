@@ -1,30 +1,42 @@
-// bf16 (and e4m3) MFMA GEMMs for the ATST encoder / heads on gfx950.
+// FROZEN COPY of audiossl_amd/csrc/gemm.hip as of round 2 (commit 623845e): every measured-and-rejected GEMM variant behind its
+// switch -- ping-pong main loop (hook 321), epilogue straight from the registers (341), 64-deep ring stages (311), 128x384
+// 4-wave tile for every epilogue (331), start-up phase skew (100000+c), wgrad interleaved issue / split loaders / 32-row
+// stages (ATST_TN_ILV / ATST_TN_SPLIT / ATST_TN_RM), ablation builds (ATST_ABLATE) and the s_memtime phase tracers
+// (ATST_TRACE, ATST_TRACE_FINE).  Results: profiles/r02_trace_epi.txt, profiles/r02_trace_gemm.txt, DESIGN.md section 3.
+// Built INSTEAD of csrc/gemm.hip by `ATST_GEMM_VARIANTS=1 python audiossl_amd/build.py` (or with any of the switches set) for
+// the stand-alone GEMM tools only; it has no EPI_LNBWD, so the encoder backward does not run on such a build.
+// bf16 MFMA GEMMs for the ATST encoder / heads on gfx950.
 //
 //   gemm_nt  : C[M,N] = A[M,K] * B[N,K]^T  (+ fused epilogue)      forward GEMMs (weights are [out,in] row-major, torch
 //              convention) and dgrad GEMMs (B = pre-transposed bf16 weight copy)
 //   gemm_tn  : dW[N,K] += dY[M,N]^T * X[M,K]  (fp32 atomic accumulate, split over M)   wgrad GEMMs; both operands are
 //              m-major in HBM, so fragments come from row-major LDS tiles through ds_read_b64_tr_b16.
 //
-// Kernels in this file (DESIGN.md section 3 has the measurements behind each choice):
-//   gemm_nt_row384_kernel   256x384 (M >= 8192) or 128x384 output tile, 8 waves, operands HBM/L2 -> LDS by global_load_lds into
-//                           a 3-stage (2-stage) ring of 32-deep k-tiles, XOR-swizzled source addresses, LDS-DMA issue spread
-//                           between the MFMA groups; every N of the encoder is a multiple of 384, and for N == 384 a block owns
-//                           whole rows: the residual epilogue also produces the next LayerNorm (forward) and the dgrad
-//                           epilogue runs the LayerNorm backward (EPI_LNBWD).  e4m3 operands: same ring, MX-scaled MFMA.
-//   gemm_nt_w4_kernel       the same wave tile (128x96) in 4-wave blocks, two per CU, for launches of <= 1.5 rounds
-//   gemm_nt_kernel          128x128 / 256x128 tiles for N % 384 != 0 (heads) and the K = 384 dGELU GEMM
-//   gemm_tn_tall[_group]_kernel  192x384 weight-gradient tile, the four gradients of a block in one launch
-//   gemm_tn_kernel          128x128 weight-gradient tile for the remaining shapes
-// Measured-and-rejected variants (ping-pong main loop, register epilogue, 64-deep stages, phase skew, split loaders, phase
-// tracers, ablation switches) live in tools/experiments/gemm_r02_variants.hip, not here.
-// Reference math being accelerated: nn.Linear in audiossl/modules/transformer.py:109,119,87-90 and
-// audiossl/models/atst/audio_transformer.py:63,69 ; audiossl/models/atst/byol.py:13 ; LayerNorm backward of
-// audiossl/modules/transformer.py:128,132,144-146.
+// Tile 128x128x64, 4 waves (2x2), each wave 64x64 = 2x2 v_mfma_f32_32x32x16_bf16 accumulators; register-staged
+// global->LDS double buffering (one barrier per K-tile); XCD-aware block->tile map so blocks that share an A row panel
+// share an L2.  Reference math being accelerated: nn.Linear in audiossl/modules/transformer.py:109,119,87-90 and
+// audiossl/models/atst/audio_transformer.py:63,69 ; audiossl/models/atst/byol.py:13.
 #include "common.h"
 #include "kernels.h"
 #include "profile.h"
+#ifndef ATST_NT_STORES
+#define ATST_NT_STORES 1    // epilogue outputs / residual reads are streamed once: non-temporal, so they do not evict operand panels from L2
+#endif
+#ifndef ATST_ABLATE
+#define ATST_ABLATE 0      // experiment switch (tools only), all without stores: 1 full, 3 loads+ds_read, 4 ds_read+MFMA, 5 loads only, 6 MFMA only; 7 (row384): epilogue only
+#endif
 
 #include <type_traits>
+#ifndef ATST_EXPERIMENTS
+#define ATST_EXPERIMENTS 0  // 1: also compile the measured-and-rejected variants behind the tuning hooks (ping-pong main loop 321,
+                            // register epilogue 341, 64-deep ring 311, 128x384 4-wave tile for every epilogue 331): profiles/r02_trace_epi.txt
+#endif
+#ifndef ATST_TRACE_FINE
+#define ATST_TRACE_FINE 0   // 1: also stamp every k-tile of the main loop (tools/trace_gemm.py; perturbs the loop)
+#endif
+#ifndef ATST_TRACE
+#define ATST_TRACE 0       // experiment builds (tools/trace_gemm.py): block ATST_TRACE-1 of the row-384 kernel stamps s_memtime at its phase boundaries into p.colsum
+#endif
 
 namespace {
 
@@ -38,6 +50,16 @@ constexpr int C_LD = BN + 4;                   // fp32 epilogue staging tile [12
 // waited on without also waiting for that store to be acknowledged by L2, so a load -> store -> load -> store sequence
 // costs one full memory round trip per store (measured: that was ~half of every GEMM's time).
 struct EpiAux { f32x4 a0, a1; float s; };
+
+// Blocks of one launch start together and every tile costs the same, so all CUs (and both blocks of a CU) run their
+// main loops -- HBM reads only -- and then their epilogues -- HBM writes only -- in lock step.  Delaying every other
+// first-round block by about half a tile time puts half of the chip in each phase at any moment.
+DEVFN void phase_skew(int cycles) {
+  if (cycles > 0) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)cycles) __builtin_amdgcn_s_sleep(16);
+  }
+}
 
 template <int EPI, bool SCALE = true>
 DEVFN void epi_fetch8(const GemmArgs& p, int row, int col, EpiAux& x) {
@@ -69,11 +91,20 @@ DEVFN void epilogue8(const GemmArgs& p, int row, int col, f32x4 v0, f32x4 v1, co
   auto st_bf16 = [](void* base, size_t i, const f32x4& lo, const f32x4& hi4) {
     const float t[8] = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
     const bf16x8 o = pack8(t);
+#if ATST_NT_STORES
     __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(base) + i));   // streamed once: keep L2 for operands
+#else
+    *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(base) + i) = o;
+#endif
   };
   auto st_f32 = [](void* base, size_t i, const f32x4& lo, const f32x4& hi4) {
+#if ATST_NT_STORES
     __builtin_nontemporal_store(lo, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + i));
     __builtin_nontemporal_store(hi4, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + i + 4));
+#else
+    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + i) = lo;
+    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + i + 4) = hi4;
+#endif
   };
   if constexpr (EPI == EPI_BF16) {
     st_bf16(p.C, idx, v0 + b0, v1 + b1);
@@ -197,20 +228,34 @@ __global__ __launch_bounds__((NtGeo<BMT, NSTG, WTM>::THREADS), (NtGeo<BMT, NSTG,
       case 8: asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory"); break;
       default: asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory"); break;
     }
+#if ATST_ABLATE != 4 && ATST_ABLATE != 6
     if (kt + NSTG - 1 < nk) issue(kt + NSTG - 1);
+#endif
     const char* st = lds + (kt % NSTG) * G::STAGE;
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       const int co = ((ks * 2 + hi) ^ xr) << 4;
       bf16x8 af[MI];
+#if ATST_ABLATE == 5 || ATST_ABLATE == 6
+      bf16x8 b0, b1;                                               // no LDS reads: operands are whatever is in registers
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) asm volatile("" : "=v"(af[mi]));
+      asm volatile("" : "=v"(b0), "=v"(b1));
+      (void)st; (void)co;
+#else
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const bf16x8*>(st + offA + mi * 32 * 64 + co);
       bf16x8 b0 = *reinterpret_cast<const bf16x8*>(st + offB + co), b1 = *reinterpret_cast<const bf16x8*>(st + offB + 32 * 64 + co);
+#endif
+#if ATST_ABLATE == 3 || ATST_ABLATE == 5
+      asm volatile("" :: "v"(af[0]), "v"(af[MI - 1]), "v"(b0), "v"(b1));
+#else
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
         acc[mi][0] = mfma32(af[mi], b0, acc[mi][0]);
         acc[mi][1] = mfma32(af[mi], b1, acc[mi][1]);
       }
+#endif
     }
   }
   asm volatile("s_barrier" ::: "memory");                         // all operand reads done before the tile is staged
@@ -249,6 +294,9 @@ __global__ __launch_bounds__((NtGeo<BMT, NSTG, WTM>::THREADS), (NtGeo<BMT, NSTG,
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {                    // phase 2: compute + stores only
       const int rl = pass * RPP + rr, row = m0 + part * 64 + rl;
+#if ATST_ABLATE
+      if (sC[rl * C_LD + c8] != 12345.678f) continue;                // experiment builds: no epilogue stores
+#endif
       if (row < p.M) {
         f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = w0;
         epilogue8<EPI>(p, row, n0 + c8, *reinterpret_cast<const f32x4*>(sC + rl * C_LD + c8),
@@ -274,219 +322,50 @@ __global__ __launch_bounds__((NtGeo<BMT, NSTG, WTM>::THREADS), (NtGeo<BMT, NSTG,
   }
 }
 
-// ---- 384-column tiles: 8 waves (2 x 4) ---------------------------------------------------------------------------------
-// Every N on the encoder path (384, 1152, 1536, 768...) is a multiple of 384.  MI = 32-row accumulator blocks per wave:
-//   MI = 2: 128 x 384 tile, wave 64 x 96, 2-stage ring of 32 KB, two blocks per CU (M < 8192)
-//   MI = 4: 256 x 384 tile, wave 128 x 96 = 12 accumulators, 3-stage ring of 40 KB, one block per CU.  Per 32-deep k-tile the
-//           block stages 16 KB of A and 24 KB of B for six 128x128 units of output: 6.7 KB / unit (10.7 for MI = 2, 16 for the
-//           square tile) -- operand delivery L2 -> LDS is what bounds these GEMMs.
-// For N = 384 one block owns whole output rows, which is what the row-wise epilogues below need.
+// ---- 128 x 384 tile: 8 waves (2 x 4), each 64 x 96 = 2 x 3 accumulators ---------------------------------------------
+// Every N on this path (384, 1152, 1536, 768...) is a multiple of 384.  Per 32-deep K step the block stages 8 KB of A
+// and 24 KB of B for three 128x128 units of output: 10.7 KB / unit instead of 16 KB for the square tile -- operand
+// staging (L2 -> LDS, ~14 TB/s chip-wide) is what bounds these GEMMs, see DESIGN.md.  For N = 384 one block owns whole
+// output rows.
 namespace row384 {
 constexpr int BNR = 384, WAVES = 8, THREADS = 512, CLD = BNR + 4;
-constexpr int CLD2 = 448, PLANE1 = 208;       // staging layout of the 8-column-slot epilogues (see the staging loop)
-template <int MI> struct Geo {
-  static constexpr int BMR = 64 * MI, ROWB = BK * 2, A_BYTES = BMR * ROWB, BB = BNR * ROWB, STAGE = A_BYTES + BB;   // 32 / 40 KB
-  static constexpr int NSTG = MI == 4 ? 3 : 2;
-  static constexpr int RPI = 1024 / ROWB;                                                        // rows per 1-KiB load instruction (16)
-  static constexpr int A_IPW = (BMR / RPI) / WAVES, B_IPW = (BNR / RPI) / WAVES;                 // load instructions per wave: 1-2 + 3
+#ifndef ATST_TALL_STAGES
+#define ATST_TALL_STAGES 3
+#endif
+#ifndef ATST_TN_ISSUE
+#define ATST_TN_ISSUE 1        // tall wgrad: 1 next stage's LDS-DMA in front of the MFMAs (2-stage ring: they need the whole stage to land; measured best), 0 one per MFMA group, 2 two per group
+#endif
+#ifndef ATST_INTERLEAVE
+#define ATST_INTERLEAVE 1      // LDS-DMA issue spread between the MFMA groups (0: in front of them; experiment builds)
+#endif
+constexpr int CLD2 = 448, PLANE1 = 208;       // staging layout of the epilogues WITHOUT the fused LayerNorm (see the staging loop)
+constexpr int B_BYTES = BNR * BK * 2, EPI_BYTES = 32 * CLD2 * 4;                                  // 24 KB ; 57,344 B
+// MI = 32-row accumulator blocks per wave: 2 -> 128-row tile, 4 -> 256-row tile.  BKT = K depth of one ring stage:
+// 32 (64-B LDS rows, 4 chunks) or 64 (128-B rows: every LDS-DMA lane group fetches a whole 128-B line, half as many
+// barriers per K; two stages then fill the CU's 160 KB).
+template <int MI, int BKT = BK> struct Geo {
+  static constexpr int BMR = 64 * MI, ROWB = BKT * 2, A_BYTES = BMR * ROWB, BB = BNR * ROWB, STAGE = A_BYTES + BB;   // 32 / 40 KB (BKT 32), 80 KB (256 rows, BKT 64)
+  static constexpr int NSTG = BKT == 64 ? 2 : (MI == 4 ? ATST_TALL_STAGES : 2);
+  static constexpr int LDS = NSTG * STAGE > EPI_BYTES + 8192 ? NSTG * STAGE : EPI_BYTES + 8192;  // 64 KB (2 blocks / CU) ; 120 KB ; 160 KB
+  static constexpr int RPI = 1024 / ROWB;                                                        // rows per 1-KiB load instruction
+  static constexpr int A_IPW = (BMR / RPI) / WAVES, B_IPW = (BNR / RPI) / WAVES;                 // load instructions per wave
+  static constexpr int CPR = ROWB / 16;                                                          // 16-B chunks per row
 };
 // XOR key of a row's 16-B chunks: the 16 rows of a ds_read_b128 service group must land on 16 distinct bank slots
-DEVFN int swz_key(int row) { return (row >> 2) & 3; }
-// LDS layout of the epilogue (floats): staging tile | bias | gamma, beta | per-row scale | row-wise: input slots of NT streamed
-// row tensors, [wave][pair][tensor][2 rows]
-template <int MI, bool ROWWISE, int NT> struct EpiLds {
-  static constexpr int SC = 32 * (ROWWISE ? CLD : CLD2), SBIAS = ROWWISE ? BNR : CLD2;
-  static constexpr int BYTES = (SC + SBIAS + 2 * BNR + 64 * MI) * 4 + (ROWWISE ? WAVES * 2 * NT * 2 * 384 * 4 : 0);
-};
-template <int MI, int EPI, bool LN> constexpr int lds_bytes() {
-  constexpr bool rowwise = (LN && EPI == EPI_RESID) || EPI == EPI_LNBWD;
-  constexpr int epi = EpiLds<MI, rowwise, EPI == EPI_LNBWD ? 2 : 1>::BYTES, ring = Geo<MI>::NSTG * Geo<MI>::STAGE;
-  return epi > ring ? epi : ring;                                 // 64 / 120 KB ; row-wise epilogues 110 KB (residual + LN) / 158 KB (LN backward)
-}
+template <int BKT> DEVFN int swz_key(int row) { return BKT == 64 ? (row >> 1) & 7 : (row >> 2) & 3; }
 }
 
-// Row-wise epilogues (N == 384: the block owns whole rows).  A wave works on TWO rows at a time, one per half-wave: lane
-// (hh = lane >> 5, li = lane & 31) owns columns 128 j + 4 li .. + 3 (j = 0..2) of row hh of the pair, so every LDS / global
-// access is 16 B per lane (fp32) or 8 B (bf16) -- the epilogue's time is set by the number of vector-memory instructions it
-// issues, not only by its bytes -- and the row reductions are 5-step butterflies inside a half-wave.
-//
-// The fp32 row tensors such an epilogue READS (residual stream ; LayerNorm input and residual gradient) do not go through
-// registers: with 192 accumulator registers live a wave cannot hold more than one part's rows, so every part exposed a full
-// HBM round trip and the CU had <= 12 KB per wave in flight (measured: the fused LayerNorm-backward GEMM was no faster than
-// GEMM + ln_bwd_kernel).  Instead each wave owns a private LDS slot per pair of rows and fills it by LDS-DMA (global_load_lds,
-// 3 x 1 KiB per tensor: the two rows of a pair are adjacent in HBM); the slot is re-issued for the NEXT part as soon as the
-// wave has copied this part's rows out of it, i.e. one part (compute, stores, barrier, staging) ahead of its use, with no
-// registers held meanwhile.  The only wait is `s_waitcnt vmcnt(0)` in front of the staging barrier.
-typedef const void __attribute__((address_space(1))) * gptr_t_;
-typedef void __attribute__((address_space(3))) * lptr_t_;
-constexpr int ROWIN_PAIR_BYTES = 2 * 384 * 4;                      // 3072 B: two adjacent fp32 rows
-template <int NT>
-DEVFN void rowin_issue(const float* t0, const float* t1, int M, int row0, char* slot, int lane) {
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const float* base = t == 0 ? t0 : t1;
-    if (!base) continue;                                           // optional tensor (residual gradient of the first LayerNorm backward)
-#pragma unroll
-    for (int pc = 0; pc < 3; ++pc) {
-      const int boff = pc * 1024 + lane * 16, second = boff >= 1536 ? 1 : 0;
-      int row = row0 + second; row = row < M ? row : M - 1;        // rows >= M: clamped, never used
-      const char* src = reinterpret_cast<const char*>(base + (size_t)row * 384) + (boff - second * 1536);
-      __builtin_amdgcn_global_load_lds((gptr_t_)src, (lptr_t_)(slot + t * ROWIN_PAIR_BYTES + pc * 1024), 16, 0, 0);
-    }
-  }
-}
-// this lane's 12 values of tensor t of its row of the pair (lane = (hh, li): row hh, columns 128 j + 4 li .. + 3)
-DEVFN void rowin_read(const char* slot, int t, int hh, int li, f32x4* v) {
-#pragma unroll
-  for (int j = 0; j < 3; ++j) v[j] = *reinterpret_cast<const f32x4*>(slot + t * ROWIN_PAIR_BYTES + hh * 1536 + j * 512 + li * 16);
-}
-// Waiting for a slot.  vmcnt retires in order, so "the refill of pair q has landed" = "at most the VMEM operations issued after
-// it are outstanding".  Between the refill of a pair and its use one part later a wave issues, in program order, the stores of
-// the pair, then the refill and the stores of the other pair (row-wise LayerNorm: refill, stores, refill, stores) -- NVM
-// operations when every row of the tile is live and every optional output exists (`exact`); the count is taken two short, and
-// anything the compiler adds (scratch traffic) only makes the wait stricter.  Otherwise: vmcnt(0).
-template <int NVM> DEVFN void rowin_wait(bool exact) {
-  if (exact) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NVM) : "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-DEVFN float half_sum(float v) {
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-DEVFN void st_bf16x4(bf16* dst, const float* v) {
-  bf16x4 o; o[0] = f2bf(v[0]); o[1] = f2bf(v[1]); o[2] = f2bf(v[2]); o[3] = f2bf(v[3]);
-  *reinterpret_cast<bf16x4*>(dst) = o;
-}
-// residual + LayerNorm forward of the new row: x_new = resid + s (acc + bias) -> fp32 stream ; h = LN(x_new) -> bf16 operand
-// of the next GEMM ; row statistics saved for the LayerNorm backward.  ref: Block.forward, audiossl/modules/transformer.py:136-150.
-DEVFN void lnf_row(const GemmArgs& p, int row, const float* sRow, const float* sBias, const float* sGamma, const float* sBeta,
-                   float sc, const f32x4* rv, int li) {
-  float v[12];
-  float sum = 0.f;
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const int col = j * 128 + li * 4;
-    const f32x4 a4 = *reinterpret_cast<const f32x4*>(sRow + col), b4 = *reinterpret_cast<const f32x4*>(sBias + col);
-    const f32x4 o = rv[j] + sc * (a4 + b4);
-    __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (size_t)row * 384 + col));
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { v[4 * j + e] = o[e]; sum += o[e]; }
-  }
-  const float mu = half_sum(sum) * (1.0f / 384.0f);
-  float qd = 0.f;
-#pragma unroll
-  for (int k = 0; k < 12; ++k) { const float d = v[k] - mu; qd += d * d; }
-  const float rs = rsqrtf(half_sum(qd) * (1.0f / 384.0f) + 1e-6f);
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const int col = j * 128 + li * 4;
-    const f32x4 g4 = *reinterpret_cast<const f32x4*>(sGamma + col), e4 = *reinterpret_cast<const f32x4*>(sBeta + col);
-    float t[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) t[e] = (v[4 * j + e] - mu) * rs * g4[e] + e4[e];
-    st_bf16x4(p.ln_out + (size_t)row * 384 + col, t);
-  }
-  if (li == 0) { p.ln_mean[row] = mu; p.ln_rstd[row] = rs; }
-}
-// LayerNorm backward of one row, fused into the N == 384 dgrad epilogues (EPI_LNBWD).  dy comes from the staged fp32
-// accumulators (never rounded to bf16, never written to HBM), x / dres were loaded before the staging barrier.  Math as in
-// ln_bwd_kernel (layernorm.hip):
-//   dx = dres + rstd (dy g - mean(dy g) - xhat mean(dy g xhat)) ; g_out = bf16(row_scale dx) ; column sums for dgamma,
-//   dbeta and the upstream bias gradient stay in registers until the block has finished its tile.
-// ref: the autograd of nn.LayerNorm(eps=1e-6) + the residual add + DropPath in Block.forward, audiossl/modules/transformer.py:136-150.
-// Column sums: the two half-waves work on different rows of the SAME columns; the contributions of a pair of rows are
-// folded with v_permlane32_swap as soon as they exist, so that the lower half-wave keeps the sums of columns e = 0, 1 of each
-// of its 4-column groups and the upper half those of e = 2, 3 (18 registers per lane instead of 36).
-struct LnbCols { float dg[6], db[6], du[6]; };
-DEVFN void lnb_fold4(float* acc2, const float* d4) {               // acc2[e] += d4[e] + partner's d4[e]  (lower: e = 0, 1 ; upper: e = 2, 3)
-#pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    const float fa = d4[e], fb = d4[e + 2];
-    auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, fa), __builtin_bit_cast(unsigned, fb), false, false);
-    const unsigned r0 = r[0], r1 = r[1];                           // lower half: d[e] of both rows ; upper half: d[e + 2] of both rows
-    acc2[e] += __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
-    // pin the update here: the sums are only read after the last part, and without this LLVM sinks the whole chain of adds and
-    // swaps down to that point -- keeping every contribution of every part alive (measured: 190 spilled registers)
-    asm volatile("" : "+v"(acc2[e]));
-  }
-}
-// slot: this pair's input slot (tensor 0 = residual gradient, tensor 1 = LayerNorm input x); everything is read from LDS in
-// both passes (the staged dy row, gamma, x, dres), so that nothing but the two row sums and the column sums lives across the
-// reduction -- with 168+ accumulator registers still live in the first parts, every value kept in a register there is a
-// spill (measured with x and dres copied to registers so that the slot could be refilled before the arithmetic: 116 B of
-// scratch per lane and 375 / 306 us instead of 307 / 237 us for the fc1 / qkv dgrad GEMMs at M = 131072).
-DEVFN void lnb_row(const GemmArgs& p, int row, bool live, const float* sRow, const float* sGamma, float sc, float mu, float rs,
-                   const char* slot, bool has_res, int hh, int li, LnbCols& cs) {
-  float s1 = 0.f, s2 = 0.f;                                        // live == false (row beyond M): every contribution is zero
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const int col = j * 128 + li * 4;
-    const f32x4 d4 = live ? *reinterpret_cast<const f32x4*>(sRow + col) : f32x4{0.f, 0.f, 0.f, 0.f};
-    const f32x4 g4 = *reinterpret_cast<const f32x4*>(sGamma + col);
-    const f32x4 x4 = *reinterpret_cast<const f32x4*>(slot + ROWIN_PAIR_BYTES + hh * 1536 + j * 512 + li * 16);
-    float ddg[4], ddb[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float xh = live ? (x4[e] - mu) * rs : 0.f, dyg = d4[e] * g4[e];
-      ddg[e] = d4[e] * xh; ddb[e] = d4[e];
-      s1 += dyg; s2 += dyg * xh;
-    }
-    lnb_fold4(cs.dg + 2 * j, ddg); lnb_fold4(cs.db + 2 * j, ddb);  // both half-waves get here: no early exit for dead rows
-  }
-  const float c1 = half_sum(s1) * (1.0f / 384.0f), c2 = half_sum(s2) * (1.0f / 384.0f);
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const int col = j * 128 + li * 4;
-    const f32x4 d4 = *reinterpret_cast<const f32x4*>(sRow + col), g4 = *reinterpret_cast<const f32x4*>(sGamma + col);
-    const f32x4 x4 = *reinterpret_cast<const f32x4*>(slot + ROWIN_PAIR_BYTES + hh * 1536 + j * 512 + li * 16);
-    f32x4 r4 = {0.f, 0.f, 0.f, 0.f};
-    if (has_res) r4 = *reinterpret_cast<const f32x4*>(slot + hh * 1536 + j * 512 + li * 16);
-    f32x4 o; float gs[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float xh = (x4[e] - mu) * rs;
-      o[e] = live ? r4[e] + rs * (d4[e] * g4[e] - c1 - xh * c2) : 0.f;
-      gs[e] = o[e] * sc;
-    }
-    if (live) {
-      __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (size_t)row * 384 + col));
-      if (p.lnb_g) st_bf16x4(p.lnb_g + (size_t)row * 384 + col, gs);
-    }
-    lnb_fold4(cs.du + 2 * j, gs);
-  }
-}
-// Block reduction of the column sums of lnb_row over the NW waves of a block (red: >= 3 * NW * 384 floats of LDS that no
-// wave reads any more), one atomic per column per block.
-template <int NW>
-DEVFN void lnb_flush(const GemmArgs& p, const LnbCols& cs, float* red, int tid) {
-  const int li = tid & 31, hh = (tid >> 5) & 1, wid = tid >> 6;
-  __syncthreads();
-#pragma unroll
-  for (int t = 0; t < 6; ++t) {
-    const int col = (t >> 1) * 128 + li * 4 + (t & 1) + 2 * hh;
-    red[(0 * NW + wid) * 384 + col] = cs.dg[t]; red[(1 * NW + wid) * 384 + col] = cs.db[t]; red[(2 * NW + wid) * 384 + col] = cs.du[t];
-  }
-  __syncthreads();
-  for (int c = tid; c < 384; c += NW * 64) {
-    float a = 0.f, b = 0.f, u = 0.f;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) { a += red[(0 * NW + w) * 384 + c]; b += red[(1 * NW + w) * 384 + c]; u += red[(2 * NW + w) * 384 + c]; }
-    atomicAdd(p.lnb_dgamma + c, a);
-    atomicAdd(p.lnb_dbeta + c, b);
-    if (p.lnb_dbias_up) atomicAdd(p.lnb_dbias_up + c, u);
-  }
-}
-
+// MI = 4 (256 x 384 tile, each wave 128 x 96 = 12 accumulators): 40 KB staged per 6 units of output = 6.7 KB / unit.
+// DIR: epilogue straight from the accumulator registers (below).  The MFMA operands are then swapped (C^T = B A^T), so
+// that a lane owns ONE output row (m = lane & 31) and its registers run along n.
 // F8: the operands are OCP e4m3 bytes.  The host passes them as pairs ("bf16" elements: K, lda, ldb halved), so the whole
 // LDS-DMA ring -- 64-byte rows, XOR swizzle, stage geometry -- is byte-identical; a k-tile then covers K = 64 and feeds ONE
 // v_mfma_scale_f32_32x32x64_f8f6f4 per accumulator (unit block scales; twice the bf16 MFMA rate) instead of two
 // 32x32x16 bf16 MFMAs: half the matrix-pipe time AND half the operand bytes per FLOP.  p.dq undoes the per-tensor scales.
-// LN (EPI_RESID only): the epilogue also produces the LayerNorm of the new residual row (the next sub-layer's pre-LN).
-template <int EPI, int MI, bool LN = false, bool F8 = false>
+template <int EPI, int MI, bool LN = false, int BKT = BK, bool PP = false, bool DIR = false, bool F8 = false>
 __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(GemmArgs p) {
   using namespace row384;
-  using RG = row384::Geo<MI>;
+  using RG = row384::Geo<MI, BKT>;
   constexpr int BMR = RG::BMR, A_BYTES = RG::A_BYTES, STAGE = RG::STAGE, NSTG = RG::NSTG, ROWB = RG::ROWB;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   typedef const void __attribute__((address_space(1))) * gptr_t;
@@ -497,32 +376,34 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
   const int ntm = (p.M + BMR - 1) / BMR;
   const int id = xcd_remap(blockIdx.x, ntm * ntn);
   const int m0 = (id / ntn) * BMR, n0 = (id % ntn) * BNR;
+  if (MI == 4 && blockIdx.x < 256 && ((blockIdx.x >> 3) & 1)) phase_skew(p.skew);     // one block per CU: every other CU of each XCD
 
-  // Operand tiles go HBM/L2 -> LDS directly (global_load_lds, 16 B per lane, 1 KiB = 16 rows per wave-instruction, no
-  // staging registers), NSTG-1 k-tiles ahead of the MFMAs.  LDS rows are 64 B; chunk c of row r is stored at chunk
-  // c ^ swz_key(r); the permutation is applied to the per-lane *source* address (the LDS destination is lane-linear).
+#if ATST_TRACE
+  if (EPI != EPI_DGELU && p.colsum && (int)blockIdx.x == ATST_TRACE - 1 && lane == 0)
+    (reinterpret_cast<unsigned long long*>(p.colsum) + (size_t)wid * 64 * 8)[7] = __builtin_amdgcn_s_memtime();
+#endif
   char* lds = smem_raw;
-  const int lrow = lane >> 2, lchunk = lane & 3;
+  const int lrow = lane / RG::CPR, lchunk = lane % RG::CPR;
   const bf16* srcA[RG::A_IPW]; const bf16* srcB[RG::B_IPW];
 #pragma unroll
   for (int j = 0; j < RG::A_IPW; ++j) {
     const int row = (wid * RG::A_IPW + j) * RG::RPI + lrow;
-    int ra = m0 + row; ra = ra < p.M ? ra : p.M - 1;              // clamp: rows >= M are never stored
-    srcA[j] = p.A + (size_t)ra * p.lda + (lchunk ^ swz_key(row)) * 8;
+    int ra = m0 + row; ra = ra < p.M ? ra : p.M - 1;
+    srcA[j] = p.A + (size_t)ra * p.lda + (lchunk ^ swz_key<BKT>(row)) * 8;
   }
 #pragma unroll
   for (int j = 0; j < RG::B_IPW; ++j) {
     const int row = (wid * RG::B_IPW + j) * RG::RPI + lrow;
-    srcB[j] = p.B + (size_t)(n0 + row) * p.ldb + (lchunk ^ swz_key(row)) * 8;
+    srcB[j] = p.B + (size_t)(n0 + row) * p.ldb + (lchunk ^ swz_key<BKT>(row)) * 8;
   }
   auto issue = [&](int kt) {
     char* st = lds + (kt % NSTG) * STAGE;
 #pragma unroll
     for (int j = 0; j < RG::A_IPW; ++j)
-      __builtin_amdgcn_global_load_lds((gptr_t)(srcA[j] + kt * BK), (lptr_t)(st + (wid * RG::A_IPW + j) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcA[j] + kt * BKT), (lptr_t)(st + (wid * RG::A_IPW + j) * 1024), 16, 0, 0);
 #pragma unroll
     for (int j = 0; j < RG::B_IPW; ++j)
-      __builtin_amdgcn_global_load_lds((gptr_t)(srcB[j] + kt * BK), (lptr_t)(st + A_BYTES + (wid * RG::B_IPW + j) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcB[j] + kt * BKT), (lptr_t)(st + A_BYTES + (wid * RG::B_IPW + j) * 1024), 16, 0, 0);
   };
   f32x16 acc[MI][3];
 #pragma unroll
@@ -532,19 +413,23 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = p.K / BK;
-  const int xr = swz_key(l31);                                     // every fragment row is l31 plus a multiple of 32
+#if ATST_ABLATE == 7
+  const int nk = p.K < 0 ? 1 : 0;                                // experiment builds: epilogue only
+#else
+  const int nk = p.K / BKT;
+#endif
+  const int xr = swz_key<BKT>(l31);                                // every fragment row is l31 plus a multiple of 32
   const int offA = (wm * 32 * MI + l31) * ROWB, offB = A_BYTES + (wn * 96 + l31) * ROWB;
   constexpr int LOADS_PER_TILE = RG::A_IPW + RG::B_IPW;           // per wave, in issue order
-  constexpr bool ILV = MI == 4;                                   // the 128-row tile has no registers to spare for the pinned order; a 2-stage ring needs its loads early
+  constexpr bool ILV = ATST_INTERLEAVE && MI == 4 && NSTG >= 3;   // the 128-row tile has no registers to spare for the pinned order; a 2-stage ring needs its loads early
   auto issue_one = [&](int kt, int j) {                           // j-th load instruction of tile kt
     char* st = lds + (kt % NSTG) * STAGE;
     if (j < RG::A_IPW)
-      __builtin_amdgcn_global_load_lds((gptr_t)(srcA[j < RG::A_IPW ? j : 0] + kt * BK), (lptr_t)(st + (wid * RG::A_IPW + j) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcA[j < RG::A_IPW ? j : 0] + kt * BKT), (lptr_t)(st + (wid * RG::A_IPW + j) * 1024), 16, 0, 0);
     else
-      __builtin_amdgcn_global_load_lds((gptr_t)(srcB[j >= RG::A_IPW ? j - RG::A_IPW : 0] + kt * BK), (lptr_t)(st + A_BYTES + (wid * RG::B_IPW + j - RG::A_IPW) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcB[j >= RG::A_IPW ? j - RG::A_IPW : 0] + kt * BKT), (lptr_t)(st + A_BYTES + (wid * RG::B_IPW + j - RG::A_IPW) * 1024), 16, 0, 0);
   };
-  // One k-tile of MFMAs.  ISSUE: the loads of tile kt + NSTG - 1 are spread BETWEEN the MFMA groups instead of in front
+  // One K-tile of MFMAs.  ISSUE: the loads of tile kt + NSTG - 1 are spread BETWEEN the MFMA groups instead of in front
   // of them: every wave leaves the barrier at the same moment, and eight waves x 4-5 LDS-DMA instructions queue on the
   // CU's one address path for longer than the tile's MFMAs take -- issued up front, each (in-order) wave reaches its
   // MFMAs only after that queue drains and the matrix pipes idle (measured: loads-only 104 us + MFMA-only 91 us gave
@@ -582,26 +467,86 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
       return;
     }
 #pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
+    for (int ks = 0; ks < BKT / 16; ++ks) {
       const int co = ((ks * 2 + hi) ^ xr) << 4;
       bf16x8 af[MI], bf[3];
+#if ATST_ABLATE == 5 || ATST_ABLATE == 6
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) asm volatile("" : "=v"(af[mi]));   // no LDS reads: operands are whatever is in registers
+#pragma unroll
+      for (int ni = 0; ni < 3; ++ni) asm volatile("" : "=v"(bf[ni]));
+      (void)st; (void)co;
+#else
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const bf16x8*>(st + offA + mi * 32 * ROWB + co);
 #pragma unroll
       for (int ni = 0; ni < 3; ++ni) bf[ni] = *reinterpret_cast<const bf16x8*>(st + offB + ni * 32 * ROWB + co);
+#endif
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
+#if ATST_ABLATE == 3 || ATST_ABLATE == 5
+        asm volatile("" :: "v"(af[mi]), "v"(bf[0]), "v"(bf[1]), "v"(bf[2]));
+#else
 #pragma unroll
-        for (int ni = 0; ni < 3; ++ni) acc[mi][ni] = mfma32(af[mi], bf[ni], acc[mi][ni]);
+        for (int ni = 0; ni < 3; ++ni) acc[mi][ni] = DIR ? mfma32(bf[ni], af[mi], acc[mi][ni]) : mfma32(af[mi], bf[ni], acc[mi][ni]);
+#endif
+#if ATST_ABLATE != 4 && ATST_ABLATE != 6
         if (ILV && ISSUE && slot < LOADS_PER_TILE) {
           __builtin_amdgcn_sched_barrier(0);
           issue_one(kt + NSTG - 1, slot);
           __builtin_amdgcn_sched_barrier(0);
           ++slot;
         }
+#endif
       }
     }
   };
+  if constexpr (PP) {
+    // Ping-pong schedule.  The two waves that share a SIMD (wid and wid + 4: wave row 0 and wave row 1 of the tile)
+    // alternate roles every half k-tile: while one runs its 24 MFMAs of tile t, the other issues its LDS-DMA share of
+    // tile t + 2 -- so the block never has all eight waves queueing on the CU's one vector-memory address path while
+    // the matrix pipes idle, nor all eight contending for the matrix pipes while the address path idles (the
+    // lock-step schedule below does exactly that: loads-only 104 us + MFMA-only 91 us = 147 us together).
+    //   phase 2t  : row 0 computes tile t        | row 1 issues tile t+2, waits for its share of tile t+1
+    //   phase 2t+1: row 0 issues tile t+2, waits | row 1 computes tile t
+    // Every wave executes two barriers per k-tile.  Stage (t+2) % 3 == (t-1) % 3 was last read in phases 2t-2 / 2t-1.
+    static_assert(!PP || (NSTG == 3 && LOADS_PER_TILE == 5), "ping-pong schedule is written for the 3-stage, 5-loads-per-wave ring");
+#if ATST_TRACE
+    unsigned long long* trc = reinterpret_cast<unsigned long long*>(p.colsum) + (size_t)wid * 64 * 8;
+    const bool trace = ATST_TRACE_FINE && EPI == EPI_BF16 && p.colsum && (int)blockIdx.x == ATST_TRACE - 1 && lane == 0;
+#define STAMP(k, i) do { if (trace && (k) < 64) trc[(k) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(k, i) do { } while (0)
+#endif
+    STAMP(0, 6);
+    issue(0);
+    if (nk > 1) { issue(1); asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int kt = 0; kt < nk; ++kt) {
+      const bool more = kt + 2 < nk;
+      STAMP(kt, 0);
+      if (wm == 0) {
+        tile(kt, std::false_type{});
+        STAMP(kt, 1);
+        asm volatile("s_barrier" ::: "memory");
+        STAMP(kt, 2);
+        if (more) { issue(kt + 2); STAMP(kt, 3); asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(kt, 4);
+        asm volatile("s_barrier" ::: "memory");
+      } else {
+        if (more) { issue(kt + 2); STAMP(kt, 3); asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(kt, 4);
+        asm volatile("s_barrier" ::: "memory");
+        STAMP(kt, 2);
+        tile(kt, std::false_type{});
+        STAMP(kt, 1);
+        asm volatile("s_barrier" ::: "memory");
+      }
+      STAMP(kt, 5);
+    }
+  } else {
 #pragma unroll
   for (int t = 0; t < NSTG - 1; ++t)
     if (t < nk) issue(t);
@@ -610,93 +555,240 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
     // my share of tile kt has landed (loads retire in order; the younger NSTG-2 tiles may still be in flight); barrier =>
     // everyone's has, and everyone is done reading stage (kt-1) % NSTG, which the next issue overwrites
     if constexpr (NSTG == 2) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    else if constexpr (LOADS_PER_TILE == 5) asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory");
+    else if constexpr ((NSTG - 2) * LOADS_PER_TILE == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    else if constexpr ((NSTG - 2) * LOADS_PER_TILE == 5) asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory");
+    else if constexpr ((NSTG - 2) * LOADS_PER_TILE == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    else if constexpr ((NSTG - 2) * LOADS_PER_TILE == 10) asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#if ATST_ABLATE != 4 && ATST_ABLATE != 6
     if (!ILV) issue(kt + NSTG - 1);
+#endif
+#if ATST_TRACE
+    { unsigned long long* trc = reinterpret_cast<unsigned long long*>(p.colsum) + (size_t)wid * 64 * 8;
+      if (ATST_TRACE_FINE && EPI == EPI_BF16 && p.colsum && (int)blockIdx.x == ATST_TRACE - 1 && lane == 0 && kt < 64) trc[kt * 8 + 0] = __builtin_amdgcn_s_memtime(); }
+#endif
     tile(kt, std::true_type{});
+#if ATST_TRACE
+    { unsigned long long* trc = reinterpret_cast<unsigned long long*>(p.colsum) + (size_t)wid * 64 * 8;
+      if (ATST_TRACE_FINE && EPI == EPI_BF16 && p.colsum && (int)blockIdx.x == ATST_TRACE - 1 && lane == 0 && kt < 64) trc[kt * 8 + 1] = __builtin_amdgcn_s_memtime(); }
+#endif
   }
   for (int kt = nfull; kt < nk; ++kt) {                           // drain: nothing left to fetch
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     tile(kt, std::false_type{});
   }
   asm volatile("s_barrier" ::: "memory");
+  }
 
+#if ATST_TRACE
+  unsigned long long* trc2 = reinterpret_cast<unsigned long long*>(p.colsum) + (size_t)wid * 64 * 8;
+  const bool trace2 = EPI != EPI_DGELU && p.colsum && (int)blockIdx.x == ATST_TRACE - 1 && lane == 0;
+#define STAMP2(i) do { if (trace2) trc2[(i) * 8 + 7] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP2(i) do { } while (0)
+#endif
+  STAMP2(1);
+  if constexpr (DIR) {
+    // ---- epilogue straight from the accumulator registers --------------------------------------------------------------
+    // Measured (tools/trace_epi.py, profiles/r02_trace_epi.txt): staging the tile through LDS costs ~1.9 k cycles for each
+    // of its 8 parts whatever the epilogue does (24 ds_write_b32 per lane, two block barriers, conflicted read-back) =
+    // 15 k cycles per tile against a 29 k main loop at K = 384; and an epilogue that loads (residual) pays one exposed HBM
+    // round trip per part (8.8 k cycles each).  With the swapped MFMA orientation a lane owns row m = lane & 31 of each
+    // 32 x 32 accumulator block and 4-column groups {8 g + 4 hi .. + 3}; one v_permlane32_swap per register pair trades
+    // groups between the half-waves so that every lane holds two runs of 8 consecutive columns (16 hi + 8 k .. + 7).  Those
+    // runs are exactly what epi_fetch8 / epilogue8 work on: 16-B (bf16) / 2 x 16-B (fp32) global accesses per run, no LDS
+    // round trip, no barrier (the fused LayerNorm needs one per 32-row block for the cross-wave row statistics), and the
+    // residual loads of a whole accumulator row block are in flight at once (12 KB per wave).
+    float* sBias = reinterpret_cast<float*>(smem_raw);
+    float* sGamma = sBias + BNR; float* sBeta = sGamma + BNR;
+    float* sScale = sBeta + BNR;                                  // [BMR]
+    float* sStat = sScale + BMR;                                  // [4 wave columns][BMR rows][2]: (mean, M2) of 96 columns
+    constexpr bool fused_ln = LN && EPI == EPI_RESID;
+    if (tid < BNR) {
+      sBias[tid] = p.bias ? p.bias[n0 + tid] : 0.f;
+      if (fused_ln) { sGamma[tid] = p.ln_gamma[tid]; sBeta[tid] = p.ln_beta[tid]; }
+    }
+    if constexpr (EPI == EPI_RESID) {
+      if (tid < BMR) { const int row = m0 + tid; sScale[tid] = (p.row_scale && row < p.M) ? p.row_scale[row / p.rows_per_seq] : 1.0f; }
+    }
+    __syncthreads();
+    auto swap_runs = [&](f32x16& v) {                             // afterwards run k = {v[4k..4k+3], v[4k+8..4k+11]}: columns 16 hi + 8 k .. + 7
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float fa = v[4 * k + e], fb = v[4 * k + 8 + e];    // (bit_cast straight on a vector-element lvalue reads element 0: clang quirk)
+          auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, fa), __builtin_bit_cast(unsigned, fb), false, false);
+          const unsigned r0 = r[0], r1 = r[1];
+          v[4 * k + e] = __builtin_bit_cast(float, r0); v[4 * k + 8 + e] = __builtin_bit_cast(float, r1);
+        }
+    };
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int trow = wm * 32 * MI + mi * 32 + l31, row = m0 + trow;
+      const bool live = row < p.M;
+      const int cbase = wn * 96 + 16 * hi;                        // + ni * 32 + 8 * k
+      if constexpr (!fused_ln) {
+        EpiAux aux[3][2];
+#pragma unroll
+        for (int ni = 0; ni < 3; ++ni)
+#pragma unroll
+          for (int k = 0; k < 2; ++k)
+            if (live) epi_fetch8<EPI, false>(p, row, n0 + cbase + ni * 32 + 8 * k, aux[ni][k]);
+#pragma unroll
+        for (int ni = 0; ni < 3; ++ni) {
+          swap_runs(acc[mi][ni]);
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int c = cbase + ni * 32 + 8 * k;
+            const f32x16& v = acc[mi][ni];
+            f32x4 v0 = {v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]}, v1 = {v[4 * k + 8], v[4 * k + 9], v[4 * k + 10], v[4 * k + 11]};
+            if (live) {
+              f32x4 w0, w1;
+              if constexpr (EPI == EPI_RESID) aux[ni][k].s = sScale[trow];
+              epilogue8<EPI>(p, row, n0 + c, v0, v1, *reinterpret_cast<const f32x4*>(sBias + c), *reinterpret_cast<const f32x4*>(sBias + c + 4), aux[ni][k], w0, w1);
+            }
+          }
+        }
+      } else {
+        // residual + LayerNorm of the next sub-layer.  Row statistics: the lane pair (hi = 0, 1) of every wave column holds
+        // 96 of the row's 384 values -> (mean, M2) of those 96, exchanged through LDS, combined exactly (equal counts).
+        f32x4 rr[3][2][2];
+#pragma unroll
+        for (int ni = 0; ni < 3; ++ni)
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const float* src = p.resid + (size_t)row * p.ldc + cbase + ni * 32 + 8 * k;
+            if (live) { rr[ni][k][0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src)); rr[ni][k][1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + 4)); }
+          }
+        const float sc = sScale[trow];
+        float s1 = 0.f;
+#pragma unroll
+        for (int ni = 0; ni < 3; ++ni) {
+          swap_runs(acc[mi][ni]);
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int c = cbase + ni * 32 + 8 * k;
+            f32x16& v = acc[mi][ni];
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(sBias + c), b1 = *reinterpret_cast<const f32x4*>(sBias + c + 4);
+            f32x4 o0, o1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              o0[e] = rr[ni][k][0][e] + sc * (v[4 * k + e] + b0[e]);
+              o1[e] = rr[ni][k][1][e] + sc * (v[4 * k + 8 + e] + b1[e]);
+              v[4 * k + e] = o0[e]; v[4 * k + 8 + e] = o1[e];
+              s1 += o0[e] + o1[e];
+            }
+            if (live) {
+              float* dst = reinterpret_cast<float*>(p.C) + (size_t)row * p.ldc + c;
+              __builtin_nontemporal_store(o0, reinterpret_cast<f32x4*>(dst));
+              __builtin_nontemporal_store(o1, reinterpret_cast<f32x4*>(dst + 4));
+            }
+          }
+        }
+        s1 += __shfl_xor(s1, 32, 64);
+        const float mw = s1 * (1.0f / 96.0f);
+        float q = 0.f;
+#pragma unroll
+        for (int ni = 0; ni < 3; ++ni)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { const float d = acc[mi][ni][r] - mw; q += d * d; }
+        q += __shfl_xor(q, 32, 64);
+        if (hi == 0) { sStat[(wn * BMR + trow) * 2] = mw; sStat[(wn * BMR + trow) * 2 + 1] = q; }
+        __syncthreads();
+        float mu = 0.f, m2 = 0.f, mws[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { mws[w] = sStat[(w * BMR + trow) * 2]; mu += mws[w]; m2 += sStat[(w * BMR + trow) * 2 + 1]; }
+        mu *= 0.25f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const float d = mws[w] - mu; m2 += 96.0f * d * d; }
+        const float rs = rsqrtf(m2 * (1.0f / 384.0f) + 1e-6f);
+#pragma unroll
+        for (int ni = 0; ni < 3; ++ni)
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int c = cbase + ni * 32 + 8 * k;
+            const f32x16& v = acc[mi][ni];
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(sGamma + c), g1 = *reinterpret_cast<const f32x4*>(sGamma + c + 4);
+            const f32x4 e0 = *reinterpret_cast<const f32x4*>(sBeta + c), e1 = *reinterpret_cast<const f32x4*>(sBeta + c + 4);
+            float t[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              t[e] = (v[4 * k + e] - mu) * rs * g0[e] + e0[e];
+              t[4 + e] = (v[4 * k + 8 + e] - mu) * rs * g1[e] + e1[e];
+            }
+            if (live) *reinterpret_cast<bf16x8*>(p.ln_out + (size_t)row * 384 + c) = pack8(t);
+          }
+        if (live && wn == 0 && hi == 0) { p.ln_mean[row] = mu; p.ln_rstd[row] = rs; }
+      }
+    }
+#if ATST_TRACE
+    STAMP2(9);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP2(10);
+#endif
+    return;
+  }
   // Epilogue: the fp32 tile goes through LDS 32 rows at a time so that every global access is a 16-B piece of a full
   // 384-column row.  Part (mi, h) takes 16 rows of accumulator block mi from EVERY wave (two 16-row groups, one per
-  // wave row), so all waves retire the same 24 accumulator registers per part.  8-column-slot epilogues: the registers
-  // freed by the dump hold that part's global loads (saved activations / residual), issued as one batch before the staging
-  // barrier while the stores follow it (see epi_fetch8).  Row-wise epilogues: see rowin_issue.
-  constexpr int RP = 32, SLOTS = RP * 48 / THREADS, LNROWS = RP / WAVES, NPAIR = LNROWS / 2, NPART = 2 * MI;
-  constexpr bool fused_ln = LN && EPI == EPI_RESID;               // residual + LayerNorm forward of the new row
-  constexpr bool lnbwd = EPI == EPI_LNBWD;                        // LayerNorm backward of the dgrad row
-  constexpr bool rowwise = fused_ln || lnbwd;                     // half a wave per row: plain staging rows, 16 B per lane
-  constexpr int NT = lnbwd ? 2 : 1;                               // streamed row tensors: residual | residual gradient + LayerNorm input
-  // VMEM operations of one pair: LayerNorm backward 6 stores (dx, g) + 8 refill (6 LDS-DMA + 2 statistics loads) ; residual +
-  // LayerNorm 8 stores (x, h, mean, rstd) + 3 refill.  Outstanding behind a refill when it is needed: see rowin_wait.
-  constexpr int NVM = (lnbwd ? 6 + 8 : 8 + 3 + 8) - 2;
-  const bool exact_vm = m0 + BMR <= p.M && (!lnbwd || (p.lnb_g && p.resid));
-  using EL = row384::EpiLds<MI, rowwise, NT>;
+  // wave row), so all waves retire the same 24 accumulator registers per part and the registers freed by the dump hold
+  // that part's global loads (residual / saved activations), which are issued as one batch before the staging barrier
+  // while the stores follow it (see epi_fetch8).
   float* sC = reinterpret_cast<float*>(smem_raw);
-  float* sBias = sC + EL::SC;                                     // bias of this block's 384 columns (zeros when absent)
-  float* sGamma = sBias + EL::SBIAS; float* sBeta = sGamma + BNR; // LayerNorm affine parameters (row-wise epilogues)
+  // rows staged per part: 32 (16 from each wave row).  64 (HPP = 2; the 256-row tile's 120 KB ring holds them: half as many
+  // staging barriers) was measured: qkv 166 -> 160 us but proj/fc2+residual 127 -> 130 / 215 -> 220, step 57.98 -> 58.89 ms.
+  constexpr int HPP = 1, RP = 32 * HPP, SLOTS = RP * 48 / THREADS, LNROWS = RP / WAVES;
+  float* sBias = sC + RP * CLD2;                                  // bias of this block's 384 columns (zeros when absent)
+  float* sGamma = sBias + CLD2; float* sBeta = sGamma + BNR;      // fused LayerNorm affine parameters
   float* sScale = sBeta + BNR;                                    // per-row DropPath scale of this block's rows
   float* sCol = sGamma;                                           // EPI_DGELU: column sums of du (fc1 bias gradient); no LN there
-  // the row-wise epilogues' index math starts from a laundered copy of the thread id: computed from `tid` it is hoisted above
-  // the main loop, where there is not a single register to spare (measured: three scratch reloads per k-tile)
-  int tid_e = tid;
-  asm volatile("" : "+v"(tid_e));
-  const int lane_e = tid_e & 63, wid_e = tid_e >> 6;
-  char* sIn = reinterpret_cast<char*>(sScale + BMR) + (wid_e * NPAIR) * NT * ROWIN_PAIR_BYTES;   // this wave's input slots [pair][tensor]
-  const int hh = lane_e >> 5, li = lane_e & 31;
-  auto tile_row_of = [&](int part, int rl) { return (rl >> 4) * (32 * MI) + (part >> 1) * 32 + (part & 1) * 16 + (rl & 15); };   // staged row -> row of the block tile
-  float rmu[lnbwd ? NPAIR : 1], rrs[lnbwd ? NPAIR : 1];            // lnbwd: row statistics, fetched one part ahead
-  auto rowin_part = [&](int part, int q) {                        // DMA of pair q of `part`; lnbwd: + its statistics
-    const int row0 = m0 + tile_row_of(part, wid_e * LNROWS + 2 * q);
-    rowin_issue<NT>(p.resid, lnbwd ? p.lnb_x : nullptr, p.M, row0, sIn + q * NT * ROWIN_PAIR_BYTES, lane_e);
-    if constexpr (lnbwd) { const int r = row0 + hh < p.M ? row0 + hh : p.M - 1; rmu[q] = p.ln_mean[r]; rrs[q] = p.ln_rstd[r]; }
-  };
-  if constexpr (rowwise) {                                        // part 0's rows arrive under its staging
-#pragma unroll
-    for (int q = 0; q < NPAIR; ++q) rowin_part(0, q);
-  }
+  constexpr int NPART = 2 * MI / HPP;
+  constexpr bool fused_ln = LN && EPI == EPI_RESID;
   const float dqv = F8 ? (p.dq ? *p.dq : 1.0f) * (p.dq_mul != 0.f ? p.dq_mul : 1.0f) : 1.0f;
   if (tid < BNR) {                                                // visible after the first staging barrier; bias in the same two-plane layout as the tile
-    sBias[rowwise ? tid : ((tid >> 3) << 2) + (tid & 3) + ((tid & 4) ? PLANE1 : 0)] = p.bias ? p.bias[n0 + tid] : 0.f;
-    if (rowwise) { sGamma[tid] = p.ln_gamma[tid]; if (fused_ln) sBeta[tid] = p.ln_beta[tid]; }
+    sBias[fused_ln ? tid : ((tid >> 3) << 2) + (tid & 3) + ((tid & 4) ? PLANE1 : 0)] = p.bias ? p.bias[n0 + tid] : 0.f;
+    if (fused_ln) { sGamma[tid] = p.ln_gamma[tid]; sBeta[tid] = p.ln_beta[tid]; }
     if (EPI == EPI_DGELU) sCol[tid] = 0.f;
   }
-  if constexpr (EPI == EPI_RESID || lnbwd) {
+  if constexpr (EPI == EPI_RESID) {
     if (tid < BMR) { const int row = m0 + tid; sScale[tid] = (p.row_scale && row < p.M) ? p.row_scale[row / p.rows_per_seq] : 1.0f; }
   }
   float dg_col = 0.f;                                             // EPI_DGELU: this thread's column of the fc1 bias gradient
-  LnbCols lcs;
-  if constexpr (lnbwd) {
-#pragma unroll
-    for (int i = 0; i < 6; ++i) lcs.dg[i] = lcs.db[i] = lcs.du[i] = 0.f;
-  }
 #pragma unroll
   for (int part = 0; part < NPART; ++part) {
-    const int mi = part >> 1, h = part & 1;
-    auto tile_row = [&](int rl) { return tile_row_of(part, rl); };
+    const int mi = HPP == 2 ? part : part >> 1, h = HPP == 2 ? 0 : part & 1;
+    auto tile_row = [&](int rl) {                                 // staged row -> row of the block tile
+      return HPP == 2 ? (rl >> 5) * (32 * MI) + mi * 32 + (rl & 31) : (rl >> 4) * (32 * MI) + mi * 32 + h * 16 + (rl & 15);
+    };
 #pragma unroll
     for (int ni = 0; ni < 3; ++ni)
 #pragma unroll
-      for (int r8 = 0; r8 < 8; ++r8) {
-        const int lrow_ = wm * 16 + (r8 & 3) + 8 * (r8 >> 2) + 4 * hi;
-        // Staging layout.  Row-wise epilogues: plain rows (pitch CLD), read back 16 B per lane -- conflict-free.  Other
+      for (int r8 = 0; r8 < 8 * HPP; ++r8) {
+        const int lrow = wm * (16 * HPP) + (r8 & 3) + 8 * (r8 >> 2) + 4 * hi;
+        // Staging layout.  Fused LayerNorm: plain rows (pitch CLD), read back as f32x2 per lane -- conflict-free.  Other
         // epilogues read 8 consecutive columns per thread as two f32x4; in plain rows the 16-lane service groups of
         // ds_read_b128 then stride 32 B and hit every bank twice (SQ counters, round 1: 15-18 % of the LDS cycles of the bf16 /
         // GELU epilogues were bank conflicts).  There the low and the high four columns of every 8-column slot live in two
         // planes (columns 0-191 / 208-399 of a 448-float row): a service group reads 16 consecutive 16-B pieces of one plane.
         const int ccol = wn * 96 + ni * 32 + l31;
-        const int pos = rowwise ? lrow_ * CLD + ccol : lrow_ * CLD2 + ((ccol >> 3) << 2) + (ccol & 3) + ((ccol & 4) ? PLANE1 : 0);
+        const int pos = fused_ln ? lrow * CLD + ccol : lrow * CLD2 + ((ccol >> 3) << 2) + (ccol & 3) + ((ccol & 4) ? PLANE1 : 0);
         sC[pos] = F8 ? acc[mi][ni][h * 8 + r8] * dqv : acc[mi][ni][h * 8 + r8];
       }
+    if (part == NPART / 2 - 1) STAMP2(20);
     // (Issuing these loads one part ahead was measured: no gain -- 219 vs 218 us on fc2+residual -- and 17 spilled
     // registers; a part's time is set by the CU's memory throughput, not by the exposed round trip.)
-    EpiAux aux[rowwise ? 1 : SLOTS];
-    if constexpr (rowwise) {
-      rowin_wait<NVM>(exact_vm && part > 0);                       // pair 0's rows (and statistics) of this part have landed in my slot (part 0: everything issued so far)
+    EpiAux aux[fused_ln ? 1 : SLOTS];
+    f32x2 rres[fused_ln ? LNROWS : 1][3];
+    if constexpr (fused_ln) {
+#pragma unroll
+      for (int q = 0; q < LNROWS; ++q) {
+        const int row = m0 + tile_row(wid * LNROWS + q);
+        if (row < p.M) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+            rres[q][k] = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p.resid + (size_t)row * p.ldc + k * 128 + lane * 2));
+        }
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < SLOTS; ++i) {
@@ -704,25 +796,45 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
         if (row < p.M) epi_fetch8<EPI, false>(p, row, n0 + (idx % 48) * 8, aux[i]);
       }
     }
+    if (part == NPART / 2 - 1) STAMP2(21);
     __syncthreads();
-    if constexpr (rowwise) {
+    if (part == NPART / 2 - 1) STAMP2(22);
+    if constexpr (fused_ln) {
+      {
+        // Fused residual + LayerNorm of the NEXT sub-layer (N == 384: the block owns whole rows): one wave per row,
+        // x_new = resid + s (acc + bias) -> fp32 stream ; h = LN(x_new) -> bf16 operand of the next GEMM ; row statistics
+        // saved for the LayerNorm backward.  Replaces a separate HBM pass (ln_fwd_kernel) over x.
 #pragma unroll
-      for (int q = 0; q < NPAIR; ++q) {
-        const int rl = wid_e * LNROWS + 2 * q + hh, trow = tile_row(rl), row = m0 + trow;
-        const char* slot = sIn + q * NT * ROWIN_PAIR_BYTES;
-        if (q > 0 && part > 0) rowin_wait<NVM>(exact_vm);          // this pair's rows have landed (pair 0: in front of the staging barrier; part 0: both)
-        if constexpr (lnbwd) {
-          const float mu = rmu[q], rs = rrs[q];
-          lnb_row(p, row, row < p.M, sC + rl * CLD, sGamma, sScale[trow], mu, rs, slot, p.resid != nullptr, hh, li, lcs);
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the slot has been read: refill it with the next part's rows
-          if (part + 1 < NPART) rowin_part(part + 1, q);
-        } else {
-          f32x4 rres[3];
-          rowin_read(slot, 0, hh, li, rres);
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the slot has been copied out: refill it with the next part's rows
-          if (part + 1 < NPART) rowin_part(part + 1, q);
-          // Fused residual + LayerNorm of the NEXT sub-layer: replaces a separate HBM pass (ln_fwd_kernel) over x.
-          if (row < p.M) lnf_row(p, row, sC + rl * CLD, sBias, sGamma, sBeta, sScale[trow], rres, li);
+        for (int q = 0; q < LNROWS; ++q) {
+          const int rl = wid * LNROWS + q, trow = tile_row(rl), row = m0 + trow;
+          if (row >= p.M) continue;
+          const float sc = sScale[trow];
+          float v[6];
+          float sum = 0.f;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const int col = k * 128 + lane * 2;
+            const f32x2 a2 = *reinterpret_cast<const f32x2*>(sC + rl * CLD + col);
+            const f32x2 b2 = *reinterpret_cast<const f32x2*>(sBias + col);
+            f32x2 o = rres[q][k] + sc * (a2 + b2);
+            __builtin_nontemporal_store(o, reinterpret_cast<f32x2*>(reinterpret_cast<float*>(p.C) + (size_t)row * p.ldc + col));
+            v[2 * k] = o[0]; v[2 * k + 1] = o[1]; sum += o[0] + o[1];
+          }
+          const float mu = wave_sum(sum) * (1.0f / 384.0f);
+          float qd = 0.f;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) { const float d = v[k] - mu; qd += d * d; }
+          const float rs = rsqrtf(wave_sum(qd) * (1.0f / 384.0f) + 1e-6f);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const int col = k * 128 + lane * 2;
+            const f32x2 g2 = *reinterpret_cast<const f32x2*>(sGamma + col), be2 = *reinterpret_cast<const f32x2*>(sBeta + col);
+            bf16x2 hv;
+            hv[0] = f2bf((v[2 * k] - mu) * rs * g2[0] + be2[0]);
+            hv[1] = f2bf((v[2 * k + 1] - mu) * rs * g2[1] + be2[1]);
+            *reinterpret_cast<bf16x2*>(p.ln_out + (size_t)row * 384 + col) = hv;
+          }
+          if (lane == 0) { p.ln_mean[row] = mu; p.ln_rstd[row] = rs; }
         }
       }
     } else {
@@ -730,6 +842,9 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
       for (int i = 0; i < SLOTS; ++i) {
         const int idx = tid + THREADS * i, rl = idx / 48, c8 = (idx % 48) * 8;
         const int trow = tile_row(rl), row = m0 + trow;
+#if ATST_ABLATE != 0 && ATST_ABLATE != 7
+        if (sC[rl * CLD2 + (c8 >> 1)] != 12345.678f) continue;        // experiment builds: no epilogue stores
+#endif
         f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = w0;
         if (row < p.M) {
           if constexpr (EPI == EPI_RESID) aux[i].s = sScale[trow];
@@ -758,12 +873,17 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
         }
       }
     }
+    if (part == NPART / 2 - 1) STAMP2(23);
     if (part < NPART - 1) __syncthreads();
+    STAMP2(2 + part);
   }
   if constexpr (EPI == EPI_DGELU) {
     if (p.colsum && tid < BNR) atomicAdd(p.colsum + n0 + tid, dg_col);
   }
-  if constexpr (lnbwd) lnb_flush<WAVES>(p, lcs, sC, tid);        // 9,216 floats of the staging area, behind a barrier
+#if ATST_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  STAMP2(10);
+#endif
 }
 
 // ---- 4-wave blocks, two per CU -----------------------------------------------------------------------------------------
@@ -773,7 +893,7 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
 // (profiles/r02_trace_gemm.txt: 2608 cycles per k-tile against 1536 of MFMA time, then an epilogue with idle matrix pipes).
 //   WM = 2: waves 2 x 2, block tile 256 x 192.  A row panel is staged by the blocks of both column halves (the second read
 //           is an L2 hit), B half as often per row: the best operand mix measured (tools/probes/mix_probe: A 6.1 TB/s).
-//   WM = 1: waves 1 x 4, block tile 128 x 384: whole rows, for the row-wise epilogues (residual + LayerNorm, LayerNorm backward).
+//   WM = 1: waves 1 x 4, block tile 128 x 384: whole rows, for the residual + LayerNorm epilogue.
 // Operand rings are split: A (the HBM stream) NA stages deep, B (L2-resident weights) two.  vmcnt retires in order per
 // wave, so the operands are issued by DIFFERENT waves (A: wave 0 [and 1]; B: the others): the A loaders keep NA - 2 tiles
 // in flight behind the one being waited for, which a wave that also issued B could not (waiting for B(t+1) would retire
@@ -788,13 +908,7 @@ template <int WM> struct Geo {
   static constexpr int CLD = BNB + 4, RP = 16 * WM;                           // staged rows per epilogue part
   static constexpr int PL1 = BNB / 2 + 16, CLD2 = BNB == 192 ? 224 : 448;     // two-plane staging of the epilogues without LayerNorm (conflict-free f32x4 read-back)
   static constexpr int EPI_BYTES = RP * CLD2 * 4 + (CLD2 + 2 * BNB) * 4 + BM * 4;
-  // row-wise epilogues (WM == 1): staging rows of pitch CLD, bias / gamma / beta / scale, NT streamed row tensors [wave][pair][tensor][2 rows]
-  template <int NT> static constexpr int rowwise_bytes() { return (RP * CLD + 3 * BNB + BM) * 4 + 4 * 2 * NT * 2 * 384 * 4; }   // 55,808 ; 80,384 B
-  template <int EPI, bool LN> static constexpr int lds_bytes() {
-    constexpr bool rowwise = (LN && EPI == EPI_RESID) || EPI == EPI_LNBWD;
-    constexpr int epi = rowwise ? (EPI == EPI_LNBWD ? rowwise_bytes<2>() : rowwise_bytes<1>()) : EPI_BYTES;
-    return RING > epi ? RING : epi;
-  }
+  static constexpr int LDS = RING > EPI_BYTES ? RING : EPI_BYTES;
   static constexpr int A_WAVES = WM == 1 ? 1 : 2, B_WAVES = 4 - A_WAVES;
   static constexpr int PA = (BM / 16) / A_WAVES, PB = (BNB / 16) / B_WAVES;   // 1-KiB pieces per loader wave per k-tile: 8, 8 ; 8, 6
   static constexpr int SPR = BNB / 8;                                        // 8-column slots per row
@@ -815,6 +929,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_w4_kernel(GemmArgs p) {
   const int ntm = (p.M + BM - 1) / BM;
   const int id = xcd_remap(blockIdx.x, ntm * ntn);
   const int m0 = (id / ntn) * BM, n0 = (id % ntn) * BNB;
+  if (blockIdx.x >= 256 && blockIdx.x < 512) phase_skew(p.skew);                      // two blocks per CU: the second of each pair
 
   char* ldsA = smem_raw; char* ldsB = smem_raw + G::A_BYTES;
   const bool a_loader = wid < G::A_WAVES;
@@ -906,60 +1021,45 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_w4_kernel(GemmArgs p) {
 
   // Epilogue: as in the 8-wave kernel, the fp32 tile goes through LDS so that every global access is a 16-B piece of a
   // contiguous row segment.  Part (mi, h) stages 16 rows of accumulator block mi from every wave: 16 * WM rows x BNB columns.
-  constexpr int NPART = 2 * MI;
-  constexpr bool fused_ln = LN && EPI == EPI_RESID;
-  constexpr bool lnbwd = EPI == EPI_LNBWD;
-  constexpr bool rowwise = fused_ln || lnbwd;                     // (WM == 1) half a wave per row, inputs through per-wave LDS slots: see rowin_issue
-  constexpr int NT = lnbwd ? 2 : 1;
-  constexpr int NVM = (lnbwd ? 6 + 8 : 8 + 3 + 8) - 2;            // see the 8-wave kernel
-  const bool exact_vm = m0 + BM <= p.M && (!lnbwd || (p.lnb_g && p.resid));
-  static_assert(!lnbwd || WM == 1, "the LayerNorm backward needs whole rows");
   float* sC = reinterpret_cast<float*>(smem_raw);
-  float* sBias = sC + G::RP * (rowwise ? CLD : G::CLD2);
-  float* sGamma = sBias + (rowwise ? BNB : G::CLD2); float* sBeta = sGamma + BNB;
+  float* sBias = sC + G::RP * G::CLD2;
+  float* sGamma = sBias + G::CLD2; float* sBeta = sGamma + BNB;
   float* sScale = sBeta + BNB;
   float* sCol = sGamma;                                           // EPI_DGELU column sums (no LN there)
-  char* sIn = reinterpret_cast<char*>(sScale + BM) + (wid * 2) * NT * ROWIN_PAIR_BYTES;      // this wave's input slots [pair][tensor]
-  const int hh = lane >> 5, li = lane & 31;
-  auto tile_row_of = [&](int part, int rl) { return (rl >> 4) * 128 + (part >> 1) * 32 + (part & 1) * 16 + (rl & 15); };   // staged row -> row of the block tile
-  float rmu[lnbwd ? 2 : 1], rrs[lnbwd ? 2 : 1];
-  auto rowin_part = [&](int part, int q) {
-    const int row0 = m0 + tile_row_of(part, wid * 4 + 2 * q);
-    rowin_issue<NT>(p.resid, lnbwd ? p.lnb_x : nullptr, p.M, row0, sIn + q * NT * ROWIN_PAIR_BYTES, lane);
-    if constexpr (lnbwd) { const int r = row0 + hh < p.M ? row0 + hh : p.M - 1; rmu[q] = p.ln_mean[r]; rrs[q] = p.ln_rstd[r]; }
-  };
-  if constexpr (rowwise) {
-#pragma unroll
-    for (int q = 0; q < 2; ++q) rowin_part(0, q);
-  }
+  constexpr int NPART = 2 * MI;
+  constexpr bool fused_ln = LN && EPI == EPI_RESID;
   for (int c = tid; c < BNB; c += 256) {
-    sBias[rowwise ? c : ((c >> 3) << 2) + (c & 3) + ((c & 4) ? G::PL1 : 0)] = p.bias ? p.bias[n0 + c] : 0.f;
-    if (rowwise) { sGamma[c] = p.ln_gamma[c]; if (fused_ln) sBeta[c] = p.ln_beta[c]; }
+    sBias[fused_ln ? c : ((c >> 3) << 2) + (c & 3) + ((c & 4) ? G::PL1 : 0)] = p.bias ? p.bias[n0 + c] : 0.f;
+    if (fused_ln) { sGamma[c] = p.ln_gamma[c]; sBeta[c] = p.ln_beta[c]; }
     if (EPI == EPI_DGELU) sCol[c] = 0.f;
   }
-  LnbCols lcs;
-  if constexpr (lnbwd) {
-#pragma unroll
-    for (int i = 0; i < 6; ++i) lcs.dg[i] = lcs.db[i] = lcs.du[i] = 0.f;
-  }
-  if constexpr (EPI == EPI_RESID || lnbwd) {
+  if constexpr (EPI == EPI_RESID) {
     if (tid < BM) { const int row = m0 + tid; sScale[tid] = (p.row_scale && row < p.M) ? p.row_scale[row / p.rows_per_seq] : 1.0f; }
   }
 #pragma unroll
   for (int part = 0; part < NPART; ++part) {
     const int mi = part >> 1, h = part & 1;
-    auto tile_row = [&](int rl) { return tile_row_of(part, rl); };
+    auto tile_row = [&](int rl) { return (rl >> 4) * 128 + mi * 32 + h * 16 + (rl & 15); };   // staged row -> row of the block tile
 #pragma unroll
     for (int ni = 0; ni < 3; ++ni)
 #pragma unroll
       for (int r8 = 0; r8 < 8; ++r8) {
         const int lr = wm * 16 + (r8 & 3) + 8 * (r8 >> 2) + 4 * hi;
         const int ccol = wn * 96 + ni * 32 + l31;
-        sC[rowwise ? lr * CLD + ccol : lr * G::CLD2 + ((ccol >> 3) << 2) + (ccol & 3) + ((ccol & 4) ? G::PL1 : 0)] = acc[mi][ni][h * 8 + r8];
+        sC[fused_ln ? lr * CLD + ccol : lr * G::CLD2 + ((ccol >> 3) << 2) + (ccol & 3) + ((ccol & 4) ? G::PL1 : 0)] = acc[mi][ni][h * 8 + r8];
       }
-    EpiAux aux[rowwise ? 1 : 3];
-    if constexpr (rowwise) {
-      rowin_wait<NVM>(exact_vm && part > 0);                       // pair 0's rows (and statistics) of this part have landed in my slot (part 0: everything issued so far)
+    EpiAux aux[fused_ln ? 1 : 3];
+    f32x2 rres[fused_ln ? 4 : 1][3];
+    if constexpr (fused_ln) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = m0 + tile_row(wid * 4 + q);
+        if (row < p.M) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+            rres[q][k] = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p.resid + (size_t)row * p.ldc + k * 128 + lane * 2));
+        }
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
@@ -968,24 +1068,38 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_w4_kernel(GemmArgs p) {
       }
     }
     __syncthreads();
-    if constexpr (rowwise) {
+    if constexpr (fused_ln) {
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int rl = wid * 4 + 2 * q + hh, trow = tile_row(rl), row = m0 + trow;
-        const char* slot = sIn + q * NT * ROWIN_PAIR_BYTES;
-        if (q > 0 && part > 0) rowin_wait<NVM>(exact_vm);          // this pair's rows have landed (pair 0: in front of the staging barrier; part 0: both)
-        if constexpr (lnbwd) {
-          const float mu = rmu[q], rs = rrs[q];
-          lnb_row(p, row, row < p.M, sC + rl * CLD, sGamma, sScale[trow], mu, rs, slot, p.resid != nullptr, hh, li, lcs);
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the slot has been read: refill it with the next part's rows
-          if (part + 1 < NPART) rowin_part(part + 1, q);
-        } else {
-          f32x4 rres[3];
-          rowin_read(slot, 0, hh, li, rres);
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the slot has been copied out: refill it with the next part's rows
-          if (part + 1 < NPART) rowin_part(part + 1, q);
-          if (row < p.M) lnf_row(p, row, sC + rl * CLD, sBias, sGamma, sBeta, sScale[trow], rres, li);
+      for (int q = 0; q < 4; ++q) {
+        const int rl = wid * 4 + q, trow = tile_row(rl), row = m0 + trow;
+        if (row >= p.M) continue;
+        const float sc = sScale[trow];
+        float v[6];
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int col = k * 128 + lane * 2;
+          const f32x2 a2 = *reinterpret_cast<const f32x2*>(sC + rl * CLD + col);
+          const f32x2 b2 = *reinterpret_cast<const f32x2*>(sBias + col);
+          f32x2 o = rres[q][k] + sc * (a2 + b2);
+          __builtin_nontemporal_store(o, reinterpret_cast<f32x2*>(reinterpret_cast<float*>(p.C) + (size_t)row * p.ldc + col));
+          v[2 * k] = o[0]; v[2 * k + 1] = o[1]; sum += o[0] + o[1];
         }
+        const float mu = wave_sum(sum) * (1.0f / 384.0f);
+        float qd = 0.f;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { const float d = v[k] - mu; qd += d * d; }
+        const float rs = rsqrtf(wave_sum(qd) * (1.0f / 384.0f) + 1e-6f);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int col = k * 128 + lane * 2;
+          const f32x2 g2 = *reinterpret_cast<const f32x2*>(sGamma + col), be2 = *reinterpret_cast<const f32x2*>(sBeta + col);
+          bf16x2 hv;
+          hv[0] = f2bf((v[2 * k] - mu) * rs * g2[0] + be2[0]);
+          hv[1] = f2bf((v[2 * k + 1] - mu) * rs * g2[1] + be2[1]);
+          *reinterpret_cast<bf16x2*>(p.ln_out + (size_t)row * 384 + col) = hv;
+        }
+        if (lane == 0) { p.ln_mean[row] = mu; p.ln_rstd[row] = rs; }
       }
     } else {
 #pragma unroll
@@ -1014,7 +1128,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_w4_kernel(GemmArgs p) {
       for (int c = tid; c < BNB; c += 256) atomicAdd(p.colsum + n0 + c, sCol[c]);
     }
   }
-  if constexpr (lnbwd) lnb_flush<4>(p, lcs, sC, tid);
 }
 
 // ---- wgrad: dW[n,k] += sum_m dY[m,n] X[m,k] -------------------------------------------------------------------------
@@ -1110,18 +1223,28 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(WgradArgs p) {
 // row are XOR-permuted (tr_swz, applied to the per-lane source address) so that the 4-row x 32-column blocks fetched by
 // ds_read_b64_tr_b16 -- the hardware transpose that turns the m-major image into MFMA fragments -- fall on distinct banks.  36.9 KB staged per 64 rows of a 192x384 tile = 8.2 KB per 128x128 unit, against
 // 16 KB for the square tile: the wgrad GEMMs are bound by that L2 -> LDS traffic.
+#ifndef ATST_TN_RM
+#define ATST_TN_RM 64          // contraction rows per ring stage: 64 (2-stage ring) | 32 (4-stage ring: measured SLOWER, 268 vs 225 us on fc2 wgrad)
+#endif
 namespace tnt {
-constexpr int TN = 192, TK = 384, RM = 64;                            // RM: contraction rows per ring stage
+constexpr int TN = 192, TK = 384, RM = ATST_TN_RM;
 constexpr int PY = TN * 2, PX = TK * 2;                               // row pitches in bytes
-constexpr int Y_BYTES = RM * PY, X_BYTES = RM * PX, STAGE = Y_BYTES + X_BYTES;   // 24,576 + 49,152
+constexpr int Y_BYTES = RM * PY, X_BYTES = RM * PX, STAGE = Y_BYTES + X_BYTES;   // RM 64: 24,576 + 49,152 ; RM 32: half
 // Both operands of a weight gradient are streamed from HBM; with 64-row stages only two fit (144 KB), i.e. one stage of
-// prefetch.  (32-row stages in a 4-deep ring, interleaved issue and dedicated loader waves were measured slower:
-// tools/experiments/gemm_r02_variants.hip, profiles/r02_trace_gemm.txt.)
-constexpr int NST = 2;
-constexpr int LDS = NST * STAGE;                                      // 147,456 B
-constexpr int Y_PIECES = Y_BYTES / 1024, PIECES = STAGE / 1024;       // 1-KiB LDS-DMA pieces per stage: 24 + 48
-constexpr int LOADERS = 8, LOADER0 = 0;
-constexpr int PPW = (PIECES + LOADERS - 1) / LOADERS;                 // pieces per wave per stage: 9
+// prefetch.  Tried (round 2): 32-row stages in a 4-deep ring (three stages = 108 KB in flight, same LDS): SLOWER -- fc2 wgrad
+// 225 -> 268 us, the grouped launch 320 -> 376 us: twice the barriers and 4-5 instead of 9 LDS-DMA pieces per wave per stage
+// cost more than the deeper prefetch returns.  Kept selectable (ATST_TN_RM=32).
+constexpr int NST = RM == 64 ? 2 : 4;
+constexpr int LDS = NST * STAGE;                                      // 147,456 B either way
+constexpr int Y_PIECES = Y_BYTES / 1024, PIECES = STAGE / 1024;       // 1-KiB LDS-DMA pieces per stage: 12 + 24 (RM 32) ; 24 + 48
+#ifndef ATST_TN_ILV
+#define ATST_TN_ILV 0          // 1: the next stage's LDS-DMA pieces are issued one per MFMA group instead of all after the barrier
+#endif
+#ifndef ATST_TN_SPLIT
+#define ATST_TN_SPLIT 0        // 1: only waves 4-7 issue the LDS-DMA of the next stage while waves 0-3 already run the stage's MFMAs (measured: no gain, see below)
+#endif
+constexpr int LOADERS = ATST_TN_SPLIT ? 4 : 8, LOADER0 = ATST_TN_SPLIT ? 4 : 0;
+constexpr int PPW = (PIECES + LOADERS - 1) / LOADERS;                 // pieces per loader wave per stage: 18 (split) / 9 (RM 64)
 }
 
 // ds_read_b64_tr_b16 is serviced 32 lanes at a time = 4 rows x 64 B of the image, over 64 banks (256 B): the four rows
@@ -1142,6 +1265,12 @@ DEVFN bf16x8 ld_frag_tr_p(const char* X, int r0, int c0, int lane) {
   return u.v;
 }
 
+#if ATST_TRACE
+__device__ unsigned long long g_tn_trc[8 * 260 * 4];            // [wave][stage][0: loop top, 1: after wait, 2: after barrier + issue, 3: after MFMAs]
+#define TSTAMP(i) do { if (ttrace && st < 260) g_tn_trc[(wid * 260 + st) * 4 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TSTAMP(i) do { } while (0)
+#endif
 // one (tile, split) of one problem
 DEVFN void tn_tall_body(const WgradArgs& p, int tile, int split, char* smem_raw) {
   using namespace tnt;
@@ -1157,8 +1286,10 @@ DEVFN void tn_tall_body(const WgradArgs& p, int tile, int split, char* smem_raw)
   const int nst = (m_end - m_begin) / RM;
 
   // lane -> (row, chunk) of the linear stage image.  Piece q (1 KiB) of a stage: q < Y_PIECES -> dY image, else X image;
-  // wave w issues pieces w, w + 8, ...  Stage timeline (tools/trace_tn.py on the variants build, profiles/r02_trace_gemm.txt):
-  // 1.5-2.0 k cycles of LDS-DMA issue, then 2.6-3.3 k cycles for the 2 x 36 MFMAs of a SIMD: 5.3 k per 64 rows.
+  // loader wave w issues pieces w', w' + LOADERS, ...
+  // Stage timeline measured with every wave issuing its 9 pieces right after the barrier (tools/trace_tn.py): 1.5-2.0 k cycles
+  // of LDS-DMA issue with idle matrix pipes, then 2.6-3.3 k cycles for the 2 x 36 MFMAs of a SIMD: 5.3 k per 64 rows.  With the
+  // issue moved to waves 4-7 alone, waves 0-3 compute meanwhile and the two waves of a SIMD no longer contend for its pipe.
   const bool loader = wid >= LOADER0;
   int off[PPW]; bool isx[PPW]; bool have[PPW]; int ldsoff[PPW];
 #pragma unroll
@@ -1197,12 +1328,31 @@ DEVFN void tn_tall_body(const WgradArgs& p, int tile, int split, char* smem_raw)
 #pragma unroll
   for (int s_ = 0; s_ < NST - 1; ++s_)
     if (s_ < nst) issue_stage(s_);
-  static_assert(NST == 2, "the wait below assumes nothing younger than the stage being waited for");
+  constexpr int MINPW = PIECES / LOADERS;                         // loads per stage of the loader waves that issue the fewest
+#if ATST_TRACE
+  const bool ttrace = (int)blockIdx.x == 100 && lane == 0;
+#endif
   for (int st = 0; st < nst; ++st) {
-    // stage st has landed (mine: vmcnt ; everyone's: barrier), and stage st - 1's buffer is free for the next issue
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    if (st + 1 < nst) issue_stage(st + 1);
+    TSTAMP(0);
+    // stage st has landed (my loads retire in order; up to NST - 2 younger stages stay in flight; waves that issue one piece
+    // more per stage simply wait for a little of stage st + 1 as well); barrier => for everyone, and stage st - 1's buffer is free
+    const int younger = nst - 1 - st < NST - 2 ? nst - 1 - st : NST - 2;
+    if (younger >= 2) {
+      if constexpr (MINPW * 2 == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (younger == 1) {
+      if constexpr (MINPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    TSTAMP(1);
+    asm volatile("s_barrier" ::: "memory");
+    const bool more = st + NST - 1 < nst;
+#if !ATST_TN_ILV
+    if (more) issue_stage(st + NST - 1);
+#endif
+    TSTAMP(2);
     const char* sY = smem_raw + (st % NST) * STAGE; const char* sX = sY + Y_BYTES;
+    int slot = 0;
 #pragma unroll
     for (int ms = 0; ms < RM / 16; ++ms) {
       bf16x8 a[3], b[3];
@@ -1214,9 +1364,21 @@ DEVFN void tn_tall_body(const WgradArgs& p, int tile, int split, char* smem_raw)
       for (int i = 0; i < 3; ++i) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+#if ATST_TN_ILV
+        if (slot < PPW) {                                         // next stage's LDS-DMA pieces spread between the MFMA groups
+          __builtin_amdgcn_sched_barrier(0);
+          if (more) issue_piece(st + NST - 1, slot);
+          __builtin_amdgcn_sched_barrier(0);
+          ++slot;
+        }
+#endif
       }
     }
+    TSTAMP(3);
   }
+#if ATST_TRACE
+  { const int st = 259; TSTAMP(0); }
+#endif
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -1224,6 +1386,9 @@ DEVFN void tn_tall_body(const WgradArgs& p, int tile, int split, char* smem_raw)
       const int n = n0 + wn * 96 + i * 32 + crow32(r, hi);
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
+#if ATST_ABLATE == 8
+        if (acc[i][j][r] != 12345.678f) continue;                   // experiment builds: no atomics
+#endif
         atomicAdd(p.dW + (size_t)n * p.ldw + k0 + wk * 96 + j * 32 + l31, acc[i][j][r]);
       }
     }
@@ -1252,16 +1417,15 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_tall_group_kernel(WgradGroup g
   tn_tall_body(g.it[k], t - g.first_tile[k], split, smem_raw);
 }
 
-// Tuning hooks (atst_tune_gemm_variant, include/atst_hip.h); the defaults are the measured best.
-int g_nt_variant = -1;      // -1 auto ; 0: 128x128 2-stage ; 1: 128x128 3-stage ; 3: 256x128 4 waves of 128x64 ; 4: force the row-384 tile
-int g_tn_tall = 1;          // 105/106: wgrad 192 x 384 LDS-DMA tile when N % 192 == 0, K % 384 == 0, M % 64 == 0
-int g_tn_rounds = 1;        // 110 + r: 128x128 wgrad grid = r rounds of 512 resident blocks; 1 measured best (-20 %)
-int g_row384_auto = 1;      // 300/301: row-384 tile whenever N % 384 == 0
-int g_row384_tall = 2;      // 302/303/304: 256 x 384 tiles for M >= 8192: never / plain bf16 GEMMs only / every epilogue
-int g_dgelu_row384 = 2;     // 306/307/308: dGELU GEMM on the 256x384 tile never / always / when K >= 768.  Measured with the staged column sums: base (K = 768) 968 -> 935 us, small (K = 384) 206 -> 227 us
-int g_w4_mode = 0;          // 330 + m: 4-wave two-blocks-per-CU kernels: 0 only for small grids ; 2 = 256x192 (plain epilogues) + 128x384 (row-wise) everywhere ; 3 = 256x192 for the plain epilogues only
-int g_w4_min_m = 8192;      // 350/351: apply the tall / 4-wave kernels from M = 8192 / from any M (parity tests run small shapes)
-int g_w4_auto = 1;          // 360/361: 4-wave kernels for launches of <= 1.5 rounds of 256 x 384 tiles
+int g_tn_tall = 1;        // wgrad: 192 x 384 LDS-DMA tile when N % 192 == 0, K % 384 == 0, M % 64 == 0 (tuning hook 105 = off, 106 = on)
+int g_row384_auto = 1;      // use the 128x384 tile whenever N % 384 == 0 (tuning hook 300 turns it off)
+int g_row384_tall = 2;      // 256 x 384 tiles for M >= 8192: 2 = every epilogue, 1 = plain bf16 GEMMs only, 0 = never (tuning hooks 304 / 303 / 302)
+int g_tn_rounds = 1;      // wgrad grid = this many rounds of 512 resident blocks (tuning hook 110 + r); 1 measured best (-20 %)
+int g_row384_dir = 0;       // 256-row tile: epilogue straight from the accumulator registers (tuning hook 341 = on)
+int g_row384_pp = 0;        // ping-pong main loop of the 256-row tile (tuning hook 321 = on)
+int g_row384_bk64 = 0;      // 256-row tile with 64-deep ring stages, whole 128-B lines per LDS-DMA lane group, 2 stages (tuning hook 311 = on): measured 2-5 % slower than 3 x 32-deep
+int g_dgelu_row384 = 2;   // dGELU GEMM on the 256x384 tile: 0 never / 1 always / 2 when K >= 768 (hooks 306 / 307 / 308).  Measured with the staged column sums: base (K = 768) 968 -> 935 us, small (K = 384) 206 -> 227 us; with per-element LDS atomics it was 2.7x slower
+int g_nt_variant = -1;    // -1 auto ; 0: 128x128 2-stage ; 1: 128x128 3-stage ; 2: 256x128 8 waves ; 3: 256x128 4 waves of 128x64
 
 // Algorithmic HBM bytes of one nt GEMM: both operands once, every epilogue input once, every output once.
 template <int EPI>
@@ -1270,14 +1434,12 @@ double nt_bytes(const GemmArgs& a) {
   double b = 2.0 * a.K * ((double)a.M + a.N);
   if (EPI == EPI_BF16) b += 2.0 * mn;
   if (EPI == EPI_F32) b += 4.0 * mn;
-  if (EPI == EPI_BIAS_GELU) b += 2.0 * mn + (a.C ? 2.0 * mn : 0.0);            // a always, u only when it is saved (training)
+  if (EPI == EPI_BIAS_GELU) b += 2.0 * mn + (a.C2 ? 2.0 * mn : 0.0);
   if (EPI == EPI_RESID) b += 8.0 * mn + (a.ln_out ? 2.0 * mn : 0.0);
   if (EPI == EPI_DGELU) b += 4.0 * mn;
   if (EPI == EPI_PATCH) b += 4.0 * mn;
-  if (EPI == EPI_LNBWD) b += 8.0 * mn + (a.resid ? 4.0 * mn : 0.0) + (a.lnb_g ? 2.0 * mn : 0.0);   // x in, dx out, dres in, g out
   return b;
 }
-template <int EPI> constexpr int prof_kind() { return EPI == EPI_LNBWD ? PK_GEMM_NT6 : PK_GEMM_NT0 + EPI; }
 
 template <int EPI, int BMT, int NSTG, int WTM>
 int launch_nt_cfg(const GemmArgs& a, hipStream_t st) {
@@ -1289,51 +1451,53 @@ int launch_nt_cfg(const GemmArgs& a, hipStream_t st) {
     attr_done = true;
   }
   const int nblk = ((a.M + BMT - 1) / BMT) * (a.N / BN);
-  ProfScope ps(prof_kind<EPI>(), 2.0 * a.M * a.N * a.K, st, nt_bytes<EPI>(a));
+  ProfScope ps(PK_GEMM_NT0 + EPI, 2.0 * a.M * a.N * a.K, st, nt_bytes<EPI>(a));
   hipLaunchKernelGGL((gemm_nt_kernel<EPI, BMT, NSTG, WTM>), dim3(nblk), dim3(G::THREADS), G::LDS, st, a);
   return (int)hipGetLastError();
 }
-template <int EPI, int MI, bool LN, bool F8 = false>
+template <int EPI, int MI, bool LN, int BKT = BK, bool PP = false, bool DIR = false, bool F8 = false>
 int launch_nt_row384_cfg(const GemmArgs& a, hipStream_t st) {
-  using RG = row384::Geo<MI>;
-  constexpr int LDS = row384::lds_bytes<MI, EPI, LN>();
+  using RG = row384::Geo<MI, BKT>;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_row384_kernel<EPI, MI, LN, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_row384_kernel<EPI, MI, LN, BKT, PP, DIR, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, RG::LDS);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
   const int nblk = ((a.M + RG::BMR - 1) / RG::BMR) * (a.N / row384::BNR);
-  hipLaunchKernelGGL((gemm_nt_row384_kernel<EPI, MI, LN, F8>), dim3(nblk), dim3(row384::THREADS), LDS, st, a);
+  hipLaunchKernelGGL((gemm_nt_row384_kernel<EPI, MI, LN, BKT, PP, DIR, F8>), dim3(nblk), dim3(row384::THREADS), RG::LDS, st, a);
   return (int)hipGetLastError();
 }
+int g_w4_auto = 1;          // hook 360 / 361: 4-wave kernels for launches of fewer than 1.5 rounds of 256 x 384 tiles
+int g_skew = 0;             // hook 100000 + c: phase skew in shader cycles per k-tile of the main loop (0 = off)
+int g_w4_min_m = 8192;     // hook 351: use the 4-wave kernels for every M (parity tests run small shapes)
+int g_w4_mode = 0;          // 4-wave two-blocks-per-CU kernels (tuning hook 330 + m): 0 off ; 1 = 128x384 for everything ; 2 = 256x192 (plain epilogues) + 128x384 (fused LayerNorm) ; 3 = 256x192 for the plain epilogues only
 template <int EPI, int WM, bool LN>
 int launch_nt_w4_cfg(const GemmArgs& a, hipStream_t st) {
   using G = w4::Geo<WM>;
-  constexpr int LDS = G::template lds_bytes<EPI, LN>();
-  static_assert(LDS <= 81920, "two blocks per CU");
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<EPI, WM, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<EPI, WM, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
   const int nblk = ((a.M + G::BM - 1) / G::BM) * (a.N / G::BNB);
-  hipLaunchKernelGGL((gemm_nt_w4_kernel<EPI, WM, LN>), dim3(nblk), dim3(256), LDS, st, a);
+  hipLaunchKernelGGL((gemm_nt_w4_kernel<EPI, WM, LN>), dim3(nblk), dim3(256), G::LDS, st, a);
   return (int)hipGetLastError();
 }
 template <int EPI>
-int launch_nt_row384(const GemmArgs& a, hipStream_t st) {
+int launch_nt_row384(const GemmArgs& a0, hipStream_t st) {
+  GemmArgs a = a0;
+  a.skew = g_skew * (a.K / BK);
   if (a.fp8) {                                                    // e4m3 operands seen as byte pairs: K, lda, ldb are already halved
     if constexpr (EPI == EPI_BF16 || EPI == EPI_BIAS_GELU || EPI == EPI_RESID || EPI == EPI_F32) {
-      ProfScope ps(prof_kind<EPI>(), 4.0 * a.M * a.N * a.K, st, nt_bytes<EPI>(a));
-      return launch_nt_row384_cfg<EPI, 4, false, true>(a, st);
+      ProfScope ps(PK_GEMM_NT0 + EPI, 4.0 * a.M * a.N * a.K, st, nt_bytes<EPI>(a));
+      return launch_nt_row384_cfg<EPI, 4, false, BK, false, false, true>(a, st);
     } else {
       return ATST_EINVAL;
     }
   }
-  ProfScope ps(prof_kind<EPI>(), 2.0 * a.M * a.N * a.K, st, nt_bytes<EPI>(a));
-  constexpr bool rowwise_only = EPI == EPI_LNBWD;                 // epilogues that exist only on whole-row tiles
+  ProfScope ps(PK_GEMM_NT0 + EPI, 2.0 * a.M * a.N * a.K, st, nt_bytes<EPI>(a));
 
   // Fewer than 1.5 rounds of 256 x 384 tiles (the 1 s local views: M = 32768, N = 384 -> 128 blocks on 256 CUs): the 4-wave
   // kernels launch twice as many, half as large blocks, two per CU.  Measured at M = 32768 (profiles/r02_gemm_bench.txt):
@@ -1346,14 +1510,36 @@ int launch_nt_row384(const GemmArgs& a, hipStream_t st) {
     if constexpr (EPI == EPI_RESID) {
       if (a.ln_out) { if (w4m != 3) return launch_nt_w4_cfg<EPI, 1, true>(a, st); }
     }
-    if constexpr (rowwise_only) {
-      if (w4m != 3) return launch_nt_w4_cfg<EPI, 1, false>(a, st);
-    } else {
-      if (!a.ln_out) return launch_nt_w4_cfg<EPI, 2, false>(a, st);
+    if constexpr (ATST_EXPERIMENTS) {
+      if (w4m == 1 && !a.ln_out) return launch_nt_w4_cfg<EPI, 1, false>(a, st);
     }
+    if (!a.ln_out) return launch_nt_w4_cfg<EPI, 2, false>(a, st);
   }
   // 256-row tiles: the operand ring of one block covers twice the output (6.7 vs 10.7 KB staged per 128x128 unit)
   const bool tall = a.M >= (g_w4_min_m < 8192 ? g_w4_min_m : 8192) && (g_row384_tall == 2 || (g_row384_tall == 1 && EPI == EPI_BF16 && (a.K >= 768 || a.N >= 768)));
+  const bool deep = tall && g_row384_bk64 && a.K % 64 == 0;        // 64-deep ring stages
+  if constexpr (ATST_EXPERIMENTS && (EPI == EPI_BF16 || EPI == EPI_F32 || EPI == EPI_BIAS_GELU || EPI == EPI_RESID)) {
+    if (tall && g_row384_dir && ATST_TALL_STAGES == 3) {            // epilogue straight from the registers (tuning hook 340 = off / 341 = on)
+      if constexpr (EPI == EPI_RESID) {
+        if (a.ln_out) return launch_nt_row384_cfg<EPI, 4, true, BK, false, true>(a, st);
+      }
+      return launch_nt_row384_cfg<EPI, 4, false, BK, false, true>(a, st);
+    }
+  }
+  if constexpr (ATST_EXPERIMENTS) {
+    if (tall && g_row384_pp && ATST_TALL_STAGES == 3) {             // ping-pong main loop (tuning hook 320 / 321)
+      if constexpr (EPI == EPI_RESID) {
+        if (a.ln_out) return launch_nt_row384_cfg<EPI, 4, true, BK, true>(a, st);
+      }
+      return launch_nt_row384_cfg<EPI, 4, false, BK, true>(a, st);
+    }
+    if (deep) {
+      if constexpr (EPI == EPI_RESID) {
+        if (a.ln_out) return launch_nt_row384_cfg<EPI, 4, true, 64>(a, st);
+      }
+      return launch_nt_row384_cfg<EPI, 4, false, 64>(a, st);
+    }
+  }
   if constexpr (EPI == EPI_RESID) {
     if (a.ln_out) return tall ? launch_nt_row384_cfg<EPI, 4, true>(a, st) : launch_nt_row384_cfg<EPI, 2, true>(a, st);
   }
@@ -1361,37 +1547,25 @@ int launch_nt_row384(const GemmArgs& a, hipStream_t st) {
 }
 template <int EPI>
 int launch_nt(const GemmArgs& a, hipStream_t st) {
-  if constexpr (EPI == EPI_LNBWD) {                               // LayerNorm backward in the dgrad epilogue: whole rows only
-    if (a.N != 384 || a.ldc != 384 || !a.ln_gamma || !a.ln_mean || !a.ln_rstd || !a.lnb_x || !a.lnb_dgamma || !a.lnb_dbeta || !a.C) return ATST_EINVAL;
-    return launch_nt_row384<EPI>(a, st);
-  } else {
-    if (a.ln_out) {                                               // fused LayerNorm needs the block to own whole rows
-      if (EPI != EPI_RESID || a.N != 384 || !a.ln_gamma || !a.ln_beta || !a.ln_mean || !a.ln_rstd) return ATST_EINVAL;
-      if constexpr (EPI == EPI_RESID) return launch_nt_row384<EPI>(a, st);
-    }
-    int v = g_nt_variant;
-    if ((v == 4 || (v < 0 && g_row384_auto)) && a.N % 384 == 0 && (EPI != EPI_DGELU || g_dgelu_row384 == 1 || (g_dgelu_row384 == 2 && a.K >= 768))) return launch_nt_row384<EPI>(a, st);
-    if (v < 0) v = (EPI == EPI_F32 && a.M >= 16384) ? 3          // ATST-Frame head Linears (83 k rows): 256x128 tile, -13 %
-                 : a.K <= 512 ? 0 : 1;
-    if (v == 3) return launch_nt_cfg<EPI, 256, 3, 128>(a, st);
-    if (v == 1) return launch_nt_cfg<EPI, 128, 3, 64>(a, st);
-    return launch_nt_cfg<EPI, 128, 2, 64>(a, st);
+  if (a.ln_out) {                                                 // fused LayerNorm needs the block to own whole rows
+    if (EPI != EPI_RESID || a.N != 384 || !a.ln_gamma || !a.ln_beta || !a.ln_mean || !a.ln_rstd) return ATST_EINVAL;
+    if constexpr (EPI == EPI_RESID) return launch_nt_row384<EPI>(a, st);
   }
+  int v = g_nt_variant;
+  if ((v == 4 || (v < 0 && g_row384_auto)) && a.N % 384 == 0 && (EPI != EPI_DGELU || g_dgelu_row384 == 1 || (g_dgelu_row384 == 2 && a.K >= 768))) return launch_nt_row384<EPI>(a, st);
+  if (v < 0) v = (EPI == EPI_F32 && a.M >= 16384) ? 3            // ATST-Frame head Linears (83 k rows): 256x128 tile, -13 %
+               : a.K <= 512 ? 0 : 1;
+  if (v == 3) return launch_nt_cfg<EPI, 256, 3, 128>(a, st);
+  if constexpr (ATST_EXPERIMENTS) {
+    if (v == 2) return launch_nt_cfg<EPI, 256, 3, 64>(a, st);
+  }
+  if (v == 1) return launch_nt_cfg<EPI, 128, 3, 64>(a, st);
+  return launch_nt_cfg<EPI, 128, 2, 64>(a, st);
 }
 
 }  // namespace
 
-void atst_gemm_nt_set_variant(int v) {
-  if (v >= 360) g_w4_auto = v - 360;
-  else if (v >= 350) g_w4_min_m = v == 351 ? 1 : 8192;
-  else if (v >= 330) g_w4_mode = v - 330;
-  else if (v >= 306) g_dgelu_row384 = v - 306;
-  else if (v >= 302) g_row384_tall = v - 302;
-  else if (v >= 300) g_row384_auto = v - 300;
-  else if (v >= 110) g_tn_rounds = v - 110;
-  else if (v >= 105) g_tn_tall = v - 105;
-  else if (v < 100) g_nt_variant = v;
-}
+void atst_gemm_nt_set_variant(int v) { if (v >= 100000) g_skew = v - 100000; else if (v >= 360) g_w4_auto = v - 360; else if (v >= 350) g_w4_min_m = v == 351 ? 1 : 8192; else if (v >= 340) g_row384_dir = v - 340; else if (v >= 330) g_w4_mode = v - 330; else if (v >= 320) g_row384_pp = v - 320; else if (v >= 310) g_row384_bk64 = v - 310; else if (v >= 306) g_dgelu_row384 = v - 306; else if (v >= 302) g_row384_tall = v - 302; else if (v >= 300) g_row384_auto = v - 300; else if (v >= 110) g_tn_rounds = v - 110; else if (v >= 105) g_tn_tall = v - 105; else if (v < 100) g_nt_variant = v; }
 
 int atst_gemm_nt(const GemmArgs& a0, hipStream_t st) {
   GemmArgs a = a0;
@@ -1414,7 +1588,6 @@ int atst_gemm_nt(const GemmArgs& a0, hipStream_t st) {
     case EPI_RESID: return launch_nt<EPI_RESID>(a, st);
     case EPI_DGELU: return launch_nt<EPI_DGELU>(a, st);
     case EPI_PATCH: return launch_nt<EPI_PATCH>(a, st);
-    case EPI_LNBWD: return launch_nt<EPI_LNBWD>(a, st);
   }
   return ATST_EINVAL;
 }
@@ -1469,6 +1642,11 @@ bool tn_tall_ok(const WgradArgs& a) {
   return g_tn_tall && a.N % tnt::TN == 0 && a.K % tnt::TK == 0 && a.M % tnt::RM == 0 && a.M >= 8192 && a.ldy % 8 == 0 && a.ldx % 8 == 0;
 }
 
+#if ATST_TRACE
+extern "C" int atst_debug_tn_trace(unsigned long long* host, int n) {   // trace builds only (tools/trace_tn.py)
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tn_trc), sizeof(unsigned long long) * (size_t)n);
+}
+#endif
 int atst_gemm_tn_group(const WgradArgs* items, int n, hipStream_t st) {
   if (n < 1 || n > ATST_WGRAD_GROUP_MAX) return ATST_EINVAL;
   bool tall = true;
