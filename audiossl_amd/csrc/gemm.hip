@@ -39,6 +39,9 @@ constexpr int C_LD = BN + 4;                   // fp32 epilogue staging tile [12
 // costs one full memory round trip per store (measured: that was ~half of every GEMM's time).
 struct EpiAux { f32x4 a0, a1; float s; };
 
+// Block barrier for LDS hand-offs inside the epilogues.  __syncthreads() also drains vmcnt (workgroup-scope fence): every part
+// would then wait for the acknowledgement of the global stores it has just issued and for the LDS-DMA refills in flight.
+DEVFN void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 template <int EPI, bool SCALE = true>
 DEVFN void epi_fetch8(const GemmArgs& p, int row, int col, EpiAux& x) {
   const size_t idx = (size_t)row * p.ldc + col;
@@ -292,11 +295,11 @@ template <int MI> struct Geo {
 };
 // XOR key of a row's 16-B chunks: the 16 rows of a ds_read_b128 service group must land on 16 distinct bank slots
 DEVFN int swz_key(int row) { return (row >> 2) & 3; }
-// LDS layout of the epilogue (floats): staging tile | bias | gamma, beta | per-row scale | row-wise: input slots of NT streamed
+// LDS layout of the epilogue (floats): staging tile | bias | gamma, beta | per-row scale | row-wise: per-row {mean, rstd}, input slots of NT streamed
 // row tensors, [wave][pair][tensor][2 rows]
 template <int MI, bool ROWWISE, int NT> struct EpiLds {
   static constexpr int SC = 32 * (ROWWISE ? CLD : CLD2), SBIAS = ROWWISE ? BNR : CLD2;
-  static constexpr int BYTES = (SC + SBIAS + 2 * BNR + 64 * MI) * 4 + (ROWWISE ? WAVES * 2 * NT * 2 * 384 * 4 : 0);
+  static constexpr int BYTES = (SC + SBIAS + 2 * BNR + 64 * MI * (ROWWISE ? 3 : 1)) * 4 + (ROWWISE ? WAVES * 2 * NT * 2 * 384 * 4 : 0);
 };
 template <int MI, int EPI, bool LN> constexpr int lds_bytes() {
   constexpr bool rowwise = (LN && EPI == EPI_RESID) || EPI == EPI_LNBWD;
@@ -354,14 +357,32 @@ DEVFN float half_sum(float v) {
   for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
-DEVFN void st_bf16x4(bf16* dst, const float* v) {
+// A row-wise epilogue is bound by the NUMBER of vector-memory instructions it issues (tools/trace_rowwise.py: a pair of rows
+// took ~4 k cycles for 8 stores + 3 LDS-DMA pieces per wave, ~50 cycles per store instruction per CU whatever its width), so
+// the bf16 row goes out in two instructions instead of three: neighbouring lanes swap 4-column groups (one DPP move per
+// dword) so that even lanes hold 8 consecutive columns of the row's first 128 and odd lanes 8 of its second 128 -- one
+// 16-B store for both -- and the last 128 columns follow as one 8-B store.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+DEVFN u32x2 pack_bf16x4(const float* v) {
   bf16x4 o; o[0] = f2bf(v[0]); o[1] = f2bf(v[1]); o[2] = f2bf(v[2]); o[3] = f2bf(v[3]);
-  *reinterpret_cast<bf16x4*>(dst) = o;
+  return __builtin_bit_cast(u32x2, o);
+}
+DEVFN void st_bf16_row(bf16* rowp, const float* v /* [12]: columns 128 j + 4 li + e */, int li) {
+  const u32x2 c0 = pack_bf16x4(v), c1 = pack_bf16x4(v + 4), c2 = pack_bf16x4(v + 8);
+  const bool odd = li & 1;
+  const u32x2 send = odd ? c0 : c1;
+  u32x2 recv;                                                      // quad_perm [1,0,3,2]: the neighbouring lane's dword
+  recv[0] = __builtin_amdgcn_update_dpp(0u, send[0], 0xB1, 0xF, 0xF, true);
+  recv[1] = __builtin_amdgcn_update_dpp(0u, send[1], 0xB1, 0xF, 0xF, true);
+  const u32x4 wide = odd ? u32x4{recv[0], recv[1], c1[0], c1[1]} : u32x4{c0[0], c0[1], recv[0], recv[1]};
+  *reinterpret_cast<u32x4*>(rowp + (odd ? 128 + 4 * (li - 1) : 4 * li)) = wide;
+  *reinterpret_cast<u32x2*>(rowp + 256 + 4 * li) = c2;
 }
 // residual + LayerNorm forward of the new row: x_new = resid + s (acc + bias) -> fp32 stream ; h = LN(x_new) -> bf16 operand
 // of the next GEMM ; row statistics saved for the LayerNorm backward.  ref: Block.forward, audiossl/modules/transformer.py:136-150.
 DEVFN void lnf_row(const GemmArgs& p, int row, const float* sRow, const float* sBias, const float* sGamma, const float* sBeta,
-                   float sc, const f32x4* rv, int li) {
+                   float sc, const f32x4* rv, int li, float* sStatRow /* LDS: {mean, rstd} of this row, written out once per tile */) {
   float v[12];
   float sum = 0.f;
 #pragma unroll
@@ -382,12 +403,11 @@ DEVFN void lnf_row(const GemmArgs& p, int row, const float* sRow, const float* s
   for (int j = 0; j < 3; ++j) {
     const int col = j * 128 + li * 4;
     const f32x4 g4 = *reinterpret_cast<const f32x4*>(sGamma + col), e4 = *reinterpret_cast<const f32x4*>(sBeta + col);
-    float t[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) t[e] = (v[4 * j + e] - mu) * rs * g4[e] + e4[e];
-    st_bf16x4(p.ln_out + (size_t)row * 384 + col, t);
+    for (int e = 0; e < 4; ++e) v[4 * j + e] = (v[4 * j + e] - mu) * rs * g4[e] + e4[e];
   }
-  if (li == 0) { p.ln_mean[row] = mu; p.ln_rstd[row] = rs; }
+  st_bf16_row(p.ln_out + (size_t)row * 384, v, li);
+  if (li == 0) { sStatRow[0] = mu; sStatRow[1] = rs; }
 }
 // LayerNorm backward of one row, fused into the N == 384 dgrad epilogues (EPI_LNBWD).  dy comes from the staged fp32
 // accumulators (never rounded to bf16, never written to HBM), x / dres were loaded before the staging barrier.  Math as in
@@ -435,6 +455,7 @@ DEVFN void lnb_row(const GemmArgs& p, int row, bool live, const float* sRow, con
     lnb_fold4(cs.dg + 2 * j, ddg); lnb_fold4(cs.db + 2 * j, ddb);  // both half-waves get here: no early exit for dead rows
   }
   const float c1 = half_sum(s1) * (1.0f / 384.0f), c2 = half_sum(s2) * (1.0f / 384.0f);
+  float gs[12];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     const int col = j * 128 + li * 4;
@@ -442,18 +463,18 @@ DEVFN void lnb_row(const GemmArgs& p, int row, bool live, const float* sRow, con
     const f32x4 x4 = *reinterpret_cast<const f32x4*>(slot + ROWIN_PAIR_BYTES + hh * 1536 + j * 512 + li * 16);
     f32x4 r4 = {0.f, 0.f, 0.f, 0.f};
     if (has_res) r4 = *reinterpret_cast<const f32x4*>(slot + hh * 1536 + j * 512 + li * 16);
-    f32x4 o; float gs[4];
+    f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float xh = (x4[e] - mu) * rs;
       o[e] = live ? r4[e] + rs * (d4[e] * g4[e] - c1 - xh * c2) : 0.f;
-      gs[e] = o[e] * sc;
+      gs[4 * j + e] = o[e] * sc;
     }
-    if (live) {
-      __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (size_t)row * 384 + col));
-      if (p.lnb_g) st_bf16x4(p.lnb_g + (size_t)row * 384 + col, gs);
-    }
-    lnb_fold4(cs.du + 2 * j, gs);
+    if (live) __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (size_t)row * 384 + col));
+    lnb_fold4(cs.du + 2 * j, gs + 4 * j);
+  }
+  if (p.lnb_g) {                                                   // every lane takes part in the DPP exchange; dead rows do not store
+    if (live) st_bf16_row(p.lnb_g + (size_t)row * 384, gs, li);
   }
 }
 // Block reduction of the column sums of lnb_row over the NW waves of a block (red: >= 3 * NW * 384 floats of LDS that no
@@ -461,13 +482,13 @@ DEVFN void lnb_row(const GemmArgs& p, int row, bool live, const float* sRow, con
 template <int NW>
 DEVFN void lnb_flush(const GemmArgs& p, const LnbCols& cs, float* red, int tid) {
   const int li = tid & 31, hh = (tid >> 5) & 1, wid = tid >> 6;
-  __syncthreads();
+  lds_barrier();
 #pragma unroll
   for (int t = 0; t < 6; ++t) {
     const int col = (t >> 1) * 128 + li * 4 + (t & 1) + 2 * hh;
     red[(0 * NW + wid) * 384 + col] = cs.dg[t]; red[(1 * NW + wid) * 384 + col] = cs.db[t]; red[(2 * NW + wid) * 384 + col] = cs.du[t];
   }
-  __syncthreads();
+  lds_barrier();
   for (int c = tid; c < 384; c += NW * 64) {
     float a = 0.f, b = 0.f, u = 0.f;
 #pragma unroll
@@ -631,9 +652,9 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
   constexpr bool lnbwd = EPI == EPI_LNBWD;                        // LayerNorm backward of the dgrad row
   constexpr bool rowwise = fused_ln || lnbwd;                     // half a wave per row: plain staging rows, 16 B per lane
   constexpr int NT = lnbwd ? 2 : 1;                               // streamed row tensors: residual | residual gradient + LayerNorm input
-  // VMEM operations of one pair: LayerNorm backward 6 stores (dx, g) + 8 refill (6 LDS-DMA + 2 statistics loads) ; residual +
-  // LayerNorm 8 stores (x, h, mean, rstd) + 3 refill.  Outstanding behind a refill when it is needed: see rowin_wait.
-  constexpr int NVM = (lnbwd ? 6 + 8 : 8 + 3 + 8) - 2;
+  // VMEM operations of one pair: 5 stores (3 x 16 B fp32 row + 2 bf16 row) + 6 / 3 LDS-DMA refill pieces (LayerNorm backward /
+  // residual + LayerNorm).  Outstanding behind a refill when it is needed: see rowin_wait.
+  constexpr int NVM = (lnbwd ? 5 + 6 : 5 + 3 + 5) - 2;
   const bool exact_vm = m0 + BMR <= p.M && (!lnbwd || (p.lnb_g && p.resid));
   using EL = row384::EpiLds<MI, rowwise, NT>;
   float* sC = reinterpret_cast<float*>(smem_raw);
@@ -646,14 +667,13 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
   int tid_e = tid;
   asm volatile("" : "+v"(tid_e));
   const int lane_e = tid_e & 63, wid_e = tid_e >> 6;
-  char* sIn = reinterpret_cast<char*>(sScale + BMR) + (wid_e * NPAIR) * NT * ROWIN_PAIR_BYTES;   // this wave's input slots [pair][tensor]
+  float* sStat = sScale + BMR;                                    // row-wise: {mean, rstd} of the block's rows (forward: written out once per tile ; backward: fetched once)
+  char* sIn = reinterpret_cast<char*>(sStat + 2 * BMR) + (wid_e * NPAIR) * NT * ROWIN_PAIR_BYTES;   // this wave's input slots [pair][tensor]
   const int hh = lane_e >> 5, li = lane_e & 31;
   auto tile_row_of = [&](int part, int rl) { return (rl >> 4) * (32 * MI) + (part >> 1) * 32 + (part & 1) * 16 + (rl & 15); };   // staged row -> row of the block tile
-  float rmu[lnbwd ? NPAIR : 1], rrs[lnbwd ? NPAIR : 1];            // lnbwd: row statistics, fetched one part ahead
-  auto rowin_part = [&](int part, int q) {                        // DMA of pair q of `part`; lnbwd: + its statistics
+  auto rowin_part = [&](int part, int q) {                        // DMA of pair q of `part`
     const int row0 = m0 + tile_row_of(part, wid_e * LNROWS + 2 * q);
     rowin_issue<NT>(p.resid, lnbwd ? p.lnb_x : nullptr, p.M, row0, sIn + q * NT * ROWIN_PAIR_BYTES, lane_e);
-    if constexpr (lnbwd) { const int r = row0 + hh < p.M ? row0 + hh : p.M - 1; rmu[q] = p.ln_mean[r]; rrs[q] = p.ln_rstd[r]; }
   };
   if constexpr (rowwise) {                                        // part 0's rows arrive under its staging
 #pragma unroll
@@ -666,7 +686,11 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
     if (EPI == EPI_DGELU) sCol[tid] = 0.f;
   }
   if constexpr (EPI == EPI_RESID || lnbwd) {
-    if (tid < BMR) { const int row = m0 + tid; sScale[tid] = (p.row_scale && row < p.M) ? p.row_scale[row / p.rows_per_seq] : 1.0f; }
+    if (tid < BMR) {
+      const int row = m0 + tid;
+      sScale[tid] = (p.row_scale && row < p.M) ? p.row_scale[row / p.rows_per_seq] : 1.0f;
+      if constexpr (lnbwd) { const int r = row < p.M ? row : p.M - 1; sStat[2 * tid] = p.ln_mean[r]; sStat[2 * tid + 1] = p.ln_rstd[r]; }
+    }
   }
   float dg_col = 0.f;                                             // EPI_DGELU: this thread's column of the fc1 bias gradient
   LnbCols lcs;
@@ -704,7 +728,7 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
         if (row < p.M) epi_fetch8<EPI, false>(p, row, n0 + (idx % 48) * 8, aux[i]);
       }
     }
-    __syncthreads();
+    lds_barrier();
     if constexpr (rowwise) {
 #pragma unroll
       for (int q = 0; q < NPAIR; ++q) {
@@ -712,7 +736,7 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
         const char* slot = sIn + q * NT * ROWIN_PAIR_BYTES;
         if (q > 0 && part > 0) rowin_wait<NVM>(exact_vm);          // this pair's rows have landed (pair 0: in front of the staging barrier; part 0: both)
         if constexpr (lnbwd) {
-          const float mu = rmu[q], rs = rrs[q];
+          const float mu = sStat[2 * trow], rs = sStat[2 * trow + 1];
           lnb_row(p, row, row < p.M, sC + rl * CLD, sGamma, sScale[trow], mu, rs, slot, p.resid != nullptr, hh, li, lcs);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the slot has been read: refill it with the next part's rows
           if (part + 1 < NPART) rowin_part(part + 1, q);
@@ -722,7 +746,7 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the slot has been copied out: refill it with the next part's rows
           if (part + 1 < NPART) rowin_part(part + 1, q);
           // Fused residual + LayerNorm of the NEXT sub-layer: replaces a separate HBM pass (ln_fwd_kernel) over x.
-          if (row < p.M) lnf_row(p, row, sC + rl * CLD, sBias, sGamma, sBeta, sScale[trow], rres, li);
+          if (row < p.M) lnf_row(p, row, sC + rl * CLD, sBias, sGamma, sBeta, sScale[trow], rres, li, sStat + 2 * trow);
         }
       }
     } else {
@@ -749,7 +773,7 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
       }
       if constexpr (EPI == EPI_DGELU) {
         if (p.colsum) {
-          __syncthreads();
+          lds_barrier();
           if (tid < BNR) {
             const int ph = ((tid >> 3) << 2) + (tid & 3) + ((tid & 4) ? PLANE1 : 0);
 #pragma unroll 8
@@ -758,12 +782,16 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
         }
       }
     }
-    if (part < NPART - 1) __syncthreads();
+    if (part < NPART - 1) lds_barrier();
   }
   if constexpr (EPI == EPI_DGELU) {
     if (p.colsum && tid < BNR) atomicAdd(p.colsum + n0 + tid, dg_col);
   }
   if constexpr (lnbwd) lnb_flush<WAVES>(p, lcs, sC, tid);        // 9,216 floats of the staging area, behind a barrier
+  if constexpr (fused_ln) {                                       // row statistics of the whole tile: two store instructions per wave instead of two per row
+    lds_barrier();
+    if (tid < BMR && m0 + tid < p.M) { p.ln_mean[m0 + tid] = sStat[2 * tid]; p.ln_rstd[m0 + tid] = sStat[2 * tid + 1]; }
+  }
 }
 
 // ---- 4-wave blocks, two per CU -----------------------------------------------------------------------------------------
@@ -789,7 +817,7 @@ template <int WM> struct Geo {
   static constexpr int PL1 = BNB / 2 + 16, CLD2 = BNB == 192 ? 224 : 448;     // two-plane staging of the epilogues without LayerNorm (conflict-free f32x4 read-back)
   static constexpr int EPI_BYTES = RP * CLD2 * 4 + (CLD2 + 2 * BNB) * 4 + BM * 4;
   // row-wise epilogues (WM == 1): staging rows of pitch CLD, bias / gamma / beta / scale, NT streamed row tensors [wave][pair][tensor][2 rows]
-  template <int NT> static constexpr int rowwise_bytes() { return (RP * CLD + 3 * BNB + BM) * 4 + 4 * 2 * NT * 2 * 384 * 4; }   // 55,808 ; 80,384 B
+  template <int NT> static constexpr int rowwise_bytes() { return (RP * CLD + 3 * BNB + 3 * BM) * 4 + 4 * 2 * NT * 2 * 384 * 4; }   // 55,552 ; 80,128 B
   template <int EPI, bool LN> static constexpr int lds_bytes() {
     constexpr bool rowwise = (LN && EPI == EPI_RESID) || EPI == EPI_LNBWD;
     constexpr int epi = rowwise ? (EPI == EPI_LNBWD ? rowwise_bytes<2>() : rowwise_bytes<1>()) : EPI_BYTES;
@@ -911,7 +939,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_w4_kernel(GemmArgs p) {
   constexpr bool lnbwd = EPI == EPI_LNBWD;
   constexpr bool rowwise = fused_ln || lnbwd;                     // (WM == 1) half a wave per row, inputs through per-wave LDS slots: see rowin_issue
   constexpr int NT = lnbwd ? 2 : 1;
-  constexpr int NVM = (lnbwd ? 6 + 8 : 8 + 3 + 8) - 2;            // see the 8-wave kernel
+  constexpr int NVM = (lnbwd ? 5 + 6 : 5 + 3 + 5) - 2;            // see the 8-wave kernel
   const bool exact_vm = m0 + BM <= p.M && (!lnbwd || (p.lnb_g && p.resid));
   static_assert(!lnbwd || WM == 1, "the LayerNorm backward needs whole rows");
   float* sC = reinterpret_cast<float*>(smem_raw);
@@ -919,14 +947,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_w4_kernel(GemmArgs p) {
   float* sGamma = sBias + (rowwise ? BNB : G::CLD2); float* sBeta = sGamma + BNB;
   float* sScale = sBeta + BNB;
   float* sCol = sGamma;                                           // EPI_DGELU column sums (no LN there)
-  char* sIn = reinterpret_cast<char*>(sScale + BM) + (wid * 2) * NT * ROWIN_PAIR_BYTES;      // this wave's input slots [pair][tensor]
+  float* sStat = sScale + BM;
+  char* sIn = reinterpret_cast<char*>(sStat + 2 * BM) + (wid * 2) * NT * ROWIN_PAIR_BYTES;   // this wave's input slots [pair][tensor]
   const int hh = lane >> 5, li = lane & 31;
   auto tile_row_of = [&](int part, int rl) { return (rl >> 4) * 128 + (part >> 1) * 32 + (part & 1) * 16 + (rl & 15); };   // staged row -> row of the block tile
-  float rmu[lnbwd ? 2 : 1], rrs[lnbwd ? 2 : 1];
   auto rowin_part = [&](int part, int q) {
     const int row0 = m0 + tile_row_of(part, wid * 4 + 2 * q);
     rowin_issue<NT>(p.resid, lnbwd ? p.lnb_x : nullptr, p.M, row0, sIn + q * NT * ROWIN_PAIR_BYTES, lane);
-    if constexpr (lnbwd) { const int r = row0 + hh < p.M ? row0 + hh : p.M - 1; rmu[q] = p.ln_mean[r]; rrs[q] = p.ln_rstd[r]; }
   };
   if constexpr (rowwise) {
 #pragma unroll
@@ -943,7 +970,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_w4_kernel(GemmArgs p) {
     for (int i = 0; i < 6; ++i) lcs.dg[i] = lcs.db[i] = lcs.du[i] = 0.f;
   }
   if constexpr (EPI == EPI_RESID || lnbwd) {
-    if (tid < BM) { const int row = m0 + tid; sScale[tid] = (p.row_scale && row < p.M) ? p.row_scale[row / p.rows_per_seq] : 1.0f; }
+    if (tid < BM) {
+      const int row = m0 + tid;
+      sScale[tid] = (p.row_scale && row < p.M) ? p.row_scale[row / p.rows_per_seq] : 1.0f;
+      if constexpr (lnbwd) { const int r = row < p.M ? row : p.M - 1; sStat[2 * tid] = p.ln_mean[r]; sStat[2 * tid + 1] = p.ln_rstd[r]; }
+    }
   }
 #pragma unroll
   for (int part = 0; part < NPART; ++part) {
@@ -967,7 +998,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_w4_kernel(GemmArgs p) {
         if (row < p.M) epi_fetch8<EPI, false>(p, row, n0 + (idx % G::SPR) * 8, aux[i]);
       }
     }
-    __syncthreads();
+    lds_barrier();
     if constexpr (rowwise) {
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
@@ -975,7 +1006,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_w4_kernel(GemmArgs p) {
         const char* slot = sIn + q * NT * ROWIN_PAIR_BYTES;
         if (q > 0 && part > 0) rowin_wait<NVM>(exact_vm);          // this pair's rows have landed (pair 0: in front of the staging barrier; part 0: both)
         if constexpr (lnbwd) {
-          const float mu = rmu[q], rs = rrs[q];
+          const float mu = sStat[2 * trow], rs = sStat[2 * trow + 1];
           lnb_row(p, row, row < p.M, sC + rl * CLD, sGamma, sScale[trow], mu, rs, slot, p.resid != nullptr, hh, li, lcs);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the slot has been read: refill it with the next part's rows
           if (part + 1 < NPART) rowin_part(part + 1, q);
@@ -984,7 +1015,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_w4_kernel(GemmArgs p) {
           rowin_read(slot, 0, hh, li, rres);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the slot has been copied out: refill it with the next part's rows
           if (part + 1 < NPART) rowin_part(part + 1, q);
-          if (row < p.M) lnf_row(p, row, sC + rl * CLD, sBias, sGamma, sBeta, sScale[trow], rres, li);
+          if (row < p.M) lnf_row(p, row, sC + rl * CLD, sBias, sGamma, sBeta, sScale[trow], rres, li, sStat + 2 * trow);
         }
       }
     } else {
@@ -1006,15 +1037,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_w4_kernel(GemmArgs p) {
         }
       }
     }
-    if (part < NPART - 1) __syncthreads();
+    if (part < NPART - 1) lds_barrier();
   }
   if constexpr (EPI == EPI_DGELU) {
     if (p.colsum) {
-      __syncthreads();
+      lds_barrier();
       for (int c = tid; c < BNB; c += 256) atomicAdd(p.colsum + n0 + c, sCol[c]);
     }
   }
   if constexpr (lnbwd) lnb_flush<4>(p, lcs, sC, tid);
+  if constexpr (fused_ln) {
+    lds_barrier();
+    if (tid < BM && m0 + tid < p.M) { p.ln_mean[m0 + tid] = sStat[2 * tid]; p.ln_rstd[m0 + tid] = sStat[2 * tid + 1]; }
+  }
 }
 
 // ---- wgrad: dW[n,k] += sum_m dY[m,n] X[m,k] -------------------------------------------------------------------------
