@@ -35,7 +35,7 @@ struct Carver {
   }
 };
 
-Ws carve(void* ws, int S, int NP, int C, int H, int depth, int train) {
+Ws carve(void* ws, int S, int NP, int C, int H, int depth, int train, int fp8) {
   Ws w{};
   Carver c{reinterpret_cast<char*>(ws), 0};
   const size_t M = (size_t)S * NP;
@@ -54,7 +54,7 @@ Ws carve(void* ws, int S, int NP, int C, int H, int depth, int train) {
   }
   for (int i = nl; i < depth; ++i) w.L[i] = w.L[0];
   w.hN = c.take<bf16>(M * C); w.meanN = c.take<float>(M); w.rstdN = c.take<float>(M);
-  w.q8a = c.take<uint8_t>(M * C); w.q8b = c.take<uint8_t>(M * 4 * C);
+  if (fp8) { w.q8a = c.take<uint8_t>(M * C); w.q8b = c.take<uint8_t>(M * 4 * C); }   // e4m3 operand copies: only the fp8 forward carves them
   if (train) {
     w.dxA = c.take<float>(M * C); w.dxB = c.take<float>(M * C);
     w.g = c.take<bf16>(M * C); w.g2 = c.take<bf16>(M * C); w.dh = c.take<bf16>(M * C); w.du = c.take<bf16>(M * 4 * C);
@@ -108,8 +108,8 @@ int wgrad(const bf16* dY, const bf16* X, int M, int N, int K, float* dW, hipStre
 }
 }  // namespace
 
-extern "C" size_t atst_encoder_ws_bytes(int S, int NP, int C, int H, int depth, int train) {
-  return carve(nullptr, S, NP, C, H, depth, train).bytes;
+extern "C" size_t atst_encoder_ws_bytes(int S, int NP, int C, int H, int depth, int train, int fp8) {
+  return carve(nullptr, S, NP, C, H, depth, train, fp8).bytes;
 }
 
 static bool check(const atst_encoder_t* e) {
@@ -117,27 +117,27 @@ static bool check(const atst_encoder_t* e) {
   if (e->C != e->H * 64 || (e->C != 384 && e->C != 768)) return false;
   if (e->NP != 32 && e->NP != 64 && e->NP != 128 && e->NP != 256) return false;
   if (e->n_tok + e->use_cls > e->NP) return false;
-  if (e->ws_bytes < atst_encoder_ws_bytes(e->S, e->NP, e->C, e->H, e->depth, e->train)) return false;
+  if (e->ws_bytes < atst_encoder_ws_bytes(e->S, e->NP, e->C, e->H, e->depth, e->train, e->fp8)) return false;
   return true;
 }
 
 extern "C" const uint16_t* atst_encoder_out(const atst_encoder_t* e) {
-  return reinterpret_cast<const uint16_t*>(carve(e->ws, e->S, e->NP, e->C, e->H, e->depth, e->train).hN);
+  return reinterpret_cast<const uint16_t*>(carve(e->ws, e->S, e->NP, e->C, e->H, e->depth, e->train, e->fp8).hN);
 }
 extern "C" uint16_t* atst_encoder_dout(const atst_encoder_t* e) {
-  return reinterpret_cast<uint16_t*>(carve(e->ws, e->S, e->NP, e->C, e->H, e->depth, e->train).dout);
+  return reinterpret_cast<uint16_t*>(carve(e->ws, e->S, e->NP, e->C, e->H, e->depth, e->train, e->fp8).dout);
 }
 extern "C" const float* atst_encoder_block_out(const atst_encoder_t* e, int i) {
-  return carve(e->ws, e->S, e->NP, e->C, e->H, e->depth, e->train).x[2 * i + 2];
+  return carve(e->ws, e->S, e->NP, e->C, e->H, e->depth, e->train, e->fp8).x[2 * i + 2];
 }
 extern "C" const float* atst_encoder_tokens(const atst_encoder_t* e) {
-  return carve(e->ws, e->S, e->NP, e->C, e->H, e->depth, e->train).x[0];
+  return carve(e->ws, e->S, e->NP, e->C, e->H, e->depth, e->train, e->fp8).x[0];
 }
 
 extern "C" int atst_encoder_fwd(const atst_encoder_t* e, void* stream) {
   if (!check(e)) return ATST_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const Ws w = carve(e->ws, e->S, e->NP, e->C, e->H, e->depth, e->train);
+  const Ws w = carve(e->ws, e->S, e->NP, e->C, e->H, e->depth, e->train, e->fp8);
   const int S = e->S, NP = e->NP, C = e->C, M = S * NP;
   const float* p = e->p32; const bf16* q = B16(e->p16);
   const atst_enc_off_t& o = e->off;
@@ -233,7 +233,7 @@ extern "C" int atst_encoder_bwd_range(const atst_encoder_t* e, int lo, int hi, v
 static int encoder_bwd_range(const atst_encoder_t* e, int lo, int hi, bool head, bool tail, void* stream) {
   if (!check(e) || !e->train || !e->p16t || !e->g32) return ATST_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const Ws w = carve(e->ws, e->S, e->NP, e->C, e->H, e->depth, e->train);
+  const Ws w = carve(e->ws, e->S, e->NP, e->C, e->H, e->depth, e->train, e->fp8);
   const int S = e->S, NP = e->NP, C = e->C, M = S * NP, D = e->depth;
   const float* p = e->p32; const bf16* qt = B16(e->p16t);
   float* G = e->g32;

@@ -166,13 +166,30 @@ __global__ void twiddle_init_kernel() {
   if (i < 512) { const double a = -2.0 * M_PI * i / 512.0; g_tw512[i] = make_float2((float)cos(a), (float)sin(a)); }
   if (i < NBIN) { const double a = -2.0 * M_PI * i / 1024.0; g_tw1024[i] = make_float2((float)cos(a), (float)sin(a)); }
 }
+// One fill per DEVICE (the __device__ tables are per device), and a launch on any OTHER stream first waits for the event
+// recorded behind that fill -- a second front-end call on a side stream must not read tables that are still being written.
 int init_twiddles(hipStream_t st) {
-  static bool done = false;                           // later launches on other streams: the caller's streams are ordered after the first step
-  if (done) return 0;
-  hipLaunchKernelGGL(twiddle_init_kernel, dim3((NBIN + 255) / 256), dim3(256), 0, st);
-  const hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return (int)e;
-  done = true;
+  constexpr int MAXDEV = 16;
+  static bool done[MAXDEV] = {};
+  static hipEvent_t ready[MAXDEV] = {};
+  static hipStream_t first[MAXDEV] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return ATST_EINVAL;
+  if (!done[dev]) {
+    hipLaunchKernelGGL(twiddle_init_kernel, dim3((NBIN + 255) / 256), dim3(256), 0, st);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    e = hipEventCreateWithFlags(&ready[dev], hipEventDisableTiming);
+    if (e != hipSuccess) return (int)e;
+    e = hipEventRecord(ready[dev], st);
+    if (e != hipSuccess) return (int)e;
+    first[dev] = st; done[dev] = true;
+    return 0;
+  }
+  if (st != first[dev]) {                              // completed events cost nothing to wait on
+    const hipError_t e = hipStreamWaitEvent(st, ready[dev], 0);
+    if (e != hipSuccess) return (int)e;
+  }
   return 0;
 }
 }  // namespace

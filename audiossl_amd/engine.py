@@ -146,7 +146,7 @@ class EncoderPass:
         self.NP = pad_tokens(self.n_tok + self.use_cls)
         self.M = S * self.NP
         lib = hip.load()
-        nbytes = lib.atst_encoder_ws_bytes(S, self.NP, cfg["embed_dim"], cfg["num_heads"], eng.depth, int(train))
+        nbytes = lib.atst_encoder_ws_bytes(S, self.NP, cfg["embed_dim"], cfg["num_heads"], eng.depth, int(train), int(eng.fp8))
         self.ws = Workspace(nbytes, eng.device)
         e = hip.Encoder()
         e.S, e.NP, e.n_tok, e.width, e.C, e.H, e.depth = S, self.NP, self.n_tok, width, cfg["embed_dim"], cfg["num_heads"], eng.depth
@@ -419,8 +419,7 @@ class AtstEngine:
                     k = f"{key}.1.{b}"
                     if k in W:
                         bufs[b].copy_(W[k].to(self.device))
-        self.sync_shadows(force=True)
-        self.broadcast_parameters()
+        self.sync_shadows(force=True)            # no collective here: replicas are aligned by ONE explicit broadcast_parameters()
 
     def init_weights(self, seed: int = 0):
         """Random init with the reference's distributions, drawn on the device: encoder Linear weights, cls/pos/mask
@@ -452,8 +451,7 @@ class AtstEngine:
             self.t32.copy_(self.p32[:self.layout.n_teacher])
             for b in ("running_mean", "running_var", "num_batches_tracked"):
                 self.bn_buffers["teacher.projector"][b].copy_(self.bn_buffers["student.projector"][b])
-        self.sync_shadows(force=True)
-        self.broadcast_parameters()
+        self.sync_shadows(force=True)            # no collective here (a rank-0-only model must be constructible): see broadcast_parameters()
 
     def sync_shadows(self, force: bool = False):
         """Refresh bf16 shadows (and W^T copies) if the fp32 masters were modified through torch (version counters)."""
@@ -685,8 +683,10 @@ class AtstEngine:
             parallel.allreduce_sum_(self.g32[a:b])
 
     def broadcast_parameters(self, optimizer_state: bool = False):
-        """DDP init: every rank takes rank 0's parameters / BN buffers (and optimizer moments after a resume), so the
-        replicas start identical whatever their seeds or checkpoints were.  ref: DDP wrapper of Trainer(strategy="ddp"),
+        """DDP init: every rank takes rank 0's parameters / BN buffers (and, after a resume, the optimizer moments and the
+        AdamW step count), so the replicas start identical whatever their seeds or checkpoints were.  A COLLECTIVE: every
+        rank must call it, exactly once, from the same place (Trainer.fit start, bench.py, the multi-rank tests) -- it is
+        deliberately not hidden inside init_weights() / load_weights().  ref: DDP wrapper of Trainer(strategy="ddp"),
         methods/atst/train.py:18-32.  No-op without a process group."""
         if not parallel._collective():
             return
@@ -695,6 +695,10 @@ class AtstEngine:
             bufs += [self.m32, self.v32]
         for t in bufs:
             dist.broadcast(t, 0)
+        if optimizer_state:
+            step = torch.tensor([self.opt_step], dtype=torch.int64, device=self.device)
+            dist.broadcast(step, 0)
+            self.opt_step = int(step.item())
         self.sync_shadows(force=True)
 
     def allreduce_grads(self):

@@ -85,7 +85,7 @@ _SIGS = {
     "atst_byol_loss_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p]),
     "atst_adamw_ema_step": (C.c_int, [C.c_void_p] * 8 + [C.c_size_t, C.c_size_t] + [C.c_double] * 8 + [C.c_void_p]),
-    "atst_encoder_ws_bytes": (C.c_size_t, [C.c_int] * 6),
+    "atst_encoder_ws_bytes": (C.c_size_t, [C.c_int] * 7),
     "atst_encoder_fwd": (C.c_int, [C.POINTER(Encoder), C.c_void_p]),
     "atst_encoder_bwd": (C.c_int, [C.POINTER(Encoder), C.c_void_p]),
     "atst_encoder_bwd_part": (C.c_int, [C.POINTER(Encoder), C.c_int, C.c_int, C.c_void_p]),

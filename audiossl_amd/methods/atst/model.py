@@ -78,6 +78,11 @@ class ATSTLightningModule(_Base):
         """ref: model.py:24-34."""
         self.schedule()
         (melspecs, lengths), _ = batch
+        if melspecs[0].dim() == 3:                      # [B,1,n] waveform crops from the worker-side transform: mel / Mixup / RRC on the GPU
+            if getattr(self, "_batch_views", None) is None:
+                from .transform import ATSTBatchViews
+                self._batch_views = ATSTBatchViews(device=self.model.engine.device)
+            melspecs = self._batch_views([m.to(self.model.engine.device, non_blocking=True) for m in melspecs], lengths)
         loss, std_cls_s, std_cls_t = self.model(melspecs, lengths)
         self.log("loss", loss, prog_bar=True, logger=True)
         self.log("std_cls_t", std_cls_t, prog_bar=True, logger=True)

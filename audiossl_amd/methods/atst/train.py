@@ -17,7 +17,7 @@ def main(args):
     if world > 1 and not dist.is_initialized():
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         dist.init_process_group("nccl")
-    args.nproc = world if world > 1 else args.nproc
+    args.nproc = world                                       # the linear-scaling rule uses the devices actually training (ref: nproc = Trainer devices)
     args.learning_rate = args.learning_rate * args.nproc * args.batch_size_per_gpu / 256        # ref: train.py:12
     dict_args = vars(args)
     model = ATSTLightningModule(**dict_args)

@@ -56,16 +56,25 @@ class Trainer:
         self.optimizers = model.configure_optimizers()
         opt = self.optimizers[0]
         epoch = 0
-        if ckpt_path and os.path.exists(ckpt_path):
+        # Resume: RANK 0 decides (its view of the file system is the only one that counts), every rank learns the decision and
+        # the counters through one broadcast, and all replicas are then aligned by ONE broadcast of rank 0's tensors -- never a
+        # per-rank os.path.exists() in front of a collective (ranks that do not see the file would deadlock the others).
+        eng = model.model.engine
+        state = [False, 0, int(model.global_step)]
+        if self.rank == 0 and ckpt_path and os.path.exists(ckpt_path):
             ckpt = load_checkpoint(ckpt_path, model)
-            epoch = int(ckpt.get("epoch", -1)) + 1          # Lightning stores the zero-based index of the finished epoch
-            model.model.engine.broadcast_parameters(optimizer_state=True)
+            state = [True, int(ckpt.get("epoch", -1)) + 1, int(model.global_step)]   # Lightning stores the zero-based index of the last FINISHED epoch
+        if self.world > 1:
+            dist.broadcast_object_list(state, src=0)
+        resumed, epoch, model.global_step = bool(state[0]), int(state[1]), int(state[2])
+        eng.broadcast_parameters(optimizer_state=resumed)
         loader = train_dataloaders if train_dataloaders is not None else datamodule.train_dataloader(self.rank, self.world)
         dev = model.model.engine.device
         t0, step0 = time.time(), model.global_step
         while True:
             if hasattr(getattr(loader, "sampler", None), "set_epoch"):
                 loader.sampler.set_epoch(epoch)
+            exhausted = False
             for batch_idx, batch in enumerate(loader):
                 inputs, labels = batch[0], batch[1]
                 # clip ATST: (views, lengths) (methods/atst/model.py:26) ; ATST-Frame: (views, lengths, masks) (atstframe/model.py:120)
@@ -87,13 +96,18 @@ class Trainer:
                     self.history.append(rec)
                     print(" ".join(f"{k}={v:.5g}" if isinstance(v, float) else f"{k}={v}" for k, v in rec.items()), flush=True)
                 if 0 < self.max_steps <= model.global_step:
+                    exhausted = hasattr(loader, "__len__") and batch_idx + 1 >= len(loader)     # stopped on the epoch's last batch
                     break
-            epoch += 1
+            else:
+                exhausted = True
+            # `epoch` counts FINISHED epochs: a max_steps stop in the middle of an epoch does not finish it, so a resume repeats
+            # that epoch from its first batch (sampler epoch unchanged) instead of skipping its remainder
+            epoch += 1 if exhausted else 0
             done = (0 < self.max_steps <= model.global_step) or (self.max_epochs and epoch >= self.max_epochs)
             if self.root and self.rank == 0:
-                if epoch % self.every_n_epochs == 0:
+                if exhausted and epoch % self.every_n_epochs == 0:
                     save_checkpoint(os.path.join(self.root, f"checkpoint-epoch={epoch - 1:05d}.ckpt"), model, opt, epoch - 1)
-                if done or epoch % self.every_n_epochs == 0:
+                if done or (exhausted and epoch % self.every_n_epochs == 0):
                     save_checkpoint(os.path.join(self.root, "last.ckpt"), model, opt, epoch - 1)
             if done:
                 break

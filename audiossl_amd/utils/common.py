@@ -1,7 +1,27 @@
-"""Schedules and optimizer parameter grouping -- same names and semantics as audiossl/utils/common.py:29-80."""
+"""Schedules and optimizer parameter grouping -- same names and semantics as audiossl/utils/common.py:3-80."""
 import argparse
 
 import numpy as np
+
+
+def concat_all_gather(tensor):
+    """all_gather + cat over ranks, no gradient. ref: utils/common.py:3-14."""
+    import torch
+    with torch.no_grad():
+        parts = [torch.ones_like(tensor) for _ in range(torch.distributed.get_world_size())]
+        torch.distributed.all_gather(parts, tensor, async_op=False)
+        return torch.cat(parts, dim=0)
+
+
+def cosine_scheduler_epoch(base_value, final_value, epochs, niter_per_ep, warmup_epochs=0, start_warmup_value=0):
+    """Per-iteration table over whole epochs (the downstream heads' schedule). ref: utils/common.py:16-27."""
+    warm = warmup_epochs * niter_per_ep
+    head = np.linspace(start_warmup_value, base_value, warm) if warmup_epochs > 0 else np.array([])
+    n = epochs * niter_per_ep - warm
+    tail = final_value + 0.5 * (base_value - final_value) * (1 + np.cos(np.pi * np.arange(n) / n))
+    table = np.concatenate((head, tail))
+    assert len(table) == epochs * niter_per_ep
+    return table
 
 
 def cosine_scheduler_step(base_value, final_value, max_steps, warmup_steps=0, start_warmup_value=0):

@@ -168,6 +168,7 @@ def main():
     ncrops = 6 if args.workload == "clip6" else 2
     eng = AtstEngine(args.arch, frame=frame, ncrops=ncrops, fp8=args.dtype == "fp8")
     eng.init_weights(seed=0)
+    eng.broadcast_parameters()                                       # DDP init: every rank takes rank 0's replica (no-op at world 1)
     eng.overlap_teacher = args.overlap
     fe = LogMelFrontend(1024 if not frame else 640)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -229,7 +230,7 @@ def main():
     dt = float(tmax)
     loss_val = float(loss)
 
-    roof, kernels = None, []
+    roof, kernels, step_hbm = None, [], None
     if not args.no_profile:
         nk = lib.atst_profile_kinds()
         ms, work, byts, cnt = (C.c_double * nk)(), (C.c_double * nk)(), (C.c_double * nk)(), (C.c_longlong * nk)()
@@ -269,11 +270,24 @@ def main():
             # counters while the step is being timed); tools/round_measure.sh regenerates the file.
             tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"traffic_{args.workload}.json")
             if os.path.exists(tf) and args.batch == 256 and args.arch == "small":
-                t = json.load(open(tf))["kernels"].get(d["kernel"])
+                tj = json.load(open(tf))
+                t = tj["kernels"].get(d["kernel"])
+                src = (f"profiles/traffic_{args.workload}.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes"
+                       f"; taken at {tj.get('head', 'an earlier HEAD')})")
                 if t:
                     roof["traffic"] = t["traffic_bytes_per_launch"]
-                    roof["traffic_source"] = (f"profiles/traffic_{args.workload}.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes"
-                                              f"; taken at {json.load(open(tf)).get('head', 'an earlier HEAD')})")
+                    roof["traffic_source"] = src
+                if tj.get("step_traffic_bytes"):                    # whole-step HBM traffic (every dispatch), priced against this run's step time
+                    step_hbm = {"traffic_bytes_per_step": tj["step_traffic_bytes"], "source": src}
+            # the kernel nearest the ridge of the two roofs (it reaches neither): priced against both
+            near = [r for r in kernels if "tflops" in r and r["flop_per_byte"] >= 0.5 * ridge]
+            if near:
+                n0 = max(near, key=lambda r: r["total_ms"])
+                roof["near_ridge_kernel"] = {"kernel": n0["kernel"], "flop_per_byte": n0["flop_per_byte"], "tflops": n0["tflops"],
+                                             "mfma_frac": round(n0["tflops"] / PEAK_BF16_TFLOPS, 4),
+                                             "hbm_GBs": round(n0["bytes_per_launch"] / (n0["avg_us"] * 1e-6) / 1e9, 1),
+                                             "hbm_frac": round(n0["bytes_per_launch"] / (n0["avg_us"] * 1e-6) / 1e9 / PEAK_HBM_GBS, 4),
+                                             "share_of_timed_kernel_ms": round(n0["total_ms"] / sum(r["total_ms"] for r in kernels), 3)}
 
     if rank == 0:
         clips = B * world * args.steps
@@ -292,6 +306,10 @@ def main():
                "flops_per_clip_G": round(fpc / 1e9, 2), "step_tflops": round(value * fpc / 1e12, 2),
                "mfma_roofline_frac_step": round(value * fpc / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
                "loss": round(loss_val, 5), "roofline": roof, "kernels": kernels[:8]}
+        if step_hbm:
+            tbs = step_hbm["traffic_bytes_per_step"] / (dt / args.steps) / 1e12
+            step_hbm.update({"TB_per_s": round(tbs, 3), "frac_of_8TBs_peak": round(tbs / (PEAK_HBM_GBS / 1e3), 4)})
+            out["step_hbm"] = step_hbm
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

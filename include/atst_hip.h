@@ -177,7 +177,7 @@ typedef struct {
   const uint8_t* p8; const float* w_dq; int fp8;
 } atst_encoder_t;
 
-size_t atst_encoder_ws_bytes(int S, int NP, int C, int H, int depth, int train);
+size_t atst_encoder_ws_bytes(int S, int NP, int C, int H, int depth, int train, int fp8 /* = atst_encoder_t.fp8: also carve the e4m3 operand copies */);
 /* forward: leaves LN(final) of every token as bf16 [S*NP, C] at atst_encoder_out(); */
 int atst_encoder_fwd(const atst_encoder_t* e, void* stream);
 const uint16_t* atst_encoder_out(const atst_encoder_t* e);

@@ -41,6 +41,7 @@ def main():
     eng.overlap_comm = bool(args.overlap)
     eng.grad_buckets = 2
     eng.init_weights(seed=100 + rank)                          # rank-dependent on purpose
+    eng.broadcast_parameters()                                 # the ONE explicit DDP-init collective: every rank takes rank 0's replica
     if world == 1:                                             # the single-process run uses what rank 0 broadcasts
         eng.init_weights(seed=100)
     # ---- the full batch, identical in every process (CPU, seeded)

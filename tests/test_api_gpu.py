@@ -261,3 +261,39 @@ def test_frame_cnn_patch_embed_vs_reference_golden():
     assert rel(scene.cpu().numpy(), G["scene"]) < 1.0e-2 and rel(frames.cpu().numpy()[:, ::5, ::4], G["frames"]) < 1.0e-2
     with pytest.raises(NotImplementedError):
         FrameATST("small", patch_embed="MLP")
+
+
+def test_downstream_harness_attribute_walk_through_aliased_imports(tmp_path):
+    """What the unchanged downstream harness does with a pre-training checkpoint (audiossl/methods/atst/downstream/
+    train_freeze.py:23-35, downstream/model.py:18-41), written with the reference's OWN import lines after
+    install_as_audiossl(): load_from_checkpoint -> .model.teacher.encoder -> .hyper_param / .embed_dim ->
+    get_intermediate_layers_chunks; and the legacy branch's AST_small() + load_state_dict."""
+    import audiossl_amd
+    audiossl_amd.install_as_audiossl()
+    try:
+        from audiossl.methods.atst.model import ATSTLightningModule as UpstreamName
+        from audiossl.models.atst import audio_transformer
+        assert UpstreamName is ATSTLightningModule
+        pl = ATSTLightningModule(arch="small", max_steps=10, warmup_steps=2, train_len=6.0)
+        path = os.path.join(str(tmp_path), "last.ckpt")
+        save_checkpoint(path, pl, None, epoch=0)
+        s = torch.load(path, weights_only=False)
+        assert "pytorch-lightning_version" in s
+        pretrained_model = UpstreamName.load_from_checkpoint(path)
+        enc = pretrained_model.model.teacher.encoder
+        assert isinstance(enc, audio_transformer.AST)
+        enc.hyper_param = s["hyper_parameters"]
+        assert enc.hyper_param["train_len"] == 6.0 and enc.embed_dim == 384
+        chunk_len, n_blocks = int((6.0 * 16000) / 160 + 1), 2                       # downstream/model.py:26
+        x = O.recipe_mel(3, 1001, seed=5).cuda()
+        length = torch.tensor([1001, 700, 333])
+        emb = enc.get_intermediate_layers_chunks(x, length, n_blocks, chunk_len, avgpool=True)
+        assert emb.shape == (3, enc.embed_dim * 2 * n_blocks) and torch.isfinite(emb).all()
+        # same weights through the legacy branch: a stand-alone AST_small() that takes the teacher encoder's state_dict
+        legacy = audio_transformer.AST_small()
+        legacy.load_state_dict(enc.state_dict())
+        legacy._owner[0].engine.sync_shadows(force=True)
+        emb2 = legacy.get_intermediate_layers_chunks(x, length, n_blocks, chunk_len, avgpool=True)
+        assert float((emb - emb2).abs().max()) == 0.0
+    finally:
+        audiossl_amd.compat.uninstall()

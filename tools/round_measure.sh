@@ -12,7 +12,7 @@ timeout 300 python bench.py --workload frame --no-cpu-baseline > $out/bench_fram
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o clip6 -- python3 bench.py > $out/bench_clip6_under_rocprof.json 2> $out/prof.err
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o f -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile > /dev/null 2> $out/pmc_fetch.err
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o w -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile > /dev/null 2> $out/pmc_write.err
-python tools/traffic_from_pmc.py $out/pmc_fetch $out/pmc_write $out/traffic_clip6.json clip6 "$head"
+python tools/traffic_from_pmc.py $out/pmc_fetch $out/pmc_write $out/traffic_clip6.json clip6 "$head" 3
 find $out -name "*_kernel_stats.csv" | head; cat $out/bench_clip6.json | cut -c1-400
 # the raw per-dispatch counter CSVs are large: keep only the summary json in the merge-back
 rm -rf $out/pmc_fetch $out/pmc_write
