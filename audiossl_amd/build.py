@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libatst_hip.so")
-SOURCES = ["api.hip", "engine.hip", "gemm.hip", "layernorm.hip", "attention.hip", "tokens.hip", "head.hip", "optim.hip",
+SOURCES = ["api.hip", "engine.hip", "engine_hp.hip", "gemm.hip", "layernorm.hip", "attention.hip", "tokens.hip", "head.hip", "optim.hip",
            "frontend.hip", "profile.hip", "augment.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
 if os.environ.get("ATST_EXTRA_FLAGS"):      # experiment builds: e.g. ATST_EXTRA_FLAGS="-DATST_ABLATE_ATTN_STORE"

@@ -179,6 +179,11 @@ int atst_bn_bwd_dx_bf16(const float* dy, const float* h, const float* mean, cons
                         uint16_t* dh, void* stream) {
   return atst_bn_bwd_dx(dy, h, mean, rstd, gamma, beta, sum_dy, sum_dy_xhat, inv_count, R, N, BF(dh), ST(stream));
 }
+int atst_bn_bwd_dx_f32(const float* dy, const float* h, const float* mean, const float* rstd, const float* gamma,
+                       const float* beta, const float* sum_dy, const float* sum_dy_xhat, float inv_count, int R, int N,
+                       float* dh, void* stream) {
+  return atst_bn_bwd_dx_fp32(dy, h, mean, rstd, gamma, beta, sum_dy, sum_dy_xhat, inv_count, R, N, dh, ST(stream));
+}
 int atst_byol_loss_f32(const float* student, const float* teacher, int B, int ncrops, int D, float* acc, float* dstudent,
                        float* stats, void* stream) {
   return atst_byol_loss(student, teacher, B, ncrops, D, acc, dstudent, stats, ST(stream));

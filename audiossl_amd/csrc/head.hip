@@ -83,15 +83,16 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const float* __restric
   }
 }
 
+template <typename OUT>   // bf16: operand of the next MFMA GEMMs ; float: parity mode (split-bf16 operands are made from it)
 __global__ void bn_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ h, const float* __restrict__ mean,
                                  const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
                                  const float* __restrict__ sum_dy, const float* __restrict__ sum_dy_xhat, float inv_count,
-                                 size_t total, int N, bf16* __restrict__ dh) {
+                                 size_t total, int N, OUT* __restrict__ dh) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % N);
     const float xh = (h[i] - mean[c]) * rstd[c];
     const float d = (xh * gamma[c] + beta[c] > 0.f) ? dy[i] : 0.f;
-    dh[i] = f2bf(gamma[c] * rstd[c] * (d - sum_dy[c] * inv_count - xh * sum_dy_xhat[c] * inv_count));
+    dh[i] = (OUT)(gamma[c] * rstd[c] * (d - sum_dy[c] * inv_count - xh * sum_dy_xhat[c] * inv_count));
   }
 }
 
@@ -214,7 +215,16 @@ int atst_bn_bwd_dx(const float* dy, const float* h, const float* mean, const flo
                    bf16* dh, hipStream_t st) {
   const size_t total = (size_t)R * N;
   int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3(grid), dim3(256), 0, st, dy, h, mean, rstd, gamma, beta, sum_dy, sum_dy_xhat,
+  hipLaunchKernelGGL(bn_bwd_dx_kernel<bf16>, dim3(grid), dim3(256), 0, st, dy, h, mean, rstd, gamma, beta, sum_dy, sum_dy_xhat,
+                     inv_count, total, N, dh);
+  return (int)hipGetLastError();
+}
+int atst_bn_bwd_dx_fp32(const float* dy, const float* h, const float* mean, const float* rstd, const float* gamma,
+                        const float* beta, const float* sum_dy, const float* sum_dy_xhat, float inv_count, int R, int N,
+                        float* dh, hipStream_t st) {
+  const size_t total = (size_t)R * N;
+  int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(bn_bwd_dx_kernel<float>, dim3(grid), dim3(256), 0, st, dy, h, mean, rstd, gamma, beta, sum_dy, sum_dy_xhat,
                      inv_count, total, N, dh);
   return (int)hipGetLastError();
 }

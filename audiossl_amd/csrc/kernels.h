@@ -98,6 +98,9 @@ int atst_bn_relu_bwd(const float* dy, const float* h, const float* mean, const f
 int atst_bn_bwd_dx(const float* dy, const float* h, const float* mean, const float* rstd, const float* gamma,
                    const float* beta, const float* sum_dy, const float* sum_dy_xhat, float inv_count, int R, int N,
                    bf16* dh, hipStream_t st);
+int atst_bn_bwd_dx_fp32(const float* dy, const float* h, const float* mean, const float* rstd, const float* gamma,
+                        const float* beta, const float* sum_dy, const float* sum_dy_xhat, float inv_count, int R, int N,
+                        float* dh, hipStream_t st);
 int atst_cast_f32_bf16(const float* x, size_t n, bf16* y, hipStream_t st);
 int atst_split3(const float* x, int R, int K, int b_layout, bf16* y, hipStream_t st);
 int atst_byol_loss(const float* student, const float* teacher, int B, int ncrops, int D, float* loss, float* dstudent,

@@ -135,8 +135,9 @@ def pad_tokens(n: int) -> int:
 class EncoderPass:
     """One encoder invocation geometry (S sequences of one mel width) with its activation workspace."""
 
-    def __init__(self, eng: "AtstEngine", net: str, S: int, width: int, train: bool):
+    def __init__(self, eng: "AtstEngine", net: str, S: int, width: int, train: bool, precise: bool = False):
         self.eng, self.net, self.S, self.width, self.train = eng, net, S, width, train
+        self.precise = bool(precise)                     # fp32 / split-bf16 twin of the encoder (csrc/engine_hp.hip): parity mode
         cfg = eng.cfg
         self.n_tok = (width - width % 4) // 4
         self.use_cls = 0 if eng.frame else 1
@@ -146,7 +147,10 @@ class EncoderPass:
         self.NP = pad_tokens(self.n_tok + self.use_cls)
         self.M = S * self.NP
         lib = hip.load()
-        nbytes = lib.atst_encoder_ws_bytes(S, self.NP, cfg["embed_dim"], cfg["num_heads"], eng.depth, int(train), int(eng.fp8))
+        if self.precise:
+            nbytes = lib.atst_encoder_hp_ws_bytes(S, self.NP, cfg["embed_dim"], cfg["num_heads"], eng.depth)
+        else:
+            nbytes = lib.atst_encoder_ws_bytes(S, self.NP, cfg["embed_dim"], cfg["num_heads"], eng.depth, int(train), int(eng.fp8))
         self.ws = Workspace(nbytes, eng.device)
         e = hip.Encoder()
         e.S, e.NP, e.n_tok, e.width, e.C, e.H, e.depth = S, self.NP, self.n_tok, width, cfg["embed_dim"], cfg["num_heads"], eng.depth
@@ -156,13 +160,17 @@ class EncoderPass:
         else:
             e.p32, e.p16, e.p16t, e.g32 = eng.t32.data_ptr(), eng.t16.data_ptr(), None, None
         e.off = eng.enc_off
-        if eng.fp8:
+        if eng.fp8 and not self.precise:
             e.fp8 = 1
             e.p8, e.w_dq = (eng.p8.data_ptr(), eng.dq_s.data_ptr()) if net == "student" else (eng.t8.data_ptr(), eng.dq_t.data_ptr())
         e.ws, e.ws_bytes = self.ws.buf.data_ptr(), nbytes
         self.e = e
-        self.out = self.ws.view(lib.atst_encoder_out(C.byref(e)), (self.M, e.C), torch.bfloat16)
-        self.dout = self.ws.view(lib.atst_encoder_dout(C.byref(e)), (self.M, e.C), torch.bfloat16) if train else None
+        if self.precise:
+            self.out = self.ws.view(lib.atst_encoder_hp_out(C.byref(e)), (self.M, e.C), torch.float32)
+            self.dout = self.ws.view(lib.atst_encoder_hp_dout(C.byref(e)), (self.M, e.C), torch.float32)
+        else:
+            self.out = self.ws.view(lib.atst_encoder_out(C.byref(e)), (self.M, e.C), torch.bfloat16)
+            self.dout = self.ws.view(lib.atst_encoder_dout(C.byref(e)), (self.M, e.C), torch.bfloat16) if train else None
         self._keep = None
 
     def forward(self, mel: torch.Tensor, valid: torch.Tensor, rowflag: Optional[torch.Tensor], dp_scale: Optional[torch.Tensor]):
@@ -172,11 +180,17 @@ class EncoderPass:
         e = self.e
         e.mel, e.valid = hip.ptr(mel), hip.ptr(valid)
         e.rowflag, e.dp_scale = hip.ptr(rowflag), hip.ptr(dp_scale)
-        hip.check(hip.load().atst_encoder_fwd(C.byref(e), hip.stream()), "atst_encoder_fwd")
+        if self.precise:
+            hip.check(hip.load().atst_encoder_hp_fwd(C.byref(e), hip.stream()), "atst_encoder_hp_fwd")
+        else:
+            hip.check(hip.load().atst_encoder_fwd(C.byref(e), hip.stream()), "atst_encoder_fwd")
         return self.out
 
     def backward(self):
-        hip.check(hip.load().atst_encoder_bwd(C.byref(self.e), hip.stream()), "atst_encoder_bwd")
+        if self.precise:
+            hip.check(hip.load().atst_encoder_hp_bwd(C.byref(self.e), hip.stream()), "atst_encoder_hp_bwd")
+        else:
+            hip.check(hip.load().atst_encoder_bwd(C.byref(self.e), hip.stream()), "atst_encoder_bwd")
 
     def backward_part(self, part: int, split: int):
         """part 0: final LayerNorm + blocks [split, depth) ; part 1: blocks [0, split) + token stage."""
@@ -190,7 +204,8 @@ class EncoderPass:
         return self.ws.view(hip.load().atst_encoder_tokens(C.byref(self.e)), (self.M, self.e.C), torch.float32)
 
     def block_out(self, i):
-        return self.ws.view(hip.load().atst_encoder_block_out(C.byref(self.e), i), (self.M, self.e.C), torch.float32)
+        f = hip.load().atst_encoder_hp_block_out if self.precise else hip.load().atst_encoder_block_out
+        return self.ws.view(f(C.byref(self.e), i), (self.M, self.e.C), torch.float32)
 
 
 class HeadPass:
@@ -253,8 +268,59 @@ class HeadPass:
             self.saved = (x16, h, mean, rstd, y16, count)
         return out
 
+    def _backward_precise(self, dout: torch.Tensor) -> torch.Tensor:
+        """Parity mode (AtstEngine(precise=True)): the same backward with split-bf16 operands everywhere -- dgrad operands split
+        along the contraction axis ([hi|lo|hi] x [hi|hi|lo]), weight-gradient operands split by rows ([hi;lo;hi] x [hi;hi;lo]) --
+        and an fp32 dh.  Same kernels (MFMA GEMMs, BatchNorm sums), ~2^-17 instead of 2^-9 per operand."""
+        eng = self.eng
+        x3, h, mean, rstd, y3, count = self.saved
+        R, dev, st, K = x3.shape[0], x3.device, hip.stream(), self.in_dim
+
+        def split_cols(x, rows, cols, b_layout):                       # fp32 [rows, cols] -> bf16 [rows, 3 cols]
+            out = torch.empty(rows, 3 * cols, dtype=torch.bfloat16, device=dev)
+            hip.call("atst_split3_bf16", hip.ptr(x.contiguous()), rows, cols, b_layout, hip.ptr(out), st)
+            return out
+
+        def rows_dy(x):                                                 # fp32 [R, n] -> bf16 [3 R, n] = [hi; lo; hi]
+            hi = x.to(torch.bfloat16)
+            lo = (x - hi.float()).to(torch.bfloat16)
+            return torch.cat([hi, lo, hi]).contiguous()
+
+        def rows_x(x3_, n):                                             # saved [R, 3 n] = [hi | lo | hi] -> bf16 [3 R, n] = [hi; hi; lo]
+            hi, lo = x3_[:, :n], x3_[:, n:2 * n]
+            return torch.cat([hi, hi, lo]).contiguous()
+
+        w3 = self._w("3.weight", f32=True).view(HEAD_OUT, HEAD_HIDDEN)
+        w0 = self._w("0.weight", f32=True).view(HEAD_HIDDEN, K)
+        _wgrad(rows_dy(dout), rows_x(y3, HEAD_HIDDEN), 3 * R, HEAD_OUT, HEAD_HIDDEN, self._w("3.weight", grad=True))
+        dy = torch.empty(R, HEAD_HIDDEN, device=dev)
+        _gemm(split_cols(dout, R, HEAD_OUT, 0), split_cols(w3.t(), HEAD_HIDDEN, HEAD_OUT, 1), R, HEAD_HIDDEN, 3 * HEAD_OUT, hip.EPI_F32, dy)
+        gamma, beta = self._w("1.weight", f32=True), self._w("1.bias", f32=True)
+        s1, s2 = torch.empty(HEAD_HIDDEN, device=dev), torch.empty(HEAD_HIDDEN, device=dev)
+        scratch = torch.empty(2 * 32 * HEAD_HIDDEN, device=dev)
+        hip.call("atst_bn_relu_bwd_sums", hip.ptr(dy), hip.ptr(h), hip.ptr(mean), hip.ptr(rstd), hip.ptr(gamma), hip.ptr(beta),
+                 R, HEAD_HIDDEN, hip.ptr(s1), hip.ptr(s2), hip.ptr(scratch), st)
+        self._w("1.bias", grad=True).add_(s1)
+        self._w("1.weight", grad=True).add_(s2)
+        s1, s2 = parallel.allreduce_bn_backward_sums(s1, s2)
+        inv = 1.0
+        if isinstance(count, torch.Tensor):
+            s1, s2 = (s1 / count).contiguous(), (s2 / count).contiguous()
+        else:
+            inv = 1.0 / count
+        dh = torch.empty(R, HEAD_HIDDEN, device=dev)
+        hip.call("atst_bn_bwd_dx_f32", hip.ptr(dy), hip.ptr(h), hip.ptr(mean), hip.ptr(rstd), hip.ptr(gamma), hip.ptr(beta),
+                 hip.ptr(s1), hip.ptr(s2), inv, R, HEAD_HIDDEN, hip.ptr(dh), st)
+        _wgrad(rows_dy(dh), rows_x(x3, K), 3 * R, HEAD_HIDDEN, K, self._w("0.weight", grad=True))
+        dx = torch.empty(R, K, device=dev)
+        _gemm(split_cols(dh, R, HEAD_HIDDEN, 0), split_cols(w0.t(), K, HEAD_HIDDEN, 1), R, K, 3 * HEAD_HIDDEN, hip.EPI_F32, dx)
+        self.saved = None
+        return dx
+
     def backward(self, dout: torch.Tensor) -> torch.Tensor:
         eng = self.eng
+        if eng.precise:
+            return self._backward_precise(dout)
         x16, h, mean, rstd, y16, count = self.saved
         R, dev, st = x16.shape[0], x16.device, hip.stream()
         d16 = torch.empty(R, HEAD_OUT, dtype=torch.bfloat16, device=dev)
@@ -309,7 +375,7 @@ class AtstEngine:
 
     def __init__(self, arch: str = "small", frame: bool = False, depth: Optional[int] = None, ncrops: int = 2,
                  device: Optional[torch.device] = None, drop_path_rate: float = 0.1, n_pos: int = 251, fp8: bool = False,
-                 symmetric: bool = True, patch_embed: str = "Linear"):
+                 symmetric: bool = True, patch_embed: str = "Linear", precise: bool = False):
         if arch not in ARCH:
             raise RuntimeError("arch {} is not implemented".format(arch))      # ref: models/atst/atst.py:17
         hip.load()                                                               # fail loudly when the .so is missing
@@ -336,6 +402,11 @@ class AtstEngine:
         # fp8 forward (BASELINE.json configs[4], ATST-base recipe): e4m3 shadows of the four Linear weights of every block,
         # per-tensor scaled, refreshed with the bf16 shadows; the backward and everything saved for it stay bf16
         self.fp8 = bool(fp8)
+        # parity mode: training passes run on the fp32 / split-bf16 twin of the encoder (csrc/engine_hp.hip), everything else
+        # (view grouping, heads -- already split-bf16 --, loss, optimizer, EMA) is this same engine.  ~30x slower: small shapes.
+        self.precise = bool(precise)
+        if self.precise and self.fp8:
+            raise hip.HipError("precise=True is the fp32 parity mode; it excludes fp8")
         if self.fp8:
             rows = []
             for i in range(self.depth):
@@ -489,7 +560,7 @@ class AtstEngine:
     def _pass(self, net: str, S: int, width: int, train: bool, slot: int) -> EncoderPass:
         key = (net, S, width, train, slot)
         if key not in self._passes:
-            self._passes[key] = EncoderPass(self, net, S, width, train)
+            self._passes[key] = EncoderPass(self, net, S, width, train, precise=self.precise)
         return self._passes[key]
 
     def inference_pass(self, net: str, S: int, width: int, keep: int = 4) -> EncoderPass:
@@ -570,8 +641,11 @@ class AtstEngine:
                 rows = self._cls_rows[key]
             dp = self.drop_path_scales(S, None if keep is None else keep[gi]) if self.dpr[-1] > 0 or keep is not None else None
             out16 = ep.forward(mel, valid, rowflag, dp)
-            f = torch.empty(rows.numel(), self.cfg["embed_dim"], device=self.device)
-            hip.call("atst_gather_rows_bf16", hip.ptr(out16), hip.ptr(rows), rows.numel(), self.cfg["embed_dim"], hip.ptr(f), hip.stream())
+            if ep.precise:                                  # fp32 rows: plain indexing (parity mode, speed is not the point)
+                f = out16.index_select(0, rows.long())
+            else:
+                f = torch.empty(rows.numel(), self.cfg["embed_dim"], device=self.device)
+                hip.call("atst_gather_rows_bf16", hip.ptr(out16), hip.ptr(rows), rows.numel(), self.cfg["embed_dim"], hip.ptr(f), hip.stream())
             feats.append(f)
             groups.append((ep, rows))
         return torch.cat(feats) if len(feats) > 1 else feats[0], groups
@@ -648,7 +722,7 @@ class AtstEngine:
         #   blocks in reverse layer order, each as soon as that group has passed it (all other groups already have).
         order = sorted(range(len(groups)), key=lambda i: groups[i][0].M)
         self._async_reduce = False
-        overlap = self.overlap_comm and parallel._collective() and zero_grad
+        overlap = self.overlap_comm and parallel._collective() and zero_grad and not self.precise
         L = self.layout
         if overlap:
             self._reduce_async(L.entries["projector.0.weight"][0], L.n_student)
@@ -658,8 +732,11 @@ class AtstEngine:
             n = rows.numel()
             ep.dout.zero_()
             src = df[offs[gi]:offs[gi] + n].contiguous()           # named: must outlive the launch call
-            hip.call("atst_scatter_rows_bf16", hip.ptr(src), hip.ptr(rows), n, self.cfg["embed_dim"],
-                     hip.ptr(ep.dout), hip.stream())
+            if ep.precise:
+                ep.dout.index_copy_(0, rows.long(), src)
+            else:
+                hip.call("atst_scatter_rows_bf16", hip.ptr(src), hip.ptr(rows), n, self.cfg["embed_dim"],
+                         hip.ptr(ep.dout), hip.stream())
             if overlap and k == len(order) - 1:
                 nb = max(1, min(self.grad_buckets, self.depth))
                 cuts = [round(self.depth * j / nb) for j in range(nb, -1, -1)]          # depth ... 0

@@ -82,10 +82,17 @@ _SIGS = {
     "atst_bn_apply_relu_split3_bf16": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "atst_bn_relu_bwd_sums": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "atst_bn_bwd_dx_bf16": (C.c_int, [C.c_void_p] * 8 + [C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "atst_bn_bwd_dx_f32": (C.c_int, [C.c_void_p] * 8 + [C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "atst_byol_loss_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p]),
     "atst_adamw_ema_step": (C.c_int, [C.c_void_p] * 8 + [C.c_size_t, C.c_size_t] + [C.c_double] * 8 + [C.c_void_p]),
     "atst_encoder_ws_bytes": (C.c_size_t, [C.c_int] * 7),
+    "atst_encoder_hp_ws_bytes": (C.c_size_t, [C.c_int] * 5),
+    "atst_encoder_hp_fwd": (C.c_int, [C.POINTER(Encoder), C.c_void_p]),
+    "atst_encoder_hp_bwd": (C.c_int, [C.POINTER(Encoder), C.c_void_p]),
+    "atst_encoder_hp_out": (C.c_void_p, [C.POINTER(Encoder)]),
+    "atst_encoder_hp_dout": (C.c_void_p, [C.POINTER(Encoder)]),
+    "atst_encoder_hp_block_out": (C.c_void_p, [C.POINTER(Encoder), C.c_int]),
     "atst_encoder_fwd": (C.c_int, [C.POINTER(Encoder), C.c_void_p]),
     "atst_encoder_bwd": (C.c_int, [C.POINTER(Encoder), C.c_void_p]),
     "atst_encoder_bwd_part": (C.c_int, [C.POINTER(Encoder), C.c_int, C.c_int, C.c_void_p]),

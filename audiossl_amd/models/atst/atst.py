@@ -173,7 +173,7 @@ class ATST(nn.Module):
         spec_w = kwargs.pop("spec_w", 1001)
         self.engine = AtstEngine(arch, frame=frame, depth=depth, ncrops=ncrops, drop_path_rate=drop,
                                  n_pos=spec_w // 4 + 1, symmetric=kwargs.pop("symmetric", True),
-                                 patch_embed=kwargs.pop("patch_embed", "Linear"))
+                                 patch_embed=kwargs.pop("patch_embed", "Linear"), precise=kwargs.pop("precise", False))
         self.ncrops, self.frame = ncrops, frame
         self.engine.init_weights()
         self.student = _Net(self.engine, "student")

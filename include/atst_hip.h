@@ -129,6 +129,10 @@ int atst_bn_relu_bwd_sums(const float* dy, const float* h, const float* mean, co
 int atst_bn_bwd_dx_bf16(const float* dy, const float* h, const float* mean, const float* rstd, const float* gamma,
                         const float* beta, const float* sum_dy, const float* sum_dy_xhat, float inv_count, int R, int N,
                         uint16_t* dh, void* stream);
+/* the same with an fp32 dh (parity mode: the head backward then runs on split-bf16 operands made from it) */
+int atst_bn_bwd_dx_f32(const float* dy, const float* h, const float* mean, const float* rstd, const float* gamma,
+                       const float* beta, const float* sum_dy, const float* sum_dy_xhat, float inv_count, int R, int N,
+                       float* dh, void* stream);
 /* ByolLoss.forward + its backward: audiossl/models/atst/byol.py:24-78.  acc[0] = sum of pair cosines,
  * loss = 2 - 2*acc/((2*ncrops-2)*B); stats [4,256] = student/teacher column sums and square sums of normalised rows.
  * ncrops == -1: the asymmetric ATST-Frame loss (methods/atstframe/byol.py:83-84, model.py:73-76): student [B,256] (view 1)
@@ -191,6 +195,17 @@ int atst_encoder_bwd_part(const atst_encoder_t* e, int part, int split, void* st
  * also the token stage.  Consecutive calls hi..lo must tile [0, depth) from the top; between two calls the parameter
  * gradients of the blocks already walked are final, so the caller can reduce them across ranks bucket by bucket.      */
 int atst_encoder_bwd_range(const atst_encoder_t* e, int lo, int hi, void* stream);
+/* ---- high-precision twin (parity mode; csrc/engine_hp.hip) ------------------------------------------------------------------
+ * The same encoder forward / backward with fp32 activations and gradients: every Linear runs on the production MFMA GEMMs with
+ * split-bf16 operands ([hi|lo|hi] x [hi|hi|lo], ~2^-17), attention / LayerNorm / GELU in plain fp32 kernels.  Same
+ * atst_encoder_t (train is implied, fp8 must be 0, p16 / p16t are not read), its own workspace size; output / upstream-gradient
+ * rows are fp32 [S*NP, C].  ~30x slower than the bf16 path: for pinning gradients to the reference at <= 2e-3 on small shapes. */
+size_t atst_encoder_hp_ws_bytes(int S, int NP, int C, int H, int depth);
+int atst_encoder_hp_fwd(const atst_encoder_t* e, void* stream);
+int atst_encoder_hp_bwd(const atst_encoder_t* e, void* stream);
+const float* atst_encoder_hp_out(const atst_encoder_t* e);
+float* atst_encoder_hp_dout(const atst_encoder_t* e);
+const float* atst_encoder_hp_block_out(const atst_encoder_t* e, int i);
 /* block-level activation taps for tests: fp32 residual stream after block i (i in [0,depth)), train=1 only */
 const float* atst_encoder_block_out(const atst_encoder_t* e, int i);
 const float* atst_encoder_tokens(const atst_encoder_t* e);
