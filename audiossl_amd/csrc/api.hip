@@ -13,10 +13,10 @@ extern "C" {
 int atst_version(void) { return 100; }
 int atst_tune_gemm_variant(int v) { if (v >= 400) atst_attn_set_variant(v - 400); else atst_gemm_nt_set_variant(v); return 0; }
 
-int atst_mel_frontend_f32(const float* wave, int n_clips, int n_samples, int win_length, const float* window,
+int atst_mel_frontend_f32(const float* wave, int n_clips, int n_samples, int wave_ld, int n_mels, int win_length, const float* window,
                           const float* fb_weights, const int* fb_start, const int* fb_len, int fb_maxlen,
                           float* out, uint32_t* clipmax, void* stream) {
-  return atst_mel_frontend(wave, n_clips, n_samples, win_length, window, fb_weights, fb_start, fb_len, fb_maxlen, out,
+  return atst_mel_frontend(wave, n_clips, n_samples, wave_ld, n_mels, win_length, window, fb_weights, fb_start, fb_len, fb_maxlen, out,
                            clipmax, ST(stream));
 }
 

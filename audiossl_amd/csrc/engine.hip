@@ -35,11 +35,11 @@ struct Carver {
   }
 };
 
-Ws carve(void* ws, int S, int NP, int C, int H, int depth, int train, int fp8) {
+Ws carve(void* ws, int S, int NP, int C, int H, int depth, int train, int fp8, int PK = 256) {
   Ws w{};
   Carver c{reinterpret_cast<char*>(ws), 0};
   const size_t M = (size_t)S * NP;
-  w.patches = c.take<bf16>(M * 256);
+  w.patches = c.take<bf16>(M * PK);                                // PK = patch_h * patch_w (256 for the shipped 64 x 4 patches)
   w.table = c.take<float>((size_t)NP * C);
   const int nx = train ? 2 * depth + 1 : 1;
   for (int i = 0; i < nx; ++i) w.x[i] = c.take<float>(M * C);
@@ -108,8 +108,12 @@ int wgrad(const bf16* dY, const bf16* X, int M, int N, int K, float* dW, hipStre
 }
 }  // namespace
 
+inline int patch_k(const atst_encoder_t* e) { return (e->patch_h > 0 ? e->patch_h : 64) * (e->patch_w > 0 ? e->patch_w : 4); }
 extern "C" size_t atst_encoder_ws_bytes(int S, int NP, int C, int H, int depth, int train, int fp8) {
   return carve(nullptr, S, NP, C, H, depth, train, fp8).bytes;
+}
+extern "C" size_t atst_encoder_ws_bytes_geo(int S, int NP, int C, int H, int depth, int train, int fp8, int patch_h, int patch_w) {
+  return carve(nullptr, S, NP, C, H, depth, train, fp8, patch_h * patch_w).bytes;
 }
 
 static bool check(const atst_encoder_t* e) {
@@ -117,27 +121,28 @@ static bool check(const atst_encoder_t* e) {
   if (e->C != e->H * 64 || (e->C != 384 && e->C != 768)) return false;
   if (e->NP != 32 && e->NP != 64 && e->NP != 128 && e->NP != 256) return false;
   if (e->n_tok + e->use_cls > e->NP) return false;
-  if (e->ws_bytes < atst_encoder_ws_bytes(e->S, e->NP, e->C, e->H, e->depth, e->train, e->fp8)) return false;
+  if (patch_k(e) % 256 || patch_k(e) > 1024) return false;         // patch GEMM / weight gradient tiles
+  if (e->ws_bytes < carve(nullptr, e->S, e->NP, e->C, e->H, e->depth, e->train, e->fp8, patch_k(e)).bytes) return false;
   return true;
 }
 
 extern "C" const uint16_t* atst_encoder_out(const atst_encoder_t* e) {
-  return reinterpret_cast<const uint16_t*>(carve(e->ws, e->S, e->NP, e->C, e->H, e->depth, e->train, e->fp8).hN);
+  return reinterpret_cast<const uint16_t*>(carve(e->ws, e->S, e->NP, e->C, e->H, e->depth, e->train, e->fp8, patch_k(e)).hN);
 }
 extern "C" uint16_t* atst_encoder_dout(const atst_encoder_t* e) {
-  return reinterpret_cast<uint16_t*>(carve(e->ws, e->S, e->NP, e->C, e->H, e->depth, e->train, e->fp8).dout);
+  return reinterpret_cast<uint16_t*>(carve(e->ws, e->S, e->NP, e->C, e->H, e->depth, e->train, e->fp8, patch_k(e)).dout);
 }
 extern "C" const float* atst_encoder_block_out(const atst_encoder_t* e, int i) {
-  return carve(e->ws, e->S, e->NP, e->C, e->H, e->depth, e->train, e->fp8).x[2 * i + 2];
+  return carve(e->ws, e->S, e->NP, e->C, e->H, e->depth, e->train, e->fp8, patch_k(e)).x[2 * i + 2];
 }
 extern "C" const float* atst_encoder_tokens(const atst_encoder_t* e) {
-  return carve(e->ws, e->S, e->NP, e->C, e->H, e->depth, e->train, e->fp8).x[0];
+  return carve(e->ws, e->S, e->NP, e->C, e->H, e->depth, e->train, e->fp8, patch_k(e)).x[0];
 }
 
 extern "C" int atst_encoder_fwd(const atst_encoder_t* e, void* stream) {
   if (!check(e)) return ATST_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const Ws w = carve(e->ws, e->S, e->NP, e->C, e->H, e->depth, e->train, e->fp8);
+  const Ws w = carve(e->ws, e->S, e->NP, e->C, e->H, e->depth, e->train, e->fp8, patch_k(e));
   const int S = e->S, NP = e->NP, C = e->C, M = S * NP;
   const float* p = e->p32; const bf16* q = B16(e->p16);
   const atst_enc_off_t& o = e->off;
@@ -145,11 +150,12 @@ extern "C" int atst_encoder_fwd(const atst_encoder_t* e, void* stream) {
   const bool f8 = e->fp8 != 0;                      // forward GEMMs on e4m3 copies of the operands (ATST-base recipe, configs[4])
   if (f8 && (!e->p8 || !e->w_dq || C % 384)) return ATST_EINVAL;
   const bool fuse_ln = C == 384 && !f8;             // N == 384: the residual GEMM blocks own whole rows
-  RUN(atst_patchify(e->mel, S, e->width, NP, e->use_cls, w.patches, st));
+  const int PK = patch_k(e);
+  RUN(atst_patchify(e->mel, S, e->width, NP, e->use_cls, w.patches, st, e->patch_h > 0 ? e->patch_h : 64, e->patch_w > 0 ? e->patch_w : 4));
   RUN(atst_token_table(e->use_cls ? p + o.cls_token : nullptr, p + o.pos_embed, p + o.patch_b, NP, e->n_tok, C, e->use_cls, w.table, st));
   {
     GemmArgs a{};
-    a.A = w.patches; a.B = q + o.patch_w; a.M = M; a.N = C; a.K = 256; a.lda = 256; a.ldb = 256; a.epi = EPI_PATCH;
+    a.A = w.patches; a.B = q + o.patch_w; a.M = M; a.N = C; a.K = PK; a.lda = PK; a.ldb = PK; a.epi = EPI_PATCH;
     a.C = w.x[0]; a.ldc = C; a.bias = p + o.patch_b; a.rows_per_seq = NP; a.table = w.table; a.rowflag = e->rowflag;
     a.alt = p + o.mask_embed;
     RUN(atst_gemm_nt(a, st));
@@ -233,7 +239,7 @@ extern "C" int atst_encoder_bwd_range(const atst_encoder_t* e, int lo, int hi, v
 static int encoder_bwd_range(const atst_encoder_t* e, int lo, int hi, bool head, bool tail, void* stream) {
   if (!check(e) || !e->train || !e->p16t || !e->g32) return ATST_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const Ws w = carve(e->ws, e->S, e->NP, e->C, e->H, e->depth, e->train, e->fp8);
+  const Ws w = carve(e->ws, e->S, e->NP, e->C, e->H, e->depth, e->train, e->fp8, patch_k(e));
   const int S = e->S, NP = e->NP, C = e->C, M = S * NP, D = e->depth;
   const float* p = e->p32; const bf16* qt = B16(e->p16t);
   float* G = e->g32;
@@ -309,6 +315,6 @@ static int encoder_bwd_range(const atst_encoder_t* e, int lo, int hi, bool head,
   // ---- token stage: x0 = (1-m) (patch W^T + b) + m mask_embed + pos  (+ CLS)
   RUN(atst_token_grad(cur, e->rowflag, S, NP, e->n_tok, C, e->use_cls, e->use_cls ? G + o.cls_token : nullptr,
                       G + o.pos_embed, G + o.patch_b, e->rowflag ? G + o.mask_embed : nullptr, w.g, st));
-  RUN(wgrad(w.g, w.patches, M, C, 256, G + o.patch_w, st));
+  RUN(wgrad(w.g, w.patches, M, C, patch_k(e), G + o.patch_w, st));
   return ATST_OK;
 }

@@ -179,13 +179,6 @@ __global__ void attn_hp_bwd_kernel(const float* __restrict__ qkv, const int* __r
 }
 
 // ---- token plumbing in fp32 ------------------------------------------------------------------------------------------------
-// patches[(s NP + tok), f 4 + t] = mel[s, 0, f, 4 (tok - use_cls) + t] (0 for rows without a patch)   ref: PatchEmbed_v2
-__global__ void patchify_hp_kernel(const float* __restrict__ mel, int width, int NP, int use_cls, int n_patch, float* __restrict__ out) {
-  const int s = blockIdx.y, tok = blockIdx.x, k = threadIdx.x, p = tok - use_cls;
-  float v = 0.f;
-  if (p >= 0 && p < n_patch) v = mel[(size_t)s * 64 * width + (size_t)(k >> 2) * width + p * 4 + (k & 3)];
-  out[((size_t)s * NP + tok) * 256 + k] = v;
-}
 // gradient of the token stage (token_grad_kernel of tokens.hip with an fp32 g0)
 __global__ void token_grad_hp_kernel(const float* __restrict__ dx0, const uint8_t* __restrict__ rowflag, int S, int NP, int n_tok, int C, int use_cls,
                                      float* dcls, float* dpos, float* dbias, float* dmask, float* __restrict__ g0) {
@@ -227,11 +220,11 @@ struct Carver {
     return p;
   }
 };
-WsHp carve_hp(void* ws, int S, int NP, int C, int H, int depth) {
+WsHp carve_hp(void* ws, int S, int NP, int C, int H, int depth, int PK) {
   WsHp w{};
   Carver c{reinterpret_cast<char*>(ws), 0};
   const size_t M = (size_t)S * NP;
-  w.patches = c.take<float>(M * 256); w.table = c.take<float>((size_t)NP * C);
+  w.patches = c.take<float>(M * PK); w.table = c.take<float>((size_t)NP * C);
   for (int i = 0; i < 2 * depth + 1; ++i) w.x[i] = c.take<float>(M * C);
   for (int i = 0; i < depth; ++i) {
     LayerHp& l = w.L[i];
@@ -241,8 +234,8 @@ WsHp carve_hp(void* ws, int S, int NP, int C, int H, int depth) {
     l.lse = c.take<float>((size_t)S * H * NP);
   }
   w.hN = c.take<float>(M * C); w.meanN = c.take<float>(M); w.rstdN = c.take<float>(M);
-  w.a3 = c.take<bf16>(M * 12 * C); w.w3 = c.take<bf16>((size_t)12 * C * C + 768 * (size_t)C);
-  w.r3a = c.take<bf16>(3 * M * 4 * C); w.r3b = c.take<bf16>(3 * M * 4 * C);
+  w.a3 = c.take<bf16>(M * (12 * C > 3 * PK ? 12 * C : 3 * PK)); w.w3 = c.take<bf16>((size_t)12 * C * C + 3 * (size_t)PK * C);
+  w.r3a = c.take<bf16>(3 * M * 4 * C); w.r3b = c.take<bf16>(3 * M * (4 * C > PK ? 4 * C : PK));
   w.dxA = c.take<float>(M * C); w.dxB = c.take<float>(M * C); w.g = c.take<float>(M * C); w.g2 = c.take<float>(M * C);
   w.dh = c.take<float>(M * C); w.du = c.take<float>(M * 4 * C); w.dA = c.take<float>(M * 4 * C); w.dqkv = c.take<float>(M * 3 * C);
   w.d_o = c.take<float>(M * C); w.dout = c.take<float>(M * C);
@@ -299,33 +292,36 @@ struct Hp {
   }
 };
 
+inline int pk_of(const atst_encoder_t* e) { return (e->patch_h > 0 ? e->patch_h : 64) * (e->patch_w > 0 ? e->patch_w : 4); }
 bool check_hp(const atst_encoder_t* e) {
   if (!e || e->depth < 1 || e->depth > ATST_MAX_DEPTH || e->C != e->H * 64 || (e->C != 384 && e->C != 768)) return false;
   if (e->NP != 32 && e->NP != 64 && e->NP != 128 && e->NP != 256) return false;
   if (e->n_tok + e->use_cls > e->NP || e->fp8) return false;
-  return e->ws_bytes >= carve_hp(nullptr, e->S, e->NP, e->C, e->H, e->depth).bytes;
+  return e->ws_bytes >= carve_hp(nullptr, e->S, e->NP, e->C, e->H, e->depth, pk_of(e)).bytes;
 }
 }  // namespace
 
-extern "C" size_t atst_encoder_hp_ws_bytes(int S, int NP, int C, int H, int depth) { return carve_hp(nullptr, S, NP, C, H, depth).bytes; }
-extern "C" const float* atst_encoder_hp_out(const atst_encoder_t* e) { return carve_hp(e->ws, e->S, e->NP, e->C, e->H, e->depth).hN; }
-extern "C" float* atst_encoder_hp_dout(const atst_encoder_t* e) { return carve_hp(e->ws, e->S, e->NP, e->C, e->H, e->depth).dout; }
-extern "C" const float* atst_encoder_hp_block_out(const atst_encoder_t* e, int i) { return carve_hp(e->ws, e->S, e->NP, e->C, e->H, e->depth).x[2 * i + 2]; }
+extern "C" size_t atst_encoder_hp_ws_bytes(int S, int NP, int C, int H, int depth, int patch_h, int patch_w) {
+  return carve_hp(nullptr, S, NP, C, H, depth, (patch_h > 0 ? patch_h : 64) * (patch_w > 0 ? patch_w : 4)).bytes;
+}
+extern "C" const float* atst_encoder_hp_out(const atst_encoder_t* e) { return carve_hp(e->ws, e->S, e->NP, e->C, e->H, e->depth, pk_of(e)).hN; }
+extern "C" float* atst_encoder_hp_dout(const atst_encoder_t* e) { return carve_hp(e->ws, e->S, e->NP, e->C, e->H, e->depth, pk_of(e)).dout; }
+extern "C" const float* atst_encoder_hp_block_out(const atst_encoder_t* e, int i) { return carve_hp(e->ws, e->S, e->NP, e->C, e->H, e->depth, pk_of(e)).x[2 * i + 2]; }
 
 extern "C" int atst_encoder_hp_fwd(const atst_encoder_t* e, void* stream) {
   if (!check_hp(e)) return ATST_EINVAL;
-  Hp hp{e, carve_hp(e->ws, e->S, e->NP, e->C, e->H, e->depth), reinterpret_cast<hipStream_t>(stream), e->S * e->NP, e->C};
+  Hp hp{e, carve_hp(e->ws, e->S, e->NP, e->C, e->H, e->depth, pk_of(e)), reinterpret_cast<hipStream_t>(stream), e->S * e->NP, e->C};
   const WsHp& w = hp.w; hipStream_t st = hp.st;
   const int S = e->S, NP = e->NP, C = e->C, M = S * NP;
   const float* p = e->p32; const atst_enc_off_t& o = e->off;
-  hipLaunchKernelGGL(patchify_hp_kernel, dim3(NP, S), dim3(256), 0, st, e->mel, e->width, NP, e->use_cls, e->n_tok, w.patches);
-  LAUNCH_OK();
+  const int PK = pk_of(e);
+  RUN(atst_patchify_f32(e->mel, S, e->width, NP, e->use_cls, w.patches, st, e->patch_h > 0 ? e->patch_h : 64, e->patch_w > 0 ? e->patch_w : 4));
   RUN(atst_token_table(e->use_cls ? p + o.cls_token : nullptr, p + o.pos_embed, p + o.patch_b, NP, e->n_tok, C, e->use_cls, w.table, st));
   {                                                     // x0 = (1 - m) (patch W^T + b) + m mask_embed + pos (+ CLS): the production EPI_PATCH epilogue
-    RUN(atst_split3(w.patches, M, 256, 0, w.a3, st));
-    RUN(atst_split3(p + o.patch_w, C, 256, 1, w.w3, st));
+    RUN(atst_split3(w.patches, M, PK, 0, w.a3, st));
+    RUN(atst_split3(p + o.patch_w, C, PK, 1, w.w3, st));
     GemmArgs a{};
-    a.A = w.a3; a.B = w.w3; a.M = M; a.N = C; a.K = 768; a.lda = 768; a.ldb = 768; a.epi = EPI_PATCH; a.C = w.x[0]; a.ldc = C;
+    a.A = w.a3; a.B = w.w3; a.M = M; a.N = C; a.K = 3 * PK; a.lda = 3 * PK; a.ldb = 3 * PK; a.epi = EPI_PATCH; a.C = w.x[0]; a.ldc = C;
     a.bias = p + o.patch_b; a.rows_per_seq = NP; a.table = w.table; a.rowflag = e->rowflag; a.alt = p + o.mask_embed;
     RUN(atst_gemm_nt(a, st));
   }
@@ -355,7 +351,7 @@ extern "C" int atst_encoder_hp_fwd(const atst_encoder_t* e, void* stream) {
 
 extern "C" int atst_encoder_hp_bwd(const atst_encoder_t* e, void* stream) {
   if (!check_hp(e) || !e->g32) return ATST_EINVAL;
-  Hp hp{e, carve_hp(e->ws, e->S, e->NP, e->C, e->H, e->depth), reinterpret_cast<hipStream_t>(stream), e->S * e->NP, e->C};
+  Hp hp{e, carve_hp(e->ws, e->S, e->NP, e->C, e->H, e->depth, pk_of(e)), reinterpret_cast<hipStream_t>(stream), e->S * e->NP, e->C};
   const WsHp& w = hp.w; hipStream_t st = hp.st;
   const int S = e->S, NP = e->NP, C = e->C, M = S * NP, D = e->depth;
   float* G = e->g32; const atst_enc_off_t& o = e->off;
@@ -391,5 +387,5 @@ extern "C" int atst_encoder_hp_bwd(const atst_encoder_t* e, void* stream) {
   hipLaunchKernelGGL(token_grad_hp_kernel, dim3(NP), dim3(128), 0, st, cur, e->rowflag, S, NP, e->n_tok, C, e->use_cls,
                      e->use_cls ? G + o.cls_token : nullptr, G + o.pos_embed, G + o.patch_b, e->rowflag ? G + o.mask_embed : nullptr, w.g);
   LAUNCH_OK();
-  return hp.wgrad(w.g, w.patches, C, 256, G + o.patch_w);
+  return hp.wgrad(w.g, w.patches, C, pk_of(e), G + o.patch_w);
 }

@@ -1,8 +1,10 @@
 // Log-mel front end on gfx950:  waveform -> reflect-pad/frame/Hann -> 1024-point real FFT -> |.|^2 -> 64-band HTK mel
 // -> 10 log10 -> (per clip) clamp at max-80 dB -> min-max to [-1,1].
-// Restates torchaudio MelSpectrogram(16000, n_fft=1024, win_length=W, hop=160, f_min=60, f_max=7800, n_mels=64) ->
+// Restates torchaudio MelSpectrogram(sr, n_fft=1024, win_length=W, hop=160, f_min=60, f_max=7800, n_mels) ->
 // AmplitudeToDB("power", top_db=80) -> MinMax(-79.6482, 50.6842) as called from audiossl/methods/atst/transform.py:14-18
-// and audiossl/methods/atstframe/transform.py:16-22  (the reference runs this on CPU dataloader workers, 1 thread each).
+// and audiossl/methods/atstframe/transform.py:14-22  (the reference runs this on CPU dataloader workers, 1 thread each).
+// n_mels = 64 (shipped recipes) or 128 (the reference's `n_mels` / `sr` parameters, transform.py:14-16: BASELINE.json
+// configs[4] "high-res mel"); the sample rate only enters through the filterbank table the caller supplies.
 //
 // HBM-bound by design (0.64 MB read + 0.26 MB written per clip-view), so no GEMM reshaping: one wave computes one frame
 // as a 512-point complex Stockham radix-8 FFT (3 passes through LDS) of the even/odd-packed real signal, un-packs the
@@ -15,7 +17,7 @@
 
 namespace {
 
-constexpr int NFFT = 1024, HOPS = 160, NBIN = 513, NMEL = 64;
+constexpr int NFFT = 1024, HOPS = 160, NBIN = 513;
 constexpr int FPB = 32;                       // frames per block (8 per wave)
 constexpr float DB_MIN = -79.6482f, DB_MAX = 50.6842f, TOP_DB = 80.0f, DB_BIAS = 200.0f;
 
@@ -53,7 +55,8 @@ DEVFN void dft8(float2* u) {
 
 DEVFN int reflect(int i, int n) { i = i < 0 ? -i : i; return i >= n ? 2 * (n - 1) - i : i; }
 
-__global__ __launch_bounds__(256) void stft_mel_db_kernel(const float* __restrict__ wave, int n_samples, int T,
+template <int NB>   // mel bands per lane: n_mels = 64 NB
+__global__ __launch_bounds__(256) void stft_mel_db_kernel(const float* __restrict__ wave, int wave_ld, int n_samples, int T,
                                                           const float* __restrict__ window, const float* __restrict__ fbw,
                                                           const int* __restrict__ fb_start, const int* __restrict__ fb_len,
                                                           int fb_maxlen, float* __restrict__ out, unsigned int* __restrict__ clipmax) {
@@ -62,12 +65,15 @@ __global__ __launch_bounds__(256) void stft_mel_db_kernel(const float* __restric
   __shared__ float2 fa[4][576];
   __shared__ float2 fb[4][576];
   __shared__ float pw[4][NBIN + 7];
+  constexpr int NMEL = 64 * NB;
   __shared__ float dbb[NMEL][FPB + 1];
   __shared__ float wmax[4];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int clip = blockIdx.y, t0 = blockIdx.x * FPB;
-  const float* w = wave + (size_t)clip * n_samples;
-  const int m_start = fb_start[lane], m_len = fb_len[lane];
+  const float* w = wave + (size_t)clip * wave_ld;
+  int m_start[NB], m_len[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) { m_start[b] = fb_start[lane + 64 * b]; m_len[b] = fb_len[lane + 64 * b]; }
   float vmax = -1e30f;
   // twiddles of the two twiddled passes depend on the lane only: fetched once per block, not once per frame
   float2 tw8[8], tw64[8];
@@ -129,11 +135,14 @@ __global__ __launch_bounds__(256) void stft_mel_db_kernel(const float* __restric
       pw[wid][k] = x.x * x.x + x.y * x.y;
     }
     wave_sync();
-    float mel = 0.f;
-    for (int q = 0; q < m_len; ++q) mel += fbw[lane * fb_maxlen + q] * pw[wid][m_start + q];
-    const float db = 10.0f * log10f(fmaxf(mel, 1e-10f));
-    dbb[lane][fl] = db;
-    if (t0 + fl < T) vmax = fmaxf(vmax, db);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      float mel = 0.f;
+      for (int q = 0; q < m_len[b]; ++q) mel += fbw[(lane + 64 * b) * fb_maxlen + q] * pw[wid][m_start[b] + q];
+      const float db = 10.0f * log10f(fmaxf(mel, 1e-10f));
+      dbb[lane + 64 * b][fl] = db;
+      if (t0 + fl < T) vmax = fmaxf(vmax, db);
+    }
   }
   vmax = wave_max(vmax);
   if (lane == 0) wmax[wid] = vmax;
@@ -194,18 +203,23 @@ int init_twiddles(hipStream_t st) {
 }
 }  // namespace
 
-int atst_mel_frontend(const float* wave, int n_clips, int n_samples, int win_length, const float* window,
+int atst_mel_frontend(const float* wave, int n_clips, int n_samples, int wave_ld, int n_mels, int win_length, const float* window,
                       const float* fb_weights, const int* fb_start, const int* fb_len, int fb_maxlen,
                       float* out, unsigned int* clipmax, hipStream_t st) {
   (void)win_length;                                   // the zero-padded 1024-tap window is supplied by the caller
-  if (n_clips <= 0 || n_samples < NFFT / 2 + 1) return ATST_EINVAL;
+  if (wave_ld <= 0) wave_ld = n_samples;
+  if (n_clips <= 0 || n_samples < NFFT / 2 + 1 || wave_ld < n_samples || (n_mels != 64 && n_mels != 128)) return ATST_EINVAL;
   int rc = init_twiddles(st);
   if (rc) return rc;
   const int T = 1 + n_samples / HOPS;
   hipMemsetAsync(clipmax, 0, n_clips * sizeof(unsigned int), st);
-  ProfScope ps(PK_MEL, (double)n_clips * (4.0 * n_samples + 4.0 * NMEL * T), st);   // wave read once + dB written once
-  hipLaunchKernelGGL(stft_mel_db_kernel, dim3((T + FPB - 1) / FPB, n_clips), dim3(256), 0, st, wave, n_samples, T, window,
-                     fb_weights, fb_start, fb_len, fb_maxlen, out, clipmax);
-  hipLaunchKernelGGL(db_finalize_kernel, dim3(16, n_clips), dim3(256), 0, st, out, clipmax, NMEL * T);
+  ProfScope ps(PK_MEL, (double)n_clips * (4.0 * n_samples + 4.0 * n_mels * T), st);   // wave read once + dB written once
+  if (n_mels == 64)
+    hipLaunchKernelGGL(stft_mel_db_kernel<1>, dim3((T + FPB - 1) / FPB, n_clips), dim3(256), 0, st, wave, wave_ld, n_samples, T, window,
+                       fb_weights, fb_start, fb_len, fb_maxlen, out, clipmax);
+  else
+    hipLaunchKernelGGL(stft_mel_db_kernel<2>, dim3((T + FPB - 1) / FPB, n_clips), dim3(256), 0, st, wave, wave_ld, n_samples, T, window,
+                       fb_weights, fb_start, fb_len, fb_maxlen, out, clipmax);
+  hipLaunchKernelGGL(db_finalize_kernel, dim3(16, n_clips), dim3(256), 0, st, out, clipmax, n_mels * T);
   return (int)hipGetLastError();
 }

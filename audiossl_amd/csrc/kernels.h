@@ -78,7 +78,8 @@ int atst_attn_bwd(const AttnArgs& a, hipStream_t st);
 void atst_attn_set_variant(int v);
 
 // token plumbing
-int atst_patchify(const float* mel, int S, int width, int NP, int use_cls, bf16* out, hipStream_t st);
+int atst_patchify(const float* mel, int S, int width, int NP, int use_cls, bf16* out, hipStream_t st, int patch_h = 64, int patch_w = 4);
+int atst_patchify_f32(const float* mel, int S, int width, int NP, int use_cls, float* out, hipStream_t st, int patch_h = 64, int patch_w = 4);
 int atst_token_table(const float* cls, const float* pos, const float* bias, int NP, int n_tok, int C, int use_cls, float* table, hipStream_t st);
 int atst_gather_rows(const bf16* src, const int* rows, int R, int C, float* dst, hipStream_t st);
 int atst_scatter_rows(const float* src, const int* rows, int R, int C, bf16* dst, hipStream_t st);
@@ -127,7 +128,7 @@ int atst_transpose_bf16(const bf16* src, int rows, int cols, bf16* dst, hipStrea
 int atst_transpose_bf16_batch(const bf16* src, bf16* dst, const int* table, int n, int total_tiles, hipStream_t st);
 
 // front end
-int atst_mel_frontend(const float* wave, int n_clips, int n_samples, int win_length, const float* window,
+int atst_mel_frontend(const float* wave, int n_clips, int n_samples, int wave_ld, int n_mels, int win_length, const float* window,
                       const float* fb_weights, const int* fb_start, const int* fb_len, int fb_maxlen,
                       float* out, unsigned int* clipmax, hipStream_t st);
 

@@ -38,6 +38,19 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
   }
 }
 
+// Any single-row patch geometry (patch height = number of mel bands FH, patch width pw; K = FH pw, k = f pw + t): one block per
+// (token, sequence), thread = k.  Used for everything but the shipped 64 x 4 patches (e.g. 128 bands x 8 frames, configs[4]).
+template <typename OUT>
+__global__ void patchify_generic_kernel(const float* __restrict__ mel, int FH, int pw, int width, int NP, int use_cls, int n_patch,
+                                        OUT* __restrict__ out) {
+  const int s = blockIdx.y, tok = blockIdx.x, p = tok - use_cls, K = FH * pw;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    float v = 0.f;
+    if (p >= 0 && p < n_patch) v = mel[((size_t)s * FH + k / pw) * width + p * pw + k % pw];
+    out[((size_t)s * NP + tok) * K + k] = (OUT)v;
+  }
+}
+
 __global__ void token_table_kernel(const float* cls, const float* pos, const float* bias, int NP, int n_tok, int C,
                                    int use_cls, float* table) {
   const int n = blockIdx.x;
@@ -117,11 +130,23 @@ __global__ void token_grad_kernel(const float* __restrict__ dx0, const uint8_t* 
 }
 }  // namespace
 
-int atst_patchify(const float* mel, int S, int width, int NP, int use_cls, bf16* out, hipStream_t st) {
+int atst_patchify(const float* mel, int S, int width, int NP, int use_cls, bf16* out, hipStream_t st, int patch_h, int patch_w) {
   if (S <= 0) return ATST_OK;
-  const int n_patch = (width - width % 4) / 4;
+  if (patch_h <= 0 || patch_w <= 0) return ATST_EINVAL;
+  const int n_patch = (width - width % patch_w) / patch_w;
   if (n_patch + use_cls > NP) return ATST_EINVAL;
-  hipLaunchKernelGGL(patchify_kernel, dim3((NP + 15) / 16, S), dim3(256), 0, st, mel, width, NP, use_cls, n_patch, out);
+  if (patch_h == 64 && patch_w == 4)
+    hipLaunchKernelGGL(patchify_kernel, dim3((NP + 15) / 16, S), dim3(256), 0, st, mel, width, NP, use_cls, n_patch, out);
+  else
+    hipLaunchKernelGGL(patchify_generic_kernel<bf16>, dim3(NP, S), dim3(256), 0, st, mel, patch_h, patch_w, width, NP, use_cls, n_patch, out);
+  return (int)hipGetLastError();
+}
+int atst_patchify_f32(const float* mel, int S, int width, int NP, int use_cls, float* out, hipStream_t st, int patch_h, int patch_w) {
+  if (S <= 0) return ATST_OK;
+  if (patch_h <= 0 || patch_w <= 0) return ATST_EINVAL;
+  const int n_patch = (width - width % patch_w) / patch_w;
+  if (n_patch + use_cls > NP) return ATST_EINVAL;
+  hipLaunchKernelGGL(patchify_generic_kernel<float>, dim3(NP, S), dim3(256), 0, st, mel, patch_h, patch_w, width, NP, use_cls, n_patch, out);
   return (int)hipGetLastError();
 }
 int atst_token_table(const float* cls, const float* pos, const float* bias, int NP, int n_tok, int C, int use_cls, float* table, hipStream_t st) {

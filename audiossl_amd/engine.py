@@ -27,7 +27,8 @@ def _round_up(n, a=ALIGN):
     return (n + a - 1) // a * a
 
 
-def encoder_param_shapes(arch: str, depth: Optional[int] = None, frame: bool = False, n_pos: int = 251, patch_embed: str = "Linear"):
+def encoder_param_shapes(arch: str, depth: Optional[int] = None, frame: bool = False, n_pos: int = 251, patch_embed: str = "Linear",
+                         patch_h: int = 64, patch_w: int = 4):
     """Parameter names/shapes in the reference's registration order (= state_dict order).
     ref: audiossl/models/atst/audio_transformer.py:80-120 ; audiossl/methods/atstframe/audio_transformer.py:101-149."""
     cfg = ARCH[arch]
@@ -37,8 +38,8 @@ def encoder_param_shapes(arch: str, depth: Optional[int] = None, frame: bool = F
         out.append(("cls_token", (1, 1, d)))
     # patch_embed="CNN" (ATST-Frame option, atstframe/audio_transformer.py:57-74,117-118): Conv2d(1, d, (64, 4), stride (64, 4)) -- the
     # same contraction over k = f * 4 + t, stored as [d, 1, 64, 4] under `patch_embed.proj.*`
-    pe = [("patch_embed.proj.weight", (d, 1, 64, 4)), ("patch_embed.proj.bias", (d,))] if patch_embed == "CNN" else \
-         [("patch_embed.patch_embed.weight", (d, 256)), ("patch_embed.patch_embed.bias", (d,))]
+    pe = [("patch_embed.proj.weight", (d, 1, patch_h, patch_w)), ("patch_embed.proj.bias", (d,))] if patch_embed == "CNN" else \
+         [("patch_embed.patch_embed.weight", (d, patch_h * patch_w)), ("patch_embed.patch_embed.bias", (d,))]
     out += [("pos_embed", (1, n_pos, d))] + pe
     for i in range(depth):
         b = f"blocks.{i}."
@@ -60,11 +61,12 @@ def head_param_shapes(in_dim: int):
 class FlatLayout:
     """name -> (offset, shape) for 'encoder.*', 'projector.*', 'predictor.*' in one flat buffer."""
 
-    def __init__(self, arch: str, depth: Optional[int], frame: bool, patch_embed: str = "Linear"):
+    def __init__(self, arch: str, depth: Optional[int], frame: bool, patch_embed: str = "Linear", n_pos: int = 251,
+                 patch_h: int = 64, patch_w: int = 4):
         d = ARCH[arch]["embed_dim"]
         self.entries: "OrderedDict[str, Tuple[int, Tuple[int, ...]]]" = OrderedDict()
         off = 0
-        groups = [("encoder.", encoder_param_shapes(arch, depth, frame, patch_embed=patch_embed)), ("projector.", head_param_shapes(d)),
+        groups = [("encoder.", encoder_param_shapes(arch, depth, frame, n_pos, patch_embed, patch_h, patch_w)), ("projector.", head_param_shapes(d)),
                   ("predictor.", head_param_shapes(HEAD_OUT))]
         for prefix, shapes in groups:
             for name, shape in shapes:
@@ -139,7 +141,8 @@ class EncoderPass:
         self.eng, self.net, self.S, self.width, self.train = eng, net, S, width, train
         self.precise = bool(precise)                     # fp32 / split-bf16 twin of the encoder (csrc/engine_hp.hip): parity mode
         cfg = eng.cfg
-        self.n_tok = (width - width % 4) // 4
+        pw = eng.patch_w
+        self.n_tok = (width - width % pw) // pw
         self.use_cls = 0 if eng.frame else 1
         if self.n_tok + 1 > eng.n_pos:                          # the table kernel reads pos row n+1 for patch n in BOTH modes
             raise hip.HipError(f"mel width {width} needs {self.n_tok + 1} positions; pos_embed has {eng.n_pos} "
@@ -148,13 +151,15 @@ class EncoderPass:
         self.M = S * self.NP
         lib = hip.load()
         if self.precise:
-            nbytes = lib.atst_encoder_hp_ws_bytes(S, self.NP, cfg["embed_dim"], cfg["num_heads"], eng.depth)
+            nbytes = lib.atst_encoder_hp_ws_bytes(S, self.NP, cfg["embed_dim"], cfg["num_heads"], eng.depth, eng.patch_h, eng.patch_w)
         else:
-            nbytes = lib.atst_encoder_ws_bytes(S, self.NP, cfg["embed_dim"], cfg["num_heads"], eng.depth, int(train), int(eng.fp8))
+            nbytes = lib.atst_encoder_ws_bytes_geo(S, self.NP, cfg["embed_dim"], cfg["num_heads"], eng.depth, int(train), int(eng.fp8),
+                                                   eng.patch_h, eng.patch_w)
         self.ws = Workspace(nbytes, eng.device)
         e = hip.Encoder()
         e.S, e.NP, e.n_tok, e.width, e.C, e.H, e.depth = S, self.NP, self.n_tok, width, cfg["embed_dim"], cfg["num_heads"], eng.depth
         e.use_cls, e.train = self.use_cls, int(train)
+        e.patch_h, e.patch_w = eng.patch_h, eng.patch_w
         if net == "student":
             e.p32, e.p16, e.p16t, e.g32 = eng.p32.data_ptr(), eng.p16.data_ptr(), eng.p16t.data_ptr(), eng.g32.data_ptr()
         else:
@@ -174,7 +179,7 @@ class EncoderPass:
         self._keep = None
 
     def forward(self, mel: torch.Tensor, valid: torch.Tensor, rowflag: Optional[torch.Tensor], dp_scale: Optional[torch.Tensor]):
-        assert mel.shape == (self.S, 1, 64, self.width) and mel.dtype == torch.float32
+        assert mel.shape == (self.S, 1, self.eng.patch_h, self.width) and mel.dtype == torch.float32
         valid = self.eng.upload(valid)                       # host-side lengths: pinned staging, no stream sync
         self._keep = (mel, valid, rowflag, dp_scale)        # keep inputs alive until backward
         e = self.e
@@ -375,7 +380,7 @@ class AtstEngine:
 
     def __init__(self, arch: str = "small", frame: bool = False, depth: Optional[int] = None, ncrops: int = 2,
                  device: Optional[torch.device] = None, drop_path_rate: float = 0.1, n_pos: int = 251, fp8: bool = False,
-                 symmetric: bool = True, patch_embed: str = "Linear", precise: bool = False):
+                 symmetric: bool = True, patch_embed: str = "Linear", precise: bool = False, patch_h: int = 64, patch_w: int = 4):
         if arch not in ARCH:
             raise RuntimeError("arch {} is not implemented".format(arch))      # ref: models/atst/atst.py:17
         hip.load()                                                               # fail loudly when the .so is missing
@@ -391,9 +396,14 @@ class AtstEngine:
         self.cfg = ARCH[arch]
         self.depth = self.cfg["depth"] if depth is None else depth
         self.n_pos = n_pos
+        # patch geometry: ONE patch row of patch_h (= n_mels) bands x patch_w frames (the reference's --patch_h / --patch_w with
+        # spec_h = n_mels, methods/atstframe/train.py:15,50-51; shipped recipes: 64 x 4; BASELINE configs[4]: 128 x 8 on 32 kHz audio)
+        if (patch_h, patch_w) not in ((64, 4), (64, 8), (128, 4), (128, 8)):
+            raise hip.HipError("supported patch geometries: 64 or 128 mel bands x 4 or 8 frames")
+        self.patch_h, self.patch_w = patch_h, patch_w
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        self.layout = L = FlatLayout(arch, self.depth, frame, patch_embed)
+        self.layout = L = FlatLayout(arch, self.depth, frame, patch_embed, n_pos, patch_h, patch_w)
         dev = self.device
         z = lambda n, dt=torch.float32: torch.zeros(n, dtype=dt, device=dev)
         self.p32, self.g32, self.m32, self.v32 = z(L.n_student), z(L.n_student), z(L.n_student), z(L.n_student)
@@ -589,7 +599,8 @@ class AtstEngine:
     def _valid(self, lengths: torch.Tensor, use_cls: int, n_max: int = 1 << 30) -> torch.Tensor:
         """patch_length + CLS per sequence, clamped to the tokens the pass holds.  ref: audio_transformer.py:70-71,194."""
         l = torch.as_tensor(lengths).to(torch.int64)
-        v = torch.clamp((l - l % 4) // 4, max=n_max - use_cls) + use_cls
+        pw = self.patch_w
+        v = torch.clamp((l - l % pw) // pw, max=n_max - use_cls) + use_cls
         return v.to(torch.int32).contiguous()                       # stays where `lengths` lives (host for DataLoader batches)
 
     def _frame_rows(self, mk: torch.Tensor, valid: torch.Tensor, NP: int, mask_input: bool):

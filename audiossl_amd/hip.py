@@ -42,13 +42,13 @@ class Encoder(C.Structure):
                [("p32", C.c_void_p), ("p16", C.c_void_p), ("p16t", C.c_void_p), ("g32", C.c_void_p), ("off", EncOff),
                 ("mel", C.c_void_p), ("valid", C.c_void_p), ("rowflag", C.c_void_p), ("dp_scale", C.c_void_p),
                 ("ws", C.c_void_p), ("ws_bytes", C.c_size_t), ("tap", C.c_void_p), ("tap_first", C.c_int),
-                ("p8", C.c_void_p), ("w_dq", C.c_void_p), ("fp8", C.c_int)]
+                ("p8", C.c_void_p), ("w_dq", C.c_void_p), ("fp8", C.c_int), ("patch_h", C.c_int), ("patch_w", C.c_int)]
 
 
 _SIGS = {
     "atst_version": (C.c_int, []),
     "atst_tune_gemm_variant": (C.c_int, [C.c_int]),
-    "atst_mel_frontend_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+    "atst_mel_frontend_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "atst_gemm_nt_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                     C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
@@ -87,7 +87,8 @@ _SIGS = {
                                      C.c_void_p]),
     "atst_adamw_ema_step": (C.c_int, [C.c_void_p] * 8 + [C.c_size_t, C.c_size_t] + [C.c_double] * 8 + [C.c_void_p]),
     "atst_encoder_ws_bytes": (C.c_size_t, [C.c_int] * 7),
-    "atst_encoder_hp_ws_bytes": (C.c_size_t, [C.c_int] * 5),
+    "atst_encoder_hp_ws_bytes": (C.c_size_t, [C.c_int] * 7),
+    "atst_encoder_ws_bytes_geo": (C.c_size_t, [C.c_int] * 9),
     "atst_encoder_hp_fwd": (C.c_int, [C.POINTER(Encoder), C.c_void_p]),
     "atst_encoder_hp_bwd": (C.c_int, [C.POINTER(Encoder), C.c_void_p]),
     "atst_encoder_hp_out": (C.c_void_p, [C.POINTER(Encoder)]),

@@ -42,10 +42,11 @@ int atst_tune_gemm_variant(int v);
 
 /* ---- front end: torchaudio MelSpectrogram -> AmplitudeToDB(top_db=80) -> MinMax ---------------------------------
  * replaces audiossl/methods/atst/transform.py:14-33 (`self.mel_feature`) / methods/atstframe/transform.py:16-41.
- * wave [n_clips, n_samples] f32 -> out [n_clips, 64, 1 + n_samples/160] f32.  window: 1024 taps (Hann(win_length)
- * zero-padded centred); fb_*: compact triangular filterbank (64 bands: start bin, length, weights [64, fb_maxlen]).
- * clipmax: n_clips uint32 scratch. */
-int atst_mel_frontend_f32(const float* wave, int n_clips, int n_samples, int win_length, const float* window,
+ * wave: n_clips rows of n_samples f32, row stride wave_ld (0 = n_samples; lets a view be a slice of a longer buffer) ->
+ * out [n_clips, n_mels, 1 + n_samples/160] f32, n_mels = 64 or 128 (the reference's `n_mels` parameter, atstframe/transform.py:14-16;
+ * the sample rate `sr` only enters through the filterbank table).  window: 1024 taps (Hann(win_length) zero-padded centred);
+ * fb_*: compact triangular filterbank (n_mels bands: start bin, length, weights [n_mels, fb_maxlen]).  clipmax: n_clips uint32 scratch. */
+int atst_mel_frontend_f32(const float* wave, int n_clips, int n_samples, int wave_ld, int n_mels, int win_length, const float* window,
                           const float* fb_weights, const int* fb_start, const int* fb_len, int fb_maxlen,
                           float* out, uint32_t* clipmax, void* stream);
 
@@ -179,9 +180,14 @@ typedef struct {
    * (atst_quant_weights_fp8), w_dq = [depth][4] per-tensor factors (qkv, proj, fc1, fc2) that undo the weight scales.
    * Activations are re-quantised per GEMM with fixed scales; saved tensors and the whole backward stay bf16.              */
   const uint8_t* p8; const float* w_dq; int fp8;
+  /* patch geometry: one patch row of patch_h mel bands x patch_w frames (the reference's --patch_h / --patch_w with
+   * patch_h = n_mels, audiossl/methods/atstframe/train.py:15,50-51); 0 = the shipped 64 x 4.  mel is [S,1,patch_h,width],
+   * n_tok = width / patch_w, the patch-embedding weight is [C, patch_h * patch_w] (a multiple of 256, <= 1024).          */
+  int patch_h, patch_w;
 } atst_encoder_t;
 
 size_t atst_encoder_ws_bytes(int S, int NP, int C, int H, int depth, int train, int fp8 /* = atst_encoder_t.fp8: also carve the e4m3 operand copies */);
+size_t atst_encoder_ws_bytes_geo(int S, int NP, int C, int H, int depth, int train, int fp8, int patch_h, int patch_w);   /* same, for a non-default patch geometry */
 /* forward: leaves LN(final) of every token as bf16 [S*NP, C] at atst_encoder_out(); */
 int atst_encoder_fwd(const atst_encoder_t* e, void* stream);
 const uint16_t* atst_encoder_out(const atst_encoder_t* e);
@@ -200,7 +206,7 @@ int atst_encoder_bwd_range(const atst_encoder_t* e, int lo, int hi, void* stream
  * split-bf16 operands ([hi|lo|hi] x [hi|hi|lo], ~2^-17), attention / LayerNorm / GELU in plain fp32 kernels.  Same
  * atst_encoder_t (train is implied, fp8 must be 0, p16 / p16t are not read), its own workspace size; output / upstream-gradient
  * rows are fp32 [S*NP, C].  ~30x slower than the bf16 path: for pinning gradients to the reference at <= 2e-3 on small shapes. */
-size_t atst_encoder_hp_ws_bytes(int S, int NP, int C, int H, int depth);
+size_t atst_encoder_hp_ws_bytes(int S, int NP, int C, int H, int depth, int patch_h, int patch_w);
 int atst_encoder_hp_fwd(const atst_encoder_t* e, void* stream);
 int atst_encoder_hp_bwd(const atst_encoder_t* e, void* stream);
 const float* atst_encoder_hp_out(const atst_encoder_t* e);

@@ -260,10 +260,12 @@ def power_spectrogram(wave: Tensor, win_length: int = N_FFT) -> Tensor:
     return p.reshape(*shape[:-1], p.shape[-2], p.shape[-1])
 
 
-def log_mel(wave: Tensor, win_length: int = N_FFT, n_mels: int = N_MELS) -> Tensor:
+def log_mel(wave: Tensor, win_length: int = N_FFT, n_mels: int = N_MELS, sample_rate: int = SAMPLE_RATE) -> Tensor:
     """wave [B, L] (one clip-view per row) -> normalised log-mel [B, 1, n_mels, T].
-    a1: MelSpectrogram; a2: AmplitudeToDB(power, top_db=80) with ONE max per clip-view; a3: MinMax."""
-    fb = mel_filterbank(n_mels=n_mels)
+    a1: MelSpectrogram; a2: AmplitudeToDB(power, top_db=80) with ONE max per clip-view; a3: MinMax.
+    sample_rate / n_mels: the reference's `sr` / `n_mels` constructor parameters (methods/atstframe/transform.py:14-16); the
+    sample rate only changes the filterbank (hop, n_fft, f_min, f_max are fixed there)."""
+    fb = mel_filterbank(n_mels=n_mels, sample_rate=sample_rate)
     power = power_spectrogram(wave.float(), win_length)                       # [B,513,T]
     mel = torch.matmul(power.transpose(-1, -2), fb).transpose(-1, -2)         # [B,64,T]
     db = 10.0 * torch.log10(torch.clamp(mel, min=1e-10))
@@ -341,10 +343,13 @@ def encoder_tokens(W: Weights, pre: str, mel: Tensor, length: Optional[Tensor], 
                    mask_index: Optional[Tensor] = None, mask_input: bool = True) -> Tuple[Tensor, Optional[Tensor]]:
     """patch-embed + (mask-token blend) + CLS + positional table ("cut").
     ref: audio_transformer.py:153-186 (clip) ; methods/atstframe/audio_transformer.py:161-181 (frame)."""
-    patches = _r(patchify(mel))
+    # patch geometry from the shapes: one patch row of patch_h = spec_h bands (reference --patch_h with spec_h = n_mels) x patch_w frames
+    ph = mel.shape[2]
+    pw = W[pre + "patch_embed.patch_embed.weight"].shape[1] // ph
+    patches = _r(patchify(mel, ph, pw))
     x = _rg(F.linear(patches, _w(W, pre + "patch_embed.patch_embed.weight"), W[pre + "patch_embed.patch_embed.bias"]))
     S, T, C = x.shape
-    plen = patch_length(length, mel.shape[2]) if length is not None else None
+    plen = patch_length(length, mel.shape[2], ph, pw) if length is not None else None
     if mask_index is not None and mask_input:
         m = mask_index.unsqueeze(2).expand(S, T, C).float()
         x = (1 - m) * x + m * W[pre + "mask_embed"].expand(S, T, C)
@@ -624,14 +629,14 @@ def random_mask(num_patches: int, available: int, ratio: float, generator: Optio
 # ----------------------------------------------------------------------------------------------------------------------
 # deterministic weight recipe shared by the golden generator, the tests, bench.py and smoke()
 # ----------------------------------------------------------------------------------------------------------------------
-def encoder_shapes(arch: str, depth: Optional[int] = None, frame: bool = False, n_pos: int = 251):
+def encoder_shapes(arch: str, depth: Optional[int] = None, frame: bool = False, n_pos: int = 251, patch_h: int = PATCH_H, patch_w: int = PATCH_W):
     cfg = ARCH[arch]
     d, depth = cfg["embed_dim"], (cfg["depth"] if depth is None else depth)
     shapes = [("mask_embed", (1, 1, d))]
     if not frame:
         shapes.append(("cls_token", (1, 1, d)))
     shapes += [("pos_embed", (1, n_pos, d)),
-               ("patch_embed.patch_embed.weight", (d, PATCH_H * PATCH_W)), ("patch_embed.patch_embed.bias", (d,))]
+               ("patch_embed.patch_embed.weight", (d, patch_h * patch_w)), ("patch_embed.patch_embed.bias", (d,))]
     for i in range(depth):
         b = f"blocks.{i}."
         shapes += [(b + "norm1.weight", (d,)), (b + "norm1.bias", (d,)),
@@ -651,24 +656,24 @@ def head_shapes(in_dim: int, hidden: int = 4096, out: int = 256):
             ("3.weight", (out, hidden))]
 
 
-def student_shapes(arch: str, depth: Optional[int] = None, frame: bool = False):
+def student_shapes(arch: str, depth: Optional[int] = None, frame: bool = False, patch_h: int = PATCH_H, patch_w: int = PATCH_W):
     """state_dict order of reference ``model.student`` (encoder, projector, predictor)."""
     d = ARCH[arch]["embed_dim"]
-    out = [("encoder." + k, s) for k, s in encoder_shapes(arch, depth, frame)]
+    out = [("encoder." + k, s) for k, s in encoder_shapes(arch, depth, frame, patch_h=patch_h, patch_w=patch_w)]
     out += [("projector." + k, s) for k, s in head_shapes(d)]
     out += [("predictor." + k, s) for k, s in head_shapes(256)]
     return out
 
 
 def recipe_weights(arch: str = "small", depth: Optional[int] = None, frame: bool = False, seed: int = 0,
-                   perturb: bool = True) -> Weights:
+                   perturb: bool = True, patch_h: int = PATCH_H, patch_w: int = PATCH_W) -> Weights:
     """Deterministic numpy (PCG64) weights for student+teacher, state_dict-keyed ('student.*', 'teacher.*').
     NOT the reference's init distribution (that needs torch's RNG stream); it is a fixed, well-conditioned
     recipe that both the golden generator (loading it into the reference model) and the tests rebuild.
     With perturb=True LN/BN affine parameters and biases are non-trivial so that every code path is exercised."""
     rng = np.random.default_rng(seed)
     W: Weights = {}
-    for name, shape in student_shapes(arch, depth, frame):
+    for name, shape in student_shapes(arch, depth, frame, patch_h, patch_w):
         if name.endswith("num_batches_tracked"):
             t = np.zeros((), dtype=np.int64)
         elif name.endswith("running_mean"):
@@ -691,11 +696,11 @@ def recipe_weights(arch: str = "small", depth: Optional[int] = None, frame: bool
     return W
 
 
-def recipe_mel(n_seq: int, width: int = 1001, seed: int = 1) -> Tensor:
-    """Synthetic normalised log-mel in about [-1,1] (smooth + noise), fp32 [n_seq,1,64,width]."""
+def recipe_mel(n_seq: int, width: int = 1001, seed: int = 1, n_mels: int = 64) -> Tensor:
+    """Synthetic normalised log-mel in about [-1,1] (smooth + noise), fp32 [n_seq,1,n_mels,width]."""
     rng = np.random.default_rng(seed)
-    base = rng.standard_normal((n_seq, 1, 64, 1)) * 0.3 + rng.standard_normal((n_seq, 1, 1, width)) * 0.3
-    x = base + 0.3 * rng.standard_normal((n_seq, 1, 64, width))
+    base = rng.standard_normal((n_seq, 1, n_mels, 1)) * 0.3 + rng.standard_normal((n_seq, 1, 1, width)) * 0.3
+    x = base + 0.3 * rng.standard_normal((n_seq, 1, n_mels, width))
     return torch.from_numpy(np.clip(x, -1.0, 1.0).astype(np.float32))
 
 

@@ -35,3 +35,32 @@ def test_mel_known_answers():
     assert abs(float(db.min()) - (float(db.max()) - 80.0)) < 1e-3      # top_db clamp, one max per clip
     sil = fe(torch.zeros(1, 160000).cuda()).cpu()
     assert torch.allclose(sil, torch.full_like(sil, (-100.0 - O.DB_MIN) / (O.DB_MAX - O.DB_MIN) * 2 - 1), atol=1e-6)
+
+
+@pytest.mark.parametrize("win,n", [(1024, 320000), (640, 64000)])
+def test_mel_hires_vs_oracle(win, n):
+    """The reference's `sr` / `n_mels` transform parameters (methods/atstframe/transform.py:14-16) at 32 kHz / 128 bands
+    (BASELINE.json configs[4]); the restated oracle is parity-unpinned at the torchaudio boundary like the 64-band one."""
+    wave = O.recipe_wave(3, n, seed=13)
+    wave[1] *= 0.01
+    wave[2, n // 3:] = 0.0
+    got = LogMelFrontend(win, sr=32000, n_mels=128)(wave.cuda()).cpu()
+    want = O.log_mel(wave, win_length=win, n_mels=128, sample_rate=32000)
+    assert got.shape == want.shape == (3, 1, 128, 1 + n // 160)
+    d = (got - want).abs()
+    assert float(d.max()) < 1e-3, float(d.max())
+    assert float(d.median()) < 2e-5
+
+
+def test_mel_strided_rows_and_shared_output_buffer():
+    """Views are slices of a longer waveform buffer (row stride > view length) and land in ONE [V*B, 1, 64, T] buffer: same
+    numbers as contiguous inputs / separate outputs, no copies (what bench.py and the training transform feed the engine)."""
+    fe = LogMelFrontend(1024)
+    buf = O.recipe_wave(4, 192000, seed=17).cuda()
+    offs = (1001, 20003)                                  # odd offsets: rows are not 8-byte aligned
+    group = torch.empty(8, 1, 64, 1001, device="cuda")
+    for v, o in enumerate(offs):
+        fe(buf[:, o:o + 160000], out=group[4 * v:4 * v + 4])
+    for v, o in enumerate(offs):
+        ref = fe(buf[:, o:o + 160000].contiguous())
+        assert torch.equal(group[4 * v:4 * v + 4], ref)

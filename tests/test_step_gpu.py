@@ -277,9 +277,12 @@ def test_clip_step_vs_reference_golden(name):
         if k in CANCELLING:
             continue
         assert abs(nerr) < (5e-2 if big else 0.4), (k, nerr)
-        # per-tensor rel-L2 vs the fp32 reference: ALL of it is ReLU-gate flips (test_gradient_gap_is_the_relu_gates);
-        # measured worst tensor 0.125 (B=16), 0.19 (6 crops, B=2), 0.8 (2 views, B=2: four BatchNorm rows) -> x1.5
-        assert r < (0.19 if big else (0.28 if ncrops == 6 else 1.2)), (k, r)
+        # per-tensor rel-L2 vs the fp32 reference: ALL of it is ReLU-gate flips (test_gradient_gap_is_the_relu_gates; the same
+        # cases agree with the gate-matched fp32 oracle to <= 9e-5 in parity mode, tests/test_precise_gpu.py);
+        # measured worst tensor 0.125 (B=16), 0.19 (6 crops, B=2) -> x1.5.  2 views at B=2 (four BatchNorm rows) measured 0.8:
+        # a bound above that says nothing, so only the norms are checked there.
+        if big or ncrops == 6:
+            assert r < (0.19 if big else 0.28), (k, r)
     for k in ("student.projector.1.running_mean", "student.projector.1.running_var", "teacher.projector.1.running_var"):
         net, which, _, buf = k.split(".")
         got = eng.bn_buffers[f"{net}.{which}"][buf].cpu()[sample_idx(4096)].numpy()
@@ -407,3 +410,53 @@ def test_optimizer_trajectory_vs_oracle():
             got = eng.param_view("teacher", name).detach().cpu()
             assert float((got - W["teacher." + name]).abs().max()) <= 1e-4, name
     print(f"\n[trajectory] worst |param diff| after 2 steps: {worst:.2e} (lr {lr})")
+
+
+@pytest.mark.parametrize("precise", [False, True])
+def test_hires_patch_geometry_encoder_vs_oracle(precise):
+    """BASELINE.json configs[4] geometry: 128 mel bands, one patch row of 128 x 8 (the reference's --patch_h / --patch_w with
+    spec_h = n_mels, methods/atstframe/train.py:15,50-51), 10 s @ 32 kHz = 2001 frames -> 250 patches, K = 1024 patch vectors.
+    Forward CLS and the gradient of the smooth objective sum(CLS * R) against the CPU oracle's autograd: bf16 path at the bf16
+    tolerances of test_base_arch_encoder_vs_oracle, parity mode at 1e-4."""
+    S, depth = 5, 2
+    W = O.recipe_weights("small", depth=depth, seed=41, patch_h=128, patch_w=8)
+    eng = AtstEngine("small", depth=depth, patch_h=128, patch_w=8, precise=precise)
+    eng.load_weights(W)
+    mel = O.recipe_mel(S, 2001, seed=43, n_mels=128)
+    length = torch.tensor([2001, 2001, 1555, 1281, 809])
+    keep = (torch.rand(depth, 2, S, generator=torch.Generator().manual_seed(9)) > 0.3).float()
+    keep[0] = 1.0
+    leaves = {k: v.requires_grad_(True) for k, v in W.items() if k.startswith("student.encoder.") and v.dtype == torch.float32}
+    cls_o = O.encoder_forward(W, "student.encoder.", mel, length, "small", depth, keep=keep)
+    R = torch.from_numpy(np.random.default_rng(45).standard_normal((S, 384)).astype(np.float32))
+    (cls_o * R).sum().backward()
+    ep = eng._pass("student", S, 2001, True, 0)
+    assert ep.n_tok == 250 and ep.NP == 256
+    valid = eng._valid(length, 1)
+    assert torch.equal(valid.cpu() - 1, O.patch_length(length, 128, 128, 8).int())         # integer: bit-exact
+    out = ep.forward(mel.cuda(), valid, None, eng.drop_path_scales(S, keep))
+    cls = out.float().reshape(S, 256, 384)[:, 0].cpu()
+    assert rel(cls.numpy(), cls_o.detach().numpy()) < (2e-5 if precise else 1e-2)
+    eng.g32.zero_(); ep.dout.zero_()
+    rows = (torch.arange(S, dtype=torch.int32, device="cuda") * 256).contiguous()
+    if precise:
+        ep.dout.index_copy_(0, rows.long(), R.cuda())
+    else:
+        hip.call("atst_scatter_rows_bf16", hip.ptr(R.cuda()), hip.ptr(rows), S, 384, hip.ptr(ep.dout), hip.stream())
+    ep.backward()
+    num = den = 0.0
+    worst = ("", 0.0)
+    for name in eng.layout.entries:
+        if not name.startswith("encoder.") or name == "encoder.mask_embed":
+            continue
+        g = eng.param_view("student", name, grad=True).double().cpu()
+        go = leaves["student." + name].grad.double()
+        r = float((g - go).norm() / (go.norm() + 1e-30))
+        num += r * g.numel(); den += g.numel()
+        if r > worst[1]:
+            worst = (name, r)
+    print(f"\n[hires 128x8 encoder grad, precise={precise}] weighted mean rel-L2 {num / den:.3e}; worst {worst[0]} {worst[1]:.3e}")
+    if precise:
+        assert worst[1] < 1e-4
+    else:
+        assert num / den < 1.0e-2 and worst[1] < 2.4e-2
