@@ -734,7 +734,9 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
       for (int q = 0; q < NPAIR; ++q) {
         const int rl = wid_e * LNROWS + 2 * q + hh, trow = tile_row(rl), row = m0 + trow;
         const char* slot = sIn + q * NT * ROWIN_PAIR_BYTES;
-        if (q > 0 && part > 0) rowin_wait<NVM>(exact_vm);          // this pair's rows have landed (pair 0: in front of the staging barrier; part 0: both)
+        // this pair's rows have landed (pair 0: in front of the staging barrier; part 0: both).  In the LAST part pair 0 issues no
+        // refill, so fewer operations follow this pair's refill than NVM assumes: wait for everything there.
+        if (q > 0 && part > 0) rowin_wait<NVM>(exact_vm && part + 1 < NPART);
         if constexpr (lnbwd) {
           const float mu = sStat[2 * trow], rs = sStat[2 * trow + 1];
           lnb_row(p, row, row < p.M, sC + rl * CLD, sGamma, sScale[trow], mu, rs, slot, p.resid != nullptr, hh, li, lcs);
@@ -1004,7 +1006,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_w4_kernel(GemmArgs p) {
       for (int q = 0; q < 2; ++q) {
         const int rl = wid * 4 + 2 * q + hh, trow = tile_row(rl), row = m0 + trow;
         const char* slot = sIn + q * NT * ROWIN_PAIR_BYTES;
-        if (q > 0 && part > 0) rowin_wait<NVM>(exact_vm);          // this pair's rows have landed (pair 0: in front of the staging barrier; part 0: both)
+        // this pair's rows have landed (pair 0: in front of the staging barrier; part 0: both).  In the LAST part pair 0 issues no
+        // refill, so fewer operations follow this pair's refill than NVM assumes: wait for everything there.
+        if (q > 0 && part > 0) rowin_wait<NVM>(exact_vm && part + 1 < NPART);
         if constexpr (lnbwd) {
           const float mu = sStat[2 * trow], rs = sStat[2 * trow + 1];
           lnb_row(p, row, row < p.M, sC + rl * CLD, sGamma, sScale[trow], mu, rs, slot, p.resid != nullptr, hh, li, lcs);

@@ -365,6 +365,20 @@ def _wgrad(dY, X, M, N, K, dW, ldx=None):
     hip.call("atst_gemm_tn_bf16", hip.ptr(dY), hip.ptr(X), M, N, K, N, K if ldx is None else ldx, hip.ptr(dW), K, 0, hip.stream())
 
 
+def as_one_buffer(views: Sequence[torch.Tensor]) -> Optional[torch.Tensor]:
+    """If the views are consecutive contiguous slices of one device buffer (LogMelFrontend(out=...) wrote them there), the
+    [sum(B_i), ...] tensor over that memory -- no torch.cat; otherwise None."""
+    v0 = views[0]
+    if not all(v.is_cuda and v.is_contiguous() and v.dtype == v0.dtype and v.shape[1:] == v0.shape[1:] for v in views):
+        return None
+    st, ptr = v0.untyped_storage().data_ptr(), v0.data_ptr()
+    for v in views:
+        if v.untyped_storage().data_ptr() != st or v.data_ptr() != ptr:
+            return None
+        ptr += v.numel() * v.element_size()
+    return torch.as_strided(v0, (sum(v.shape[0] for v in views),) + tuple(v0.shape[1:]), v0.stride())
+
+
 def group_views(widths: Sequence[int]) -> List[Tuple[int, int]]:
     """consecutive equal-width views share one encoder pass. ref: audiossl/models/atst/byol.py:107-112."""
     groups, start = [], 0
@@ -636,8 +650,10 @@ class AtstEngine:
         feats, groups = [], []
         use_cls = 0 if self.frame else 1
         for gi, (a, b) in enumerate(group_views([m.shape[-1] for m in mels])):
-            mel = torch.cat([m.to(self.device, torch.float32) for m in mels[a:b]]).contiguous() if b - a > 1 else \
-                mels[a].to(self.device, torch.float32).contiguous()
+            grp = [m.to(self.device, torch.float32) for m in mels[a:b]]
+            mel = grp[0].contiguous() if b - a == 1 else as_one_buffer(grp)
+            if mel is None:
+                mel = torch.cat(grp).contiguous()
             S, width = mel.shape[0], mel.shape[-1]
             ep = self._pass(net, S, width, train, gi)
             valid = self._valid(torch.cat([torch.as_tensor(l).reshape(-1) for l in lengths[a:b]]), use_cls, ep.n_tok + use_cls)

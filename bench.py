@@ -25,10 +25,10 @@ PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak, /opt/skills/guides
 PEAK_HBM_GBS = 8000.0
 
 
-def flops_per_clip(workload: str, d=384, depth=12) -> float:
+def flops_per_clip(workload: str, d=384, depth=12, patch_k=256) -> float:
     """Algorithmic GEMM FLOPs per clip (SURVEY.md 8(d) / BASELINE.md 2): fwd = 1x, bwd = 2x, padding not counted."""
     def enc(N, P):
-        return depth * (24 * N * d * d + 4 * N * N * d) + 2 * P * 256 * d
+        return depth * (24 * N * d * d + 4 * N * N * d) + 2 * P * patch_k * d
     proj, pred = 2 * (d * 4096 + 4096 * 256), 2 * (256 * 4096 + 4096 * 256)
     if workload == "clip2":
         return 2 * enc(251, 250) + 3 * 2 * enc(251, 250) + 2 * proj + 3 * 2 * (proj + pred)
@@ -125,6 +125,9 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"],
                     help="fp8: the four Linear layers of every block run their FORWARD on OCP e4m3 operands (MX-scaled MFMA); "
                          "backward and saved activations stay bf16 (BASELINE.json configs[4]: use with --arch base)")
+    ap.add_argument("--hires", action="store_true",
+                    help="BASELINE.json configs[4] input geometry: 10 s @ 32 kHz, 128 mel bands, one patch row of 128 x 8 (the reference's "
+                         "sr / n_mels / patch_h / patch_w parameters) -> 2001 frames, 250 patches of 1024 values; use with --arch base --dtype fp8")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--profile-stride", type=int, default=7,
@@ -166,19 +169,21 @@ def main():
 
     B, frame = args.batch, args.workload == "frame"
     ncrops = 6 if args.workload == "clip6" else 2
-    eng = AtstEngine(args.arch, frame=frame, ncrops=ncrops, fp8=args.dtype == "fp8")
+    sr, n_mels, patch = (32000, 128, (128, 8)) if args.hires else (16000, 64, (64, 4))
+    clip_len, buf_len = 10 * sr, 12 * sr
+    eng = AtstEngine(args.arch, frame=frame, ncrops=ncrops, fp8=args.dtype == "fp8", patch_h=patch[0], patch_w=patch[1])
     eng.init_weights(seed=0)
     eng.broadcast_parameters()                                       # DDP init: every rank takes rank 0's replica (no-op at world 1)
     eng.overlap_teacher = args.overlap
-    fe = LogMelFrontend(1024 if not frame else 640)
+    fe = LogMelFrontend(1024 if not frame else 640, sr=sr, n_mels=n_mels)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    buf = torch.clamp(0.1 * torch.randn(B, 192000, device=dev, generator=g), -1.0, 1.0)      # 12 s, resident in HBM
+    buf = torch.clamp(0.1 * torch.randn(B, buf_len, device=dev, generator=g), -1.0, 1.0)      # 12 s, resident in HBM
     total = args.warmup + args.steps + 2
     lr_tab = cosine_scheduler_step(5e-4 * world * B / 256, 1e-6, 39100, 1300)
     wd_tab = cosine_scheduler_step(0.04, 0.4, 39100, 0)
     ema_tab = cosine_scheduler_step(0.99, 1, 39100, 0)
     cpu_gen = torch.Generator().manual_seed(99 + rank)
-    offs = torch.randint(0, 192000 - 160000, (total, 6), generator=cpu_gen).tolist()
+    offs = torch.randint(0, buf_len - clip_len, (total, 6), generator=cpu_gen).tolist()
     masks = None
     if frame:
         import numpy as np
@@ -188,18 +193,25 @@ def main():
         # with numpy on the workers: methods/atstframe/transform.py:84-101); generated before the timed region
         mask_sets = [torch.from_numpy(np.stack([block_mask(250, 0.65, 5, rng=rs) for _ in range(B)])) for _ in range(total)]
 
+    # every view group gets ONE [V * B, 1, n_mels, T] buffer: the front end reads the waveform slices in place (row stride) and
+    # writes each view into its rows, so the engine sees a ready concatenated group (no slice copies, no torch.cat)
+    n_glob = 1 if frame else 2
+    g_buf = torch.empty(n_glob * B, 1, n_mels, 1 + clip_len // 160, device=dev)
+    l_buf = torch.empty(4 * B, 1, n_mels, 1 + (clip_len // 10) // 160, device=dev) if ncrops == 6 else None
+    Tg, Tl = 1 + clip_len // 160, 1 + (clip_len // 10) // 160
+
     def step(k):
         nonlocal masks
         o = offs[k]
         if frame:
-            mel = fe(buf[:, o[0]:o[0] + 160000])
-            mels, lens = [mel, mel], [torch.full((B,), 1001)] * 2
+            mel = fe(buf[:, o[0]:o[0] + clip_len], out=g_buf)
+            mels, lens = [mel, mel], [torch.full((B,), Tg)] * 2
         else:
-            mels = [fe(buf[:, o[v]:o[v] + 160000]) for v in range(2)]
-            lens = [torch.full((B,), 1001)] * 2
+            mels = [fe(buf[:, o[v]:o[v] + clip_len], out=g_buf[v * B:(v + 1) * B]) for v in range(2)]
+            lens = [torch.full((B,), Tg)] * 2
             if ncrops == 6:                                  # 4 local views of 1 s -> 101 frames -> 25 patches + CLS
-                mels += [fe(buf[:, o[2 + v]:o[2 + v] + 16000]) for v in range(4)]
-                lens += [torch.full((B,), 101)] * 4
+                mels += [fe(buf[:, o[2 + v]:o[2 + v] + clip_len // 10], out=l_buf[v * B:(v + 1) * B]) for v in range(4)]
+                lens += [torch.full((B,), Tl)] * 4
         if frame:
             masks = [mask_sets[k], mask_sets[k]]              # ONE mask shared by both views (transform.py:99)
         loss, _, _ = eng.forward(mels, lens, masks)
@@ -292,15 +304,17 @@ def main():
     if rank == 0:
         clips = B * world * args.steps
         value = clips / dt
-        fpc = flops_per_clip(args.workload, d=768 if args.arch == "base" else 384)
-        out = {"metric": "pretrain clips/sec (10s@16kHz, ATST-small)" if args.arch == "small" else "pretrain clips/sec (10s@16kHz, ATST-base)", "value": round(value, 2), "unit": "clips/s",
+        fpc = flops_per_clip(args.workload, d=768 if args.arch == "base" else 384, patch_k=patch[0] * patch[1])
+        khz = "32kHz" if args.hires else "16kHz"
+        out = {"metric": f"pretrain clips/sec (10s@{khz}, ATST-{args.arch})", "value": round(value, 2), "unit": "clips/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "bf16" if args.dtype == "bf16" else "fp8 (e4m3 forward GEMMs) + bf16", "data": "synthetic",
                "config": {"workload": {"clip6": "ATST-small clip-level, 2 global (10 s) + 4 local (1 s) views",
                                        "clip2": "ATST-small clip-level, 2 views (10 s)",
                                        "frame": "ATST-Frame small, masked frame objective (10 s)"}[args.workload].replace("small", args.arch) +
-                          ", synthetic AudioSet-shaped 10s@16kHz waveforms, mel front end inside the timed step",
+                          f", synthetic AudioSet-shaped 10s@{khz} waveforms" + (", 128 mel bands, 128 x 8 patches (2001 frames -> 250 tokens)" if args.hires else "") +
+                          ", mel front end inside the timed step",
                           "clips_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
                           "optimizer": "HF-AdamW + EMA teacher (fused)", "drop_path": 0.1},
                "flops_per_clip_G": round(fpc / 1e9, 2), "step_tflops": round(value * fpc / 1e12, 2),
