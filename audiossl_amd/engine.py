@@ -220,6 +220,7 @@ class HeadPass:
     def __init__(self, eng: "AtstEngine", net: str, which: str, in_dim: int):
         self.eng, self.net, self.which, self.in_dim = eng, net, which, in_dim
         self.saved = None
+        self._pending = None
 
     def _w(self, name, transposed=False, f32=False, grad=False):
         eng = self.eng
@@ -234,6 +235,13 @@ class HeadPass:
         return (eng.p16 if self.net == "student" else eng.t16)[off:off + n]
 
     def forward(self, x: torch.Tensor, train: bool) -> torch.Tensor:
+        """One head on its own: local statistics, cross-rank combine, BatchNorm + ReLU + second Linear."""
+        local = self.forward_stats(x)
+        return self.forward_finish(*parallel.combine_bn_stats(*local), train)
+
+    def forward_stats(self, x: torch.Tensor):
+        """First Linear + LOCAL BatchNorm statistics (mean, M2, row count).  Split from forward_finish() so that heads whose inputs
+        do not depend on each other (teacher projector, student projector) share ONE cross-rank exchange."""
         eng, R = self.eng, x.shape[0]
         dev, st = x.device, hip.stream()
         # split-bf16 operands ([hi|lo|hi] x [hi|hi|lo] along K): the Linear in front of BatchNorm+ReLU is evaluated to
@@ -249,9 +257,16 @@ class HeadPass:
         mean, m2 = torch.empty(HEAD_HIDDEN, device=dev), torch.empty(HEAD_HIDDEN, device=dev)
         scratch = torch.empty(32 * HEAD_HIDDEN, device=dev)                          # row-block partials (fixed-order reduction)
         hip.call("atst_bn_stats_f32", hip.ptr(h), R, HEAD_HIDDEN, hip.ptr(mean), hip.ptr(m2), hip.ptr(scratch), st)
-        # SyncBatchNorm: count-weighted combine over ranks (ragged per-rank row counts of ATST-Frame are handled)
-        # count: python float at world size 1, 0-dim device tensor across ranks (ragged per-rank rows: never read back)
-        mean, m2, count = parallel.combine_bn_stats(mean, m2, float(R))
+        self._pending = (x16, h)
+        return mean, m2, float(R)
+
+    def forward_finish(self, mean, m2, count, train: bool) -> torch.Tensor:
+        """SyncBatchNorm with the GLOBAL statistics (count-weighted combine over ranks; ragged per-rank row counts of ATST-Frame are
+        handled; count: python float at world size 1, 0-dim device tensor across ranks, never read back) -> ReLU -> second Linear."""
+        eng = self.eng
+        x16, h = self._pending
+        self._pending = None
+        R, dev, st = h.shape[0], h.device, hip.stream()
         var = m2 / count
         rstd = torch.rsqrt(var + BN_EPS)
         bn = eng.bn_buffers[f"{self.net}.{self.which}"]
@@ -699,9 +714,17 @@ class AtstEngine:
                 t_out = self.heads["teacher.projector"].forward(tf, False)
         else:
             tf, _ = self._run_net("teacher", mels[t_sl], lengths[t_sl], sub(masks, t_sl), False, keep_teacher, False)
-            t_out = self.heads["teacher.projector"].forward(tf, False)
+            t_out = None
         sf, groups = self._run_net("student", mels[s_sl], lengths[s_sl], sub(masks, s_sl), True, keep_student, train)
-        z = self.heads["student.projector"].forward(sf, train)
+        if t_out is None:
+            # the two projectors' BatchNorm statistics do not depend on each other: ONE cross-rank exchange for both
+            # (2 forward SyncBN collectives per step instead of 3; the predictor's needs the student projector's output)
+            tp, sp = self.heads["teacher.projector"], self.heads["student.projector"]
+            st_t, st_s = parallel.combine_bn_stats_multi([tp.forward_stats(tf), sp.forward_stats(sf)])
+            t_out = tp.forward_finish(*st_t, False)
+            z = sp.forward_finish(*st_s, train)
+        else:
+            z = self.heads["student.projector"].forward(sf, train)
         s_out = self.heads["student.predictor"].forward(z, train)
         if self.overlap_teacher:
             main.wait_stream(self._side)
@@ -765,8 +788,7 @@ class AtstEngine:
                 hip.call("atst_scatter_rows_bf16", hip.ptr(src), hip.ptr(rows), n, self.cfg["embed_dim"],
                          hip.ptr(ep.dout), hip.stream())
             if overlap and k == len(order) - 1:
-                nb = max(1, min(self.grad_buckets, self.depth))
-                cuts = [round(self.depth * j / nb) for j in range(nb, -1, -1)]          # depth ... 0
+                cuts = self.bucket_cuts()                                               # depth ... 0
                 top = L.entries["projector.0.weight"][0]
                 for hi, lo in zip(cuts[:-1], cuts[1:]):
                     if hi == lo:
@@ -778,6 +800,16 @@ class AtstEngine:
                     top = a
             else:
                 ep.backward()
+
+    def bucket_cuts(self) -> List[int]:
+        """Block indices at which the encoder gradient is cut into all-reduce buckets, descending from depth to 0.  grad_buckets
+        even slices, then the LAST one (the only one whose reduction is not hidden under backward work) is cut again so that the
+        exposed tail is block 0 + the token stage only (~7 % of the gradient for 12 blocks; it was blocks 0-2 = 25 %)."""
+        nb = max(1, min(self.grad_buckets, self.depth))
+        cuts = [round(self.depth * j / nb) for j in range(nb, -1, -1)]
+        if len(cuts) >= 2 and cuts[-2] > 1:
+            cuts.insert(-1, 1)
+        return cuts
 
     def _reduce_async(self, a: int, b: int):
         """Sum g32[a:b] over ranks on the communication stream, ordered after everything enqueued so far."""

@@ -51,6 +51,30 @@ def combine_bn_stats(mean: torch.Tensor, m2: torch.Tensor, count: float):
     return gmean, gm2, total
 
 
+def combine_bn_stats_multi(items):
+    """combine_bn_stats for several independent BatchNorms in ONE collective.  items: [(mean, M2, count), ...] -> same structure
+    with global values.  (Small collectives are latency-bound: the teacher and student projector exchanges of a step ride together.)"""
+    if not _collective():
+        return [(m, q, float(c)) for m, q, c in items]
+    packs = [torch.cat([m, q, m.new_full((1,), float(c))]) for m, q, c in items]
+    sizes = [p_.numel() for p_ in packs]
+    pack = torch.cat(packs)
+    allp = pack.new_zeros(world_size(), pack.numel())
+    allp[dist.get_rank()] = pack
+    dist.all_reduce(allp)
+    out, off = [], 0
+    for (m, _, _), sz in zip(items, sizes):
+        n = m.numel()
+        blk = allp[:, off:off + sz]
+        means, m2s, cnts = blk[:, :n], blk[:, n:2 * n], blk[:, -1:]
+        total = cnts.sum()
+        gmean = (means * cnts).sum(0) / total
+        gm2 = (m2s + cnts * (means - gmean) ** 2).sum(0)
+        out.append((gmean, gm2, total))
+        off += sz
+    return out
+
+
 def allreduce_bn_backward_sums(sum_dy: torch.Tensor, sum_dy_xhat: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """Global sums for the BatchNorm input gradient; the local sums remain the (to-be-averaged) gamma/beta gradients."""
     if not _collective():

@@ -48,6 +48,13 @@ def _worker(rank, world, port, q):
     summed = P.allreduce_sum_(flat)
     g_full = (2 * (X @ w - t)[:, None] * X).mean(0)
     ok = ok and summed and torch.allclose(flat / world, g_full)
+    # ---- two independent BatchNorms in ONE exchange (teacher + student projector of a step): same numbers as one by one
+    h2 = torch.randn(R, N, dtype=torch.float64) * 0.7 - 1.0
+    h2l = h2[lo:hi + 0] if rank == 0 else h2[lo:hi]
+    m_b = h2l.mean(0); q_b = ((h2l - m_b) ** 2).sum(0)
+    (ma, qa, ca), (mb, qb, cb) = P.combine_bn_stats_multi([(mean_l, m2_l, hl.shape[0]), (m_b, q_b, h2l.shape[0])])
+    ok = ok and torch.allclose(ma, mean) and torch.allclose(qa, m2) and float(ca) == R
+    ok = ok and torch.allclose(mb, h2.mean(0)) and torch.allclose(qb / cb, h2.var(0, unbiased=False)) and float(cb) == R
     # ---- fused monitor all-reduce
     stats = torch.arange(8, dtype=torch.float64).view(4, 2) * (rank + 1)
     st, ns, nt = P.allreduce_monitor_sums(stats, 4.0 + rank, 2.0)
@@ -73,6 +80,8 @@ def test_single_process_helpers_are_identity():
     m, v = torch.randn(8), torch.rand(8)
     assert P.combine_bn_stats(m, v, 5)[2] == 5.0 and P.combine_bn_stats(m, v, 5)[0] is m
     assert P.allreduce_sum_(torch.zeros(3)) is False
+    (a, b, c), = P.combine_bn_stats_multi([(m, v, 5)])
+    assert a is m and b is v and c == 5.0
     assert list(P.shard(10, 1, 4)) == [1, 5] and P.world_size() == 1
     s = torch.tensor([2.0, 4.0]); q = torch.tensor([3.0, 9.0])
     assert torch.isfinite(P.feature_std(s, q, 4.0))
