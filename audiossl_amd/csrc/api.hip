@@ -68,6 +68,13 @@ int atst_gemm_nt_fp8(const uint8_t* A8, const uint8_t* B8, int M, int N, int K, 
   return atst_gemm_nt(a, ST(stream));
 }
 int atst_quant_fp8_bf16(const uint16_t* x, size_t n, float scale, uint8_t* y, void* stream) { return atst_quant_fp8(CBF(x), n, scale, y, ST(stream)); }
+int atst_quant_fp8_dyn_bf16(const uint16_t* x, size_t n, const float* scale, uint8_t* y, float* amax, void* stream) {
+  return atst_quant_fp8_dyn(CBF(x), n, scale, y, amax, ST(stream));
+}
+int atst_fp8_update_scales(float* amax, float* scale, int n, float margin, void* stream) { return ::atst_fp8_update_scales(amax, scale, n, margin, ST(stream)); }
+int atst_quant_bf16_table_fp8(const uint16_t* p16, const int32_t* table, int n, const float* dq, uint8_t* p8, void* stream) {
+  return ::atst_quant_bf16_table_fp8(CBF(p16), table, n, dq, p8, ST(stream));
+}
 int atst_quant_weights_fp8(const float* p32, const int32_t* table, int n, uint8_t* p8, float* dq, float* amax, void* stream) {
   return ::atst_quant_weights_fp8(p32, table, n, p8, dq, amax, ST(stream));
 }

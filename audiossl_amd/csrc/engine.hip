@@ -21,6 +21,7 @@ struct Ws {
   // backward scratch
   float *dxA, *dxB;
   bf16 *g, *g2, *dh, *du, *dqkv, *d_o, *dout;
+  uint8_t *g8, *g28, *du8;            // fp8 dgrad: e4m3 copies of g, g2, du
   float* dscr;
   size_t bytes;
 };
@@ -60,6 +61,7 @@ Ws carve(void* ws, int S, int NP, int C, int H, int depth, int train, int fp8, i
     w.g = c.take<bf16>(M * C); w.g2 = c.take<bf16>(M * C); w.dh = c.take<bf16>(M * C); w.du = c.take<bf16>(M * 4 * C);
     w.dqkv = c.take<bf16>(M * 3 * C); w.d_o = c.take<bf16>(M * C); w.dout = c.take<bf16>(M * C);
     w.dscr = c.take<float>((size_t)S * H * NP);
+    if (fp8) { w.g8 = c.take<uint8_t>(M * C); w.g28 = c.take<uint8_t>(M * C); w.du8 = c.take<uint8_t>(M * 4 * C); }
   }
   w.bytes = (c.off + 255) & ~(size_t)255;
   return w;
@@ -99,6 +101,16 @@ int gemm_lnbwd(const bf16* dY, const bf16* Wt, int M, int K, const float* x, con
   a.A = dY; a.B = Wt; a.M = M; a.N = 384; a.K = K; a.lda = K; a.ldb = K; a.epi = EPI_LNBWD; a.C = dx; a.ldc = 384;
   a.resid = dres; a.row_scale = row_scale; a.rows_per_seq = rps; a.ln_gamma = gamma; a.ln_mean = const_cast<float*>(mean);
   a.ln_rstd = const_cast<float*>(rstd); a.lnb_x = x; a.lnb_g = g; a.lnb_dgamma = dgamma; a.lnb_dbeta = dbeta; a.lnb_dbias_up = dbias_up;
+  return atst_gemm_nt(a, st);
+}
+// e4m3 dgrad GEMM: dY8 [M,K] (gradient operand, quantised with the device scale *a_scale), Wt8 [N,K] (transposed weight shadow, per-tensor
+// factor *w_dq); out = acc * *w_dq / *a_scale.  EPI_DGELU: also the e4m3 copy of du for the next dgrad GEMM + its amax.
+int gemm8_bwd(const uint8_t* dY8, const uint8_t* Wt8, int M, int N, int K, int epi, void* C, hipStream_t st, const float* w_dq, const float* a_scale,
+              const bf16* U = nullptr, float* colsum = nullptr, uint8_t* q8 = nullptr, const float* q8_scale = nullptr, float* q8_amax = nullptr) {
+  GemmArgs a{};
+  a.A = reinterpret_cast<const bf16*>(dY8); a.B = reinterpret_cast<const bf16*>(Wt8); a.M = M; a.N = N; a.K = K; a.lda = K; a.ldb = K;
+  a.epi = epi; a.C = C; a.ldc = N; a.fp8 = 1; a.dq = w_dq; a.dq_mul = 1.0f; a.dq_div = a_scale; a.U = U; a.colsum = colsum;
+  a.q8 = q8; a.q8_scale_ptr = q8_scale; a.q8_amax = q8_amax;
   return atst_gemm_nt(a, st);
 }
 int wgrad(const bf16* dY, const bf16* X, int M, int N, int K, float* dW, hipStream_t st) {
@@ -251,12 +263,21 @@ static int encoder_bwd_range(const atst_encoder_t* e, int lo, int hi, bool head,
   // C == 384: the two N = 384 dgrad GEMMs of a block own whole rows, so their epilogue runs the LayerNorm backward itself
   // (no dh round trip through HBM, no separate pass over x and the residual gradient)
   const bool fuse_lnb = C == 384;
+  // fp8 dgrad (BASELINE.json configs[4]): the fc2 / fc1 / proj dgrad GEMMs of a block on e4m3 operands; qkv dgrad and weight gradients stay bf16.  Gradient
+  // operands use DELAYED scaling: site (block i, k) -- k = 0: g (into fc2), 1: du (into fc1), 2: g2 (into proj); 3 (dqkv) unused -- is
+  // quantised with g8_scale[4 i + k], the scale derived from the amax seen in the previous step, and records this step's amax in
+  // g8_amax[4 i + k]; fp8_bwd == 1 only records (first step: bf16 dgrad), == 2 also computes in fp8.
+  const bool rec8 = e->fp8 && e->fp8_bwd >= 1 && e->g8_amax && !fuse_lnb;
+  const bool use8 = rec8 && e->fp8_bwd >= 2 && e->p8t && e->g8_scale && e->w_dq;
+  auto gs8 = [&](int layer, int k) -> const float* { return use8 ? e->g8_scale + 4 * layer + k : nullptr; };
+  auto ga8 = [&](int layer, int k) -> float* { return rec8 ? e->g8_amax + 4 * layer + k : nullptr; };
   float* cur = w.dxA; float* oth = w.dxB;
   if (head) {
     LnBwdArgs a{};
     a.dy = w.dout; a.x = w.x[2 * D]; a.mean = w.meanN; a.rstd = w.rstdN; a.gamma = p + o.norm_w; a.dres = nullptr;
     a.dx = cur; a.g = w.g; a.row_scale = dps(D - 1, 1); a.rows_per_seq = NP;
     a.dgamma = G + o.norm_w; a.dbeta = G + o.norm_b; a.dbias_up = G + o.layer[D - 1].fc2_b; a.M = M; a.C = C;
+    a.g8 = use8 ? w.g8 : nullptr; a.g8_scale = gs8(D - 1, 0); a.g_amax = ga8(D - 1, 0);
     RUN(atst_ln_bwd(a, st));
   }
   for (int i = hi - 1; i >= lo; --i) {
@@ -265,14 +286,24 @@ static int encoder_bwd_range(const atst_encoder_t* e, int lo, int hi, bool head,
     // ---- MLP branch: x_out = x_mid + s2 * (fc2(gelu(fc1(LN2(x_mid)))) + b2) ; w.g = s2 * d(x_out)
     // The block's four weight gradients are independent of everything downstream: they are launched together after the
     // attention backward (atst_gemm_tn_group), which is why the two residual-branch gradients live in separate buffers.
-    RUN(gemm(w.g, qt + lo_.fc2_w, M, 4 * C, C, EPI_DGELU, w.du, st, nullptr, nullptr, nullptr, 1, nullptr, l.u, G + lo_.fc1_b));
+    if (use8) {
+      RUN(gemm8_bwd(w.g8, e->p8t + lo_.fc2_w, M, 4 * C, C, EPI_DGELU, w.du, st, e->w_dq + 4 * i + 3, gs8(i, 0), l.u, G + lo_.fc1_b,
+                    w.du8, gs8(i, 1), ga8(i, 1)));
+    } else {
+      GemmArgs a{};
+      a.A = w.g; a.B = qt + lo_.fc2_w; a.M = M; a.N = 4 * C; a.K = C; a.lda = C; a.ldb = C; a.epi = EPI_DGELU; a.C = w.du; a.ldc = 4 * C;
+      a.U = l.u; a.colsum = G + lo_.fc1_b; a.rows_per_seq = 1; a.q8_amax = ga8(i, 1);
+      RUN(atst_gemm_nt(a, st));
+    }
     if (fuse_lnb) {
       RUN(gemm_lnbwd(w.du, qt + lo_.fc1_w, M, 4 * C, w.x[2 * i + 1], l.mean2, l.rstd2, p + lo_.ln2_w, cur, oth, w.g2, dps(i, 0), NP,
                      G + lo_.ln2_w, G + lo_.ln2_b, G + lo_.proj_b, st));
       float* t = cur; cur = oth; oth = t;
     } else {
-      RUN(gemm(w.du, qt + lo_.fc1_w, M, C, 4 * C, EPI_BF16, w.dh, st));
+      if (use8) RUN(gemm8_bwd(w.du8, e->p8t + lo_.fc1_w, M, C, 4 * C, EPI_BF16, w.dh, st, e->w_dq + 4 * i + 2, gs8(i, 1)));
+      else RUN(gemm(w.du, qt + lo_.fc1_w, M, C, 4 * C, EPI_BF16, w.dh, st));
       LnBwdArgs a{};
+      a.g8 = use8 ? w.g28 : nullptr; a.g8_scale = gs8(i, 2); a.g_amax = ga8(i, 2);
       a.dy = w.dh; a.x = w.x[2 * i + 1]; a.mean = l.mean2; a.rstd = l.rstd2; a.gamma = p + lo_.ln2_w; a.dres = cur;
       a.dx = oth; a.g = w.g2; a.row_scale = dps(i, 0); a.rows_per_seq = NP;
       a.dgamma = G + lo_.ln2_w; a.dbeta = G + lo_.ln2_b; a.dbias_up = G + lo_.proj_b; a.M = M; a.C = C;
@@ -280,7 +311,8 @@ static int encoder_bwd_range(const atst_encoder_t* e, int lo, int hi, bool head,
       float* t = cur; cur = oth; oth = t;
     }
     // ---- attention branch: x_mid = x_in + s1 * (proj(attn(LN1(x_in))) + bp) ; w.g = s1 * d(x_mid)
-    RUN(gemm(w.g2, qt + lo_.proj_w, M, C, C, EPI_BF16, w.d_o, st));
+    if (use8) RUN(gemm8_bwd(w.g28, e->p8t + lo_.proj_w, M, C, C, EPI_BF16, w.d_o, st, e->w_dq + 4 * i + 1, gs8(i, 2)));
+    else RUN(gemm(w.g2, qt + lo_.proj_w, M, C, C, EPI_BF16, w.d_o, st));
     AttnArgs at{};
     at.qkv = l.qkv; at.valid = e->valid; at.o = l.o; at.lse = l.lse; at.d_o = w.d_o; at.dqkv = w.dqkv; at.dscratch = w.dscr;
     at.S = S; at.H = e->H; at.NP = NP;
@@ -301,8 +333,11 @@ static int encoder_bwd_range(const atst_encoder_t* e, int lo, int hi, bool head,
                      i > 0 ? dps(i - 1, 1) : nullptr, NP, G + lo_.ln1_w, G + lo_.ln1_b, i > 0 ? G + o.layer[i - 1].fc2_b : nullptr, st));
       float* t = cur; cur = oth; oth = t;
     } else {
+      // the qkv dgrad stays bf16: its operand dqkv comes out of the attention backward, and a quantisation pass of its own (906 MB,
+      // 255 us at M = 131072) costs more than the e4m3 GEMM saves (355 -> 188 us); measured 125.4 vs 124.x ms per step
       RUN(gemm(w.dqkv, qt + lo_.qkv_w, M, C, 3 * C, EPI_BF16, w.dh, st));
       LnBwdArgs a{};
+      if (i > 0) { a.g8 = use8 ? w.g8 : nullptr; a.g8_scale = gs8(i - 1, 0); a.g_amax = ga8(i - 1, 0); }
       a.dy = w.dh; a.x = w.x[2 * i]; a.mean = l.mean1; a.rstd = l.rstd1; a.gamma = p + lo_.ln1_w; a.dres = cur;
       a.dx = oth; a.g = i > 0 ? w.g : nullptr; a.row_scale = i > 0 ? dps(i - 1, 1) : nullptr; a.rows_per_seq = NP;
       a.dgamma = G + lo_.ln1_w; a.dbeta = G + lo_.ln1_b; a.dbias_up = i > 0 ? G + o.layer[i - 1].fc2_b : nullptr;

@@ -105,6 +105,13 @@ DEVFN void epilogue8(const GemmArgs& p, int row, int col, f32x4 v0, f32x4 v1, co
     for (int e = 0; e < 4; ++e) { v0[e] *= gelu_grad_f(bf2f(u[e])); v1[e] *= gelu_grad_f(bf2f(u[4 + e])); }
     st_bf16(p.C, idx, v0, v1);
     w0 = v0; w1 = v1;
+    if (p.q8) {                                                    // fp8 dgrad: e4m3 copy of the SAME bf16 values for the fc1 dgrad GEMM (scale in x.s)
+      auto c = [&](float a_) { return __builtin_amdgcn_fmed3f(bf2f(f2bf(a_)) * x.s, -448.f, 448.f); };
+      int lo = __builtin_amdgcn_cvt_pk_fp8_f32(c(v0[0]), c(v0[1]), 0, false); lo = __builtin_amdgcn_cvt_pk_fp8_f32(c(v0[2]), c(v0[3]), lo, true);
+      int hi_w = __builtin_amdgcn_cvt_pk_fp8_f32(c(v1[0]), c(v1[1]), 0, false); hi_w = __builtin_amdgcn_cvt_pk_fp8_f32(c(v1[2]), c(v1[3]), hi_w, true);
+      typedef int v2i_ __attribute__((ext_vector_type(2)));
+      *reinterpret_cast<v2i_*>(p.q8 + idx) = v2i_{lo, hi_w};
+    }
   } else if constexpr (EPI == EPI_PATCH) {
     f32x4 o0 = v0 + x.a0, o1 = v1 + x.a1;
     if (x.s != 0.f) {                                              // mask-token substitution (ATST-Frame)
@@ -679,7 +686,7 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
 #pragma unroll
     for (int q = 0; q < NPAIR; ++q) rowin_part(0, q);
   }
-  const float dqv = F8 ? (p.dq ? *p.dq : 1.0f) * (p.dq_mul != 0.f ? p.dq_mul : 1.0f) : 1.0f;
+  const float dqv = F8 ? (p.dq ? *p.dq : 1.0f) * (p.dq_mul != 0.f ? p.dq_mul : 1.0f) / (p.dq_div ? *p.dq_div : 1.0f) : 1.0f;
   if (tid < BNR) {                                                // visible after the first staging barrier; bias in the same two-plane layout as the tile
     sBias[rowwise ? tid : ((tid >> 3) << 2) + (tid & 3) + ((tid & 4) ? PLANE1 : 0)] = p.bias ? p.bias[n0 + tid] : 0.f;
     if (rowwise) { sGamma[tid] = p.ln_gamma[tid]; if (fused_ln) sBeta[tid] = p.ln_beta[tid]; }
@@ -693,6 +700,8 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
     }
   }
   float dg_col = 0.f;                                             // EPI_DGELU: this thread's column of the fc1 bias gradient
+  float q8s = 1.0f, omax = 0.f;                                   // EPI_DGELU: scale of the e4m3 copy of du ; running max |du| (next step's scale)
+  if constexpr (EPI == EPI_DGELU) { if (p.q8 && p.q8_scale_ptr) q8s = *p.q8_scale_ptr; }
   LnbCols lcs;
   if constexpr (lnbwd) {
 #pragma unroll
@@ -759,10 +768,15 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
         f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = w0;
         if (row < p.M) {
           if constexpr (EPI == EPI_RESID) aux[i].s = sScale[trow];
+          if constexpr (EPI == EPI_DGELU) aux[i].s = q8s;
           epilogue8<EPI>(p, row, n0 + c8, *reinterpret_cast<const f32x4*>(sC + rl * CLD2 + (c8 >> 1)), *reinterpret_cast<const f32x4*>(sC + rl * CLD2 + PLANE1 + (c8 >> 1)),
                          *reinterpret_cast<const f32x4*>(sBias + (c8 >> 1)), *reinterpret_cast<const f32x4*>(sBias + PLANE1 + (c8 >> 1)), aux[i], w0, w1);
         }
         if constexpr (EPI == EPI_DGELU) {
+          if (p.q8_amax) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) omax = fmaxf(omax, fmaxf(fabsf(w0[e]), fabsf(w1[e])));
+          }
           // fc1 bias gradient = column sums of du.  The products go back into this thread's own staging slot (zeros for rows
           // beyond M); after a barrier 384 threads add up one column each over the 32 staged rows -- conflict-free in the
           // two-plane layout -- and keep the running sum in a register.  (One LDS atomic per element made this tile 2.7x
@@ -788,6 +802,10 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
   }
   if constexpr (EPI == EPI_DGELU) {
     if (p.colsum && tid < BNR) atomicAdd(p.colsum + n0 + tid, dg_col);
+    if (p.q8_amax) {
+      omax = wave_max(omax);
+      if (lane == 0 && omax > 0.f) atomicMax(reinterpret_cast<unsigned*>(p.q8_amax), __float_as_uint(omax));
+    }
   }
   if constexpr (lnbwd) lnb_flush<WAVES>(p, lcs, sC, tid);        // 9,216 floats of the staging area, behind a barrier
   if constexpr (fused_ln) {                                       // row statistics of the whole tile: two store instructions per wave instead of two per row
@@ -1364,7 +1382,7 @@ int launch_nt_w4_cfg(const GemmArgs& a, hipStream_t st) {
 template <int EPI>
 int launch_nt_row384(const GemmArgs& a, hipStream_t st) {
   if (a.fp8) {                                                    // e4m3 operands seen as byte pairs: K, lda, ldb are already halved
-    if constexpr (EPI == EPI_BF16 || EPI == EPI_BIAS_GELU || EPI == EPI_RESID || EPI == EPI_F32) {
+    if constexpr (EPI == EPI_BF16 || EPI == EPI_BIAS_GELU || EPI == EPI_RESID || EPI == EPI_F32 || EPI == EPI_DGELU) {
       ProfScope ps(prof_kind<EPI>(), 4.0 * a.M * a.N * a.K, st, nt_bytes<EPI>(a));
       return launch_nt_row384_cfg<EPI, 4, false, true>(a, st);
     } else {
@@ -1442,6 +1460,7 @@ int atst_gemm_nt(const GemmArgs& a0, hipStream_t st) {
       case EPI_F32: return launch_nt_row384<EPI_F32>(a, st);
       case EPI_BIAS_GELU: return launch_nt_row384<EPI_BIAS_GELU>(a, st);
       case EPI_RESID: return launch_nt_row384<EPI_RESID>(a, st);
+      case EPI_DGELU: return launch_nt_row384<EPI_DGELU>(a, st);
     }
     return ATST_EINVAL;
   }
@@ -1527,7 +1546,23 @@ int atst_gemm_tn_group(const WgradArgs* items, int n, hipStream_t st) {
     bytes += 2.0 * items[i].M * ((double)items[i].N + items[i].K) + 4.0 * items[i].N * items[i].K;
   }
   for (int i = n; i <= ATST_WGRAD_GROUP_MAX; ++i) g.first_tile[i] = tiles;
-  int splits = 256 / tiles; if (splits < 1) splits = 1;          // one block per CU, one round
+  // M-splits.  One block per CU is resident; a grid of tiles x splits blocks runs in ceil(tiles splits / 256) rounds of M / splits rows
+  // each, and every split adds one pass of fp32 atomics over the outputs (measured ~1.5 TB/s).  With few tiles (d = 384: 24) one
+  // round of 256 / tiles splits is best; with many (d = 768: 96 tiles -> 2 splits = 192 blocks, a quarter of the chip idle for the
+  // whole launch) several full rounds of shorter blocks win: 96 x 8 = 768 blocks = 3 full rounds.  Cost model per candidate:
+  // rounds / splits x T_M + splits x T_atom, T_M = 41 ns per row of one tile (measured), T_atom = output bytes / 1.5 TB/s.
+  int splits = 1;
+  {
+    double out_bytes = 0; int Mmax = 0;
+    for (int i = 0; i < n; ++i) { out_bytes += 4.0 * items[i].N * items[i].K; Mmax = items[i].M > Mmax ? items[i].M : Mmax; }
+    const double t_m = Mmax * 0.041, t_atom = out_bytes / 1.5e6;          // microseconds
+    double best = 1e30;
+    for (int sp = 1; sp <= 32; ++sp) {
+      if ((long)Mmax / sp < 4 * tnt::RM) break;
+      const double cost = (double)((tiles * sp + 255) / 256) / sp * t_m + sp * t_atom;
+      if (cost < best) { best = cost; splits = sp; }
+    }
+  }
   int max_splits = 1;
   for (int i = 0; i < n; ++i) {
     int mps = (items[i].M + splits - 1) / splits;

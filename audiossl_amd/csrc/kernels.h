@@ -28,6 +28,9 @@ struct GemmArgs {
   const float* lnb_x; bf16* lnb_g; float* lnb_dgamma; float* lnb_dbeta; float* lnb_dbias_up;
   uint8_t* q8; float q8_scale;       // EPI_BIAS_GELU: optional e4m3 copy of the activation * q8_scale (A operand of the fp8 fc2 GEMM)
   float dq_mul;                      // fp8 GEMMs: host factor on top of *dq (1 / activation scale); 0 is read as 1
+  const float* dq_div;               // fp8 GEMMs: optional device scalar the accumulators are DIVIDED by (delayed-scaling quantisation scale of A)
+  const float* q8_scale_ptr;         // EPI_DGELU: device scale of the optional e4m3 copy (q8) of the output; amax of the output -> q8_amax
+  float* q8_amax;
   const float* dq;                   // fp8 GEMMs: device scalar multiplied into the accumulators (1 / (scale_A * scale_B)); null = 1
   int fp8;                           // operands are OCP e4m3 bytes (K, lda, ldb in elements = bytes); MX-scaled MFMA, unit block scales
   int skew;                          // only read by tools/experiments/gemm_r02_variants.hip (start-up skew experiment)
@@ -56,6 +59,7 @@ struct LnBwdArgs {
   float* dx;                         // [M,C] fp32 out: dres + LN backward
   bf16* g;                           // [M,C] bf16 out: row_scale * dx   (operand of the upstream proj / fc2 backward), or null
   const float* row_scale; int rows_per_seq;
+  uint8_t* g8; const float* g8_scale; float* g_amax;   // optional e4m3 copy of g * *g8_scale (fp8 dgrad operand) ; amax of |g| (atomicMax)
   float* dgamma; float* dbeta;       // [C] fp32 accumulated
   float* dbias_up;                   // [C] fp32 accumulated: column sum of g (bias gradient of the upstream linear) or null
   int M, C;
@@ -111,6 +115,9 @@ int atst_byol_loss(const float* student, const float* teacher, int B, int ncrops
 int atst_quant_fp8(const bf16* x, size_t n, float scale, uint8_t* y, hipStream_t st);               // y = e4m3(clamp(x * scale, +-448))
 // every tensor of `table` (device int32 [n][2] = {element offset, numel}, 256-aligned) of a flat fp32 buffer -> e4m3 at the same
 // offsets with a per-tensor scale 448 / amax; dq[t] = amax / 448 (the factor that undoes it).  amax: device scratch [n].
+int atst_quant_fp8_dyn(const bf16* x, size_t n, const float* scale /* device */, uint8_t* y /* or null: amax only */, float* amax /* device, atomicMax */, hipStream_t st);
+int atst_fp8_update_scales(float* amax, float* scale, int n, float margin, hipStream_t st);
+int atst_quant_bf16_table_fp8(const bf16* p16, const int* table, int n, const float* dq, uint8_t* p8, hipStream_t st);
 int atst_quant_weights_fp8(const float* p32, const int* table, int n, uint8_t* p8, float* dq, float* amax, hipStream_t st);
 
 // optimizer

@@ -69,6 +69,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs p) {
   float gm[VPT], dg[VPT], db[VPT], du[VPT];
 #pragma unroll
   for (int i = 0; i < VPT; ++i) { gm[i] = p.gamma[(i >> 1) * 128 + lane * 2 + (i & 1)]; dg[i] = db[i] = du[i] = 0.f; }
+  const float s8 = (p.g8 && p.g8_scale) ? *p.g8_scale : 1.0f;     // fp8 dgrad: delayed-scaling quantisation scale of g
+  float gmax = 0.f;
   for (int row = wave; row < p.M; row += nwaves) {
     const size_t base = (size_t)row * C;
     const float mu = p.mean[row], rs = p.rstd[row];
@@ -102,10 +104,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs p) {
         const float gs = o[e] * sc;
         gq[e] = f2bf(gs);
         du[k] += gs;
+        gmax = fmaxf(gmax, fabsf(gs));
       }
       *reinterpret_cast<f32x2*>(p.dx + base + i * 128 + lane * 2) = o;
       if (p.g) *reinterpret_cast<bf16x2*>(p.g + base + i * 128 + lane * 2) = gq;
+      if (p.g8) {                                                  // e4m3 copy of the SAME bf16 values (A operand of the fp8 dgrad GEMM)
+        const int q = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(bf2f(gq[0]) * s8, -448.f, 448.f),
+                                                      __builtin_amdgcn_fmed3f(bf2f(gq[1]) * s8, -448.f, 448.f), 0, false);
+        *reinterpret_cast<unsigned short*>(p.g8 + base + i * 128 + lane * 2) = (unsigned short)q;
+      }
     }
+  }
+  if (p.g_amax) {
+    gmax = wave_max(gmax);
+    if (lane == 0 && gmax > 0.f) atomicMax(reinterpret_cast<unsigned*>(p.g_amax), __float_as_uint(gmax));
   }
   // block reduction of the three column accumulators, then one atomic per column per block
 #pragma unroll

@@ -150,6 +150,66 @@ __global__ void quant_weights_kernel(const float* __restrict__ p, const int* __r
 }
 }  // namespace
 
+// Gradient operands of the fp8 dgrad GEMMs (delayed scaling): y = e4m3(clamp(x * *scale)) when y != null, and
+// *amax = max(*amax, max |x|) (float bits of a non-negative value order like unsigned) for the NEXT step's scale.
+__global__ void quant_fp8_dyn_kernel(const bf16* __restrict__ x, size_t n8, const float* __restrict__ scale, unsigned* __restrict__ y,
+                                     unsigned* __restrict__ amax) {
+  const float sc = scale ? *scale : 1.0f;
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + i * 8);
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float t = bf2f(v[e]); m = fmaxf(m, fabsf(t)); f[e] = __builtin_amdgcn_fmed3f(t * sc, -448.f, 448.f); }
+    if (y) {
+      int lo = 0, hi = 0;
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false); lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false); hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+      y[i * 2] = (unsigned)lo; y[i * 2 + 1] = (unsigned)hi;
+    }
+  }
+  m = wave_max(m);
+  if (amax && (threadIdx.x & 63) == 0 && m > 0.f) atomicMax(amax, __float_as_uint(m));
+}
+// after a backward: scale[i] = 448 / (margin * amax[i]) for the next step (unchanged where nothing was observed), amax[i] = 0
+__global__ void fp8_update_scales_kernel(float* __restrict__ amax, float* __restrict__ scale, int n, float margin) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float a = amax[i];
+  if (a > 0.f) scale[i] = 448.0f / (margin * a);
+  amax[i] = 0.f;
+}
+// e4m3 copy of the TRANSPOSED bf16 weight shadows (dgrad B operands) with the per-tensor scales of the forward copies (dq = amax / 448)
+__global__ void quant_bf16_table_kernel(const bf16* __restrict__ p, const int* __restrict__ table, const float* __restrict__ dq,
+                                        unsigned char* __restrict__ p8) {
+  const int t = blockIdx.y;
+  const size_t off = (size_t)table[2 * t], n = (size_t)table[2 * t + 1];
+  const float sc = dq[t] > 0.f ? 1.0f / dq[t] : 0.f;
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2; i < n; i += (size_t)gridDim.x * blockDim.x * 2) {
+    const bf16x2 v = *reinterpret_cast<const bf16x2*>(p + off + i);
+    const int q = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(bf2f(v[0]) * sc, -448.f, 448.f),
+                                                  __builtin_amdgcn_fmed3f(bf2f(v[1]) * sc, -448.f, 448.f), 0, false);
+    *reinterpret_cast<unsigned short*>(p8 + off + i) = (unsigned short)q;
+  }
+}
+
+int atst_quant_fp8_dyn(const bf16* x, size_t n, const float* scale, uint8_t* y, float* amax, hipStream_t st) {
+  if (n == 0) return ATST_OK;
+  if (n % 8) return ATST_EINVAL;
+  int grid = (int)((n / 8 + 255) / 256); if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(quant_fp8_dyn_kernel, dim3(grid), dim3(256), 0, st, x, n / 8, scale, reinterpret_cast<unsigned*>(y), reinterpret_cast<unsigned*>(amax));
+  return (int)hipGetLastError();
+}
+int atst_fp8_update_scales(float* amax, float* scale, int n, float margin, hipStream_t st) {
+  if (n <= 0) return ATST_OK;
+  hipLaunchKernelGGL(fp8_update_scales_kernel, dim3((n + 255) / 256), dim3(256), 0, st, amax, scale, n, margin);
+  return (int)hipGetLastError();
+}
+int atst_quant_bf16_table_fp8(const bf16* p16, const int* table, int n, const float* dq, uint8_t* p8, hipStream_t st) {
+  if (n <= 0) return ATST_OK;
+  hipLaunchKernelGGL(quant_bf16_table_kernel, dim3(32, n), dim3(256), 0, st, p16, table, dq, p8);
+  return (int)hipGetLastError();
+}
 int atst_quant_fp8(const bf16* x, size_t n, float scale, uint8_t* y, hipStream_t st) {
   if (n == 0) return ATST_OK;
   if (n % 8) return ATST_EINVAL;

@@ -168,6 +168,8 @@ class EncoderPass:
         if eng.fp8 and not self.precise:
             e.fp8 = 1
             e.p8, e.w_dq = (eng.p8.data_ptr(), eng.dq_s.data_ptr()) if net == "student" else (eng.t8.data_ptr(), eng.dq_t.data_ptr())
+            if net == "student" and train:
+                e.p8t, e.g8_scale, e.g8_amax = eng.p8t.data_ptr(), eng.g8_scale.data_ptr(), eng.g8_amax.data_ptr()
         e.ws, e.ws_bytes = self.ws.buf.data_ptr(), nbytes
         self.e = e
         if self.precise:
@@ -192,6 +194,7 @@ class EncoderPass:
         return self.out
 
     def backward(self):
+        self.e.fp8_bwd = int(getattr(self.eng, "fp8_bwd_state", 0)) if self.eng.fp8 else 0
         if self.precise:
             hip.check(hip.load().atst_encoder_hp_bwd(C.byref(self.e), hip.stream()), "atst_encoder_hp_bwd")
         else:
@@ -203,6 +206,7 @@ class EncoderPass:
 
     def backward_range(self, lo: int, hi: int):
         """blocks [lo, hi) descending (+ final LayerNorm when hi == depth, + token stage when lo == 0)."""
+        self.e.fp8_bwd = int(getattr(self.eng, "fp8_bwd_state", 0)) if self.eng.fp8 else 0
         hip.check(hip.load().atst_encoder_bwd_range(C.byref(self.e), lo, hi, hip.stream()), "atst_encoder_bwd_range")
 
     def tokens(self):
@@ -455,6 +459,13 @@ class AtstEngine:
             self._f8_table = torch.tensor(rows, dtype=torch.int32, device=dev).contiguous()
             self.p8, self.t8 = z(L.n_student, torch.uint8), z(L.n_teacher, torch.uint8)
             self.dq_s, self.dq_t, self._f8_amax = z(len(rows)), z(len(rows)), z(len(rows))
+            # fp8 dgrad (d = 768): e4m3 copy of the transposed weight shadows + delayed-scaling state of the four gradient operands
+            # of every block ([depth][4]: g -> fc2, du -> fc1, g2 -> proj, dqkv -> qkv).  fp8_bwd_state: 0 off, 1 recording, 2 on.
+            self.p8t = z(L.n_student, torch.uint8)
+            self.g8_scale, self.g8_amax = torch.ones(4 * self.depth, device=dev), z(4 * self.depth)
+            import os as _os
+            self.fp8_bwd_state = 1 if (self.cfg["embed_dim"] == 768 and _os.environ.get("ATST_FP8_BWD", "1") != "0") else 0
+            self.fp8_margin = 2.0
         self.bn_buffers: Dict[str, Dict[str, torch.Tensor]] = {}
         for key in ("student.projector", "student.predictor", "teacher.projector"):
             self.bn_buffers[key] = dict(running_mean=z(HEAD_HIDDEN), running_var=torch.ones(HEAD_HIDDEN, device=dev),
@@ -582,6 +593,12 @@ class AtstEngine:
             hip.call("atst_quant_weights_fp8", hip.ptr(p32), hip.ptr(self._f8_table), n, hip.ptr(p8), hip.ptr(dq), hip.ptr(self._f8_amax),
                      hip.stream())
 
+    def _refresh_fp8_transposed(self):
+        """e4m3 copy of the transposed bf16 shadows (dgrad B operands), same per-tensor factors as the forward copies."""
+        if self.fp8 and getattr(self, "fp8_bwd_state", 0):
+            hip.call("atst_quant_bf16_table_fp8", hip.ptr(self.p16t), hip.ptr(self._f8_table), self._f8_table.shape[0], hip.ptr(self.dq_s),
+                     hip.ptr(self.p8t), hip.stream())
+
     def _refresh_transposes(self):
         self._refresh_fp8()
         if getattr(self, "_tr_table", None) is None:
@@ -594,6 +611,7 @@ class AtstEngine:
             self._tr_tiles = tiles
         hip.call("atst_transpose_bf16_batch", hip.ptr(self.p16), hip.ptr(self.p16t), hip.ptr(self._tr_table),
                  self._tr_table.shape[0], self._tr_tiles, hip.stream())
+        self._refresh_fp8_transposed()
 
     # ---------------------------------------------------------------------------------------------------------------
     def _pass(self, net: str, S: int, width: int, train: bool, slot: int) -> EncoderPass:
@@ -800,6 +818,7 @@ class AtstEngine:
                     top = a
             else:
                 ep.backward()
+        self._fp8_after_backward()
 
     def bucket_cuts(self) -> List[int]:
         """Block indices at which the encoder gradient is cut into all-reduce buckets, descending from depth to 0.  grad_buckets
@@ -810,6 +829,13 @@ class AtstEngine:
         if len(cuts) >= 2 and cuts[-2] > 1:
             cuts.insert(-1, 1)
         return cuts
+
+    def _fp8_after_backward(self):
+        """Delayed scaling: this step's amax of every gradient operand becomes the next step's quantisation scale (448 / (margin amax));
+        the first backward only records (bf16 dgrad), every later one runs the dgrad GEMMs on e4m3 operands."""
+        if self.fp8 and getattr(self, "fp8_bwd_state", 0):
+            hip.call("atst_fp8_update_scales", hip.ptr(self.g8_amax), hip.ptr(self.g8_scale), self.g8_amax.numel(), float(self.fp8_margin), hip.stream())
+            self.fp8_bwd_state = 2
 
     def _reduce_async(self, a: int, b: int):
         """Sum g32[a:b] over ranks on the communication stream, ordered after everything enqueued so far."""

@@ -42,7 +42,8 @@ class Encoder(C.Structure):
                [("p32", C.c_void_p), ("p16", C.c_void_p), ("p16t", C.c_void_p), ("g32", C.c_void_p), ("off", EncOff),
                 ("mel", C.c_void_p), ("valid", C.c_void_p), ("rowflag", C.c_void_p), ("dp_scale", C.c_void_p),
                 ("ws", C.c_void_p), ("ws_bytes", C.c_size_t), ("tap", C.c_void_p), ("tap_first", C.c_int),
-                ("p8", C.c_void_p), ("w_dq", C.c_void_p), ("fp8", C.c_int), ("patch_h", C.c_int), ("patch_w", C.c_int)]
+                ("p8", C.c_void_p), ("w_dq", C.c_void_p), ("fp8", C.c_int), ("patch_h", C.c_int), ("patch_w", C.c_int),
+                ("p8t", C.c_void_p), ("g8_scale", C.c_void_p), ("g8_amax", C.c_void_p), ("fp8_bwd", C.c_int)]
 
 
 _SIGS = {
@@ -58,6 +59,9 @@ _SIGS = {
     "atst_gemm_nt_fp8": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_void_p,
                                    C.c_float, C.c_void_p]),
     "atst_quant_fp8_bf16": (C.c_int, [C.c_void_p, C.c_size_t, C.c_float, C.c_void_p, C.c_void_p]),
+    "atst_quant_fp8_dyn_bf16": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "atst_fp8_update_scales": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]),
+    "atst_quant_bf16_table_fp8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "atst_quant_weights_fp8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "atst_gemm_tn_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                     C.c_int, C.c_void_p]),

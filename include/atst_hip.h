@@ -80,6 +80,11 @@ int atst_gemm_nt_fp8(const uint8_t* A8, const uint8_t* B8, int M, int N, int K, 
 int atst_quant_fp8_bf16(const uint16_t* x, size_t n, float scale, uint8_t* y, void* stream);
 /* per-tensor-scaled e4m3 shadows of n tensors of a flat fp32 buffer: table int32 [n][2] = {element offset, numel};
  * dq[t] = amax_t / 448; amax = device scratch [n]                                                                             */
+/* fp8 dgrad support: y = e4m3(clamp(x * *scale)) (y may be NULL: record only) and *amax = max(*amax, max |x|) ; scale[i] = 448 / (margin
+ * amax[i]) then amax[i] = 0 ; e4m3 copy of the transposed bf16 weight shadows with the forward copies' per-tensor factors dq.       */
+int atst_quant_fp8_dyn_bf16(const uint16_t* x, size_t n, const float* scale, uint8_t* y, float* amax, void* stream);
+int atst_fp8_update_scales(float* amax, float* scale, int n, float margin, void* stream);
+int atst_quant_bf16_table_fp8(const uint16_t* p16, const int32_t* table, int n, const float* dq, uint8_t* p8, void* stream);
 int atst_quant_weights_fp8(const float* p32, const int32_t* table, int n, uint8_t* p8, float* dq, float* amax, void* stream);
 /* dW[N,K] += dY[M,N]^T X[M,K]  (fp32 accumulate); autograd of the same nn.Linear calls.                              */
 int atst_gemm_tn_bf16(const uint16_t* dY, const uint16_t* X, int M, int N, int K, int ldy, int ldx, float* dW, int ldw,
@@ -184,6 +189,12 @@ typedef struct {
    * patch_h = n_mels, audiossl/methods/atstframe/train.py:15,50-51); 0 = the shipped 64 x 4.  mel is [S,1,patch_h,width],
    * n_tok = width / patch_w, the patch-embedding weight is [C, patch_h * patch_w] (a multiple of 256, <= 1024).          */
   int patch_h, patch_w;
+  /* fp8 dgrad (C = 768, fp8 != 0): p8t = e4m3 copy of the TRANSPOSED weight shadows (same offsets / per-tensor factors as p8);
+   * g8_scale / g8_amax = [depth][4] device floats, one per gradient operand (g into fc2, du into fc1, g2 into proj, dqkv into qkv):
+   * the operand is quantised with g8_scale (delayed scaling: derived from the previous step's amax by atst_fp8_update_scales) and this
+   * step's max |x| is recorded in g8_amax.  fp8_bwd: 0 = bf16 backward, 1 = bf16 backward + amax recording (first step), 2 = fp8 dgrad.
+   * Weight gradients always use the bf16 operands.                                                                          */
+  const uint8_t* p8t; const float* g8_scale; float* g8_amax; int fp8_bwd;
 } atst_encoder_t;
 
 size_t atst_encoder_ws_bytes(int S, int NP, int C, int H, int depth, int train, int fp8 /* = atst_encoder_t.fp8: also carve the e4m3 operand copies */);

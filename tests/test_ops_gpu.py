@@ -443,3 +443,65 @@ def test_fp8_encoder_forward_and_step_base():
     eng.backward(); eng.optimizer_step(1e-3, 0.04, 0.99)
     assert abs(l8 - l16) < 5e-2 and torch.isfinite(eng.g32).all() and torch.isfinite(eng.p32).all()
     assert float(eng.dq_s.min()) > 0 and not torch.equal(eng.p8[:1 << 20], torch.zeros(1 << 20, dtype=torch.uint8, device=DEV))
+
+
+def test_fp8_dynamic_quantiser_and_scale_update():
+    """Gradient-operand quantiser of the fp8 dgrad path: y = e4m3(clamp(x * scale)), amax recorded by atomicMax, scale update."""
+    n = 8 * 4099
+    x = bf(rnd(n, scale=3e-4, seed=3))
+    scale = torch.tensor([448.0 / (2.0 * 1.2e-3)], device=DEV)
+    amax = torch.zeros(1, device=DEV)
+    y = torch.empty(n, dtype=torch.uint8, device=DEV)
+    hip.call("atst_quant_fp8_dyn_bf16", hip.ptr(x), n, hip.ptr(scale), hip.ptr(y), hip.ptr(amax), hip.stream())
+    assert float(amax) == float(x.float().abs().max())
+    want = torch.clamp(x.float() * scale, -448, 448).to(torch.float8_e4m3fn)
+    assert torch.equal(y.view(torch.float8_e4m3fn).float(), want.float())
+    # record-only mode leaves no output and still tracks amax; the update turns amax into the next scale and clears it
+    amax2 = torch.zeros(2, device=DEV); sc2 = torch.ones(2, device=DEV)
+    hip.call("atst_quant_fp8_dyn_bf16", hip.ptr(x), n, None, None, hip.ptr(amax2), hip.stream())
+    hip.call("atst_fp8_update_scales", hip.ptr(amax2), hip.ptr(sc2), 2, 2.0, hip.stream())
+    assert abs(float(sc2[0]) - 448.0 / (2.0 * float(x.float().abs().max()))) < 1e-3 * float(sc2[0])
+    assert float(sc2[1]) == 1.0 and float(amax2.abs().max()) == 0.0          # nothing observed at site 1: scale unchanged
+
+
+def test_fp8_dgrad_step_base():
+    """BASELINE.json configs[4]: ATST-base with e4m3 forward AND fc2 / fc1 / proj dgrad GEMMs (qkv dgrad and weight gradients on bf16
+    operands).  Delayed scaling:
+    the first backward records the amax of every gradient operand and runs in bf16, every later one quantises with the previous
+    step's scale.  The fp8-dgrad gradients are compared with the bf16-dgrad gradients of the SAME fp8-forward engine state
+    (identical forward, identical weights): e4m3 operands are a 6 % staircase, measured difference per tensor see the print."""
+    from audiossl_amd.engine import AtstEngine
+    from oracle import atst_oracle as O
+    depth = 2
+    W = O.recipe_weights("base", depth=depth, seed=7)
+    mels = [O.recipe_mel(8, 1001, seed=1).to(DEV), O.recipe_mel(8, 1001, seed=2).to(DEV)]
+    lens = [torch.full((8,), 1001)] * 2
+    eng = AtstEngine("base", depth=depth, drop_path_rate=0.0, fp8=True)
+    eng.load_weights(W)
+    assert eng.fp8_bwd_state == 1
+    eng.forward(mels, lens); eng.backward()                       # step 1: bf16 dgrad, amax recorded
+    g_first = eng.g32.clone()
+    sc = eng.g8_scale.view(depth, 4)
+    assert eng.fp8_bwd_state == 2 and float(sc[:, :3].min()) > 1.0 and float(eng.g8_amax.abs().max()) == 0.0   # sites g, du, g2 (qkv dgrad stays bf16)
+    eng.forward(mels, lens); eng.backward()                       # same weights, same inputs: now e4m3 dgrad operands
+    g_fp8 = eng.g32.clone()
+    assert torch.isfinite(g_fp8).all()
+    worst = ("", 0.0)
+    num = den = 0.0
+    for name, (off, shape) in eng.layout.entries.items():
+        n = math.prod(shape)
+        a, b = g_fp8[off:off + n], g_first[off:off + n]
+        if float(b.norm()) == 0.0 or name in ("encoder.pos_embed", "encoder.norm.bias"):
+            continue
+        r = relerr(a, b)
+        num += r * n; den += n
+        if r > worst[1]:
+            worst = (name, r)
+    print(f"\\n[fp8 dgrad vs bf16 dgrad, base depth {depth}] parameter-weighted mean rel-L2 {num / den:.3e}; worst {worst[0]} {worst[1]:.3e}")
+    assert num / den < 8e-2 and worst[1] < 0.2
+    # predictor / projector weight gradients do not pass through any encoder dgrad GEMM: unchanged up to atomics order
+    off, shape = eng.layout.entries["predictor.3.weight"]
+    assert relerr(g_fp8[off:off + math.prod(shape)], g_first[off:off + math.prod(shape)]) < 1e-5
+    eng.optimizer_step(1e-3, 0.04, 0.99)
+    l1 = float(eng.forward(mels, lens)[0]); eng.backward()
+    assert math.isfinite(l1) and torch.isfinite(eng.p32).all()
