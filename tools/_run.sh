@@ -1,4 +1,11 @@
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_ops_gpu.py -x -q -s -k "fp8 or gemm_tn" 2>&1 | grep -E "dgrad|passed|failed|assert" | head
-timeout 300 python bench.py --no-cpu-baseline --steps 20 --workload clip2 --arch base --dtype fp8 --hires 2>/dev/null > gpurun_out/r03_bench_base_fp8_hires.json; cut -c1-120 gpurun_out/r03_bench_base_fp8_hires.json
-timeout 300 python bench.py --no-cpu-baseline --steps 20 --workload clip2 --arch base --dtype fp8 2>/dev/null > gpurun_out/r03_bench_base_fp8.json; cut -c1-120 gpurun_out/r03_bench_base_fp8.json
+for i in 1 2; do
+  (cd _r02 && timeout 300 python bench.py --no-cpu-baseline --steps 40 2>/dev/null | cut -c1-100 | sed 's/^/r02 /')
+  timeout 300 python bench.py --no-cpu-baseline --steps 40 2>/dev/null | cut -c1-100 | sed 's/^/r03 /'
+done
+(cd _r02 && timeout 300 python bench.py --no-cpu-baseline --steps 30 --workload clip2 2>/dev/null | cut -c1-100 | sed 's/^/r02 clip2 /')
+timeout 300 python bench.py --no-cpu-baseline --steps 30 --workload clip2 2>/dev/null | cut -c1-100 | sed 's/^/r03 clip2 /'
+(cd _r02 && timeout 300 python bench.py --no-cpu-baseline --steps 30 --workload frame 2>/dev/null | cut -c1-100 | sed 's/^/r02 frame /')
+timeout 300 python bench.py --no-cpu-baseline --steps 30 --workload frame 2>/dev/null | cut -c1-100 | sed 's/^/r03 frame /')
+(cd _r02 && timeout 300 python bench.py --no-cpu-baseline --steps 20 --workload clip2 --arch base --dtype fp8 2>/dev/null | cut -c1-100 | sed 's/^/r02 base fp8 /')
+timeout 300 python bench.py --no-cpu-baseline --steps 20 --workload clip2 --arch base --dtype fp8 2>/dev/null | cut -c1-100 | sed 's/^/r03 base fp8 /'
