@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
+#include <utility>
 
 typedef __bf16 bf16;
 typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -68,6 +70,32 @@ DEVFN bf16x8 ld_frag(const bf16* p) { return *reinterpret_cast<const bf16x8*>(p)
 DEVFN s16x4 lds_tr4(const bf16* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
 }
+// The same read as inline assembly, for kernels that ALSO fill LDS by LDS-DMA (global_load_lds).  Through the builtin, hipcc's
+// waitcnt insertion treats every ds_read_b64_tr_b16 as a possible reader of every LDS-DMA write in flight and puts
+// `s_waitcnt vmcnt(0)` in front of the first such read after an issue: whatever was just requested -- the NEXT stage / head -- has to
+// land before the CURRENT one can be read, and the prefetch is gone (plain ds_read_b128 loads do not get that wait).  The price:
+// the compiler does not count these reads, so the code waits for them itself -- lds_wait_tied(), which also names the fragments as
+// "+v" operands so that no MFMA consuming them moves above the wait.  Extra reads in flight only make the compiler's own lgkmcnt
+// waits stricter (LDS returns in order), never wrong.
+template <int OFF> DEVFN s16x4 lds_tr4_at(unsigned addr) {         // addr: LDS byte address ; OFF: immediate byte offset
+  s16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <int OFF_LO, int OFF_HI> DEVFN bf16x8 lds_tr8_at(unsigned addr_lo, unsigned addr_hi) {   // rows r.. and r + 8..: one MFMA operand
+  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+  u.s.a = lds_tr4_at<OFF_LO>(addr_lo); u.s.b = lds_tr4_at<OFF_HI>(addr_hi);
+  return u.v;
+}
+DEVFN unsigned lds_addr(const void* p) { return (unsigned)(size_t)(const char __attribute__((address_space(3)))*)p; }
+DEVFN void lds_wait_tied(bf16x8& a, bf16x8& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)); }
+DEVFN void lds_wait_tied(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& d) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+DEVFN void lds_wait_tied(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& d, bf16x8& e, bf16x8& f, bf16x8& g, bf16x8& h) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
+}
+template <int... I, class F> DEVFN void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F> DEVFN void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
 // A-operand fragment of X^T taken from a row-major LDS image X[row][col] (ld elements per row):
 // lane (c = l&31, hi = l>>5) receives X[r0 + 8*(e>>2) + 4*hi + (e&3)][c0 + c], e = 0..7  -- the k-order that a
 // C-layout register block (regs 8t..8t+7) has when it is re-used as the B operand.

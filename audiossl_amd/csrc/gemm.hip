@@ -16,7 +16,7 @@
 //   gemm_tn_tall[_group]_kernel  192x384 weight-gradient tile, the four gradients of a block in one launch
 //   gemm_tn_kernel          128x128 weight-gradient tile for the remaining shapes
 // Measured-and-rejected variants (ping-pong main loop, register epilogue, 64-deep stages, phase skew, split loaders, phase
-// tracers, ablation switches) live in tools/experiments/gemm_r02_variants.hip, not here.
+// tracers, ablation switches) live in tools/experiments/ (gemm_r02_variants.hip ; wgrad_schedule_variants.patch), not here.
 // Reference math being accelerated: nn.Linear in audiossl/modules/transformer.py:109,119,87-90 and
 // audiossl/models/atst/audio_transformer.py:63,69 ; audiossl/models/atst/byol.py:13 ; LayerNorm backward of
 // audiossl/modules/transformer.py:128,132,144-146.
@@ -25,6 +25,7 @@
 #include "profile.h"
 
 #include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -1165,140 +1166,221 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(WgradArgs p) {
 // is 64 contraction rows of both operands, row-major as they lie in HBM ([64][192] and [64][384] bf16 = 24 + 48 KB),
 // brought in by global_load_lds (9 x 1 KiB per wave) into a 2-stage ring (144 KB, one block per CU); the 16-B chunks of a
 // row are XOR-permuted (tr_swz, applied to the per-lane source address) so that the 4-row x 32-column blocks fetched by
-// ds_read_b64_tr_b16 -- the hardware transpose that turns the m-major image into MFMA fragments -- fall on distinct banks.  36.9 KB staged per 64 rows of a 192x384 tile = 8.2 KB per 128x128 unit, against
-// 16 KB for the square tile: the wgrad GEMMs are bound by that L2 -> LDS traffic.
+// ds_read_b64_tr_b16 -- the hardware transpose that turns the m-major image into MFMA fragments -- fall on distinct banks.
+// 36.9 KB staged per 64 rows of a 192x384 tile = 8.2 KB per 128x128 unit, against 16 KB for the square tile.
+// Round 3: the transposing reads are inline assembly and the loop is software-pipelined by hand (tn_tall_body): through the
+// builtin the compiler put `s_waitcnt vmcnt(0)` in front of the first fragment read after every LDS-DMA issue, i.e. the ring never
+// prefetched (706 -> 471 us for the four gradients of a block at M = 131072; profiles/r03_wgrad_schedule.txt).
 namespace tnt {
-constexpr int TN = 192, TK = 384, RM = 64;                            // RM: contraction rows per ring stage
+constexpr int TN = 192, TK = 384;
 constexpr int PY = TN * 2, PX = TK * 2;                               // row pitches in bytes
-constexpr int Y_BYTES = RM * PY, X_BYTES = RM * PX, STAGE = Y_BYTES + X_BYTES;   // 24,576 + 49,152
-// Both operands of a weight gradient are streamed from HBM; with 64-row stages only two fit (144 KB), i.e. one stage of
-// prefetch.  (32-row stages in a 4-deep ring, interleaved issue and dedicated loader waves were measured slower:
-// tools/experiments/gemm_r02_variants.hip, profiles/r02_trace_gemm.txt.)
-constexpr int NST = 2;
-constexpr int LDS = NST * STAGE;                                      // 147,456 B
-constexpr int Y_PIECES = Y_BYTES / 1024, PIECES = STAGE / 1024;       // 1-KiB LDS-DMA pieces per stage: 24 + 48
-constexpr int LOADERS = 8, LOADER0 = 0;
-constexpr int PPW = (PIECES + LOADERS - 1) / LOADERS;                 // pieces per wave per stage: 9
+constexpr int RM_ALIGN = 64;                                          // M-splits are cut at multiples of this (every configuration's stage divides it)
+// NW waves (NW/4 x 4), RM contraction rows per ring stage, NST stages, STAG: the wave rows issue their LDS-DMA share at different
+// points of the stage instead of all together behind the barrier.
+template <int NW_, int RM_, int NST_, int STAG_> struct Cfg {
+  static constexpr int NW = NW_, RM = RM_, NST = NST_, STAG = STAG_, THREADS = NW * 64;
+  static constexpr int WN = NW / 4, WI = 6 / WN;                      // wave rows over the 192 dY columns ; 32-column MFMA tiles per wave along n
+  static constexpr int Y_BYTES = RM * PY, X_BYTES = RM * PX, STAGE = Y_BYTES + X_BYTES, LDS = NST * STAGE;
+  static constexpr int Y_PIECES = Y_BYTES / 1024, PIECES = STAGE / 1024;      // 1-KiB LDS-DMA pieces per stage
+  static constexpr int PPW = (PIECES + NW - 1) / NW, REM = PIECES % NW;       // pieces per wave per stage: PPW (waves < REM when REM != 0) or PPW - 1
+  static_assert(NST >= 2 && NST <= 4 && LDS <= 160 * 1024 && RM_ALIGN % RM == 0 && 6 % WN == 0, "configuration");
+};
 }
 
 // ds_read_b64_tr_b16 is serviced 32 lanes at a time = 4 rows x 64 B of the image, over 64 banks (256 B): the four rows
 // must land in four different 64-B windows.  768-B pitch (== 0 mod 256): window index ^= row & 3; 384-B pitch (rows
 // alternate between offsets 0 and 128): window index ^= (row >> 1) & 1.
 template <int P> DEVFN int tr_swz(int row) { return P % 256 == 0 ? (row & 3) << 2 : ((row >> 1) & 1) << 2; }
-template <int P>
-DEVFN bf16x8 ld_frag_tr_p(const char* X, int r0, int c0, int lane) {
-  const int a = lane & 15, g = lane >> 4;
-  const int row = r0 + 4 * (g >> 1) + (a >> 2);
-  const int col = c0 + (g & 1) * 16 + 4 * (a & 3);                 // element column; 8 elements per 16-B chunk
-  const int pch = (col >> 3) ^ tr_swz<P>(row);
-  const bf16* ptr = reinterpret_cast<const bf16*>(X + row * P + pch * 16) + (col & 7);
-  s16x4 lo = lds_tr4(ptr);
-  s16x4 hi = lds_tr4(ptr + 8 * (P / 2));                           // +8 rows: same swizzle key
+// Transposing reads as inline assembly with explicit waits (common.h: lds_tr4_at): the ring prefetches only with them -- through
+// the builtin every read waited for the stage just requested (5.3 k cycles per 64-row stage for 2.3 k of MFMA).
+template <int OFF, int P> DEVFN bf16x8 ld_frag_tr_at(unsigned addr) {       // rows r and r + 8 of the 16-row group: same swizzle key
   union { struct { s16x4 a, b; } s; bf16x8 v; } u;
-  u.s.a = lo; u.s.b = hi;
+  u.s.a = lds_tr4_at<OFF>(addr); u.s.b = lds_tr4_at<OFF + 8 * P>(addr);
   return u.v;
+}
+// per-lane byte offset of a fragment's first read inside an operand image (row group 0); later row groups are immediate offsets
+template <int P> DEVFN unsigned tr_frag_off(int c0, int lane) {
+  const int a = lane & 15, g = lane >> 4;
+  const int row = 4 * (g >> 1) + (a >> 2);
+  const int col = c0 + (g & 1) * 16 + 4 * (a & 3);                 // element column; 8 elements per 16-B chunk
+  const int pch = (col >> 3) ^ tr_swz<P>(row);                     // the key depends on row bits 0-1 only: unchanged by + 8, + 16 rows
+  return row * P + pch * 16 + (col & 7) * 2;
+}
+
+// Waits for the inline-assembly fragment reads.  The fragments are "+v" operands so that no MFMA that consumes them moves above the wait.
+template <int N> DEVFN void tn_wait_frags(bf16x8 (&f)[5]) {           // N younger reads may stay outstanding
+  asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]) : "n"(N));
+}
+template <int N> DEVFN void tn_wait_frags(bf16x8 (&f)[6]) {
+  asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]) : "n"(N));
+}
+// Stage hand-off: my LDS-DMA pieces up to the stage wanted have landed (N younger ones may be in flight), all my fragment reads are
+// complete; barrier.
+template <int N> DEVFN void tn_handoff(bf16x8 (&f)[5]) {
+  asm volatile("s_waitcnt vmcnt(%5) lgkmcnt(0)\n\ts_barrier" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]) : "n"(N) : "memory");
+}
+template <int N> DEVFN void tn_handoff(bf16x8 (&f)[6]) {
+  asm volatile("s_waitcnt vmcnt(%6) lgkmcnt(0)\n\ts_barrier" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]) : "n"(N) : "memory");
 }
 
 // one (tile, split) of one problem
-DEVFN void tn_tall_body(const WgradArgs& p, int tile, int split, char* smem_raw) {
+template <class C>
+DEVFN void tn_tall_body(const WgradArgs& pa, int tile, int split, char* smem_raw) {
   using namespace tnt;
+  constexpr int RM = C::RM, NST = C::NST, PPW = C::PPW, WI = C::WI, STAGE = C::STAGE, Y_BYTES = C::Y_BYTES, Y_PIECES = C::Y_PIECES;
+  constexpr int NMS = RM / 16, NF = WI + 3, NR = 2 * NF;            // 16-row steps per stage ; fragments / transposing reads per step
+  static_assert(NMS % 2 == 0 && NR <= 15 && (NST - 1) * PPW <= 63, "fragment double buffer parity ; lgkmcnt / vmcnt field widths");
   typedef const void __attribute__((address_space(1))) * gptr_t;
   typedef void __attribute__((address_space(3))) * lptr_t;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  typedef char __attribute__((address_space(3))) * lchar_t;
+  // Everything that is uniform over the wave is made visibly so (SGPRs): the wave index, and the problem's strides -- read through
+  // `pa` (a kernel-argument array indexed by the tile) they were re-loaded from memory next to each use, by a VECTOR load behind a
+  // lane-typed select of the field address, and the s_waitcnt for that load drained every LDS-DMA piece issued before it.
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wid >> 2, wk = wid & 3, hi = lane >> 5, l31 = lane & 31;
-  const int ntk = p.K / TK;
+  const int M = __builtin_amdgcn_readfirstlane(pa.M), K = __builtin_amdgcn_readfirstlane(pa.K);
+  const int ldy = __builtin_amdgcn_readfirstlane(pa.ldy), ldx = __builtin_amdgcn_readfirstlane(pa.ldx), ldw = __builtin_amdgcn_readfirstlane(pa.ldw);
+  const int mps = __builtin_amdgcn_readfirstlane(pa.m_per_split);
+  const int ntk = K / TK;
   const int n0 = (tile / ntk) * TN, k0 = (tile % ntk) * TK;
-  const int m_begin = split * p.m_per_split;
-  int m_end = m_begin + p.m_per_split; if (m_end > p.M) m_end = p.M;
+  const int m_begin = split * mps;
+  int m_end = m_begin + mps; if (m_end > M) m_end = M;
   if (m_begin >= m_end) return;
   const int nst = (m_end - m_begin) / RM;
 
   // lane -> (row, chunk) of the linear stage image.  Piece q (1 KiB) of a stage: q < Y_PIECES -> dY image, else X image;
-  // wave w issues pieces w, w + 8, ...  Stage timeline (tools/trace_tn.py on the variants build, profiles/r02_trace_gemm.txt):
-  // 1.5-2.0 k cycles of LDS-DMA issue, then 2.6-3.3 k cycles for the 2 x 36 MFMAs of a SIMD: 5.3 k per 64 rows.
-  const bool loader = wid >= LOADER0;
-  int off[PPW]; bool isx[PPW]; bool have[PPW]; int ldsoff[PPW];
+  // wave w issues pieces w, w + NW, ...  One source pointer per piece and lane, advanced by RM rows per issued stage.  (Wave-uniform
+  // bases + constant 32-bit lane offsets save registers but put a dependent v_lshl_add_u64 in front of every issue: 4-8 % slower.)
+  const bool hiw = C::REM == 0 || wid < C::REM;                    // this wave issues PPW pieces per stage (else PPW - 1)
+  const bf16* src[PPW]; int step[PPW], ldsoff[PPW];
 #pragma unroll
   for (int j = 0; j < PPW; ++j) {
-    const int q = (wid - LOADER0) + LOADERS * j;
-    have[j] = loader && q < PIECES;
-    isx[j] = q >= Y_PIECES;
-    if (!isx[j]) {
+    const int q = wid + C::NW * j < C::PIECES ? wid + C::NW * j : 0;
+    if (q < Y_PIECES) {
       const int c_ = q * 64 + lane, row = c_ / 24, c = (c_ % 24) ^ tr_swz<PY>(row);
-      off[j] = row * p.ldy + n0 + c * 8; ldsoff[j] = q * 1024;
+      src[j] = pa.dY + (size_t)(m_begin + row) * ldy + n0 + c * 8; step[j] = RM * ldy; ldsoff[j] = q * 1024;
     } else {
       const int c_ = (q - Y_PIECES) * 64 + lane, row = c_ / 48, c = (c_ % 48) ^ tr_swz<PX>(row);
-      off[j] = row * p.ldx + k0 + c * 8; ldsoff[j] = Y_BYTES + (q - Y_PIECES) * 1024;
+      src[j] = pa.X + (size_t)(m_begin + row) * ldx + k0 + c * 8; step[j] = RM * ldx; ldsoff[j] = Y_BYTES + (q - Y_PIECES) * 1024;
     }
   }
-  const bf16* baseY = p.dY + (size_t)m_begin * p.ldy;
-  const bf16* baseX = p.X + (size_t)m_begin * p.ldx;
-  auto issue_piece = [&](int st, int j) {
-    char* buf = smem_raw + (st % NST) * STAGE;
-    if (!have[j]) return;
-    const bf16* src = isx[j] ? baseX + (size_t)st * RM * p.ldx + off[j] : baseY + (size_t)st * RM * p.ldy + off[j];
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + ldsoff[j]), 16, 0, 0);
-  };
-  auto issue_stage = [&](int st) {
+  int issued = 0;                                                  // stages this wave has issued (in order)
+  auto issue_stage = [&]() {
+    char* buf = smem_raw + (issued % NST) * STAGE;
 #pragma unroll
-    for (int j = 0; j < PPW; ++j) issue_piece(st, j);
+    for (int j = 0; j < PPW; ++j) {
+      if (C::REM != 0 && j == PPW - 1 && !hiw) break;
+      __builtin_amdgcn_global_load_lds((gptr_t)src[j], (lptr_t)(buf + ldsoff[j]), 16, 0, 0);
+      src[j] += step[j];
+    }
+    ++issued;
   };
-  f32x16 acc[3][3];
+  f32x16 acc[WI][3];
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
+  for (int i = 0; i < WI; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  const unsigned lds0 = (unsigned)(size_t)(lchar_t)smem_raw;
+  unsigned fa[WI], fb[3];                                          // fragment read addresses inside stage 0
 #pragma unroll
-  for (int s_ = 0; s_ < NST - 1; ++s_)
-    if (s_ < nst) issue_stage(s_);
-  static_assert(NST == 2, "the wait below assumes nothing younger than the stage being waited for");
+  for (int i = 0; i < WI; ++i) fa[i] = lds0 + tr_frag_off<PY>(wn * (WI * 32) + i * 32, lane);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) fb[j] = lds0 + Y_BYTES + tr_frag_off<PX>(wk * 96 + j * 32, lane);
+
+  // Software pipeline over 16-row steps.  The fragments of step t + 1 are requested before the MFMAs of step t (two register
+  // sets); the reads are inline assembly, so every wait is written here and the fragments are tied to it ("+v") to keep the MFMAs
+  // behind it.  The hand-off of a stage sits in the LAST step of the stage before it: wait for my pieces of stage st + 1 (vmcnt; the
+  // younger stages stay in flight) and for my outstanding fragment reads (all of stage st), barrier -- now stage st + 1 is complete
+  // and nobody reads stage st any more, so its buffer takes stage st + NST at once, and step 0 of stage st + 1 is requested under
+  // the last MFMAs of stage st.
+  // STAG: the wave rows issue their pieces at different points, so that the LDS-DMA issue of one wave per SIMD (which blocks that
+  // wave for as long as the memory pipeline is backed up: ~1-2 k cycles per stage) overlaps the MFMAs of the other: row 0 right behind
+  // the hand-off barrier, row 1 in front of the MFMAs of step 0 of the following stage -- before the next hand-off, so the vmcnt counts
+  // there are the same for all.  (Measured, round-robin medians at M = 131072: 471 us ; un-staggered 487 ; 32-row stages in a 4-deep
+  // ring 498, with the issue spread between the MFMAs 485 ; 12 waves of 64 x 96 spill at 168 registers: profiles/r03_wgrad_schedule.txt.)
+  bf16x8 fr[2][NF];
+  auto rd = [&](auto ms_tag, auto set_tag, unsigned so) {
+    constexpr int MS = decltype(ms_tag)::value, SET = decltype(set_tag)::value;
+#pragma unroll
+    for (int i = 0; i < WI; ++i) fr[SET][i] = ld_frag_tr_at<MS * 16 * PY, PY>(fa[i] + so);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) fr[SET][WI + j] = ld_frag_tr_at<MS * 16 * PX, PX>(fb[j] + so);
+  };
+  auto mm = [&](auto set_tag) {
+    constexpr int SET = decltype(set_tag)::value;
+#pragma unroll
+    for (int i = 0; i < WI; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[i][j] = mfma32(fr[SET][i], fr[SET][WI + j], acc[i][j]);
+    // MFMAs are ordinary instructions to the scheduler: without this it floats them across the (volatile) reads and waits of the
+    // following steps -- e.g. two steps' MFMAs merged behind the third wait -- and the overlap becomes an accident of code shape
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto wait_frags = [&](auto set_tag, auto n_tag) { tn_wait_frags<decltype(n_tag)::value>(fr[decltype(set_tag)::value]); };
+  auto handoff = [&](auto set_tag, auto n_tag) { tn_handoff<decltype(n_tag)::value>(fr[decltype(set_tag)::value]); };
+  using I0 = std::integral_constant<int, 0>;
+
+#pragma unroll
+  for (int s_ = 0; s_ < NST; ++s_)
+    if (s_ < nst) issue_stage();
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");     // once per block: everything issued so far has landed
+  rd(I0{}, I0{}, 0u);
   for (int st = 0; st < nst; ++st) {
-    // stage st has landed (mine: vmcnt ; everyone's: barrier), and stage st - 1's buffer is free for the next issue
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    if (st + 1 < nst) issue_stage(st + 1);
-    const char* sY = smem_raw + (st % NST) * STAGE; const char* sX = sY + Y_BYTES;
-#pragma unroll
-    for (int ms = 0; ms < RM / 16; ++ms) {
-      bf16x8 a[3], b[3];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) a[i] = ld_frag_tr_p<PY>(sY, ms * 16, wn * 96 + i * 32, lane);
-#pragma unroll
-      for (int i = 0; i < 3; ++i) b[i] = ld_frag_tr_p<PX>(sX, ms * 16, wk * 96 + i * 32, lane);
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+    const unsigned so = (unsigned)(st % NST) * STAGE, so_next = (unsigned)((st + 1) % NST) * STAGE;
+    const int want = st + NST < nst ? st + NST : nst;              // stages that may have been issued while stage st is being read
+    static_for<NMS>([&](auto ms_tag) {
+      constexpr int MS = decltype(ms_tag)::value;
+      using CUR = std::integral_constant<int, MS & 1>; using NXT = std::integral_constant<int, (MS & 1) ^ 1>;
+      if constexpr (MS < NMS - 1) {
+        rd(std::integral_constant<int, MS + 1>{}, NXT{}, so);
+        if (C::STAG && MS == 0 && wn >= 1 && issued < want) issue_stage();
+        wait_frags(CUR{}, std::integral_constant<int, NR>{});
+        mm(CUR{});
+      } else {
+        const int want1 = st + 1 + NST < nst ? st + 1 + NST : nst; // ... once stage st's buffer is free
+        if (st + 1 < nst) {
+          const int younger = issued - (st + 2);                   // every wave row has issued `want` stages by now
+          if (NST >= 4 && younger >= 2) { if (hiw) handoff(CUR{}, std::integral_constant<int, 2 * PPW>{}); else handoff(CUR{}, std::integral_constant<int, 2 * (PPW - 1)>{}); }
+          else if (NST >= 3 && younger == 1) { if (hiw) handoff(CUR{}, std::integral_constant<int, PPW>{}); else handoff(CUR{}, std::integral_constant<int, PPW - 1>{}); }
+          else handoff(CUR{}, I0{});
+          if ((!C::STAG || wn == 0) && issued < want1) issue_stage();
+          rd(I0{}, NXT{}, so_next);
+        } else {
+          wait_frags(CUR{}, I0{});
+        }
+        mm(CUR{});
       }
-    }
+    });
   }
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
+  for (int i = 0; i < WI; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int n = n0 + wn * 96 + i * 32 + crow32(r, hi);
+      const int n = n0 + wn * (WI * 32) + i * 32 + crow32(r, hi);
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        atomicAdd(p.dW + (size_t)n * p.ldw + k0 + wk * 96 + j * 32 + l31, acc[i][j][r]);
+        atomicAdd(pa.dW + (size_t)n * ldw + k0 + wk * 96 + j * 32 + l31, acc[i][j][r]);
       }
     }
 }
 
-
-__global__ __launch_bounds__(512, 2) void gemm_tn_tall_kernel(WgradArgs p) {
+template <class C>
+__global__ __launch_bounds__(C::THREADS, C::NW / 4) void gemm_tn_tall_kernel(WgradArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int ntiles = (p.N / tnt::TN) * (p.K / tnt::TK);
   const int id = xcd_remap(blockIdx.x, gridDim.x);                // all tiles of one M-split on one XCD (they stream the same rows)
-  tn_tall_body(p, id % ntiles, id / ntiles, smem_raw);
+  tn_tall_body<C>(p, id % ntiles, id / ntiles, smem_raw);
 }
 
 // Several weight gradients in ONE launch (the four of a transformer block): the grid is one round of the chip however
 // many problems share it, so each problem needs 1/n-th of the M-splits it would need alone -- and the fp32 atomics that
 // combine the splits (measured ~1.5 TB/s, 45-50 us per GEMM when each is launched alone) shrink by the same factor.
 struct WgradGroup { WgradArgs it[ATST_WGRAD_GROUP_MAX]; int first_tile[ATST_WGRAD_GROUP_MAX + 1]; int n; };
-__global__ __launch_bounds__(512, 2) void gemm_tn_tall_group_kernel(WgradGroup g) {
+template <class C>
+__global__ __launch_bounds__(C::THREADS, C::NW / 4) void gemm_tn_tall_group_kernel(WgradGroup g) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int ntiles = g.first_tile[g.n];
   const int id = xcd_remap(blockIdx.x, gridDim.x);
@@ -1306,8 +1388,38 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_tall_group_kernel(WgradGroup g
   int k = 0;
 #pragma unroll
   for (int i = 1; i < ATST_WGRAD_GROUP_MAX; ++i) if (i < g.n && t >= g.first_tile[i]) k = i;
-  tn_tall_body(g.it[k], t - g.first_tile[k], split, smem_raw);
+  tn_tall_body<C>(g.it[k], t - g.first_tile[k], split, smem_raw);
 }
+
+int g_tn_cfg = 1;           // 120 + c: wgrad schedule: 0 = every wave issues behind the hand-off ; 1 = wave rows staggered (default) ; 2 = 32-row stages, 4-deep ring
+template <class C> int launch_tn_tall(const WgradArgs& p, int nblk, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_tall_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  hipLaunchKernelGGL(gemm_tn_tall_kernel<C>, dim3(nblk), dim3(C::THREADS), C::LDS, st, p);
+  return (int)hipGetLastError();
+}
+template <class C> int launch_tn_tall_group(const WgradGroup& g, int nblk, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_tall_group_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  hipLaunchKernelGGL(gemm_tn_tall_group_kernel<C>, dim3(nblk), dim3(C::THREADS), C::LDS, st, g);
+  return (int)hipGetLastError();
+}
+#define TN_CFG_DISPATCH(FN, ...)                                              \
+  switch (g_tn_cfg) {                                                         \
+    case 0: return FN<tnt::Cfg<8, 64, 2, 0>>(__VA_ARGS__);                    \
+    case 2: return FN<tnt::Cfg<8, 32, 4, 1>>(__VA_ARGS__);                    \
+    default: return FN<tnt::Cfg<8, 64, 2, 1>>(__VA_ARGS__);                   \
+  }
+int dispatch_tn_tall(const WgradArgs& p, int nblk, hipStream_t st) { TN_CFG_DISPATCH(launch_tn_tall, p, nblk, st) }
+int dispatch_tn_tall_group(const WgradGroup& g, int nblk, hipStream_t st) { TN_CFG_DISPATCH(launch_tn_tall_group, g, nblk, st) }
 
 // Tuning hooks (atst_tune_gemm_variant, include/atst_hip.h); the defaults are the measured best.
 int g_nt_variant = -1;      // -1 auto ; 0: 128x128 2-stage ; 1: 128x128 3-stage ; 3: 256x128 4 waves of 128x64 ; 4: force the row-384 tile
@@ -1445,6 +1557,7 @@ void atst_gemm_nt_set_variant(int v) {
   else if (v >= 306) g_dgelu_row384 = v - 306;
   else if (v >= 302) g_row384_tall = v - 302;
   else if (v >= 300) g_row384_auto = v - 300;
+  else if (v >= 120 && v < 130) g_tn_cfg = v - 120;
   else if (v >= 110) g_tn_rounds = v - 110;
   else if (v >= 105) g_tn_tall = v - 105;
   else if (v < 100) g_nt_variant = v;
@@ -1486,18 +1599,11 @@ int atst_gemm_tn(const WgradArgs& a, hipStream_t st) {
     const int tiles = (a.N / tnt::TN) * (a.K / tnt::TK);
     int splits = 256 / tiles; if (splits < 1) splits = 1;        // one block per CU, one round
     int mps = (a.M + splits - 1) / splits;
-    mps = ((mps + tnt::RM - 1) / tnt::RM) * tnt::RM;
+    mps = ((mps + tnt::RM_ALIGN - 1) / tnt::RM_ALIGN) * tnt::RM_ALIGN;
     p.m_per_split = mps;
     const int nblk = tiles * ((a.M + mps - 1) / mps);
     ProfScope ps(PK_GEMM_TN, 2.0 * p.M * p.N * p.K, st, 2.0 * p.M * ((double)p.N + p.K) + 4.0 * p.N * p.K);
-    static bool tall_attr = false;
-    if (!tall_attr) {
-      hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_tall_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, tnt::LDS);
-      if (e != hipSuccess) return (int)e;
-      tall_attr = true;
-    }
-    hipLaunchKernelGGL(gemm_tn_tall_kernel, dim3(nblk), dim3(512), tnt::LDS, st, p);
-    return (int)hipGetLastError();
+    return dispatch_tn_tall(p, nblk, st);
   }
   const int tiles = (a.N / 128) * (a.K / 128);
   if (p.m_per_split <= 0) {
@@ -1524,7 +1630,7 @@ int atst_gemm_tn(const WgradArgs& a, hipStream_t st) {
 }
 
 bool tn_tall_ok(const WgradArgs& a) {
-  return g_tn_tall && a.N % tnt::TN == 0 && a.K % tnt::TK == 0 && a.M % tnt::RM == 0 && a.M >= 8192 && a.ldy % 8 == 0 && a.ldx % 8 == 0;
+  return g_tn_tall && a.N % tnt::TN == 0 && a.K % tnt::TK == 0 && a.M % tnt::RM_ALIGN == 0 && a.M >= 8192 && a.ldy % 8 == 0 && a.ldx % 8 == 0;
 }
 
 int atst_gemm_tn_group(const WgradArgs* items, int n, hipStream_t st) {
@@ -1558,7 +1664,7 @@ int atst_gemm_tn_group(const WgradArgs* items, int n, hipStream_t st) {
     const double t_m = Mmax * 0.041, t_atom = out_bytes / 1.5e6;          // microseconds
     double best = 1e30;
     for (int sp = 1; sp <= 32; ++sp) {
-      if ((long)Mmax / sp < 4 * tnt::RM) break;
+      if ((long)Mmax / sp < 4 * tnt::RM_ALIGN) break;
       const double cost = (double)((tiles * sp + 255) / 256) / sp * t_m + sp * t_atom;
       if (cost < best) { best = cost; splits = sp; }
     }
@@ -1566,19 +1672,12 @@ int atst_gemm_tn_group(const WgradArgs* items, int n, hipStream_t st) {
   int max_splits = 1;
   for (int i = 0; i < n; ++i) {
     int mps = (items[i].M + splits - 1) / splits;
-    mps = ((mps + tnt::RM - 1) / tnt::RM) * tnt::RM;
+    mps = ((mps + tnt::RM_ALIGN - 1) / tnt::RM_ALIGN) * tnt::RM_ALIGN;
     g.it[i].m_per_split = mps;
     const int sp = (items[i].M + mps - 1) / mps;
     if (sp > max_splits) max_splits = sp;
   }
   ProfScope ps(PK_GEMM_TN, flops, st, bytes);
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_tall_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, tnt::LDS);
-    if (e != hipSuccess) return (int)e;
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(gemm_tn_tall_group_kernel, dim3(tiles * max_splits), dim3(512), tnt::LDS, st, g);
-  return (int)hipGetLastError();
+  return dispatch_tn_tall_group(g, tiles * max_splits, st);
 }
 

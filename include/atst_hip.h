@@ -30,6 +30,7 @@ int atst_version(void);
  * measured best.
  *   -1 auto | 0..3 force a 128x128 / 256x128 nt tile config | 4 force the row-384 tile
  *   105/106 wgrad 192x384 LDS-DMA tile off/on        110+r wgrad grid = r rounds of resident blocks (128x128 tile)
+ *   120/121/122 192x384 wgrad schedule: all waves issue behind the hand-off / wave rows staggered (default) / 32-row stages in a 4-deep ring
  *   300/301 row-384 tile off/on      302/303/304 256-row tile: never / plain bf16 GEMMs / every epilogue
  *   306/307/308 dGELU GEMM on the 256x384 tile: never / always / when K >= 768 (default)
  *   330+m 4-wave two-blocks-per-CU kernels: 0 only for small grids (default, see 360/361) ; 2 everywhere (256x192 + 128x384/LN)
