@@ -34,19 +34,30 @@ DEVFN float wave_max(float v) {
   return v;
 }
 
-// erf-GELU and its derivative (nn.GELU default, ref: audiossl/modules/transformer.py:70-92).  erf by Abramowitz-Stegun
-// 7.1.26 (|abs err| <= 1.5e-7, far below the bf16 rounding of the stored activation); the Gaussian exp(-x^2/2) is shared
-// between cdf and pdf.
-DEVFN void gelu_parts(float x, float& cdf, float& ex) {
+// erf-GELU and its derivative (nn.GELU default, ref: audiossl/modules/transformer.py:70-92).  The Gaussian tail
+// Q(t) = 0.5 erfc(t / sqrt 2), 0 <= t <= 5.5, is exp2 of a degree-6 polynomial in t (weighted minimax fit of log2 Q, tools/gelu_fit.py:
+// |Q err| <= 3e-7, |gelu err| <= 5.7e-7, |gelu' err| <= 6e-7 -- the Abramowitz-Stegun 7.1.26 form it replaces had the same errors but
+// cost a reciprocal, a second exponential argument, and a select): gelu(x) = max(x, 0) - t Q(t), t = min(|x|, 5.5) ; Q(5.5) = 1.9e-8.
+// 6 FMAs (the compiler pairs them into v_pk_fma_f32 across elements) + one v_exp_f32 + 3 more instructions per element; the GELU
+// epilogues are VALU-heavy enough for that to show (fc1 + GELU 317 -> see DESIGN.md).
+DEVFN float gelu_tail(float t) {
+  float r = 2.766765283e-05f;
+  r = fmaf(r, t, -7.205239381e-04f); r = fmaf(r, t, 7.916423492e-03f); r = fmaf(r, t, -5.315121263e-02f);
+  r = fmaf(r, t, -4.589697719e-01f); r = fmaf(r, t, -1.151136756e+00f); r = fmaf(r, t, -9.999993443e-01f);
+  return __builtin_amdgcn_exp2f(r);                     // raw v_exp_f32: the argument is in [-25.7, -1]
+}
+DEVFN float gelu_f(float x) { const float t = fminf(fabsf(x), 5.5f); return fmaf(-t, gelu_tail(t), fmaxf(x, 0.f)); }
+// Derivative Phi(x) + x phi(x): erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7), the Gaussian exp(-x^2/2) shared between cdf and
+// pdf.  (The exp2-polynomial tail + a second exp2 for the pdf is 3 instructions shorter but keeps more values live: the 128x128 dGELU
+// GEMM's epilogue spilled 35 registers with it and went 312 -> 431 us.)
+DEVFN float gelu_grad_f(float x) {
   const float z = fabsf(x) * 0.70710678118654752f;
   const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);   // v_rcp_f32 (1 ulp); __frcp_rn expands to a 10-instruction IEEE division
-  ex = __expf(-z * z);                                  // = exp(-x^2 / 2)
+  const float ex = __expf(-z * z);                                // = exp(-x^2 / 2)
   // half the A&S coefficients: h = 0.5 erfc(|x| / sqrt 2) ; Phi(x) = h for x < 0, 1 - h otherwise (no cancellation in the tail)
   const float h = ((((0.5307027145f * t - 0.7265760135f) * t + 0.7107068705f) * t - 0.142248368f) * t + 0.127414796f) * t * ex;
-  cdf = x < 0.f ? h : 1.0f - h;
+  return (x < 0.f ? h : 1.0f - h) + x * 0.3989422804014327f * ex;
 }
-DEVFN float gelu_f(float x) { float c, e; gelu_parts(x, c, e); return x * c; }
-DEVFN float gelu_grad_f(float x) { float c, e; gelu_parts(x, c, e); return c + x * 0.3989422804014327f * e; }
 
 // XCD-aware, bijective remap of a 1-D grid: block b runs on XCD b%8 (observed, speed only); give every XCD a
 // contiguous chunk of logical ids so that neighbouring tiles share one L2.
