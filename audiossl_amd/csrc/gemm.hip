@@ -331,6 +331,13 @@ template <int MI, int EPI, bool LN> constexpr int lds_bytes() {
 typedef const void __attribute__((address_space(1))) * gptr_t_;
 typedef void __attribute__((address_space(3))) * lptr_t_;
 constexpr int ROWIN_PAIR_BYTES = 2 * 384 * 4;                      // 3072 B: two adjacent fp32 rows
+// 64 floats (one per lane, any per-lane source address) into 64 consecutive LDS floats, asynchronously.  The row-wise epilogues fill
+// their small tables (bias, gamma, beta, per-row DropPath scale, LayerNorm statistics) this way: fetched into registers they cost
+// two exposed round trips (load -> s_waitcnt -> ds_write, twice) at the head of every tile's epilogue, with no register free to
+// start them earlier; as LDS-DMA they land under the staging of part 0, whose vmcnt(0) + barrier covers them.
+DEVFN void lds_fill64(const float* src_lane, float* dst_wave) {
+  __builtin_amdgcn_global_load_lds((gptr_t_)src_lane, (lptr_t_)dst_wave, 4, 0, 0);
+}
 template <int NT>
 DEVFN void rowin_issue(const float* t0, const float* t1, int M, int row0, char* slot, int lane) {
 #pragma unroll
@@ -688,16 +695,32 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
     for (int q = 0; q < NPAIR; ++q) rowin_part(0, q);
   }
   const float dqv = F8 ? (p.dq ? *p.dq : 1.0f) * (p.dq_mul != 0.f ? p.dq_mul : 1.0f) / (p.dq_div ? *p.dq_div : 1.0f) : 1.0f;
-  if (tid < BNR) {                                                // visible after the first staging barrier; bias in the same two-plane layout as the tile
-    sBias[rowwise ? tid : ((tid >> 3) << 2) + (tid & 3) + ((tid & 4) ? PLANE1 : 0)] = p.bias ? p.bias[n0 + tid] : 0.f;
-    if (rowwise) { sGamma[tid] = p.ln_gamma[tid]; if (fused_ln) sBeta[tid] = p.ln_beta[tid]; }
-    if (EPI == EPI_DGELU) sCol[tid] = 0.f;
-  }
-  if constexpr (EPI == EPI_RESID || lnbwd) {
-    if (tid < BMR) {
-      const int row = m0 + tid;
-      sScale[tid] = (p.row_scale && row < p.M) ? p.row_scale[row / p.rows_per_seq] : 1.0f;
-      if constexpr (lnbwd) { const int r = row < p.M ? row : p.M - 1; sStat[2 * tid] = p.ln_mean[r]; sStat[2 * tid + 1] = p.ln_rstd[r]; }
+  if constexpr (rowwise) {                                        // tables by LDS-DMA (lds_fill64): landed by the vmcnt(0) + barrier of part 0
+    const int c = wid_e * 64 + lane_e;                            // column (waves 0-5) / row of the tile (waves 0-3)
+    if (wid_e < BNR / 64) {
+      if (p.bias) lds_fill64(p.bias + n0 + c, sBias + wid_e * 64); else sBias[c] = 0.f;
+      lds_fill64(p.ln_gamma + c, sGamma + wid_e * 64);
+      if (fused_ln) lds_fill64(p.ln_beta + c, sBeta + wid_e * 64);
+    }
+    if (wid_e < BMR / 64) {
+      const int r = m0 + c < p.M ? m0 + c : p.M - 1;              // rows >= M: clamped, never used
+      if (p.row_scale) lds_fill64(p.row_scale + r / p.rows_per_seq, sScale + wid_e * 64); else sScale[c] = 1.0f;
+      if constexpr (lnbwd) { lds_fill64(p.ln_mean + r, sStat + wid_e * 64); lds_fill64(p.ln_rstd + r, sStat + BMR + wid_e * 64); }   // backward: [mean | rstd]
+    }
+  } else {
+    // bias in the same two-plane layout as the tile (position 4 g + e of plane h <- column 8 g + 4 h + e), also by LDS-DMA: the
+    // gather is on the source side.  Landed by the vmcnt(0) in front of part 0's staging barrier.
+    if (wid_e < 6) {
+      const int pos = (wid_e % 3) * 64 + lane_e, plane = wid_e / 3;
+      float* dst = sBias + plane * PLANE1 + (wid_e % 3) * 64;
+      if (p.bias) lds_fill64(p.bias + n0 + 8 * (pos >> 2) + 4 * plane + (pos & 3), dst); else dst[lane_e] = 0.f;
+    }
+    if (EPI == EPI_DGELU && tid < BNR) sCol[tid] = 0.f;
+    if constexpr (EPI == EPI_RESID) {
+      if (tid < BMR) {
+        const int row = m0 + tid;
+        sScale[tid] = (p.row_scale && row < p.M) ? p.row_scale[row / p.rows_per_seq] : 1.0f;
+      }
     }
   }
   float dg_col = 0.f;                                             // EPI_DGELU: this thread's column of the fc1 bias gradient
@@ -737,6 +760,7 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
         const int idx = tid + THREADS * i, row = m0 + tile_row(idx / 48);
         if (row < p.M) epi_fetch8<EPI, false>(p, row, n0 + (idx % 48) * 8, aux[i]);
       }
+      if (part == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the bias table (LDS-DMA) has landed -- mine; the barrier makes it everyone's
     }
     lds_barrier();
     if constexpr (rowwise) {
@@ -748,7 +772,7 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
         // refill, so fewer operations follow this pair's refill than NVM assumes: wait for everything there.
         if (q > 0 && part > 0) rowin_wait<NVM>(exact_vm && part + 1 < NPART);
         if constexpr (lnbwd) {
-          const float mu = sStat[2 * trow], rs = sStat[2 * trow + 1];
+          const float mu = sStat[trow], rs = sStat[BMR + trow];
           lnb_row(p, row, row < p.M, sC + rl * CLD, sGamma, sScale[trow], mu, rs, slot, p.resid != nullptr, hh, li, lcs);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the slot has been read: refill it with the next part's rows
           if (part + 1 < NPART) rowin_part(part + 1, q);
@@ -980,21 +1004,35 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_w4_kernel(GemmArgs p) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) rowin_part(0, q);
   }
-  for (int c = tid; c < BNB; c += 256) {
-    sBias[rowwise ? c : ((c >> 3) << 2) + (c & 3) + ((c & 4) ? G::PL1 : 0)] = p.bias ? p.bias[n0 + c] : 0.f;
-    if (rowwise) { sGamma[c] = p.ln_gamma[c]; if (fused_ln) sBeta[c] = p.ln_beta[c]; }
-    if (EPI == EPI_DGELU) sCol[c] = 0.f;
+  if constexpr (rowwise) {                                        // tables by LDS-DMA (lds_fill64), see the 8-wave kernel
+#pragma unroll
+    for (int c0 = wid * 64; c0 < BNB; c0 += 256) {
+      const int c = c0 + lane;
+      if (p.bias) lds_fill64(p.bias + n0 + c, sBias + c0); else sBias[c] = 0.f;
+      lds_fill64(p.ln_gamma + c, sGamma + c0);
+      if (fused_ln) lds_fill64(p.ln_beta + c, sBeta + c0);
+    }
+  } else {
+    for (int c = tid; c < BNB; c += 256) {
+      sBias[((c >> 3) << 2) + (c & 3) + ((c & 4) ? G::PL1 : 0)] = p.bias ? p.bias[n0 + c] : 0.f;
+      if (EPI == EPI_DGELU) sCol[c] = 0.f;
+    }
   }
   LnbCols lcs;
   if constexpr (lnbwd) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) lcs.dg[i] = lcs.db[i] = lcs.du[i] = 0.f;
   }
-  if constexpr (EPI == EPI_RESID || lnbwd) {
+  if constexpr (rowwise) {
+    if (wid < BM / 64) {
+      const int t = wid * 64 + lane, r = m0 + t < p.M ? m0 + t : p.M - 1;
+      if (p.row_scale) lds_fill64(p.row_scale + r / p.rows_per_seq, sScale + wid * 64); else sScale[t] = 1.0f;
+      if constexpr (lnbwd) { lds_fill64(p.ln_mean + r, sStat + wid * 64); lds_fill64(p.ln_rstd + r, sStat + BM + wid * 64); }   // backward: [mean | rstd]
+    }
+  } else if constexpr (EPI == EPI_RESID) {
     if (tid < BM) {
       const int row = m0 + tid;
       sScale[tid] = (p.row_scale && row < p.M) ? p.row_scale[row / p.rows_per_seq] : 1.0f;
-      if constexpr (lnbwd) { const int r = row < p.M ? row : p.M - 1; sStat[2 * tid] = p.ln_mean[r]; sStat[2 * tid + 1] = p.ln_rstd[r]; }
     }
   }
 #pragma unroll
@@ -1029,7 +1067,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_w4_kernel(GemmArgs p) {
         // refill, so fewer operations follow this pair's refill than NVM assumes: wait for everything there.
         if (q > 0 && part > 0) rowin_wait<NVM>(exact_vm && part + 1 < NPART);
         if constexpr (lnbwd) {
-          const float mu = sStat[2 * trow], rs = sStat[2 * trow + 1];
+          const float mu = sStat[trow], rs = sStat[BM + trow];
           lnb_row(p, row, row < p.M, sC + rl * CLD, sGamma, sScale[trow], mu, rs, slot, p.resid != nullptr, hh, li, lcs);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the slot has been read: refill it with the next part's rows
           if (part + 1 < NPART) rowin_part(part + 1, q);

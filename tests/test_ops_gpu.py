@@ -108,9 +108,11 @@ def test_gemm_tn(M, N, K, split):
     assert relerr(dW, ref) < 2e-5
 
 
-@pytest.mark.parametrize("M", [8192, 1000])          # 192x384 LDS-DMA tiles in one launch / per-problem fallback
-def test_gemm_tn_group(M):
+@pytest.mark.parametrize("hook", [121, 120, 122])    # wgrad schedules: staggered issue (default) / all waves behind the hand-off / 32-row stages in a 4-deep ring
+@pytest.mark.parametrize("M", [8192, 8192 + 192, 32768 + 64, 1000])   # 192x384 LDS-DMA tiles in one launch (whole / ragged last split) / per-problem fallback
+def test_gemm_tn_group(M, hook):
     import ctypes as C
+    hip.load().atst_tune_gemm_variant(hook)
     shapes = [(1536, 384), (384, 1536), (1152, 384), (384, 384)]
     items = (hip.Wgrad * 4)()
     keep, want = [], []
@@ -121,6 +123,8 @@ def test_gemm_tn_group(M):
         want.append(dY.float().t() @ X.float() + 0.25)
         items[i] = hip.Wgrad(hip.ptr(dY), hip.ptr(X), hip.ptr(dW), M, N, K, N, K, K)
     hip.call("atst_gemm_tn_group_bf16", C.cast(items, C.c_void_p), 4, hip.stream())
+    torch.cuda.synchronize()
+    hip.load().atst_tune_gemm_variant(121)
     for (dY, X, dW), ref in zip(keep, want):
         assert relerr(dW, ref) < 2e-5
 
