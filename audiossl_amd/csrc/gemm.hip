@@ -1290,8 +1290,11 @@ DEVFN void tn_tall_body(const WgradArgs& pa, int tile, int split, char* smem_raw
   const int M = __builtin_amdgcn_readfirstlane(pa.M), K = __builtin_amdgcn_readfirstlane(pa.K);
   const int ldy = __builtin_amdgcn_readfirstlane(pa.ldy), ldx = __builtin_amdgcn_readfirstlane(pa.ldx), ldw = __builtin_amdgcn_readfirstlane(pa.ldw);
   const int mps = __builtin_amdgcn_readfirstlane(pa.m_per_split);
-  const int ntk = K / TK;
-  const int n0 = (tile / ntk) * TN, k0 = (tile % ntk) * TK;
+  // Tile order inside a problem: the operand with FEWER panels varies fastest, so that neighbouring tiles -- which is where an M-split
+  // gets cut between two XCDs (30 blocks per XCD, 24 tiles per split) -- differ in the cheaper operand: fc2 (2 dY panels x 4 X panels)
+  // cut in the middle re-fetches its 768 B/row of dY on the second XCD instead of 3072 B/row of X (measured: -0.6 %).
+  const int ntk = K / TK, ntn = __builtin_amdgcn_readfirstlane(pa.N) / TN;
+  const int n0 = (ntn < ntk ? tile % ntn : tile / ntk) * TN, k0 = (ntn < ntk ? tile / ntn : tile % ntk) * TK;
   const int m_begin = split * mps;
   int m_end = m_begin + mps; if (m_end > M) m_end = M;
   if (m_begin >= m_end) return;
