@@ -734,7 +734,13 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
       }
     }
   }
-  float dg_col = 0.f;                                             // EPI_DGELU: this thread's column of the fc1 bias gradient
+  // EPI_DGELU: column sums of du (fc1 bias gradient).  A thread's slot i covers the same 8 columns in every part, so it keeps 8 running
+  // sums per slot in registers (the accumulator blocks retired by the staging make room) and the block folds them ONCE, after the
+  // last part.  (Writing each part's products back to the staging tile and summing columns behind two more barriers per part cost
+  // the base-geometry dGELU GEMM ~25 %; one LDS atomic per element 2.7x.)
+  f32x4 csr[EPI == EPI_DGELU ? SLOTS : 1][2];
+#pragma unroll
+  for (int i = 0; i < (EPI == EPI_DGELU ? SLOTS : 1); ++i) { csr[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; csr[i][1] = csr[i][0]; }
   float q8s = 1.0f, omax = 0.f;                                   // EPI_DGELU: scale of the e4m3 copy of du ; running max |du| (next step's scale)
   if constexpr (EPI == EPI_DGELU) { if (p.q8 && p.q8_scale_ptr) q8s = *p.q8_scale_ptr; }
   LnbCols lcs;
@@ -813,31 +819,30 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
 #pragma unroll
             for (int e = 0; e < 4; ++e) omax = fmaxf(omax, fmaxf(fabsf(w0[e]), fabsf(w1[e])));
           }
-          // fc1 bias gradient = column sums of du.  The products go back into this thread's own staging slot (zeros for rows
-          // beyond M); after a barrier 384 threads add up one column each over the 32 staged rows -- conflict-free in the
-          // two-plane layout -- and keep the running sum in a register.  (One LDS atomic per element made this tile 2.7x
-          // slower than the 128x128 kernel: 2624 vs 950 us at the base geometry.)
-          if (p.colsum) {
-            *reinterpret_cast<f32x4*>(sC + rl * CLD2 + (c8 >> 1)) = w0;
-            *reinterpret_cast<f32x4*>(sC + rl * CLD2 + PLANE1 + (c8 >> 1)) = w1;
-          }
-        }
-      }
-      if constexpr (EPI == EPI_DGELU) {
-        if (p.colsum) {
-          lds_barrier();
-          if (tid < BNR) {
-            const int ph = ((tid >> 3) << 2) + (tid & 3) + ((tid & 4) ? PLANE1 : 0);
-#pragma unroll 8
-            for (int r = 0; r < RP; ++r) dg_col += sC[r * CLD2 + ph];
-          }
+          csr[i][0] += w0; csr[i][1] += w1;                        // rows beyond M contribute zeros
         }
       }
     }
     if (part < NPART - 1) lds_barrier();
   }
   if constexpr (EPI == EPI_DGELU) {
-    if (p.colsum && tid < BNR) atomicAdd(p.colsum + n0 + tid, dg_col);
+    if (p.colsum) {                                               // fold the 32 row slots of every column: the slots' sums go to their staging positions once
+      lds_barrier();
+#pragma unroll
+      for (int i = 0; i < SLOTS; ++i) {
+        const int idx = tid + THREADS * i, rl = idx / 48, c8 = (idx % 48) * 8;
+        *reinterpret_cast<f32x4*>(sC + rl * CLD2 + (c8 >> 1)) = csr[i][0];
+        *reinterpret_cast<f32x4*>(sC + rl * CLD2 + PLANE1 + (c8 >> 1)) = csr[i][1];
+      }
+      lds_barrier();
+      if (tid < BNR) {
+        const int ph = ((tid >> 3) << 2) + (tid & 3) + ((tid & 4) ? PLANE1 : 0);
+        float t = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < RP; ++r) t += sC[r * CLD2 + ph];
+        atomicAdd(p.colsum + n0 + tid, t);
+      }
+    }
     if (p.q8_amax) {
       omax = wave_max(omax);
       if (lane == 0 && omax > 0.f) atomicMax(reinterpret_cast<unsigned*>(p.q8_amax), __float_as_uint(omax));
@@ -1479,7 +1484,7 @@ int g_tn_tall = 1;          // 105/106: wgrad 192 x 384 LDS-DMA tile when N % 19
 int g_tn_rounds = 1;        // 110 + r: 128x128 wgrad grid = r rounds of 512 resident blocks; 1 measured best (-20 %)
 int g_row384_auto = 1;      // 300/301: row-384 tile whenever N % 384 == 0
 int g_row384_tall = 2;      // 302/303/304: 256 x 384 tiles for M >= 8192: never / plain bf16 GEMMs only / every epilogue
-int g_dgelu_row384 = 2;     // 306/307/308: dGELU GEMM on the 256x384 tile never / always / when K >= 768.  Measured with the staged column sums: base (K = 768) 968 -> 935 us, small (K = 384) 206 -> 227 us
+int g_dgelu_row384 = 2;     // 306/307/308: dGELU GEMM on the 256x384 tile never / always / when K >= 768.  With the register column sums (tools/dgelu_probe.py): base (K = 768) 991 -> 889 us, small (K = 384) 314-342 -> 339 us
 int g_w4_mode = 0;          // 330 + m: 4-wave two-blocks-per-CU kernels: 0 only for small grids ; 2 = 256x192 (plain epilogues) + 128x384 (row-wise) everywhere ; 3 = 256x192 for the plain epilogues only
 int g_w4_min_m = 8192;      // 350/351: apply the tall / 4-wave kernels from M = 8192 / from any M (parity tests run small shapes)
 int g_w4_auto = 1;          // 360/361: 4-wave kernels for launches of <= 1.5 rounds of 256 x 384 tiles
