@@ -23,10 +23,27 @@ typedef unsigned int u32;
 DEVFN float bf2f(bf16 v) { return (float)v; }
 DEVFN bf16 f2bf(float v) { return (bf16)v; }
 
-DEVFN float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+// Sum over the 32 lanes of a half-wave, result in every lane, without the LDS crossbar: __shfl_xor compiles to ds_bpermute_b32, and a
+// 5-step butterfly is five DEPENDENT LDS round trips (~120 cycles each) -- ten per row pair in the LayerNorm epilogues, 160 per tile.
+// Here: four rotate-and-add steps inside each row of 16 lanes (DPP row_ror 8 / 4 / 2 / 1) and one v_permlane16_swap that pairs
+// rows 0 <-> 1 and 2 <-> 3 -- VALU only.
+template <int CTRL> DEVFN float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+DEVFN float half_sum(float v) {
+  v += dpp_mov<0x128>(v);                                          // row_ror:8
+  v += dpp_mov<0x124>(v);                                          // row_ror:4
+  v += dpp_mov<0x122>(v);                                          // row_ror:2
+  v += dpp_mov<0x121>(v);                                          // row_ror:1 : every lane holds the sum of its row of 16
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);   // {rows 0 0 2 2, rows 1 1 3 3} of the row sums
+  return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+DEVFN float wave_sum(float v) {                                    // all 64 lanes: the two half-wave sums meet through v_permlane32_swap
+  v = half_sum(v);
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
 }
 DEVFN float wave_max(float v) {
 #pragma unroll

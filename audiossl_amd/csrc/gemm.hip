@@ -367,22 +367,6 @@ template <int NVM> DEVFN void rowin_wait(bool exact) {
   if (exact) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NVM) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
-// Sum over the 32 lanes of a half-wave, result in every lane, without the LDS crossbar: __shfl_xor compiles to ds_bpermute_b32, and a
-// 5-step butterfly is five DEPENDENT LDS round trips (~120 cycles each) -- ten per row pair in the LayerNorm epilogues, 160 per tile.
-// Here: four rotate-and-add steps inside each row of 16 lanes (DPP row_ror 8 / 4 / 2 / 1) and one v_permlane16_swap that pairs
-// rows 0 <-> 1 and 2 <-> 3 -- VALU only.
-template <int CTRL> DEVFN float dpp_mov(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
-}
-DEVFN float half_sum(float v) {
-  v += dpp_mov<0x128>(v);                                          // row_ror:8
-  v += dpp_mov<0x124>(v);                                          // row_ror:4
-  v += dpp_mov<0x122>(v);                                          // row_ror:2
-  v += dpp_mov<0x121>(v);                                          // row_ror:1 : every lane holds the sum of its row of 16
-  const unsigned u = __builtin_bit_cast(unsigned, v);
-  auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);   // {rows 0 0 2 2, rows 1 1 3 3} of the row sums
-  return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
-}
 // A row-wise epilogue is bound by the NUMBER of vector-memory instructions it issues (tools/trace_rowwise.py: a pair of rows
 // took ~4 k cycles for 8 stores + 3 LDS-DMA pieces per wave, ~50 cycles per store instruction per CU whatever its width), so
 // the bf16 row goes out in two instructions instead of three: neighbouring lanes swap 4-column groups (one DPP move per

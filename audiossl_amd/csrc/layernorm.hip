@@ -9,30 +9,52 @@
 namespace {
 constexpr float LN_EPS = 1e-6f;
 
+// Element map of a row: lane l owns W consecutive columns of every chunk of 64 W columns (W = 4 when C is a multiple of 256:
+// 16-B fp32 / 8-B bf16 / 4-B e4m3 accesses; W = 2 for C = 384).  Half as many memory instructions per row as the 8-byte version
+// (ln_bwd at C = 768: 36 -> 18): 558 -> see profiles / DESIGN.md.
+template <int VPT> struct LnMap {
+  static constexpr int W = VPT % 4 == 0 ? 4 : 2, CH = VPT / W;
+  static DEVFN int col(int chunk, int lane) { return chunk * 64 * W + lane * W; }
+};
+template <int W> struct VecOf;
+template <> struct VecOf<2> { typedef f32x2 f; typedef bf16x2 h; };
+template <> struct VecOf<4> { typedef f32x4 f; typedef bf16x4 h; };
+template <int W> DEVFN void st_fp8(uint8_t* dst, const float* v, float s) {      // v: the bf16-rounded values
+  int q = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(v[0] * s, -448.f, 448.f), __builtin_amdgcn_fmed3f(v[1] * s, -448.f, 448.f), 0, false);
+  if constexpr (W == 2) { *reinterpret_cast<unsigned short*>(dst) = (unsigned short)q; }
+  else {
+    q = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(v[2] * s, -448.f, 448.f), __builtin_amdgcn_fmed3f(v[3] * s, -448.f, 448.f), q, true);
+    *reinterpret_cast<int*>(dst) = q;
+  }
+}
+
 template <int VPT, typename OUT = bf16>   // values per lane = C / 64 ; OUT = bf16 (GEMM operand) or float (inference taps)
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, OUT* __restrict__ y,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out, int M,
                                                      uint8_t* __restrict__ y8 = nullptr, float s8 = 1.0f) {
-  constexpr int C = VPT * 64;
+  using MP = LnMap<VPT>; constexpr int C = VPT * 64, W = MP::W, CH = MP::CH;
+  typedef typename VecOf<W>::f fvec; typedef typename VecOf<W>::h hvec;
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
   float gm[VPT], bt[VPT];
 #pragma unroll
-  for (int i = 0; i < VPT / 2; ++i) {
-    const f32x2 g2 = *reinterpret_cast<const f32x2*>(gamma + i * 128 + lane * 2);
-    const f32x2 b2 = *reinterpret_cast<const f32x2*>(beta + i * 128 + lane * 2);
-    gm[2 * i] = g2[0]; gm[2 * i + 1] = g2[1]; bt[2 * i] = b2[0]; bt[2 * i + 1] = b2[1];
+  for (int i = 0; i < CH; ++i) {
+    const fvec g2 = *reinterpret_cast<const fvec*>(gamma + MP::col(i, lane));
+    const fvec b2 = *reinterpret_cast<const fvec*>(beta + MP::col(i, lane));
+#pragma unroll
+    for (int e = 0; e < W; ++e) { gm[W * i + e] = g2[e]; bt[W * i + e] = b2[e]; }
   }
   for (int row = wave; row < M; row += nwaves) {
     const float* xr = x + (size_t)row * C;
     float v[VPT];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < VPT / 2; ++i) {
-      const f32x2 t = *reinterpret_cast<const f32x2*>(xr + i * 128 + lane * 2);
-      v[2 * i] = t[0]; v[2 * i + 1] = t[1]; s += t[0] + t[1];
+    for (int i = 0; i < CH; ++i) {
+      const fvec t = *reinterpret_cast<const fvec*>(xr + MP::col(i, lane));
+#pragma unroll
+      for (int e = 0; e < W; ++e) { v[W * i + e] = t[e]; s += t[e]; }
     }
     const float mu = wave_sum(s) * (1.0f / C);
     float q = 0.f;
@@ -41,18 +63,21 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     const float rs = rsqrtf(wave_sum(q) * (1.0f / C) + LN_EPS);
     OUT* yr = y + (size_t)row * C;
 #pragma unroll
-    for (int i = 0; i < VPT / 2; ++i) {
-      const float o0 = (v[2 * i] - mu) * rs * gm[2 * i] + bt[2 * i], o1 = (v[2 * i + 1] - mu) * rs * gm[2 * i + 1] + bt[2 * i + 1];
+    for (int i = 0; i < CH; ++i) {
+      float o[W];
+#pragma unroll
+      for (int e = 0; e < W; ++e) o[e] = (v[W * i + e] - mu) * rs * gm[W * i + e] + bt[W * i + e];
       if constexpr (sizeof(OUT) == 2) {
-        bf16x2 o; o[0] = f2bf(o0); o[1] = f2bf(o1);
-        *reinterpret_cast<bf16x2*>(yr + i * 128 + lane * 2) = o;
-        if (y8) {                                                  // fp8 forward: e4m3 copy of the SAME bf16 values (the next GEMM's A operand)
-          const int q = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(bf2f(o[0]) * s8, -448.f, 448.f),
-                                                        __builtin_amdgcn_fmed3f(bf2f(o[1]) * s8, -448.f, 448.f), 0, false);
-          *reinterpret_cast<unsigned short*>(y8 + (size_t)row * C + i * 128 + lane * 2) = (unsigned short)q;
-        }
+        hvec ob; float r[W];
+#pragma unroll
+        for (int e = 0; e < W; ++e) { ob[e] = f2bf(o[e]); r[e] = bf2f(ob[e]); }
+        *reinterpret_cast<hvec*>(yr + MP::col(i, lane)) = ob;
+        if (y8) st_fp8<W>(y8 + (size_t)row * C + MP::col(i, lane), r, s8);   // fp8 forward: e4m3 copy of the SAME bf16 values (the next GEMM's A operand)
       } else {
-        *reinterpret_cast<f32x2*>(yr + i * 128 + lane * 2) = f32x2{o0, o1};
+        fvec of;
+#pragma unroll
+        for (int e = 0; e < W; ++e) of[e] = o[e];
+        *reinterpret_cast<fvec*>(yr + MP::col(i, lane)) = of;
       }
     }
     if (lane == 0 && mean_out) { mean_out[row] = mu; rstd_out[row] = rs; }
@@ -61,14 +86,15 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 
 template <int VPT>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs p) {
-  constexpr int C = VPT * 64;
+  using MP = LnMap<VPT>; constexpr int C = VPT * 64, W = MP::W, CH = MP::CH;
+  typedef typename VecOf<W>::f fvec; typedef typename VecOf<W>::h hvec;
   __shared__ float red[3][4][C];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
   float gm[VPT], dg[VPT], db[VPT], du[VPT];
 #pragma unroll
-  for (int i = 0; i < VPT; ++i) { gm[i] = p.gamma[(i >> 1) * 128 + lane * 2 + (i & 1)]; dg[i] = db[i] = du[i] = 0.f; }
+  for (int i = 0; i < VPT; ++i) { gm[i] = p.gamma[MP::col(i / W, lane) + i % W]; dg[i] = db[i] = du[i] = 0.f; }
   const float s8 = (p.g8 && p.g8_scale) ? *p.g8_scale : 1.0f;     // fp8 dgrad: delayed-scaling quantisation scale of g
   float gmax = 0.f;
   for (int row = wave; row < p.M; row += nwaves) {
@@ -77,12 +103,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs p) {
     float xh[VPT], dyg[VPT];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < VPT / 2; ++i) {
-      const f32x2 xv = *reinterpret_cast<const f32x2*>(p.x + base + i * 128 + lane * 2);
-      const bf16x2 dv = *reinterpret_cast<const bf16x2*>(p.dy + base + i * 128 + lane * 2);
+    for (int i = 0; i < CH; ++i) {
+      const fvec xv = *reinterpret_cast<const fvec*>(p.x + base + MP::col(i, lane));
+      const hvec dv = *reinterpret_cast<const hvec*>(p.dy + base + MP::col(i, lane));
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int k = 2 * i + e;
+      for (int e = 0; e < W; ++e) {
+        const int k = W * i + e;
         const float d = bf2f(dv[e]);
         xh[k] = (xv[e] - mu) * rs;
         dyg[k] = d * gm[k];
@@ -93,26 +119,24 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs p) {
     const float c1 = wave_sum(s1) * (1.0f / C), c2 = wave_sum(s2) * (1.0f / C);
     const float sc = p.row_scale ? p.row_scale[row / p.rows_per_seq] : 1.0f;
 #pragma unroll
-    for (int i = 0; i < VPT / 2; ++i) {
-      f32x2 o; bf16x2 gq;
-      f32x2 rv = {0.f, 0.f};
-      if (p.dres) rv = *reinterpret_cast<const f32x2*>(p.dres + base + i * 128 + lane * 2);
+    for (int i = 0; i < CH; ++i) {
+      fvec o; hvec gq; float r[W];
+      fvec rv;
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int k = 2 * i + e;
+      for (int e = 0; e < W; ++e) rv[e] = 0.f;
+      if (p.dres) rv = *reinterpret_cast<const fvec*>(p.dres + base + MP::col(i, lane));
+#pragma unroll
+      for (int e = 0; e < W; ++e) {
+        const int k = W * i + e;
         o[e] = rv[e] + rs * (dyg[k] - c1 - xh[k] * c2);
         const float gs = o[e] * sc;
-        gq[e] = f2bf(gs);
+        gq[e] = f2bf(gs); r[e] = bf2f(gq[e]);
         du[k] += gs;
         gmax = fmaxf(gmax, fabsf(gs));
       }
-      *reinterpret_cast<f32x2*>(p.dx + base + i * 128 + lane * 2) = o;
-      if (p.g) *reinterpret_cast<bf16x2*>(p.g + base + i * 128 + lane * 2) = gq;
-      if (p.g8) {                                                  // e4m3 copy of the SAME bf16 values (A operand of the fp8 dgrad GEMM)
-        const int q = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(bf2f(gq[0]) * s8, -448.f, 448.f),
-                                                      __builtin_amdgcn_fmed3f(bf2f(gq[1]) * s8, -448.f, 448.f), 0, false);
-        *reinterpret_cast<unsigned short*>(p.g8 + base + i * 128 + lane * 2) = (unsigned short)q;
-      }
+      *reinterpret_cast<fvec*>(p.dx + base + MP::col(i, lane)) = o;
+      if (p.g) *reinterpret_cast<hvec*>(p.g + base + MP::col(i, lane)) = gq;
+      if (p.g8) st_fp8<W>(p.g8 + base + MP::col(i, lane), r, s8);   // e4m3 copy of the SAME bf16 values (A operand of the fp8 dgrad GEMM)
     }
   }
   if (p.g_amax) {
@@ -122,7 +146,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs p) {
   // block reduction of the three column accumulators, then one atomic per column per block
 #pragma unroll
   for (int i = 0; i < VPT; ++i) {
-    const int col = (i >> 1) * 128 + lane * 2 + (i & 1);
+    const int col = MP::col(i / W, lane) + i % W;
     red[0][wid][col] = dg[i]; red[1][wid][col] = db[i]; red[2][wid][col] = du[i];
   }
   __syncthreads();
