@@ -131,13 +131,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
         pv[r] = sc[r] * scale + (kv >= valid ? MASK_NEG : 0.f);
         mx = fmaxf(mx, pv[r]);
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = pair32_max(mx);
       const float m_new = fmaxf(m_run, mx);
       const float alpha = fast_exp2((m_run - m_new) * LOG2E);
       float rs = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { pv[r] = fast_exp2((pv[r] - m_new) * LOG2E); rs += pv[r]; }
-      rs += __shfl_xor(rs, 32, 64);
+      rs = pair32_sum(rs);
       l_run = l_run * alpha + rs;
       m_run = m_new;
 #pragma unroll
@@ -226,13 +226,13 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256_kernel(AttnArgs p) {
         pv[r] = sc[r] * scale + (kv >= valid ? MASK_NEG : 0.f);
         mx = fmaxf(mx, pv[r]);
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = pair32_max(mx);
       const float m_new = fmaxf(m_run, mx);
       const float alpha = fast_exp2((m_run - m_new) * LOG2E);
       float rs = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { pv[r] = fast_exp2((pv[r] - m_new) * LOG2E); rs += pv[r]; }
-      rs += __shfl_xor(rs, 32, 64);
+      rs = pair32_sum(rs);
       l_run = l_run * alpha + rs;
       m_run = m_new;
 #pragma unroll
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256v2_kernel(AttnArgs p) {
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[j][r]);
       }
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = pair32_max(mx);
     const float c0 = -mx * c1;
     // pass 2: p = exp2(c1 s - c1 max) ; O^T += V^T P^T
     float rs = 0.f;
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256v2_kernel(AttnArgs p) {
         }
       }
     }
-    rs += __shfl_xor(rs, 32, 64);
+    rs = pair32_sum(rs);
     const float inv = 1.0f / rs;
     bf16* orow = p.o + ((size_t)s * NP + q0 + l31) * C + h * HD;
 #ifdef ATST_ABLATE_ATTN_STORE
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) dpart += bf2f(dof[ks][e]) * bf2f(of[e]);
     }
-    const float D = dpart + __shfl_xor(dpart, 32, 64);
+    const float D = pair32_sum(dpart);
     const float lse = p.lse[((size_t)s * p.H + h) * NP + q0 + l31];
     f32x16 dq0, dq1; zero16(dq0); zero16(dq1);
     for (int j = 0; j < ntile; ++j) {

@@ -45,10 +45,22 @@ DEVFN float wave_sum(float v) {                                    // all 64 lan
   auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
   return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
 }
+// the value of the other half-wave's lane (l ^ 32), and max / sum over the pair, through v_permlane32_swap (VALU)
+DEVFN float pair32_sum(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // {lower half in both halves, upper half in both halves}
+  return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+DEVFN float pair32_max(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+}
 DEVFN float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dpp_mov<0x128>(v)); v = fmaxf(v, dpp_mov<0x124>(v)); v = fmaxf(v, dpp_mov<0x122>(v)); v = fmaxf(v, dpp_mov<0x121>(v));
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return pair32_max(fmaxf(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1])));
 }
 
 // erf-GELU and its derivative (nn.GELU default, ref: audiossl/modules/transformer.py:70-92).  The Gaussian tail
