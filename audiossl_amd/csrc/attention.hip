@@ -35,14 +35,17 @@ template <int NP> struct Geo {
   static constexpr int LDS_MAT = NP * A_LD;                       // elements of one staged [NP][72] matrix
 };
 
-// stage rows [0,NP) x 64 columns (col0..) of a [*, ld] bf16 matrix into sm[NP][A_LD] with `nthr` threads
+// stage rows [0,NP) x 64 columns (col0..) of a [*, ld] bf16 matrix into sm[NP][A_LD] with `nthr` threads; rows >= rs (packed
+// sequences: they belong to the next sequence) are staged as zeros, i.e. exactly what a padded layout holds there
 template <int NP>
-DEVFN void stage_rows(bf16* sm, const bf16* g, size_t ld, int t, int nthr) {
+DEVFN void stage_rows(bf16* sm, const bf16* g, size_t ld, int t, int nthr, int rs) {
+  const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int c = t; c < NP * 8; c += nthr) {
     const int r = c >> 3, k = (c & 7) * 8;
-    *reinterpret_cast<bf16x8*>(sm + r * A_LD + k) = ld_frag(g + (size_t)r * ld + k);
+    *reinterpret_cast<bf16x8*>(sm + r * A_LD + k) = r < rs ? ld_frag(g + (size_t)r * ld + k) : z;
   }
 }
+DEVFN bf16x8 ld_frag_if(bool live, const bf16* p) { const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0}; return live ? ld_frag(p) : z; }
 
 // v_exp_f32 as is.  exp2f() adds a compare / two selects / ldexp around it for results in the denormal range; every use
 // here has an argument <= ~0 whose underflow to 0 is the wanted result.
@@ -99,11 +102,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
   const int s = active ? pair / p.H : 0, h = active ? pair % p.H : 0;
   bf16* sK = reinterpret_cast<bf16*>(smem_raw) + pair_in_blk * 2 * GE::LDS_MAT;
   bf16* sV = sK + GE::LDS_MAT;
-  const bf16* base = p.qkv + (size_t)s * NP * ld + h * HD;
+  const int RS = p.stride > 0 ? p.stride : NP;                    // rows between sequences (packed when < NP)
+  const bf16* base = p.qkv + (size_t)s * RS * ld + h * HD;
   if (active) {
     const int t = wave_in_pair * 64 + lane, nthr = GE::WPP * 64;
-    stage_rows<NP>(sK, base + C, ld, t, nthr);
-    stage_rows<NP>(sV, base + 2 * C, ld, t, nthr);
+    stage_rows<NP>(sK, base + C, ld, t, nthr, RS);
+    stage_rows<NP>(sV, base + 2 * C, ld, t, nthr, RS);
   }
   __syncthreads();
   if (!active) return;
@@ -113,9 +117,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
 
   for (int cw = 0; cw < GE::CPW; ++cw) {
     const int q0 = (wave_in_pair * GE::CPW + cw) * 32;
+    const bool qlive = q0 + l31 < RS;
     bf16x8 qf[4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = ld_frag(base + (size_t)(q0 + l31) * ld + ks * 16 + hi * 8);
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = ld_frag_if(qlive, base + (size_t)(q0 + l31) * ld + ks * 16 + hi * 8);
     float m_run = -1e30f, l_run = 0.f;
     f32x16 o0, o1; zero16(o0); zero16(o1);
     for (int j = 0; j < ntile; ++j) {
@@ -150,16 +155,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
       }
     }
     const float inv = 1.0f / l_run;
-    bf16* orow = p.o + ((size_t)s * NP + q0 + l31) * C + h * HD;
+    bf16* orow = p.o + ((size_t)s * RS + q0 + l31) * C + h * HD;
+    if (qlive) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      bf16x4 a, b;
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 a, b;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { a[e] = f2bf(o0[4 * g + e] * inv); b[e] = f2bf(o1[4 * g + e] * inv); }
-      *reinterpret_cast<bf16x4*>(orow + 8 * g + 4 * hi) = a;
-      *reinterpret_cast<bf16x4*>(orow + 32 + 8 * g + 4 * hi) = b;
+        for (int e = 0; e < 4; ++e) { a[e] = f2bf(o0[4 * g + e] * inv); b[e] = f2bf(o1[4 * g + e] * inv); }
+        *reinterpret_cast<bf16x4*>(orow + 8 * g + 4 * hi) = a;
+        *reinterpret_cast<bf16x4*>(orow + 32 + 8 * g + 4 * hi) = b;
+      }
     }
-    if (hi == 0) p.lse[((size_t)s * p.H + h) * NP + q0 + l31] = m_run + __logf(l_run);
+    if (hi == 0) p.lse[((size_t)s * p.H + h) * NP + q0 + l31] = m_run + __logf(l_run);   // lse is [S, H, NP] whatever the row stride
   }
 }
 
@@ -422,18 +429,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
   bf16* sDO = sQ + GE::LDS_MAT;
   float* sLse = reinterpret_cast<float*>(sDO + GE::LDS_MAT);
   float* sD = sLse + NP;
-  const bf16* base = p.qkv + (size_t)s * NP * ld + h * HD;
-  const bf16* dobase = p.d_o + (size_t)s * NP * C + h * HD;
-  const bf16* obase = p.o + (size_t)s * NP * C + h * HD;
+  const int RS = p.stride > 0 ? p.stride : NP;                    // rows between sequences (packed when < NP)
+  const bf16* base = p.qkv + (size_t)s * RS * ld + h * HD;
+  const bf16* dobase = p.d_o + (size_t)s * RS * C + h * HD;
+  const bf16* obase = p.o + (size_t)s * RS * C + h * HD;
   if (active) {
     const int t = wave_in_pair * 64 + lane, nthr = GE::WPP * 64;
-    stage_rows<NP>(sQ, base, ld, t, nthr);
-    stage_rows<NP>(sDO, dobase, (size_t)C, t, nthr);
+    stage_rows<NP>(sQ, base, ld, t, nthr, RS);
+    stage_rows<NP>(sDO, dobase, (size_t)C, t, nthr, RS);
     for (int q = t; q < NP; q += nthr) {
       float d = 0.f;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const bf16x8 a = ld_frag(dobase + (size_t)q * C + k * 8), b = ld_frag(obase + (size_t)q * C + k * 8);
+        const bf16x8 a = ld_frag_if(q < RS, dobase + (size_t)q * C + k * 8), b = ld_frag_if(q < RS, obase + (size_t)q * C + k * 8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) d += bf2f(a[e]) * bf2f(b[e]);
       }
@@ -448,15 +456,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
   // queries beyond the valid range still exist in the reference (their dO is exactly zero), so all query tiles run
   for (int cw = 0; cw < GE::CPW; ++cw) {
     const int k0 = (wave_in_pair * GE::CPW + cw) * 32;
-    bf16* dkrow = p.dqkv + ((size_t)s * NP + k0 + l31) * ld + C + h * HD;
+    bf16* dkrow = p.dqkv + ((size_t)s * RS + k0 + l31) * ld + C + h * HD;
     bf16* dvrow = dkrow + C;
+    const bool klive = k0 + l31 < RS;
     f32x16 dk0, dk1, dv0, dv1; zero16(dk0); zero16(dk1); zero16(dv0); zero16(dv1);
     if (k0 < valid) {
       bf16x8 kf[4], vf[4];
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        kf[ks] = ld_frag(base + C + (size_t)(k0 + l31) * ld + ks * 16 + hi * 8);
-        vf[ks] = ld_frag(base + 2 * C + (size_t)(k0 + l31) * ld + ks * 16 + hi * 8);
+        kf[ks] = ld_frag_if(klive, base + C + (size_t)(k0 + l31) * ld + ks * 16 + hi * 8);
+        vf[ks] = ld_frag_if(klive, base + 2 * C + (size_t)(k0 + l31) * ld + ks * 16 + hi * 8);
       }
       const float kbias = (k0 + l31 >= valid) ? MASK_NEG : 0.f;
       for (int i = 0; i < GE::CHUNKS; ++i) {
@@ -491,18 +500,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
         }
       }
     }
+    if (klive) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      bf16x4 a, b, c, d;
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 a, b, c, d;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        a[e] = f2bf(dk0[4 * g + e]); b[e] = f2bf(dk1[4 * g + e]);
-        c[e] = f2bf(dv0[4 * g + e]); d[e] = f2bf(dv1[4 * g + e]);
+        for (int e = 0; e < 4; ++e) {
+          a[e] = f2bf(dk0[4 * g + e]); b[e] = f2bf(dk1[4 * g + e]);
+          c[e] = f2bf(dv0[4 * g + e]); d[e] = f2bf(dv1[4 * g + e]);
+        }
+        *reinterpret_cast<bf16x4*>(dkrow + 8 * g + 4 * hi) = a;
+        *reinterpret_cast<bf16x4*>(dkrow + 32 + 8 * g + 4 * hi) = b;
+        *reinterpret_cast<bf16x4*>(dvrow + 8 * g + 4 * hi) = c;
+        *reinterpret_cast<bf16x4*>(dvrow + 32 + 8 * g + 4 * hi) = d;
       }
-      *reinterpret_cast<bf16x4*>(dkrow + 8 * g + 4 * hi) = a;
-      *reinterpret_cast<bf16x4*>(dkrow + 32 + 8 * g + 4 * hi) = b;
-      *reinterpret_cast<bf16x4*>(dvrow + 8 * g + 4 * hi) = c;
-      *reinterpret_cast<bf16x4*>(dvrow + 32 + 8 * g + 4 * hi) = d;
     }
   }
 }
@@ -522,11 +533,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
   const int s = active ? pair / p.H : 0, h = active ? pair % p.H : 0;
   bf16* sK = reinterpret_cast<bf16*>(smem_raw) + pair_in_blk * 2 * GE::LDS_MAT;
   bf16* sV = sK + GE::LDS_MAT;
-  const bf16* base = p.qkv + (size_t)s * NP * ld + h * HD;
+  const int RS = p.stride > 0 ? p.stride : NP;                    // rows between sequences (packed when < NP)
+  const bf16* base = p.qkv + (size_t)s * RS * ld + h * HD;
   if (active) {
     const int t = wave_in_pair * 64 + lane, nthr = GE::WPP * 64;
-    stage_rows<NP>(sK, base + C, ld, t, nthr);
-    stage_rows<NP>(sV, base + 2 * C, ld, t, nthr);
+    stage_rows<NP>(sK, base + C, ld, t, nthr, RS);
+    stage_rows<NP>(sV, base + 2 * C, ld, t, nthr, RS);
   }
   __syncthreads();
   if (!active) return;
@@ -535,14 +547,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
   const float scale = 0.125f;
   for (int cw = 0; cw < GE::CPW; ++cw) {
     const int q0 = (wave_in_pair * GE::CPW + cw) * 32;
-    const size_t qrow = (size_t)s * NP + q0 + l31;
+    const size_t qrow = (size_t)s * RS + q0 + l31;
+    const bool qlive = q0 + l31 < RS;
     bf16x8 qf[4], dof[4];
     float dpart = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      qf[ks] = ld_frag(base + (size_t)(q0 + l31) * ld + ks * 16 + hi * 8);
-      dof[ks] = ld_frag(p.d_o + qrow * C + h * HD + ks * 16 + hi * 8);
-      const bf16x8 of = ld_frag(p.o + qrow * C + h * HD + ks * 16 + hi * 8);
+      qf[ks] = ld_frag_if(qlive, base + (size_t)(q0 + l31) * ld + ks * 16 + hi * 8);
+      dof[ks] = ld_frag_if(qlive, p.d_o + qrow * C + h * HD + ks * 16 + hi * 8);
+      const bf16x8 of = ld_frag_if(qlive, p.o + qrow * C + h * HD + ks * 16 + hi * 8);
 #pragma unroll
       for (int e = 0; e < 8; ++e) dpart += bf2f(dof[ks][e]) * bf2f(of[e]);
     }
@@ -573,13 +586,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
       }
     }
     bf16* dqrow = p.dqkv + qrow * ld + h * HD;
+    if (qlive) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      bf16x4 a, b;
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 a, b;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { a[e] = f2bf(dq0[4 * g + e]); b[e] = f2bf(dq1[4 * g + e]); }
-      *reinterpret_cast<bf16x4*>(dqrow + 8 * g + 4 * hi) = a;
-      *reinterpret_cast<bf16x4*>(dqrow + 32 + 8 * g + 4 * hi) = b;
+        for (int e = 0; e < 4; ++e) { a[e] = f2bf(dq0[4 * g + e]); b[e] = f2bf(dq1[4 * g + e]); }
+        *reinterpret_cast<bf16x4*>(dqrow + 8 * g + 4 * hi) = a;
+        *reinterpret_cast<bf16x4*>(dqrow + 32 + 8 * g + 4 * hi) = b;
+      }
     }
   }
 }
@@ -864,6 +879,7 @@ void atst_attn_set_variant(int v) { if (v == 4) g_fwd256 = 2; else if (v >= 2) g
 
 int atst_attn_fwd(const AttnArgs& a, hipStream_t st) {
   if (a.S <= 0) return ATST_OK;
+  if (a.stride < 0 || a.stride > a.NP || (a.NP == 256 && a.stride != 0 && a.stride != 256)) return ATST_EINVAL;   // packed sequences: NP < 256 kernels only
   if (a.NP == 256 && g_fwd256 == 2 && (size_t)a.NP * 3 * a.H * HD * 2 < (1u << 30)) {
     static bool done2 = false;
     if (!done2) {
@@ -896,6 +912,7 @@ int atst_attn_fwd(const AttnArgs& a, hipStream_t st) {
 }
 int atst_attn_bwd(const AttnArgs& a, hipStream_t st) {
   if (a.S <= 0) return ATST_OK;
+  if (a.stride < 0 || a.stride > a.NP || (a.NP == 256 && a.stride != 0 && a.stride != 256)) return ATST_EINVAL;
   if (a.NP == 256 && g_bwd256 && a.dscratch) {
     static bool done = false;
     if (!done) {

@@ -121,6 +121,12 @@ int wgrad(const bf16* dY, const bf16* X, int M, int N, int K, float* dW, hipStre
 }  // namespace
 
 inline int patch_k(const atst_encoder_t* e) { return (e->patch_h > 0 ? e->patch_h : 64) * (e->patch_w > 0 ? e->patch_w : 4); }
+// Rows between consecutive sequences in every [tokens, *] tensor of a pass.  Default NP (the 32-row-tile-aligned token count the
+// attention kernels work on); a smaller value packs the sequences -- 1 s local views are 26 tokens in tiles of 32: the GEMM,
+// LayerNorm and weight-gradient kernels then run over 19 % fewer rows, and the NP < 256 attention kernels treat the rows that
+// complete a sequence's last tile as absent (attention.hip: stride).  The workspace is sized for NP rows per sequence either way.
+static inline int row_stride(const atst_encoder_t* e) { return e->row_stride > 0 ? e->row_stride : e->NP; }
+
 extern "C" size_t atst_encoder_ws_bytes(int S, int NP, int C, int H, int depth, int train, int fp8) {
   return carve(nullptr, S, NP, C, H, depth, train, fp8).bytes;
 }
@@ -133,6 +139,7 @@ static bool check(const atst_encoder_t* e) {
   if (e->C != e->H * 64 || (e->C != 384 && e->C != 768)) return false;
   if (e->NP != 32 && e->NP != 64 && e->NP != 128 && e->NP != 256) return false;
   if (e->n_tok + e->use_cls > e->NP) return false;
+  if (e->row_stride != 0 && (e->row_stride < e->n_tok + e->use_cls || e->row_stride > e->NP || (e->NP == 256 && e->row_stride != 256))) return false;
   if (patch_k(e) % 256 || patch_k(e) > 1024) return false;         // patch GEMM / weight gradient tiles
   if (e->ws_bytes < carve(nullptr, e->S, e->NP, e->C, e->H, e->depth, e->train, e->fp8, patch_k(e)).bytes) return false;
   return true;
@@ -155,7 +162,7 @@ extern "C" int atst_encoder_fwd(const atst_encoder_t* e, void* stream) {
   if (!check(e)) return ATST_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const Ws w = carve(e->ws, e->S, e->NP, e->C, e->H, e->depth, e->train, e->fp8, patch_k(e));
-  const int S = e->S, NP = e->NP, C = e->C, M = S * NP;
+  const int S = e->S, NP = e->NP, C = e->C, RS = row_stride(e), M = S * RS;   // RS < NP: packed sequences (see row_stride)
   const float* p = e->p32; const bf16* q = B16(e->p16);
   const atst_enc_off_t& o = e->off;
 
@@ -163,12 +170,12 @@ extern "C" int atst_encoder_fwd(const atst_encoder_t* e, void* stream) {
   if (f8 && (!e->p8 || !e->w_dq || C % 384)) return ATST_EINVAL;
   const bool fuse_ln = C == 384 && !f8;             // N == 384: the residual GEMM blocks own whole rows
   const int PK = patch_k(e);
-  RUN(atst_patchify(e->mel, S, e->width, NP, e->use_cls, w.patches, st, e->patch_h > 0 ? e->patch_h : 64, e->patch_w > 0 ? e->patch_w : 4));
-  RUN(atst_token_table(e->use_cls ? p + o.cls_token : nullptr, p + o.pos_embed, p + o.patch_b, NP, e->n_tok, C, e->use_cls, w.table, st));
+  RUN(atst_patchify(e->mel, S, e->width, RS, e->use_cls, w.patches, st, e->patch_h > 0 ? e->patch_h : 64, e->patch_w > 0 ? e->patch_w : 4));
+  RUN(atst_token_table(e->use_cls ? p + o.cls_token : nullptr, p + o.pos_embed, p + o.patch_b, RS, e->n_tok, C, e->use_cls, w.table, st));
   {
     GemmArgs a{};
     a.A = w.patches; a.B = q + o.patch_w; a.M = M; a.N = C; a.K = PK; a.lda = PK; a.ldb = PK; a.epi = EPI_PATCH;
-    a.C = w.x[0]; a.ldc = C; a.bias = p + o.patch_b; a.rows_per_seq = NP; a.table = w.table; a.rowflag = e->rowflag;
+    a.C = w.x[0]; a.ldc = C; a.bias = p + o.patch_b; a.rows_per_seq = RS; a.table = w.table; a.rowflag = e->rowflag;
     a.alt = p + o.mask_embed;
     RUN(atst_gemm_nt(a, st));
   }
@@ -185,36 +192,36 @@ extern "C" int atst_encoder_fwd(const atst_encoder_t* e, void* stream) {
       RUN(atst_ln_fwd(w.x[2 * i], p + lo.ln1_w, p + lo.ln1_b, l.h1, l.mean1, l.rstd1, M, C, st, w.q8a, ACT_SCALE));
       RUN(gemm8(w.q8a, q8 + lo.qkv_w, M, 3 * C, C, EPI_BF16, l.qkv, st, dq + 0, ACT_SCALE));
       AttnArgs at{};
-      at.qkv = l.qkv; at.valid = e->valid; at.o = l.o; at.lse = l.lse; at.S = S; at.H = e->H; at.NP = NP;
+      at.qkv = l.qkv; at.valid = e->valid; at.o = l.o; at.lse = l.lse; at.S = S; at.H = e->H; at.NP = NP; at.stride = RS;
       RUN(atst_attn_fwd(at, st));
       RUN(atst_quant_fp8(l.o, MC, ACT_SCALE, w.q8a, st));
-      RUN(gemm8(w.q8a, q8 + lo.proj_w, M, C, C, EPI_RESID, w.x[2 * i + 1], st, dq + 1, ACT_SCALE, p + lo.proj_b, w.x[2 * i], s1, NP));
+      RUN(gemm8(w.q8a, q8 + lo.proj_w, M, C, C, EPI_RESID, w.x[2 * i + 1], st, dq + 1, ACT_SCALE, p + lo.proj_b, w.x[2 * i], s1, RS));
       RUN(atst_ln_fwd(w.x[2 * i + 1], p + lo.ln2_w, p + lo.ln2_b, l.h2, l.mean2, l.rstd2, M, C, st, w.q8a, ACT_SCALE));
       RUN(gemm8(w.q8a, q8 + lo.fc1_w, M, 4 * C, C, EPI_BIAS_GELU, e->train ? l.u : nullptr, st, dq + 2, ACT_SCALE, p + lo.fc1_b, nullptr, nullptr, 1, l.a,
                 w.q8b, ACT_SCALE_GELU));
-      RUN(gemm8(w.q8b, q8 + lo.fc2_w, M, C, 4 * C, EPI_RESID, w.x[2 * i + 2], st, dq + 3, ACT_SCALE_GELU, p + lo.fc2_b, w.x[2 * i + 1], s2, NP));
+      RUN(gemm8(w.q8b, q8 + lo.fc2_w, M, C, 4 * C, EPI_RESID, w.x[2 * i + 2], st, dq + 3, ACT_SCALE_GELU, p + lo.fc2_b, w.x[2 * i + 1], s2, RS));
     } else {
       if (i == 0 || !fuse_ln) RUN(atst_ln_fwd(w.x[2 * i], p + lo.ln1_w, p + lo.ln1_b, l.h1, l.mean1, l.rstd1, M, C, st));
       RUN(gemm(l.h1, q + lo.qkv_w, M, 3 * C, C, EPI_BF16, l.qkv, st));
       AttnArgs at{};
-      at.qkv = l.qkv; at.valid = e->valid; at.o = l.o; at.lse = l.lse; at.S = S; at.H = e->H; at.NP = NP;
+      at.qkv = l.qkv; at.valid = e->valid; at.o = l.o; at.lse = l.lse; at.S = S; at.H = e->H; at.NP = NP; at.stride = RS;
       RUN(atst_attn_fwd(at, st));
       if (fuse_ln) {                                  // proj + residual + LN2 in one kernel
-        RUN(gemm(l.o, q + lo.proj_w, M, C, C, EPI_RESID, w.x[2 * i + 1], st, p + lo.proj_b, w.x[2 * i], s1, NP, nullptr, nullptr,
+        RUN(gemm(l.o, q + lo.proj_w, M, C, C, EPI_RESID, w.x[2 * i + 1], st, p + lo.proj_b, w.x[2 * i], s1, RS, nullptr, nullptr,
                  nullptr, p + lo.ln2_w, p + lo.ln2_b, l.h2, l.mean2, l.rstd2));
       } else {
-        RUN(gemm(l.o, q + lo.proj_w, M, C, C, EPI_RESID, w.x[2 * i + 1], st, p + lo.proj_b, w.x[2 * i], s1, NP));
+        RUN(gemm(l.o, q + lo.proj_w, M, C, C, EPI_RESID, w.x[2 * i + 1], st, p + lo.proj_b, w.x[2 * i], s1, RS));
         RUN(atst_ln_fwd(w.x[2 * i + 1], p + lo.ln2_w, p + lo.ln2_b, l.h2, l.mean2, l.rstd2, M, C, st));
       }
       RUN(gemm(l.h2, q + lo.fc1_w, M, 4 * C, C, EPI_BIAS_GELU, e->train ? l.u : nullptr, st, p + lo.fc1_b, nullptr, nullptr, 1, l.a));
       if (fuse_ln) {                                  // fc2 + residual + (LN1 of the next block | final norm)
         const bool last = i + 1 == e->depth;
         const LayerWs& nl = w.L[last ? i : i + 1];
-        RUN(gemm(l.a, q + lo.fc2_w, M, C, 4 * C, EPI_RESID, w.x[2 * i + 2], st, p + lo.fc2_b, w.x[2 * i + 1], s2, NP, nullptr, nullptr,
+        RUN(gemm(l.a, q + lo.fc2_w, M, C, 4 * C, EPI_RESID, w.x[2 * i + 2], st, p + lo.fc2_b, w.x[2 * i + 1], s2, RS, nullptr, nullptr,
                  nullptr, p + (last ? o.norm_w : o.layer[i + 1].ln1_w), p + (last ? o.norm_b : o.layer[i + 1].ln1_b),
                  last ? w.hN : nl.h1, last ? w.meanN : nl.mean1, last ? w.rstdN : nl.rstd1));
       } else {
-        RUN(gemm(l.a, q + lo.fc2_w, M, C, 4 * C, EPI_RESID, w.x[2 * i + 2], st, p + lo.fc2_b, w.x[2 * i + 1], s2, NP));
+        RUN(gemm(l.a, q + lo.fc2_w, M, C, 4 * C, EPI_RESID, w.x[2 * i + 2], st, p + lo.fc2_b, w.x[2 * i + 1], s2, RS));
       }
     }
     if (e->tap && i >= e->tap_first) {
@@ -252,7 +259,7 @@ static int encoder_bwd_range(const atst_encoder_t* e, int lo, int hi, bool head,
   if (!check(e) || !e->train || !e->p16t || !e->g32) return ATST_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const Ws w = carve(e->ws, e->S, e->NP, e->C, e->H, e->depth, e->train, e->fp8, patch_k(e));
-  const int S = e->S, NP = e->NP, C = e->C, M = S * NP, D = e->depth;
+  const int S = e->S, NP = e->NP, C = e->C, RS = row_stride(e), M = S * RS, D = e->depth;
   const float* p = e->p32; const bf16* qt = B16(e->p16t);
   float* G = e->g32;
   const atst_enc_off_t& o = e->off;
@@ -275,7 +282,7 @@ static int encoder_bwd_range(const atst_encoder_t* e, int lo, int hi, bool head,
   if (head) {
     LnBwdArgs a{};
     a.dy = w.dout; a.x = w.x[2 * D]; a.mean = w.meanN; a.rstd = w.rstdN; a.gamma = p + o.norm_w; a.dres = nullptr;
-    a.dx = cur; a.g = w.g; a.row_scale = dps(D - 1, 1); a.rows_per_seq = NP;
+    a.dx = cur; a.g = w.g; a.row_scale = dps(D - 1, 1); a.rows_per_seq = RS;
     a.dgamma = G + o.norm_w; a.dbeta = G + o.norm_b; a.dbias_up = G + o.layer[D - 1].fc2_b; a.M = M; a.C = C;
     a.g8 = use8 ? w.g8 : nullptr; a.g8_scale = gs8(D - 1, 0); a.g_amax = ga8(D - 1, 0);
     RUN(atst_ln_bwd(a, st));
@@ -296,7 +303,7 @@ static int encoder_bwd_range(const atst_encoder_t* e, int lo, int hi, bool head,
       RUN(atst_gemm_nt(a, st));
     }
     if (fuse_lnb) {
-      RUN(gemm_lnbwd(w.du, qt + lo_.fc1_w, M, 4 * C, w.x[2 * i + 1], l.mean2, l.rstd2, p + lo_.ln2_w, cur, oth, w.g2, dps(i, 0), NP,
+      RUN(gemm_lnbwd(w.du, qt + lo_.fc1_w, M, 4 * C, w.x[2 * i + 1], l.mean2, l.rstd2, p + lo_.ln2_w, cur, oth, w.g2, dps(i, 0), RS,
                      G + lo_.ln2_w, G + lo_.ln2_b, G + lo_.proj_b, st));
       float* t = cur; cur = oth; oth = t;
     } else {
@@ -305,7 +312,7 @@ static int encoder_bwd_range(const atst_encoder_t* e, int lo, int hi, bool head,
       LnBwdArgs a{};
       a.g8 = use8 ? w.g28 : nullptr; a.g8_scale = gs8(i, 2); a.g_amax = ga8(i, 2);
       a.dy = w.dh; a.x = w.x[2 * i + 1]; a.mean = l.mean2; a.rstd = l.rstd2; a.gamma = p + lo_.ln2_w; a.dres = cur;
-      a.dx = oth; a.g = w.g2; a.row_scale = dps(i, 0); a.rows_per_seq = NP;
+      a.dx = oth; a.g = w.g2; a.row_scale = dps(i, 0); a.rows_per_seq = RS;
       a.dgamma = G + lo_.ln2_w; a.dbeta = G + lo_.ln2_b; a.dbias_up = G + lo_.proj_b; a.M = M; a.C = C;
       RUN(atst_ln_bwd(a, st));
       float* t = cur; cur = oth; oth = t;
@@ -315,7 +322,7 @@ static int encoder_bwd_range(const atst_encoder_t* e, int lo, int hi, bool head,
     else RUN(gemm(w.g2, qt + lo_.proj_w, M, C, C, EPI_BF16, w.d_o, st));
     AttnArgs at{};
     at.qkv = l.qkv; at.valid = e->valid; at.o = l.o; at.lse = l.lse; at.d_o = w.d_o; at.dqkv = w.dqkv; at.dscratch = w.dscr;
-    at.S = S; at.H = e->H; at.NP = NP;
+    at.S = S; at.H = e->H; at.NP = NP; at.stride = RS;
     RUN(atst_attn_bwd(at, st));
     {
       WgradArgs wg[4] = {};
@@ -330,7 +337,7 @@ static int encoder_bwd_range(const atst_encoder_t* e, int lo, int hi, bool head,
     }
     if (fuse_lnb) {
       RUN(gemm_lnbwd(w.dqkv, qt + lo_.qkv_w, M, 3 * C, w.x[2 * i], l.mean1, l.rstd1, p + lo_.ln1_w, cur, oth, i > 0 ? w.g : nullptr,
-                     i > 0 ? dps(i - 1, 1) : nullptr, NP, G + lo_.ln1_w, G + lo_.ln1_b, i > 0 ? G + o.layer[i - 1].fc2_b : nullptr, st));
+                     i > 0 ? dps(i - 1, 1) : nullptr, RS, G + lo_.ln1_w, G + lo_.ln1_b, i > 0 ? G + o.layer[i - 1].fc2_b : nullptr, st));
       float* t = cur; cur = oth; oth = t;
     } else {
       // the qkv dgrad stays bf16: its operand dqkv comes out of the attention backward, and a quantisation pass of its own (906 MB,
@@ -339,7 +346,7 @@ static int encoder_bwd_range(const atst_encoder_t* e, int lo, int hi, bool head,
       LnBwdArgs a{};
       if (i > 0) { a.g8 = use8 ? w.g8 : nullptr; a.g8_scale = gs8(i - 1, 0); a.g_amax = ga8(i - 1, 0); }
       a.dy = w.dh; a.x = w.x[2 * i]; a.mean = l.mean1; a.rstd = l.rstd1; a.gamma = p + lo_.ln1_w; a.dres = cur;
-      a.dx = oth; a.g = i > 0 ? w.g : nullptr; a.row_scale = i > 0 ? dps(i - 1, 1) : nullptr; a.rows_per_seq = NP;
+      a.dx = oth; a.g = i > 0 ? w.g : nullptr; a.row_scale = i > 0 ? dps(i - 1, 1) : nullptr; a.rows_per_seq = RS;
       a.dgamma = G + lo_.ln1_w; a.dbeta = G + lo_.ln1_b; a.dbias_up = i > 0 ? G + o.layer[i - 1].fc2_b : nullptr;
       a.M = M; a.C = C;
       RUN(atst_ln_bwd(a, st));
@@ -348,7 +355,7 @@ static int encoder_bwd_range(const atst_encoder_t* e, int lo, int hi, bool head,
   }
   if (!tail) return ATST_OK;
   // ---- token stage: x0 = (1-m) (patch W^T + b) + m mask_embed + pos  (+ CLS)
-  RUN(atst_token_grad(cur, e->rowflag, S, NP, e->n_tok, C, e->use_cls, e->use_cls ? G + o.cls_token : nullptr,
+  RUN(atst_token_grad(cur, e->rowflag, S, RS, e->n_tok, C, e->use_cls, e->use_cls ? G + o.cls_token : nullptr,
                       G + o.pos_embed, G + o.patch_b, e->rowflag ? G + o.mask_embed : nullptr, w.g, st));
   RUN(wgrad(w.g, w.patches, M, C, patch_k(e), G + o.patch_w, st));
   return ATST_OK;

@@ -76,6 +76,9 @@ struct AttnArgs {
   bf16* dqkv;                        // bwd out [S*NP, 3*C]
   float* dscratch;                   // bwd scratch [S, H, NP] fp32 (rowsum(dO*O)); null -> two-kernel backward
   int S, H, NP;
+  int stride;                        // rows between consecutive sequences in qkv / o / d_o / dqkv (0 = NP).  stride < NP: sequences are PACKED --
+                                     // the NP - stride rows that complete a sequence's last 32-row tile belong to the next sequence and are treated
+                                     // as absent (read as zeros, never written).  NP < 256 kernels only.
 };
 int atst_attn_fwd(const AttnArgs& a, hipStream_t st);
 int atst_attn_bwd(const AttnArgs& a, hipStream_t st);

@@ -72,7 +72,7 @@ class EncoderView(_Node):
         gw, gb = eng.param_view(self._netname, nf + ".weight"), eng.param_view(self._netname, nf + ".bias")
         y = torch.empty(n, ep.M, C, device=eng.device)
         hip.call("atst_layernorm_fwd_f32", hip.ptr(tap), hip.ptr(gw), hip.ptr(gb), hip.ptr(y), n * ep.M, C, hip.stream())
-        outs = [y[i].view(S, ep.NP, C)[:, :ep.n_tok + ep.use_cls] for i in range(n)]
+        outs = [y[i].view(S, ep.RS, C)[:, :ep.n_tok + ep.use_cls] for i in range(n)]
         return outs, eng.upload(plen), ep.n_tok
 
     def forward(self, x, mask_index=None, length=None, avg=False):

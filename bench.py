@@ -274,8 +274,10 @@ def main():
             if "tflops" in d:
                 roof["tflops"], roof["flop_per_byte"] = d["tflops"], d["flop_per_byte"]
                 roof["mfma_frac"] = round(d["tflops"] / PEAK_BF16_TFLOPS, 4)       # the same kernel priced against the dense bf16 MFMA peak
-            # tiles are padded to 256 / 32 tokens per sequence (10 s: 251 real, 1 s: 26): what the real tokens alone amount to
-            real = {"clip2": 251 / 256, "frame": 250 / 256, "clip6": (3 * 2 * 251 + 4 * 26 * 1.0) / (3 * 2 * 256 + 4 * 32 * 1.0)}[args.workload]
+            # 10 s sequences are padded to 256 rows (251 / 250 real tokens); 1 s views are packed (26 rows for 26 tokens, unless
+            # ATST_PACK=0): what the real tokens alone amount to
+            loc = 26 if os.environ.get("ATST_PACK", "1") != "0" else 32
+            real = {"clip2": 251 / 256, "frame": 250 / 256, "clip6": (3 * 2 * 251 + 4 * 26 * 1.0) / (3 * 2 * 256 + 4 * loc * 1.0)}[args.workload]
             roof["real_token_fraction"] = round(real, 4)
             roof["achieved_real_tokens_only"] = round(d["achieved"] * real, 2)
             # HBM bytes per launch from the committed PMC passes of this same command (rocprofv3 cannot collect

@@ -196,11 +196,15 @@ typedef struct {
    * step's max |x| is recorded in g8_amax.  fp8_bwd: 0 = bf16 backward, 1 = bf16 backward + amax recording (first step), 2 = fp8 dgrad.
    * Weight gradients always use the bf16 operands.                                                                          */
   const uint8_t* p8t; const float* g8_scale; float* g8_amax; int fp8_bwd;
+  /* rows between consecutive sequences in every [tokens, *] tensor of the pass (tokens, activations, gradients, atst_encoder_out):
+   * 0 = NP.  n_tok + use_cls <= row_stride < NP packs the sequences (NP < 256 only): 1 s views are 26 tokens in tiles of 32, and the
+   * GEMM / LayerNorm / weight-gradient kernels then run over S * row_stride rows.  The workspace is sized for NP either way.      */
+  int row_stride;
 } atst_encoder_t;
 
 size_t atst_encoder_ws_bytes(int S, int NP, int C, int H, int depth, int train, int fp8 /* = atst_encoder_t.fp8: also carve the e4m3 operand copies */);
 size_t atst_encoder_ws_bytes_geo(int S, int NP, int C, int H, int depth, int train, int fp8, int patch_h, int patch_w);   /* same, for a non-default patch geometry */
-/* forward: leaves LN(final) of every token as bf16 [S*NP, C] at atst_encoder_out(); */
+/* forward: leaves LN(final) of every token as bf16 [S*row_stride, C] at atst_encoder_out(); */
 int atst_encoder_fwd(const atst_encoder_t* e, void* stream);
 const uint16_t* atst_encoder_out(const atst_encoder_t* e);
 /* backward: d(LN(final)) bf16 [S*NP, C] must have been written to atst_encoder_dout() (zero for unused rows) */

@@ -149,27 +149,29 @@ def test_base_arch_encoder_vs_oracle():
     assert num / den < 1.0e-2 and worst[1] < 2.4e-2             # measured 6.9e-3 / 1.6e-2 (x1.5)
 
 
+@pytest.mark.parametrize("S", [5, 64])                  # 64 sequences: the packed layout (row stride = token count < tile rows)
 @pytest.mark.parametrize("width,NP", [(401, 128), (201, 64), (101, 32), (41, 32)])
-def test_short_clip_geometries_vs_oracle(width, NP):
+def test_short_clip_geometries_vs_oracle(width, NP, S):
     """4 s / 2 s / 1 s / 0.4 s inputs (token tiles of 128 / 64 / 32 rows; the generic attention kernels), depth 2, ragged
-    lengths: CLS and the gradient of sum(CLS * R) against the CPU oracle's autograd."""
-    S, depth = 5, 2
+    lengths: CLS and the gradient of sum(CLS * R) against the CPU oracle's autograd.  With S = 64 the engine packs the
+    sequences (EncoderPass.RS = tokens per sequence instead of the tile-aligned NP)."""
+    depth = 2
     W = O.recipe_weights("small", depth=depth, seed=41)
     eng = AtstEngine("small", depth=depth, drop_path_rate=0.0)
     eng.load_weights(W)
     mel = O.recipe_mel(S, width, seed=43)
-    length = torch.tensor([width, width - 4, max(width // 2, 8), width - 1, max(width // 3, 5)])
+    length = torch.tensor([width, width - 4, max(width // 2, 8), width - 1, max(width // 3, 5)] * ((S + 4) // 5))[:S]
     leaves = {k: v.requires_grad_(True) for k, v in W.items() if k.startswith("student.encoder.") and v.dtype == torch.float32}
     cls_o = O.encoder_forward(W, "student.encoder.", mel, length, "small", depth, drop_path_rate=0.0)
     R = torch.from_numpy(np.random.default_rng(45).standard_normal((S, 384)).astype(np.float32))
     (cls_o * R).sum().backward()
     ep = eng._pass("student", S, width, True, 0)
-    assert ep.NP == NP
+    assert ep.NP == NP and ep.RS == (ep.n_tok + 1 if S == 64 else NP)
     out = ep.forward(mel.cuda(), eng._valid(length, 1), None, None)
-    cls = out.float().reshape(S, NP, 384)[:, 0].cpu()
+    cls = out.float().reshape(S, ep.RS, 384)[:, 0].cpu()
     assert rel(cls.numpy(), cls_o.detach().numpy()) < 1e-2
     eng.g32.zero_(); ep.dout.zero_()
-    rows = (torch.arange(S, dtype=torch.int32, device="cuda") * NP).contiguous()
+    rows = (torch.arange(S, dtype=torch.int32, device="cuda") * ep.RS).contiguous()
     hip.call("atst_scatter_rows_bf16", hip.ptr(R.cuda()), hip.ptr(rows), S, 384, hip.ptr(ep.dout), hip.stream())
     ep.backward()
     num = den = 0.0
