@@ -7,7 +7,11 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
-LIB = os.path.join(LIBDIR, "libatst_hip.so")
+# ATST_LIB_TAG=x: an experiment build next to the product library (lib/libatst_hip_x.so, objects in lib/obj_x/), picked up by
+# audiossl_amd.hip under the same variable -- several builds (ATST_EXTRA_FLAGS=...) can then be A/B-timed inside ONE gpurun call.
+TAG = os.environ.get("ATST_LIB_TAG", "")
+LIB = os.path.join(LIBDIR, f"libatst_hip_{TAG}.so" if TAG else "libatst_hip.so")
+OBJDIR = os.path.join(LIBDIR, f"obj_{TAG}") if TAG else LIBDIR
 SOURCES = ["api.hip", "engine.hip", "engine_hp.hip", "gemm.hip", "layernorm.hip", "attention.hip", "tokens.hip", "head.hip", "optim.hip",
            "frontend.hip", "profile.hip", "augment.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
@@ -45,15 +49,15 @@ def _digest():
 
 
 def build(force=False, verbose=True):
-    os.makedirs(LIBDIR, exist_ok=True)
-    stamp = os.path.join(LIBDIR, "build.sha256")
+    os.makedirs(OBJDIR, exist_ok=True)
+    stamp = os.path.join(OBJDIR, "build.sha256")
     dig = _digest()
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
         return LIB
     hipcc = _hipcc()
     objs, procs = [], []
     for s in SOURCES:
-        o = os.path.join(LIBDIR, s.replace(".hip", ".o"))
+        o = os.path.join(OBJDIR, s.replace(".hip", ".o"))
         objs.append(o)
         src = VARIANT_SRC if (GEMM_VARIANTS and s == "gemm.hip") else os.path.join(CSRC, s)
         cmd = [hipcc, *FLAGS, "-c", src, "-o", o]

@@ -88,7 +88,7 @@ DEVFN void epilogue8(const GemmArgs& p, int row, int col, f32x4 v0, f32x4 v1, co
     if (p.C) st_bf16(p.C, idx, v0, v1);                            // pre-activation u (saved for backward; skipped in inference)
     f32x4 g0, g1;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { g0[e] = gelu_f(v0[e]); g1[e] = gelu_f(v1[e]); }
+    for (int e = 0; e < 4; ++e) { g0[e] = gelu_bf16dst(v0[e]); g1[e] = gelu_bf16dst(v1[e]); }
     st_bf16(p.C2, idx, g0, g1);                                    // activation a
     if (p.q8) {                                                    // fp8 forward: e4m3 copy of the SAME bf16 values for the fc2 GEMM
       const float s = p.q8_scale;
@@ -103,7 +103,7 @@ DEVFN void epilogue8(const GemmArgs& p, int row, int col, f32x4 v0, f32x4 v1, co
   } else if constexpr (EPI == EPI_DGELU) {
     const bf16x8 u = __builtin_bit_cast(bf16x8, x.a0);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { v0[e] *= gelu_grad_f(bf2f(u[e])); v1[e] *= gelu_grad_f(bf2f(u[4 + e])); }
+    for (int e = 0; e < 4; ++e) { v0[e] *= gelu_grad_bf16dst(bf2f(u[e])); v1[e] *= gelu_grad_bf16dst(bf2f(u[4 + e])); }
     st_bf16(p.C, idx, v0, v1);
     w0 = v0; w1 = v1;
     if (p.q8) {                                                    // fp8 dgrad: e4m3 copy of the SAME bf16 values for the fc1 dgrad GEMM (scale in x.s)

@@ -660,7 +660,9 @@ class AtstEngine:
         return v.to(torch.int32).contiguous()                       # stays where `lengths` lives (host for DataLoader batches)
 
     def _frame_rows(self, mk: torch.Tensor, valid: torch.Tensor, NP: int, mask_input: bool):
-        """ATST-Frame row bookkeeping for one width group.  mk [S, n_tok] bool, valid [S] (frames per sequence).
+        """ATST-Frame row bookkeeping for one width group.  mk [S, n_tok] bool, valid [S] (frames per sequence); NP = the pass's ROW
+        STRIDE between sequences (EncoderPass.RS: the padded token count, or the token count itself when short sequences are packed --
+        every kernel indexes rows and rowflag by s * RS + n).
         Returns (rows int32 [R] device: flat token indices s*NP+n of masked valid frames in (b, n) order,
                  rowflag uint8 [S*NP] device or None).  With host-side masks (what the DataLoader delivers: the transform
         draws them with numpy, methods/atstframe/transform.py:84-101) everything is computed on the host and uploaded
@@ -702,7 +704,7 @@ class AtstEngine:
             rowflag = None
             if self.frame:
                 mk = torch.cat([torch.as_tensor(m) for m in masks[a:b]]).bool()               # [S, n_tok]
-                rows, rowflag = self._frame_rows(mk, valid, ep.NP, mask_input)
+                rows, rowflag = self._frame_rows(mk, valid, ep.RS, mask_input)
             else:
                 key = (S, ep.RS)
                 if key not in self._cls_rows:

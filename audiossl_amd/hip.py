@@ -13,6 +13,8 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libatst_hip.so")
+if os.environ.get("ATST_LIB_TAG"):          # experiment builds side by side (audiossl_amd/build.py): A/B runs inside one gpurun call
+    LIB_PATH = os.path.join(_HERE, "lib", f"libatst_hip_{os.environ['ATST_LIB_TAG']}.so")
 ATST_MAX_DEPTH = 24
 
 EPI_BF16, EPI_F32, EPI_BIAS_GELU, EPI_RESID, EPI_DGELU, EPI_PATCH, EPI_LNBWD = range(7)

@@ -60,7 +60,8 @@ class EncoderView(_Node):
         if length is None:
             length = torch.full((S,), width, dtype=torch.int64)
         l = torch.as_tensor(length).to(torch.int64)
-        plen = (l - l % 4) // 4                                   # reference patch_length, NOT clipped to the chunk
+        pw = eng.patch_w
+        plen = (l - l % pw) // pw                                 # reference patch_length, NOT clipped to the chunk
         valid = (torch.clamp(plen, max=ep.n_tok) + ep.use_cls).to(torch.int32)
         C = eng.cfg["embed_dim"]
         n = min(n, eng.depth)
@@ -171,9 +172,13 @@ class ATST(nn.Module):
         drop = kwargs.pop("drop_path_rate", 0.1)
         depth = kwargs.pop("depth", None)
         spec_w = kwargs.pop("spec_w", 1001)
+        # patch geometry (the reference's patch_h / patch_w factory arguments, audio_transformer.py:367-374, with spec_h = n_mels = patch_h:
+        # one patch row); pos_embed has spec_w // patch_w + 1 rows (audio_transformer.py:95-102)
+        patch_h, patch_w = kwargs.pop("patch_h", 64), kwargs.pop("patch_w", 4)
         self.engine = AtstEngine(arch, frame=frame, depth=depth, ncrops=ncrops, drop_path_rate=drop,
-                                 n_pos=spec_w // 4 + 1, symmetric=kwargs.pop("symmetric", True),
-                                 patch_embed=kwargs.pop("patch_embed", "Linear"), precise=kwargs.pop("precise", False))
+                                 n_pos=spec_w // patch_w + 1, symmetric=kwargs.pop("symmetric", True),
+                                 patch_embed=kwargs.pop("patch_embed", "Linear"), precise=kwargs.pop("precise", False),
+                                 fp8=kwargs.pop("fp8", False), patch_h=patch_h, patch_w=patch_w)
         self.ncrops, self.frame = ncrops, frame
         self.engine.init_weights()
         self.student = _Net(self.engine, "student")

@@ -17,14 +17,11 @@ def _encoder(arch, **kwargs):
 
 
 def AST_small(patch_h=64, patch_w=4, **kwargs):
-    """ref: audio_transformer.py:367-370 (embed_dim 384, depth 12, 6 heads, 64 x 4 patches)."""
-    if (patch_h, patch_w) != (64, 4):
-        raise NotImplementedError("the HIP encoder implements the shipped 64 x 4 patch geometry")
-    return _encoder("small", **kwargs)
+    """ref: audio_transformer.py:367-370 (embed_dim 384, depth 12, 6 heads; patch_h x patch_w patches, shipped 64 x 4).  The HIP
+    engine takes one patch row of 64 / 128 mel bands x 4 / 8 frames (AtstEngine raises for anything else)."""
+    return _encoder("small", patch_h=patch_h, patch_w=patch_w, **kwargs)
 
 
 def AST_base(patch_h=64, patch_w=4, **kwargs):
-    """ref: audio_transformer.py:371-374 (embed_dim 768, depth 12, 12 heads)."""
-    if (patch_h, patch_w) != (64, 4):
-        raise NotImplementedError("the HIP encoder implements the shipped 64 x 4 patch geometry")
-    return _encoder("base", **kwargs)
+    """ref: audio_transformer.py:371-374 (embed_dim 768, depth 12, 12 heads); configs[4] uses 128 x 8 on 32 kHz / 128-mel input."""
+    return _encoder("base", patch_h=patch_h, patch_w=patch_w, **kwargs)
