@@ -138,7 +138,9 @@ __global__ __launch_bounds__(256) void stft_mel_db_kernel(const float* __restric
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       float mel = 0.f;
-      for (int q = 0; q < m_len[b]; ++q) mel += fbw[(lane + 64 * b) * fb_maxlen + q] * pw[wid][m_start[b] + q];
+      // the weight table is [tap][band]: one coalesced 256-B row per tap (band-major it was a 64-line gather per tap -- 39 taps per
+      // frame --, ~40 % of the kernel's time in round 3: tools/mel_probe.py)
+      for (int q = 0; q < m_len[b]; ++q) mel += fbw[q * NMEL + lane + 64 * b] * pw[wid][m_start[b] + q];
       const float db = 10.0f * log10f(fmaxf(mel, 1e-10f));
       dbb[lane + 64 * b][fl] = db;
       if (t0 + fl < T) vmax = fmaxf(vmax, db);
@@ -206,7 +208,7 @@ int init_twiddles(hipStream_t st) {
 int atst_mel_frontend(const float* wave, int n_clips, int n_samples, int wave_ld, int n_mels, int win_length, const float* window,
                       const float* fb_weights, const int* fb_start, const int* fb_len, int fb_maxlen,
                       float* out, unsigned int* clipmax, hipStream_t st) {
-  (void)win_length;                                   // the zero-padded 1024-tap window is supplied by the caller
+  (void)win_length; (void)fb_maxlen;                  // the zero-padded 1024-tap window is supplied by the caller ; fb_weights is [fb_maxlen][n_mels] (tap-major)
   if (wave_ld <= 0) wave_ld = n_samples;
   if (n_clips <= 0 || n_samples < NFFT / 2 + 1 || wave_ld < n_samples || (n_mels != 64 && n_mels != 128)) return ATST_EINVAL;
   int rc = init_twiddles(st);

@@ -1419,19 +1419,67 @@ __global__ __launch_bounds__(C::THREADS, C::NW / 4) void gemm_tn_tall_kernel(Wgr
 // Several weight gradients in ONE launch (the four of a transformer block): the grid is one round of the chip however
 // many problems share it, so each problem needs 1/n-th of the M-splits it would need alone -- and the fp32 atomics that
 // combine the splits (measured ~1.5 TB/s, 45-50 us per GEMM when each is launched alone) shrink by the same factor.
-struct WgradGroup { WgradArgs it[ATST_WGRAD_GROUP_MAX]; int first_tile[ATST_WGRAD_GROUP_MAX + 1]; int n; };
+// Block -> (problem, tile, M-split) map (round 4).  Blocks run on XCD blockIdx % 8 and xcd_remap gives every XCD a contiguous chunk of
+// logical ids; the tiles of ONE problem inside ONE M-split stream the same rows of dY / X (fc1: 8 tiles share the 768 B/row of h2, ...),
+// so a chunk boundary that falls inside such a group makes the second L2 fetch the shared panel again: with 24 tiles x 10 splits = 30
+// blocks per XCD every split straddled two L2s and the launch fetched 1.09x its algorithmic bytes (PMC, round 3).  The host packs whole
+// groups into the per-XCD chunks instead (first fit, largest first; a group is cut only when nothing else fits) and hands the kernel the
+// resulting table: 10 x {8, 8, 6, 2} blocks pack into 8 chunks of 30 without a single cut.
+constexpr int WG_MAP_MAX = 1024;
+struct WgradGroup {
+  WgradArgs it[ATST_WGRAD_GROUP_MAX]; int first_tile[ATST_WGRAD_GROUP_MAX + 1]; int n;
+  int use_map;                                  // 0: logical id = tile + ntiles * split (round-3 order)
+  uint16_t map[WG_MAP_MAX];                     // [logical id] = problem << 14 | tile in problem << 8 | split   (<= 4 problems, <= 64 tiles, <= 256 splits)
+};
 template <class C>
 __global__ __launch_bounds__(C::THREADS, C::NW / 4) void gemm_tn_tall_group_kernel(WgradGroup g) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int ntiles = g.first_tile[g.n];
   const int id = xcd_remap(blockIdx.x, gridDim.x);
+  if (g.use_map) {
+    const int e = __builtin_amdgcn_readfirstlane((int)g.map[id]);
+    tn_tall_body<C>(g.it[e >> 14], (e >> 8) & 63, e & 255, smem_raw);
+    return;
+  }
   const int t = id % ntiles, split = id / ntiles;
   int k = 0;
 #pragma unroll
   for (int i = 1; i < ATST_WGRAD_GROUP_MAX; ++i) if (i < g.n && t >= g.first_tile[i]) k = i;
   tn_tall_body<C>(g.it[k], t - g.first_tile[k], split, smem_raw);
 }
+// host side of the map: groups = (problem, split) with tiles(problem) members each; bins = the chunks xcd_remap gives the 8 XCDs
+static bool build_wgrad_map(WgradGroup& g, int splits, int nblk) {
+  const int ntiles = g.first_tile[g.n];
+  if (nblk != ntiles * splits || nblk > WG_MAP_MAX || splits > 256) return false;
+  int gsz[ATST_WGRAD_GROUP_MAX];
+  for (int k = 0; k < g.n; ++k) { gsz[k] = g.first_tile[k + 1] - g.first_tile[k]; if (gsz[k] > 64) return false; }
+  // remaining members of every group: left[k][split] tiles not yet placed (placed from tile 0 upwards)
+  static thread_local int left[ATST_WGRAD_GROUP_MAX][256];
+  for (int k = 0; k < g.n; ++k) for (int sp = 0; sp < splits; ++sp) left[k][sp] = gsz[k];
+  const int q = nblk >> 3, r = nblk & 7;
+  int pos = 0;
+  for (int x = 0; x < 8; ++x) {
+    int cap = q + (x < r ? 1 : 0);
+    while (cap > 0) {
+      // largest untouched group that fits; else the largest remainder (cut it)
+      int bk = -1, bs = -1, best = 0; bool fits = false;
+      for (int k = 0; k < g.n; ++k)
+        for (int sp = 0; sp < splits; ++sp) {
+          const int l = left[k][sp];
+          if (l == 0) continue;
+          const bool f = l <= cap;
+          if ((f && !fits) || (f == fits && l > best)) { bk = k; bs = sp; best = l; fits = f; }
+        }
+      if (bk < 0) return false;
+      const int take = best <= cap ? best : cap, t0 = gsz[bk] - left[bk][bs];
+      for (int t = 0; t < take; ++t) g.map[pos++] = (uint16_t)((bk << 14) | ((t0 + t) << 8) | bs);
+      left[bk][bs] -= take; cap -= take;
+    }
+  }
+  return pos == nblk;
+}
 
+int g_tn_map = 1;           // 130/131: grouped wgrad: (problem, split) groups packed onto XCDs (131, default) / round-3 order tile + ntiles * split (130)
 int g_tn_cfg = 1;           // 120 + c: wgrad schedule: 0 = every wave issues behind the hand-off ; 1 = wave rows staggered (default) ; 2 = 32-row stages, 4-deep ring
 template <class C> int launch_tn_tall(const WgradArgs& p, int nblk, hipStream_t st) {
   static bool attr = false;
@@ -1598,6 +1646,7 @@ void atst_gemm_nt_set_variant(int v) {
   else if (v >= 306) g_dgelu_row384 = v - 306;
   else if (v >= 302) g_row384_tall = v - 302;
   else if (v >= 300) g_row384_auto = v - 300;
+  else if (v >= 130 && v < 132) g_tn_map = v - 130;
   else if (v >= 120 && v < 130) g_tn_cfg = v - 120;
   else if (v >= 110) g_tn_rounds = v - 110;
   else if (v >= 105) g_tn_tall = v - 105;
@@ -1710,14 +1759,17 @@ int atst_gemm_tn_group(const WgradArgs* items, int n, hipStream_t st) {
       if (cost < best) { best = cost; splits = sp; }
     }
   }
-  int max_splits = 1;
+  int max_splits = 1, min_splits = 1 << 30;
   for (int i = 0; i < n; ++i) {
     int mps = (items[i].M + splits - 1) / splits;
     mps = ((mps + tnt::RM_ALIGN - 1) / tnt::RM_ALIGN) * tnt::RM_ALIGN;
     g.it[i].m_per_split = mps;
     const int sp = (items[i].M + mps - 1) / mps;
     if (sp > max_splits) max_splits = sp;
+    if (sp < min_splits) min_splits = sp;
   }
+  // every problem cut into the same number of splits (always, on the encoder path: one M): groups packed onto XCDs, see build_wgrad_map
+  g.use_map = (g_tn_map && min_splits == max_splits && build_wgrad_map(g, max_splits, tiles * max_splits)) ? 1 : 0;
   ProfScope ps(PK_GEMM_TN, flops, st, bytes);
   return dispatch_tn_tall_group(g, tiles * max_splits, st);
 }

@@ -472,9 +472,14 @@ class AtstEngine:
             # of every block ([depth][4]: g -> fc2, du -> fc1, g2 -> proj, dqkv -> qkv).  fp8_bwd_state: 0 off, 1 recording, 2 on.
             self.p8t = z(L.n_student, torch.uint8)
             self.g8_scale, self.g8_amax = torch.ones(4 * self.depth, device=dev), z(4 * self.depth)
-            import os as _os
-            self.fp8_bwd_state = 1 if (self.cfg["embed_dim"] == 768 and _os.environ.get("ATST_FP8_BWD", "1") != "0") else 0
+            self.fp8_bwd_state = 1 if (self.cfg["embed_dim"] == 768 and os.environ.get("ATST_FP8_BWD", "1") != "0") else 0
             self.fp8_margin = 2.0
+            # amax HISTORY: the scale of a site is 448 / (margin * max amax over the last FP8_HISTORY steps), so one quiet step does not
+            # shrink the headroom of the next (round-3 ADVICE: a single previous step with margin 2 saturates on any 2x spike); the
+            # window, its cursor and the scales are optimizer state (checkpointed, broadcast on resume), and amax is MAX-reduced
+            # over the ranks so that every replica quantises on the same grid.
+            self.FP8_HISTORY = 16
+            self.g8_hist, self._g8_hist_k = z(self.FP8_HISTORY * 4 * self.depth).view(self.FP8_HISTORY, 4 * self.depth), 0
         self.bn_buffers: Dict[str, Dict[str, torch.Tensor]] = {}
         for key in ("student.projector", "student.predictor", "teacher.projector"):
             self.bn_buffers[key] = dict(running_mean=z(HEAD_HIDDEN), running_var=torch.ones(HEAD_HIDDEN, device=dev),
@@ -845,8 +850,26 @@ class AtstEngine:
         """Delayed scaling: this step's amax of every gradient operand becomes the next step's quantisation scale (448 / (margin amax));
         the first backward only records (bf16 dgrad), every later one runs the dgrad GEMMs on e4m3 operands."""
         if self.fp8 and getattr(self, "fp8_bwd_state", 0):
-            hip.call("atst_fp8_update_scales", hip.ptr(self.g8_amax), hip.ptr(self.g8_scale), self.g8_amax.numel(), float(self.fp8_margin), hip.stream())
+            if parallel._collective():
+                dist.all_reduce(self.g8_amax, op=dist.ReduceOp.MAX)            # 4 * depth floats: every rank derives the same scales
+            self.g8_hist[self._g8_hist_k % self.FP8_HISTORY].copy_(self.g8_amax)
+            self._g8_hist_k += 1
+            win = self.g8_hist.max(dim=0).values.contiguous()                   # sites never observed stay 0: their scale is left alone
+            hip.call("atst_fp8_update_scales", hip.ptr(win), hip.ptr(self.g8_scale), win.numel(), float(self.fp8_margin), hip.stream())
+            self.g8_amax.zero_()
             self.fp8_bwd_state = 2
+
+    def fp8_state(self) -> Optional[dict]:
+        """Delayed-scaling state of the fp8 dgrad path (optimizer state: saved with the moments, see trainer.save_checkpoint)."""
+        if not (self.fp8 and getattr(self, "fp8_bwd_state", 0)):
+            return None
+        return {"g8_scale": self.g8_scale.cpu(), "g8_hist": self.g8_hist.cpu(), "hist_k": int(self._g8_hist_k), "state": int(self.fp8_bwd_state)}
+
+    def load_fp8_state(self, st: Optional[dict]):
+        if not st or not (self.fp8 and getattr(self, "fp8_bwd_state", 0)):
+            return
+        self.g8_scale.copy_(st["g8_scale"]); self.g8_hist.copy_(st["g8_hist"])
+        self._g8_hist_k, self.fp8_bwd_state = int(st["hist_k"]), int(st["state"])
 
     def _reduce_async(self, a: int, b: int):
         """Sum g32[a:b] over ranks on the communication stream, ordered after everything enqueued so far."""
@@ -864,14 +887,19 @@ class AtstEngine:
         if not parallel._collective():
             return
         bufs = [self.p32, self.t32] + [t for b in self.bn_buffers.values() for t in b.values()]
+        f8 = optimizer_state and self.fp8 and getattr(self, "fp8_bwd_state", 0)
         if optimizer_state:
             bufs += [self.m32, self.v32]
+        if f8:
+            bufs += [self.g8_scale, self.g8_hist]
         for t in bufs:
             dist.broadcast(t, 0)
         if optimizer_state:
-            step = torch.tensor([self.opt_step], dtype=torch.int64, device=self.device)
+            step = torch.tensor([self.opt_step, self._g8_hist_k if f8 else 0, self.fp8_bwd_state if f8 else 0], dtype=torch.int64, device=self.device)
             dist.broadcast(step, 0)
-            self.opt_step = int(step.item())
+            self.opt_step = int(step[0].item())
+            if f8:
+                self._g8_hist_k, self.fp8_bwd_state = int(step[1].item()), int(step[2].item())
         self.sync_shadows(force=True)
 
     def allreduce_grads(self):

@@ -53,7 +53,7 @@ class LogMelFrontend:
         wts = torch.zeros(n_mels, self.maxlen)
         for m in range(n_mels):
             wts[m, : end[m] - start[m]] = fb[start[m]:end[m], m]
-        self.fb_w = wts.to(self.device).contiguous()
+        self.fb_w = wts.t().contiguous().to(self.device)          # [tap, band]: the kernel reads one coalesced row of all bands per tap
         self.fb_start = start.to(torch.int32).to(self.device)
         self.fb_len = (end - start).to(torch.int32).to(self.device)
 

@@ -30,6 +30,20 @@ def _collective() -> bool:
     return dist.get_world_size() > 1 or os.environ.get("ATST_FORCE_COLLECTIVES") == "1"
 
 
+def _gather_rows(pack: torch.Tensor) -> torch.Tensor:
+    """Every rank's `pack` (1-D, equal length) as the rows of a [world, n] tensor.  RCCL: one all_gather_into_tensor (n floats sent per
+    rank).  Other transports (gloo has no all_gather for device tensors): the same table as an all-reduce of zeros with this
+    rank's row filled -- world x the bytes plus a fill, which is what every step paid before round 4."""
+    out = pack.new_empty(world_size(), pack.numel())
+    if dist.get_backend() == "nccl":
+        dist.all_gather_into_tensor(out, pack.contiguous())
+    else:
+        out.zero_()
+        out[dist.get_rank()] = pack
+        dist.all_reduce(out)
+    return out
+
+
 def combine_bn_stats(mean: torch.Tensor, m2: torch.Tensor, count: float):
     """Local per-feature (mean, M2 = sum (x-mean)^2, row count) -> global (mean, M2, count) over all ranks
     (Chan et al. parallel variance).  Identity at world size 1 (count stays a python float); across ranks the global
@@ -39,11 +53,7 @@ def combine_bn_stats(mean: torch.Tensor, m2: torch.Tensor, count: float):
         return mean, m2, float(count)
     n = mean.numel()
     pack = torch.cat([mean, m2, mean.new_full((1,), float(count))])                 # fill kernel: no host->device copy, no sync
-    # all-gather expressed as an all-reduce of a [world, 2n+1] table with only this rank's row filled: one collective
-    # that every transport supports for device tensors (8 KB x world)
-    allp = pack.new_zeros(world_size(), pack.numel())
-    allp[dist.get_rank()] = pack
-    dist.all_reduce(allp)
+    allp = _gather_rows(pack)                                                       # [world, 2n+1]
     means, m2s, cnts = allp[:, :n], allp[:, n:2 * n], allp[:, -1:]
     total = cnts.sum()
     gmean = (means * cnts).sum(0) / total
@@ -59,9 +69,7 @@ def combine_bn_stats_multi(items):
     packs = [torch.cat([m, q, m.new_full((1,), float(c))]) for m, q, c in items]
     sizes = [p_.numel() for p_ in packs]
     pack = torch.cat(packs)
-    allp = pack.new_zeros(world_size(), pack.numel())
-    allp[dist.get_rank()] = pack
-    dist.all_reduce(allp)
+    allp = _gather_rows(pack)
     out, off = [], 0
     for (m, _, _), sz in zip(items, sizes):
         n = m.numel()

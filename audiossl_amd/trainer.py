@@ -16,13 +16,16 @@ LIGHTNING_VERSION = "2.2.1"                           # setup.cfg:22 of the refe
 
 
 def save_checkpoint(path, module, optimizer=None, epoch=0):
+    """epoch: zero-based index of the last FINISHED epoch (Lightning's convention); -1 = none finished yet (a max_steps stop inside
+    epoch 0): stored as `epoch` 0 for Lightning-format consumers, with the exact count in `epochs_finished` for our own resume."""
     sd = {k: v.detach().cpu() for k, v in module.state_dict().items()}
     eng = module.model.engine
     ckpt = {"state_dict": sd, "hyper_parameters": dict(getattr(module, "hparams", {})), "global_step": int(module.global_step),
-            "epoch": int(epoch), "pytorch-lightning_version": LIGHTNING_VERSION, "loops": {}, "callbacks": {},
+            "epoch": max(int(epoch), 0), "epochs_finished": int(epoch) + 1,
+            "pytorch-lightning_version": LIGHTNING_VERSION, "loops": {}, "callbacks": {},
             "lr_schedulers": [],
             "optimizer_states": [{"flat_exp_avg": eng.m32.cpu(), "flat_exp_avg_sq": eng.v32.cpu(), "step": eng.opt_step,
-                                  "layout": "audiossl_amd.FlatLayout"}]}
+                                  "layout": "audiossl_amd.FlatLayout", "fp8_dgrad": eng.fp8_state()}]}
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     torch.save(ckpt, path)
 
@@ -37,6 +40,7 @@ def load_checkpoint(path, module, strict=True):
     if st and st.get("layout") == "audiossl_amd.FlatLayout":
         eng = module.model.engine
         eng.m32.copy_(st["flat_exp_avg"]); eng.v32.copy_(st["flat_exp_avg_sq"]); eng.opt_step = int(st["step"])
+        eng.load_fp8_state(st.get("fp8_dgrad"))                    # delayed-scaling scales + amax window: a resumed run quantises as the saved one did
     return ckpt
 
 
@@ -60,12 +64,19 @@ class Trainer:
         # the counters through one broadcast, and all replicas are then aligned by ONE broadcast of rank 0's tensors -- never a
         # per-rank os.path.exists() in front of a collective (ranks that do not see the file would deadlock the others).
         eng = model.model.engine
-        state = [False, 0, int(model.global_step)]
+        state = [False, 0, int(model.global_step), None]
         if self.rank == 0 and ckpt_path and os.path.exists(ckpt_path):
-            ckpt = load_checkpoint(ckpt_path, model)
-            state = [True, int(ckpt.get("epoch", -1)) + 1, int(model.global_step)]   # Lightning stores the zero-based index of the last FINISHED epoch
+            try:
+                ckpt = load_checkpoint(ckpt_path, model)
+                # Lightning stores the zero-based index of the last FINISHED epoch; `epochs_finished` (ours) is exact when no epoch was finished
+                done_epochs = int(ckpt["epochs_finished"]) if "epochs_finished" in ckpt else int(ckpt.get("epoch", -1)) + 1
+                state = [True, done_epochs, int(model.global_step), None]
+            except Exception as e:                                # a corrupt / partial file on rank 0: every rank must learn it, not hang in the broadcast
+                state = [False, 0, int(model.global_step), f"{type(e).__name__}: {e}"]
         if self.world > 1:
             dist.broadcast_object_list(state, src=0)
+        if state[3] is not None:
+            raise RuntimeError(f"resume from {ckpt_path} failed on rank 0: {state[3]}")
         resumed, epoch, model.global_step = bool(state[0]), int(state[1]), int(state[2])
         eng.broadcast_parameters(optimizer_state=resumed)
         loader = train_dataloaders if train_dataloaders is not None else datamodule.train_dataloader(self.rank, self.world)

@@ -123,8 +123,12 @@ def main():
     ap.add_argument("--arch", default="small", choices=["small", "base"],
                     help="small = the headline model (BASELINE configs[1..3]); base (d = 768, 12 heads) is an extra data point")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"],
-                    help="fp8: the four Linear layers of every block run their FORWARD on OCP e4m3 operands (MX-scaled MFMA); "
-                         "backward and saved activations stay bf16 (BASELINE.json configs[4]: use with --arch base)")
+                    help="fp8: the four Linear layers of every block run their forward AND (d = 768) their fc2 / fc1 / proj dgrad GEMMs on "
+                         "OCP e4m3 operands (MX-scaled MFMA, delayed scaling for the gradient operands); qkv dgrad, weight gradients and "
+                         "saved activations stay bf16 (BASELINE.json configs[4]: use with --arch base)")
+    ap.add_argument("--precise", action="store_true",
+                    help="parity mode (AtstEngine(precise=True)): fp32 activations / gradients, every Linear as a split-bf16 MFMA GEMM (~2^-16); "
+                         "the mode that meets north_star's 1e-3 gradient tolerance -- reported next to the bf16 number, never as the headline")
     ap.add_argument("--hires", action="store_true",
                     help="BASELINE.json configs[4] input geometry: 10 s @ 32 kHz, 128 mel bands, one patch row of 128 x 8 (the reference's "
                          "sr / n_mels / patch_h / patch_w parameters) -> 2001 frames, 250 patches of 1024 values; use with --arch base --dtype fp8")
@@ -171,7 +175,11 @@ def main():
     ncrops = 6 if args.workload == "clip6" else 2
     sr, n_mels, patch = (32000, 128, (128, 8)) if args.hires else (16000, 64, (64, 4))
     clip_len, buf_len = 10 * sr, 12 * sr
-    eng = AtstEngine(args.arch, frame=frame, ncrops=ncrops, fp8=args.dtype == "fp8", patch_h=patch[0], patch_w=patch[1])
+    if args.precise:
+        if args.dtype != "bf16":
+            ap.error("--precise is the fp32 parity mode; it excludes --dtype fp8")
+        args.no_profile = True                                      # the parity-mode kernels are not instrumented
+    eng = AtstEngine(args.arch, frame=frame, ncrops=ncrops, fp8=args.dtype == "fp8", patch_h=patch[0], patch_w=patch[1], precise=args.precise)
     eng.init_weights(seed=0)
     eng.broadcast_parameters()                                       # DDP init: every rank takes rank 0's replica (no-op at world 1)
     eng.overlap_teacher = args.overlap
@@ -311,7 +319,8 @@ def main():
         out = {"metric": f"pretrain clips/sec (10s@{khz}, ATST-{args.arch})", "value": round(value, 2), "unit": "clips/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "bf16" if args.dtype == "bf16" else "fp8 (e4m3 forward GEMMs) + bf16", "data": "synthetic",
+               "dtype": ("fp32 activations, split-bf16 MFMA GEMMs (parity mode)" if args.precise else "bf16") if args.dtype == "bf16"
+                        else "fp8 (e4m3 forward + fc2/fc1/proj dgrad GEMMs) + bf16", "data": "synthetic",
                "config": {"workload": {"clip6": "ATST-small clip-level, 2 global (10 s) + 4 local (1 s) views",
                                        "clip2": "ATST-small clip-level, 2 views (10 s)",
                                        "frame": "ATST-Frame small, masked frame objective (10 s)"}[args.workload].replace("small", args.arch) +

@@ -46,7 +46,7 @@ int atst_tune_gemm_variant(int v);
  * wave: n_clips rows of n_samples f32, row stride wave_ld (0 = n_samples; lets a view be a slice of a longer buffer) ->
  * out [n_clips, n_mels, 1 + n_samples/160] f32, n_mels = 64 or 128 (the reference's `n_mels` parameter, atstframe/transform.py:14-16;
  * the sample rate `sr` only enters through the filterbank table).  window: 1024 taps (Hann(win_length) zero-padded centred);
- * fb_*: compact triangular filterbank (n_mels bands: start bin, length, weights [n_mels, fb_maxlen]).  clipmax: n_clips uint32 scratch. */
+ * fb_*: compact triangular filterbank (n_mels bands: start bin, length, weights [fb_maxlen, n_mels] = tap-major, zero beyond a band's length).  clipmax: n_clips uint32 scratch. */
 int atst_mel_frontend_f32(const float* wave, int n_clips, int n_samples, int wave_ld, int n_mels, int win_length, const float* window,
                           const float* fb_weights, const int* fb_start, const int* fb_len, int fb_maxlen,
                           float* out, uint32_t* clipmax, void* stream);

@@ -174,24 +174,63 @@ def _q8(x: Tensor, scale) -> Tensor:
     return (x * scale).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32) / scale
 
 
+_FP8_BWD = None                                     # emulate_fp8_dgrad instance while active
+
+
+class emulate_fp8_dgrad:
+    """On top of emulate_bf16 + emulate_fp8: the dgrad GEMMs of fc2, fc1 and proj (d = 768: csrc/engine.hip encoder_bwd_range, `use8`)
+    run on OCP e4m3 copies of their operands.  The gradient operand of site k (= the bf16 gradient arriving at that Linear's output) is
+    quantised with a DELAYED scale -- 448 / (margin * amax of the same site in the previous step), csrc/optim.hip fp8_update_scales --
+    and the transposed weight shadow with the per-tensor factor of the forward copy (448 / amax of the fp32 master, applied to the bf16
+    shadow: atst_quant_bf16_table_fp8).  The qkv dgrad and every weight gradient stay on bf16 operands.
+      scales = None  -> record only (what the engine's first backward does): bf16 dgrad, self.amax[site] filled
+      scales = {site: s} -> e4m3 dgrad at those sites with those scales; self.amax again holds this step's amax.
+    `site` is the weight key ("student.encoder.blocks.0.mlp.fc2.weight").  next_scales() turns the recorded amax into the next step's
+    scales exactly like the device kernel."""
+    SITES = ("mlp.fc2.weight", "mlp.fc1.weight", "attn.proj.weight")
+
+    def __init__(self, scales=None, margin: float = 2.0):
+        self.scales, self.margin, self.amax = scales, margin, {}
+
+    def next_scales(self):
+        return {k: 448.0 / (self.margin * v) for k, v in self.amax.items() if v > 0}
+
+    def __enter__(self):
+        global _FP8_BWD
+        self.prev, _FP8_BWD = _FP8_BWD, self
+        return self
+
+    def __exit__(self, *a):
+        global _FP8_BWD
+        _FP8_BWD = self.prev
+
+
 class _Fp8Linear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, w_master, act_scale):
-        ctx.save_for_backward(x, w)
+    def forward(ctx, x, w, w_master, act_scale, key):
+        ctx.save_for_backward(x, w, w_master)
+        ctx.key = key
         ws = 448.0 / w_master.abs().max().clamp_min(1e-30)          # the e4m3 shadow is cut from the fp32 master
         return _q8(x, act_scale) @ _q8(w_master, ws).t()
 
     @staticmethod
     def backward(ctx, g):
-        x, w = ctx.saved_tensors                                     # gradients as if the bf16 operands had been used
-        return g @ w, g.reshape(-1, g.shape[-1]).t() @ x.reshape(-1, x.shape[-1]), None, None
+        x, w, w_master = ctx.saved_tensors                           # weight gradient: as if the bf16 operands had been used
+        dw = g.reshape(-1, g.shape[-1]).t() @ x.reshape(-1, x.shape[-1])
+        st, key = _FP8_BWD, ctx.key
+        if st is not None and key.endswith(emulate_fp8_dgrad.SITES):
+            st.amax[key] = max(st.amax.get(key, 0.0), float(g.abs().max()))      # g is the bf16 gradient operand (emulate_bf16 rounds it)
+            if st.scales is not None and key in st.scales:
+                ws = 448.0 / w_master.abs().max().clamp_min(1e-30)
+                return _q8(g, st.scales[key]) @ _q8(w, ws), dw, None, None, None    # w = the bf16 shadow (its transposed copy is what gets quantised)
+        return g @ w, dw, None, None, None
 
 
 def _linear(x: Tensor, W: Weights, key: str, b: Optional[Tensor], act_scale: float = FP8_ACT_SCALE) -> Tensor:
     """F.linear on the (bf16-shadow when emulating) weight W[key], or its e4m3-forward version inside emulate_fp8()."""
     if not _FP8:
         return F.linear(x, _w(W, key), b)
-    y = _Fp8Linear.apply(x, _w(W, key), W[key].detach(), act_scale)
+    y = _Fp8Linear.apply(x, _w(W, key), W[key].detach(), act_scale, key)
     return y if b is None else y + b
 
 

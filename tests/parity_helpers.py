@@ -17,11 +17,15 @@ def rel(a, b):
     return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
 
 
-def oracle_grads(W, fwd, emu, gates=None):
+def oracle_grads(W, fwd, emu, gates=None, ctxs=()):
+    """ctxs: further oracle contexts entered inside emulate_bf16 (emulate_fp8, emulate_fp8_dgrad)"""
+    import contextlib
     leaves = {k: v.detach().clone().requires_grad_(True) for k, v in W.items() if k.startswith("student.") and v.dtype == torch.float32
               and "running" not in k}
     Wl = {k: (leaves[k] if k in leaves else v.clone()) for k, v in W.items()}
-    with O.emulate_bf16(emu), O.relu_gates(gates or {}):
+    with O.emulate_bf16(emu), O.relu_gates(gates or {}), contextlib.ExitStack() as stack:
+        for c in ctxs:
+            stack.enter_context(c)
         loss = fwd(Wl)[0]
         loss.backward()
     return float(loss.detach()), {k[len("student."):]: v.grad.detach() for k, v in leaves.items() if v.grad is not None}

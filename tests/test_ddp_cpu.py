@@ -1,5 +1,6 @@
-"""World-size-2 (gloo, CPU) tests of the cross-rank logic in audiossl_amd/parallel.py: a 2-rank sharded evaluation must
-equal the 1-rank evaluation on the concatenated batch -- which is what DDP-mean + SyncBatchNorm guarantee."""
+"""World-size-2 and -8 (gloo, CPU) tests of the cross-rank logic in audiossl_amd/parallel.py: a sharded evaluation must equal the
+1-rank evaluation on the concatenated batch -- which is what DDP-mean + SyncBatchNorm guarantee; world 8 is the
+geometry of BASELINE.json configs[3] (one node, 8 GPUs)."""
 import os
 import socket
 
@@ -18,11 +19,13 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from audiossl_amd import parallel as P
     torch.manual_seed(0)
-    R, N = 22, 64                                        # ragged shards: 9 rows on rank 0, 13 on rank 1
+    N = 64
+    cuts = [0, 9, 22] if world == 2 else [0, 3, 9, 10, 17, 22, 30, 33, 41]     # ragged shards (ATST-Frame: masked-row counts differ per rank)
+    R = cuts[-1]
     h = torch.randn(R, N, dtype=torch.float64) * 2 + 0.5
     gamma, beta = torch.rand(N, dtype=torch.float64) + 0.5, torch.randn(N, dtype=torch.float64) * 0.1
     w_out = torch.randn(N, dtype=torch.float64)
-    lo, hi = (0, 9) if rank == 0 else (9, R)
+    lo, hi = cuts[rank], cuts[rank + 1]
     hl = h[lo:hi]
     # ---- forward statistics
     mean_l = hl.mean(0); m2_l = ((hl - mean_l) ** 2).sum(0)
@@ -50,7 +53,7 @@ def _worker(rank, world, port, q):
     ok = ok and summed and torch.allclose(flat / world, g_full)
     # ---- two independent BatchNorms in ONE exchange (teacher + student projector of a step): same numbers as one by one
     h2 = torch.randn(R, N, dtype=torch.float64) * 0.7 - 1.0
-    h2l = h2[lo:hi + 0] if rank == 0 else h2[lo:hi]
+    h2l = h2[lo:hi]
     m_b = h2l.mean(0); q_b = ((h2l - m_b) ** 2).sum(0)
     (ma, qa, ca), (mb, qb, cb) = P.combine_bn_stats_multi([(mean_l, m2_l, hl.shape[0]), (m_b, q_b, h2l.shape[0])])
     ok = ok and torch.allclose(ma, mean) and torch.allclose(qa, m2) and float(ca) == R
@@ -58,21 +61,23 @@ def _worker(rank, world, port, q):
     # ---- fused monitor all-reduce
     stats = torch.arange(8, dtype=torch.float64).view(4, 2) * (rank + 1)
     st, ns, nt = P.allreduce_monitor_sums(stats, 4.0 + rank, 2.0)
-    ok = ok and torch.equal(st, torch.arange(8, dtype=torch.float64).view(4, 2) * 3) and float(ns) == 9.0 and float(nt) == 4.0
+    tri = world * (world + 1) // 2
+    ok = ok and torch.equal(st, torch.arange(8, dtype=torch.float64).view(4, 2) * tri) and float(ns) == 4.0 * world + tri - world and float(nt) == 2.0 * world
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 
 
-def test_two_rank_equals_one_rank():
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_ranks_equal_one_rank(world):
     ctx = mp.get_context("spawn")
     q, port = ctx.Queue(), _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in procs)
+    res = sorted(q.get(timeout=240) for _ in procs)
     for p in procs:
         p.join(timeout=60)
-    assert res == [(0, True), (1, True)]
+    assert res == [(r, True) for r in range(world)]
 
 
 def test_single_process_helpers_are_identity():

@@ -38,14 +38,15 @@ def test_torchrun_single_rank_rccl(workload):
     assert abs(dist["loss"] - plain["loss"]) < 2e-3, (dist["loss"], plain["loss"])      # wgrad atomics: not bit-reproducible
 
 
-def _worker(tmp_path, tag, world, mode, overlap=1, batch=16):
+def _worker(tmp_path, tag, world, mode, overlap=1, batch=16, ranks=2):
     out = os.path.join(str(tmp_path), f"{tag}.npz")
-    base = [os.path.join(ROOT, "tests", "dist_worker.py"), "--mode", mode, "--out", out, "--overlap", str(overlap), "--batch", str(batch)]
+    base = [os.path.join(ROOT, "tests", "dist_worker.py"), "--mode", mode, "--out", out, "--overlap", str(overlap), "--batch", str(batch),
+            "--ranks", str(ranks)]
     if world == 1:
         cmd = [sys.executable] + base
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
-               "127.0.0.1", "--master-port", str(29560 + overlap + (7 if mode != "clip" else 0))] + base
+               "127.0.0.1", "--master-port", str(29560 + overlap + (7 if mode != "clip" else 0) + 20 * (world > 2))] + base
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
@@ -79,6 +80,29 @@ def test_two_ranks_equal_one_rank_on_the_concatenated_batch(tmp_path, mode, over
             assert _rel(two[k], one[k]) < 1e-4, k
     # the first Adam step is lr * g / (|g| + eps): gradient entries near zero turn fp32 noise into +-lr (1e-3 on 2e-2 weights)
     assert _rel(two["params"], one["params"]) < 2e-3 and _rel(two["teacher"], one["teacher"]) < 2e-5
+
+
+@pytest.mark.parametrize("mode", ["clip", "frame"])
+def test_eight_ranks_equal_one_rank_on_the_concatenated_batch(tmp_path, mode):
+    """configs[3] readiness on the single-GPU box (BASELINE.json: 8 x MI355X DDP): EIGHT ranks (gloo, all on cuda:0 unless the node has
+    8 GPUs), 4 clips each, against one process on the 32-clip batch.  Exercises what world 2 cannot: the bucket cuts with seven
+    peers, the SyncBN combine of eight [mean, M2, count] rows, rank -> device mapping, eight DIFFERENT initial seeds aligned by the one
+    init broadcast.  Tolerances: the 4-clips-per-rank regime of the two-rank test (BatchNorm-backward cancellation amplifies the fp32
+    summation-order difference more with fewer rows per rank)."""
+    one = _worker(tmp_path, f"one8_{mode}", 1, mode, batch=4, ranks=8)
+    eight = _worker(tmp_path, f"eight_{mode}", 8, mode, 1, batch=4, ranks=8)
+    assert int(eight["world"]) == 8 and float(eight["same"][0]) == 1.0      # all ranks hold identical parameters after the step
+    g = _rel(eight["grads"], one["grads"])
+    n_pred = 2 * 4096 * 256 + 2 * 4096
+    gp = _rel(eight["grads"][-n_pred:], one["grads"][-n_pred:])
+    print(f"\n[8 ranks vs 1, {mode}] loss {float(eight['loss'][0]):.6f} vs {float(one['loss'][0]):.6f}; flat gradient rel {g:.2e}; predictor {gp:.2e}")
+    assert abs(float(eight["loss"][0]) - float(one["loss"][0])) < 3e-4
+    assert abs(float(eight["std_s"]) - float(one["std_s"])) < 1e-4 and abs(float(eight["std_t"]) - float(one["std_t"])) < 1e-4
+    assert g < 2.5e-2 and gp < 5e-3, (g, gp)
+    for k in one.files:
+        if k.startswith("bn/") and not k.endswith("num_batches_tracked"):
+            assert _rel(eight[k], one[k]) < 1e-4, k
+    assert _rel(eight["teacher"], one["teacher"]) < 5e-5
 
 
 def test_two_ranks_ragged_frame_rows(tmp_path):

@@ -5,6 +5,8 @@ Tolerances: products of bf16 inputs are exact in fp32, so fp32 outputs differ on
 bf16 outputs carry one rounding (2^-9 = 2e-3 rel); integer / index work is bit-exact.
 """
 import math
+import os
+import sys
 
 import numpy as np
 import pytest
@@ -108,7 +110,7 @@ def test_gemm_tn(M, N, K, split):
     assert relerr(dW, ref) < 2e-5
 
 
-@pytest.mark.parametrize("hook", [121, 120, 122])    # wgrad schedules: staggered issue (default) / all waves behind the hand-off / 32-row stages in a 4-deep ring
+@pytest.mark.parametrize("hook", [121, 120, 122, 130])    # wgrad schedules: staggered issue (default) / all waves behind the hand-off / 32-row stages in a 4-deep ring ; 130: round-3 block order (no XCD group map)
 @pytest.mark.parametrize("M", [8192, 8192 + 192, 32768 + 64, 1000])   # 192x384 LDS-DMA tiles in one launch (whole / ragged last split) / per-problem fallback
 def test_gemm_tn_group(M, hook):
     import ctypes as C
@@ -125,6 +127,7 @@ def test_gemm_tn_group(M, hook):
     hip.call("atst_gemm_tn_group_bf16", C.cast(items, C.c_void_p), 4, hip.stream())
     torch.cuda.synchronize()
     hip.load().atst_tune_gemm_variant(121)
+    hip.load().atst_tune_gemm_variant(131)
     for (dY, X, dW), ref in zip(keep, want):
         assert relerr(dW, ref) < 2e-5
 
@@ -470,39 +473,75 @@ def test_fp8_dynamic_quantiser_and_scale_update():
 
 def test_fp8_dgrad_step_base():
     """BASELINE.json configs[4]: ATST-base with e4m3 forward AND fc2 / fc1 / proj dgrad GEMMs (qkv dgrad and weight gradients on bf16
-    operands).  Delayed scaling:
-    the first backward records the amax of every gradient operand and runs in bf16, every later one quantises with the previous
-    step's scale.  The fp8-dgrad gradients are compared with the bf16-dgrad gradients of the SAME fp8-forward engine state
-    (identical forward, identical weights): e4m3 operands are a 6 % staircase, measured difference per tensor see the print."""
+    operands).  Delayed scaling: the first backward records the amax of every gradient operand and runs in bf16, every later one
+    quantises with the previous step's scale.  Checked against the ORACLE's emulation of the same scheme (oracle.emulate_fp8_dgrad:
+    e4m3 rounding of the bf16 gradient operand with the delayed scale, e4m3 copy of the bf16 weight shadow), with the HIP run's ReLU
+    gates injected as in tests/test_step_gpu.py:
+      1. recording step: HIP's next-step scales = 448 / (2 amax) agree with the oracle's at all 3 x depth sites;
+      2. fp8-dgrad step: per-tensor gradients HIP vs oracle (the oracle quantises on HIP's grid: the recorded scales are injected);
+      3. the fp8-dgrad gradients stay within the e4m3 staircase of the bf16-dgrad gradients of the same engine state."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from parity_helpers import oracle_grads
     from audiossl_amd.engine import AtstEngine
     from oracle import atst_oracle as O
-    depth = 2
+    depth, B = 2, 8
     W = O.recipe_weights("base", depth=depth, seed=7)
-    mels = [O.recipe_mel(8, 1001, seed=1).to(DEV), O.recipe_mel(8, 1001, seed=2).to(DEV)]
-    lens = [torch.full((8,), 1001)] * 2
+    mels_c = [O.recipe_mel(B, 1001, seed=1), O.recipe_mel(B, 1001, seed=2)]
+    mels = [m.to(DEV) for m in mels_c]
+    lens = [torch.full((B,), 1001)] * 2
     eng = AtstEngine("base", depth=depth, drop_path_rate=0.0, fp8=True)
     eng.load_weights(W)
     assert eng.fp8_bwd_state == 1
-    eng.forward(mels, lens); eng.backward()                       # step 1: bf16 dgrad, amax recorded
+    eng.forward(mels, lens)
+    gates = {f"student.{w}.": (eng.heads[f"student.{w}"].saved[4][:, :4096].float() > 0).cpu() for w in ("projector", "predictor")}
+    eng.backward()                                                # step 1: bf16 dgrad, amax recorded
     g_first = eng.g32.clone()
-    sc = eng.g8_scale.view(depth, 4)
+    sc = eng.g8_scale.view(depth, 4).clone()
     assert eng.fp8_bwd_state == 2 and float(sc[:, :3].min()) > 1.0 and float(eng.g8_amax.abs().max()) == 0.0   # sites g, du, g2 (qkv dgrad stays bf16)
+    fwd = lambda Wl: O.atst_forward(Wl, mels_c, lens, "base", 2, depth=depth, drop_path_rate=0.0)
+    rec = O.emulate_fp8_dgrad(None)
+    _, o_first = oracle_grads(W, fwd, True, gates, ctxs=(O.emulate_fp8(), rec))
+    site = {0: "mlp.fc2.weight", 1: "mlp.fc1.weight", 2: "attn.proj.weight"}
+    nxt, inject = rec.next_scales(), {}
+    for i in range(depth):
+        for k, nm in site.items():
+            key = f"student.encoder.blocks.{i}.{nm}"
+            ratio = float(sc[i, k]) / nxt[key]
+            print(f"  scale site block {i} {nm}: HIP {float(sc[i, k]):.4e} oracle {nxt[key]:.4e} ratio {ratio:.4f}")
+            assert abs(ratio - 1.0) < 0.1, (key, ratio)           # an amax (one element decides): measured within 3 %
+            inject[key] = float(sc[i, k])
     eng.forward(mels, lens); eng.backward()                       # same weights, same inputs: now e4m3 dgrad operands
     g_fp8 = eng.g32.clone()
     assert torch.isfinite(g_fp8).all()
-    worst = ("", 0.0)
-    num = den = 0.0
-    for name, (off, shape) in eng.layout.entries.items():
-        n = math.prod(shape)
-        a, b = g_fp8[off:off + n], g_first[off:off + n]
-        if float(b.norm()) == 0.0 or name in ("encoder.pos_embed", "encoder.norm.bias"):
-            continue
-        r = relerr(a, b)
-        num += r * n; den += n
-        if r > worst[1]:
-            worst = (name, r)
-    print(f"\\n[fp8 dgrad vs bf16 dgrad, base depth {depth}] parameter-weighted mean rel-L2 {num / den:.3e}; worst {worst[0]} {worst[1]:.3e}")
-    assert num / den < 8e-2 and worst[1] < 0.2
+    _, o_fp8 = oracle_grads(W, fwd, True, gates, ctxs=(O.emulate_fp8(), O.emulate_fp8_dgrad(inject)))
+
+    def table(get_a, get_b):
+        worst, num, den = ("", 0.0), 0.0, 0.0
+        for name, (off, shape) in eng.layout.entries.items():
+            n = math.prod(shape)
+            a, b = get_a(name, off, n), get_b(name, off, n)
+            if b is None or float(b.norm()) == 0.0 or name in ("encoder.pos_embed", "encoder.norm.bias"):
+                continue
+            r = relerr(a, b)
+            num += r * n; den += n
+            if r > worst[1]:
+                worst = (name, r)
+        return num / den, worst
+    hip_of = lambda g: (lambda name, off, n: g[off:off + n].cpu())
+    or_of = lambda o: (lambda name, off, n: o[name].reshape(-1) if name in o else None)
+    m1, w1 = table(hip_of(g_first), or_of(o_first))
+    m2, w2 = table(hip_of(g_fp8), or_of(o_fp8))
+    m3, w3 = table(hip_of(g_fp8), hip_of(g_first))
+    mo, wo = table(lambda name, off, n: o_fp8[name].reshape(-1) if name in o_fp8 else torch.zeros(n), or_of(o_first))
+    print(f"\n[fp8 base depth {depth}] HIP vs oracle, bf16 dgrad (fp8 forward): mean {m1:.3e} worst {w1[0]} {w1[1]:.3e}")
+    print(f"[fp8 base depth {depth}] HIP vs oracle, e4m3 dgrad:               mean {m2:.3e} worst {w2[0]} {w2[1]:.3e}")
+    print(f"[fp8 base depth {depth}] HIP e4m3 dgrad vs HIP bf16 dgrad:        mean {m3:.3e} worst {w3[0]} {w3[1]:.3e}   (oracle's own: mean {mo:.3e} worst {wo[1]:.3e})")
+    # e4m3 is a 6-12 % staircase: a 2e-3 difference between two realisations of an operand moves ~2 % of its elements to the neighbouring code
+    # (forward: test_fp8_encoder_forward_and_step_base measures 3.6e-2 on the features), and the gradient inherits the forward's difference
+    assert m1 < 9e-2 and m2 < 9e-2 and w2[1] < 0.2, (m1, m2, w2)
+    assert m2 < 1.5 * m1 + 2e-2                                   # quantising the gradient operands adds little on top of the fp8-forward gap
+    assert m3 < 8e-2 and w3[1] < 0.2
+    assert abs(m3 - mo) < 0.6 * max(m3, mo)                       # HIP moves by about as much as the oracle predicts when the dgrad goes e4m3
     # predictor / projector weight gradients do not pass through any encoder dgrad GEMM: unchanged up to atomics order
     off, shape = eng.layout.entries["predictor.3.weight"]
     assert relerr(g_fp8[off:off + math.prod(shape)], g_first[off:off + math.prod(shape)]) < 1e-5
