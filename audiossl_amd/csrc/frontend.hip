@@ -55,8 +55,16 @@ DEVFN void dft8(float2* u) {
 
 DEVFN int reflect(int i, int n) { i = i < 0 ? -i : i; return i >= n ? 2 * (n - 1) - i : i; }
 
-template <int NB>   // mel bands per lane: n_mels = 64 NB
-__global__ __launch_bounds__(256) void stft_mel_db_kernel(const float* __restrict__ wave, int wave_ld, int n_samples, int T,
+// NB: mel bands per lane (n_mels = 64 NB).  MAXLEN > 0: the filter taps of this lane's bands live in REGISTERS (tap-major table
+// [fb_maxlen][n_mels], fb_maxlen <= MAXLEN, zero beyond a band's length) and the triangular product is a fully unrolled chain of
+// MAXLEN LDS reads at immediate offsets + FMAs; MAXLEN = 0: generic per-lane loop for longer filters.  Round 3 ran that loop for
+// every frame -- 39 iterations of a dependent global load (a 64-line gather, band-major table) + LDS read + FMA that the compiler
+// cannot pipeline across a per-lane trip count: ~40 % of the kernel (tools/mel_probe.py).
+#ifndef ATST_MEL_OCC
+#define ATST_MEL_OCC 3                 // waves per SIMD the register allocation is held to (3 blocks of 54 KB LDS fit a CU); experiment builds: 2
+#endif
+template <int NB, int MAXLEN>
+__global__ __launch_bounds__(256, ATST_MEL_OCC) void stft_mel_db_kernel(const float* __restrict__ wave, int wave_ld, int n_samples, int T,
                                                           const float* __restrict__ window, const float* __restrict__ fbw,
                                                           const int* __restrict__ fb_start, const int* __restrict__ fb_len,
                                                           int fb_maxlen, float* __restrict__ out, unsigned int* __restrict__ clipmax) {
@@ -64,7 +72,7 @@ __global__ __launch_bounds__(256) void stft_mel_db_kernel(const float* __restric
   // 8-way bank conflicts), pb(i) = i + 8 (i/64) (the second pass scatters groups of 8 lanes 512 B apart)
   __shared__ float2 fa[4][576];
   __shared__ float2 fb[4][576];
-  __shared__ float pw[4][NBIN + 7];
+  __shared__ float pw[4][NBIN + 7 + MAXLEN];                        // the tail is read (with zero weights) by bands whose filter is shorter than MAXLEN: kept zero
   constexpr int NMEL = 64 * NB;
   __shared__ float dbb[NMEL][FPB + 1];
   __shared__ float wmax[4];
@@ -75,6 +83,14 @@ __global__ __launch_bounds__(256) void stft_mel_db_kernel(const float* __restric
 #pragma unroll
   for (int b = 0; b < NB; ++b) { m_start[b] = fb_start[lane + 64 * b]; m_len[b] = fb_len[lane + 64 * b]; }
   float vmax = -1e30f;
+  float fw[NB][MAXLEN > 0 ? MAXLEN : 1];
+  if constexpr (MAXLEN > 0) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int q = 0; q < MAXLEN; ++q) fw[b][q] = q < fb_maxlen ? fbw[q * NMEL + lane + 64 * b] : 0.f;
+    for (int i = lane; i < 7 + MAXLEN; i += 64) pw[wid][NBIN + i] = 0.f;
+  }
   // twiddles of the two twiddled passes depend on the lane only: fetched once per block, not once per frame
   float2 tw8[8], tw64[8];
   f32x2 win[8];                                                    // this lane's 16 window taps
@@ -138,9 +154,13 @@ __global__ __launch_bounds__(256) void stft_mel_db_kernel(const float* __restric
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       float mel = 0.f;
-      // the weight table is [tap][band]: one coalesced 256-B row per tap (band-major it was a 64-line gather per tap -- 39 taps per
-      // frame --, ~40 % of the kernel's time in round 3: tools/mel_probe.py)
-      for (int q = 0; q < m_len[b]; ++q) mel += fbw[q * NMEL + lane + 64 * b] * pw[wid][m_start[b] + q];
+      if constexpr (MAXLEN > 0) {
+        const float* pp = &pw[wid][m_start[b]];
+#pragma unroll
+        for (int q = 0; q < MAXLEN; ++q) mel = fmaf(fw[b][q], pp[q], mel);     // same summation order as the loop
+      } else {
+        for (int q = 0; q < m_len[b]; ++q) mel += fbw[q * NMEL + lane + 64 * b] * pw[wid][m_start[b] + q];
+      }
       const float db = 10.0f * log10f(fmaxf(mel, 1e-10f));
       dbb[lane + 64 * b][fl] = db;
       if (t0 + fl < T) vmax = fmaxf(vmax, db);
@@ -208,7 +228,7 @@ int init_twiddles(hipStream_t st) {
 int atst_mel_frontend(const float* wave, int n_clips, int n_samples, int wave_ld, int n_mels, int win_length, const float* window,
                       const float* fb_weights, const int* fb_start, const int* fb_len, int fb_maxlen,
                       float* out, unsigned int* clipmax, hipStream_t st) {
-  (void)win_length; (void)fb_maxlen;                  // the zero-padded 1024-tap window is supplied by the caller ; fb_weights is [fb_maxlen][n_mels] (tap-major)
+  (void)win_length;                  // the zero-padded 1024-tap window is supplied by the caller ; fb_weights is [fb_maxlen][n_mels] (tap-major)
   if (wave_ld <= 0) wave_ld = n_samples;
   if (n_clips <= 0 || n_samples < NFFT / 2 + 1 || wave_ld < n_samples || (n_mels != 64 && n_mels != 128)) return ATST_EINVAL;
   int rc = init_twiddles(st);
@@ -216,12 +236,14 @@ int atst_mel_frontend(const float* wave, int n_clips, int n_samples, int wave_ld
   const int T = 1 + n_samples / HOPS;
   hipMemsetAsync(clipmax, 0, n_clips * sizeof(unsigned int), st);
   ProfScope ps(PK_MEL, (double)n_clips * (4.0 * n_samples + 4.0 * n_mels * T), st);   // wave read once + dB written once
-  if (n_mels == 64)
-    hipLaunchKernelGGL(stft_mel_db_kernel<1>, dim3((T + FPB - 1) / FPB, n_clips), dim3(256), 0, st, wave, wave_ld, n_samples, T, window,
-                       fb_weights, fb_start, fb_len, fb_maxlen, out, clipmax);
-  else
-    hipLaunchKernelGGL(stft_mel_db_kernel<2>, dim3((T + FPB - 1) / FPB, n_clips), dim3(256), 0, st, wave, wave_ld, n_samples, T, window,
-                       fb_weights, fb_start, fb_len, fb_maxlen, out, clipmax);
+#define MEL_LAUNCH(NB_, ML_) hipLaunchKernelGGL((stft_mel_db_kernel<NB_, ML_>), dim3((T + FPB - 1) / FPB, n_clips), dim3(256), 0, st, wave, wave_ld, \
+                                                n_samples, T, window, fb_weights, fb_start, fb_len, fb_maxlen, out, clipmax)
+  if (n_mels == 64) {                                 // 16 kHz / 64 bands: longest filter 39 bins
+    if (fb_maxlen <= 40) MEL_LAUNCH(1, 40); else MEL_LAUNCH(1, 0);
+  } else {                                            // 32 kHz / 128 bands: 10 bins ; 16 kHz / 128 bands: ~20
+    if (fb_maxlen <= 16) MEL_LAUNCH(2, 16); else if (fb_maxlen <= 40) MEL_LAUNCH(2, 40); else MEL_LAUNCH(2, 0);
+  }
+#undef MEL_LAUNCH
   hipLaunchKernelGGL(db_finalize_kernel, dim3(16, n_clips), dim3(256), 0, st, out, clipmax, n_mels * T);
   return (int)hipGetLastError();
 }

@@ -98,7 +98,7 @@ def test_eight_ranks_equal_one_rank_on_the_concatenated_batch(tmp_path, mode):
     print(f"\n[8 ranks vs 1, {mode}] loss {float(eight['loss'][0]):.6f} vs {float(one['loss'][0]):.6f}; flat gradient rel {g:.2e}; predictor {gp:.2e}")
     assert abs(float(eight["loss"][0]) - float(one["loss"][0])) < 3e-4
     assert abs(float(eight["std_s"]) - float(one["std_s"])) < 1e-4 and abs(float(eight["std_t"]) - float(one["std_t"])) < 1e-4
-    assert g < 2.5e-2 and gp < 5e-3, (g, gp)
+    assert g < 5e-3 and gp < 1e-4, (g, gp)                                  # measured: clip 1.7e-3 / 2.8e-5, frame 3.4e-4 / 1.5e-5
     for k in one.files:
         if k.startswith("bn/") and not k.endswith("num_batches_tracked"):
             assert _rel(eight[k], one[k]) < 1e-4, k
