@@ -641,6 +641,11 @@ __global__ void attn_rowdot_kernel(const bf16* __restrict__ d_o, const bf16* __r
   }
 }
 
+// Experiment builds (tools/attn_ablate.sh): ATST_ATTN_ABL bit 0 = no softmax arithmetic (P := S), bit 1 = no dK / dV products (transposed fragment
+// reads + 8 MFMAs per query block), bit 2 = no dQ phase, bit 3 = no global stores, bit 4 = no S / dP products in the dK / dV phase.
+#ifndef ATST_ATTN_ABL
+#define ATST_ATTN_ABL 0
+#endif
 __global__ __launch_bounds__(512, 2) void attn_bwd256_kernel(AttnArgs p, const float* __restrict__ Dg) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int NP = 256;
@@ -751,6 +756,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd256_kernel(AttnArgs p, const f
         const float kbias = (k0 + l31 >= valid) ? -3.0e38f : 0.f;  // padded key: P = 0 (reference: exp(-10000 + ...) == 0 in fp32)
         for (int i = 0; i < 8; ++i) {
           f32x16 sc, dp;
+#if ATST_ATTN_ABL & 16
+          sc = zero; dp = zero; asm volatile("" : "+v"(sc), "+v"(dp));
+#else
           sc = mfma32(rfrag(sQ, i * 32, 0), kf[0], zero);
           dp = mfma32(rfrag(sDO, i * 32, 0), vf[0], zero);
 #pragma unroll
@@ -758,6 +766,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd256_kernel(AttnArgs p, const f
             sc = mfma32(rfrag(sQ, i * 32, ks), kf[ks], sc);
             dp = mfma32(rfrag(sDO, i * 32, ks), vf[ks], dp);
           }
+#endif
           float pv[16], ds[16];                                    // ds without the softmax scale: applied once to dK at the end
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
@@ -766,23 +775,35 @@ __global__ __launch_bounds__(512, 2) void attn_bwd256_kernel(AttnArgs p, const f
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const int r = 4 * g + e;
+#if ATST_ATTN_ABL & 1
+              const float pr = sc[r];
+#else
               const float pr = fast_exp2(fmaf(sc[r], c1, l4[e]) + kbias);
+#endif
               pv[r] = pr;
               ds[r] = pr * (dp[r] - d4[e]);
             }
           }
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
-            const bf16x8 pf = pack8(pv + 8 * t), dsf = pack8(ds + 8 * t);
+            bf16x8 pf = pack8(pv + 8 * t), dsf = pack8(ds + 8 * t);
+#if ATST_ATTN_ABL & 2
+            asm volatile("" :: "v"(pf), "v"(dsf));
+#else
             dv0 = mfma32(tfrag(sDO, i * 32 + 16 * t, 0), pf, dv0);
             dv1 = mfma32(tfrag(sDO, i * 32 + 16 * t, 1), pf, dv1);
             dk0 = mfma32(tfrag(sQ, i * 32 + 16 * t, 0), dsf, dk0);
             dk1 = mfma32(tfrag(sQ, i * 32 + 16 * t, 1), dsf, dk1);
+#endif
           }
         }
       }
+#if ATST_ATTN_ABL & 8
+      asm volatile("" :: "v"(dk0), "v"(dk1), "v"(dv0), "v"(dv1));
+#else
       store_row64(dkrow, dk0, dk1, scale, hi);
       store_row64(dvrow, dv0, dv1, 1.0f, hi);
+#endif
     }
     // ---------------- dQ : this wave owns queries [32 wid, 32 wid + 32)
     {
@@ -801,7 +822,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd256_kernel(AttnArgs p, const f
         load_kv(h + 1);
       }
       f32x16 dq0, dq1; zero16(dq0); zero16(dq1);
-      for (int j = 0; j < ntile; ++j) {
+      for (int j = 0; j < ((ATST_ATTN_ABL & 4) ? 0 : ntile); ++j) {
         f32x16 sc, dp;
         sc = mfma32(rfrag(sK, j * 32, 0), qf[0], zero);
         dp = mfma32(rfrag(sV, j * 32, 0), dof[0], zero);
@@ -814,7 +835,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd256_kernel(AttnArgs p, const f
         const unsigned mb = j == ntile - 1 ? mbits : 0u;           // only the last key tile can hold padded keys
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
+#if ATST_ATTN_ABL & 1
+          float pr = sc[r];
+#else
           float pr = fast_exp2(fmaf(sc[r], c1, nlse));
+#endif
           if ((mb >> r) & 1u) pr = 0.f;
           ds[r] = pr * (dp[r] - Dq);
         }
@@ -826,7 +851,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd256_kernel(AttnArgs p, const f
         }
       }
       bf16* dqrow = p.dqkv + ((size_t)s * NP + q0 + l31) * ld + h * HD;
+#if ATST_ATTN_ABL & 8
+      asm volatile("" :: "v"(dq0), "v"(dq1));
+#else
       store_row64(dqrow, dq0, dq1, scale, hi);
+#endif
     }
     __syncthreads();                                               // everyone is done with this head's LDS image
   }

@@ -61,7 +61,7 @@ DEVFN int reflect(int i, int n) { i = i < 0 ? -i : i; return i >= n ? 2 * (n - 1
 // every frame -- 39 iterations of a dependent global load (a 64-line gather, band-major table) + LDS read + FMA that the compiler
 // cannot pipeline across a per-lane trip count: ~40 % of the kernel (tools/mel_probe.py).
 #ifndef ATST_MEL_OCC
-#define ATST_MEL_OCC 3                 // waves per SIMD the register allocation is held to (3 blocks of 54 KB LDS fit a CU); experiment builds: 2
+#define ATST_MEL_OCC 2                 // waves per SIMD the register allocation is held to.  3 (what the 54 KB of LDS would allow) spills 7 registers: 1170 vs 1069 us per 512 clips (profiles/r04_mel_probe.txt)
 #endif
 template <int NB, int MAXLEN>
 __global__ __launch_bounds__(256, ATST_MEL_OCC) void stft_mel_db_kernel(const float* __restrict__ wave, int wave_ld, int n_samples, int T,

@@ -655,7 +655,9 @@ class AtstEngine:
             keep = torch.floor((1.0 - rates) + torch.rand(self.depth, 2, S, device=self.device))
         else:
             keep = keep.to(self.device, torch.float32)
-        return (keep / (1.0 - rates)).contiguous()
+        # a block whose rate is 0 (block 0 of the linspace schedule) never drops in the reference, whatever was drawn: drop_path()
+        # returns its input when drop_prob == 0 (modules/transformer.py:49-50)
+        return torch.where(rates > 0, keep / (1.0 - rates), torch.ones_like(keep)).contiguous()
 
     def _valid(self, lengths: torch.Tensor, use_cls: int, n_max: int = 1 << 30) -> torch.Tensor:
         """patch_length + CLS per sequence, clamped to the tokens the pass holds.  ref: audio_transformer.py:70-71,194."""

@@ -17,6 +17,7 @@ mask = torch.from_numpy(rng.random((B, n_tok)) < 0.6)
 masks = [mask, mask]
 keep_t = [torch.from_numpy((rng.random((12, 2, 2 * B)) < 0.95).astype(np.float32))]
 keep_s = [torch.from_numpy((rng.random((12, 2, 2 * B)) < 0.95).astype(np.float32))]
+keep_t[0][0] = 1.0; keep_s[0][0] = 1.0
 eng = AtstEngine("small", frame=True)
 eng.load_weights(W)
 loss, _, _ = eng.forward(mels, lens, masks, keep_t, keep_s)
