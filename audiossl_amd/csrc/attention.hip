@@ -292,12 +292,22 @@ DEVFN bf16x8 ld_frag_tr_v(const char* X, int r0, int c0, int lane) {
   return u.v;
 }
 
+// Asynchronous transfers issued as inline assembly, i.e. outside the compiler's vmcnt bookkeeping (it then inserts no wait of its own: with
+// the builtin / plain loads it put `s_waitcnt vmcnt(0)` in front of every later use while an LDS-DMA was in flight, which also waited
+// for the output stores just issued).  The kernels wait by hand with exact counts; see attn_bwd256_kernel for the rules.
+DEVFN void glds16_asm(const void* gsrc, unsigned lds_dst /* wave-uniform LDS byte address */) {
+  unsigned keep;                                     // M0 is compiler-reserved and not preserved around a statement: saved, set, restored inside it
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+DEVFN void gload16_asm(bf16x8& dst, const void* src) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(src) : "memory"); }
+DEVFN void gload4_asm(float& dst, const void* src) { asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(src) : "memory"); }
 __global__ __launch_bounds__(512, 2) void attn_fwd256v2_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   typedef const void __attribute__((address_space(1))) * gptr_t;
   typedef void __attribute__((address_space(3))) * lptr_t;
   constexpr int NP = 256;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), hi = lane >> 5, l31 = lane & 31;
   const int H = p.H, C = H * HD;
   const size_t ld = 3 * (size_t)C;
   const int s = blockIdx.x;
@@ -315,18 +325,19 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256v2_kernel(AttnArgs p) {
     offK[i] = row * (int)ld + C + (pc ^ ((row >> 1) & 7)) * 8;
     offV[i] = row * (int)ld + 2 * C + (pc ^ (((row >> 1) & 1) << 2)) * 8;
   }
+  const unsigned lbase = lds_addr(smem_raw) + wid * 4096;
   auto issue = [&](int h) {
-    char* buf = smem_raw + (h & 1) * F2_BUF;
+    const unsigned buf = lbase + (h & 1) * F2_BUF;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      __builtin_amdgcn_global_load_lds((gptr_t)(base + offK[i] + h * HD), (lptr_t)(buf + (wid * 4 + i) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(base + offV[i] + h * HD), (lptr_t)(buf + F2_MAT + (wid * 4 + i) * 1024), 16, 0, 0);
+      glds16_asm(base + offK[i] + h * HD, buf + i * 1024);
+      glds16_asm(base + offV[i] + h * HD, buf + F2_MAT + i * 1024);
     }
   };
   bf16x8 qn[4];
   auto qload = [&](int h) {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qn[ks] = ld_frag(base + (size_t)(q0 + l31) * ld + h * HD + ks * 16 + hi * 8);
+    for (int ks = 0; ks < 4; ++ks) gload16_asm(qn[ks], base + (size_t)(q0 + l31) * ld + h * HD + ks * 16 + hi * 8);
   };
   // lane-only parts of the swizzled fragment addresses (tile offsets are compile-time constants added by the reads)
   int kofs[4], vofs[2];
@@ -350,14 +361,20 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256v2_kernel(AttnArgs p) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) mbits |= ((ntile - 1) * 32 + crow32(r, hi) >= valid ? 1u : 0u) << r;
   asm volatile("" : "+v"(mbits));
-  issue(0);
-  qload(0);
-  for (int h = 0; h < H; ++h) {
+  // Rotated loop (iteration -1 only issues head 0's transfers): ONE definition site and ONE wait site for the asm-loaded Q fragments,
+  // see attn_bwd256_kernel.  Behind the transfers of head h a wave issues the 4 output-row stores (+ the lse store) of head h - 1:
+  // vmcnt(4) at the top leaves those in flight instead of draining them in front of every head (round 3: vmcnt(0)).
+  for (int h = -1; h < H; ++h) {
     bf16x8 qf[4];
+    if (h >= 0) {
+      if (h == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(4)" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]) :: "memory");
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = qn[ks];
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // head h landed everywhere; buffer (h+1)&1 no longer read
+      for (int ks = 0; ks < 4; ++ks) qf[ks] = qn[ks];
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // head h landed everywhere; buffer (h+1)&1 no longer read
+    }
     if (h + 1 < H) { issue(h + 1); qload(h + 1); }
+    if (h < 0) continue;
     const char* sK = smem_raw + (h & 1) * F2_BUF;
     const char* sV = sK + F2_MAT;
     // pass 1: the wave's 32 x 256 score strip (raw q.k, scale folded into the exponent) and its row maximum
@@ -646,7 +663,7 @@ __global__ void attn_rowdot_kernel(const bf16* __restrict__ d_o, const bf16* __r
 #ifndef ATST_ATTN_ABL
 #define ATST_ATTN_ABL 0
 #endif
-__global__ __launch_bounds__(512, 2) void attn_bwd256_kernel(AttnArgs p, const float* __restrict__ Dg) {
+__global__ __launch_bounds__(512, 2) void attn_bwd256_r3_kernel(AttnArgs p, const float* __restrict__ Dg) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int NP = 256;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hi = lane >> 5, l31 = lane & 31;
@@ -861,6 +878,255 @@ __global__ __launch_bounds__(512, 2) void attn_bwd256_kernel(AttnArgs p, const f
   }
 }
 
+
+// ---- round 4: the same backward with every asynchronous transfer issued and waited for BY HAND ----------------------------------
+// What the ablation of the round-3 kernel showed (tools/attn_ablate.sh, profiles/r04_attn_ablate.txt): removing the global stores alone
+// took 67 of 300 us off -- the stores were not overlapped with anything.  The ISA says why: hipcc's waitcnt insertion put
+// `s_waitcnt vmcnt(0)` (a) between the register prefetch loads of the next head, right behind the dK / dV stores and the LDS-DMA issue,
+// (b) in front of the first transposing LDS read of the dQ loop (it treats the builtin as a reader of every LDS-DMA in flight) and
+// (c) at the top of every head -- vmcnt retires in order, so each of them also waited for the stores just issued to be acknowledged by
+// HBM, and for the next head's operands to land before the current head went on: nothing was prefetched, every head paid two store
+// drains and one full load latency.  Here:
+//   * every load is inline assembly (LDS-DMA: glds16_asm ; register loads: gload16_asm), invisible to the compiler's scoreboard, so it
+//     inserts no wait; the waits are written below as exact `vmcnt(N)` counts, N = the number of STORE instructions issued behind the
+//     loads being waited for (vmcnt counts loads and stores in issue order; more stores than counted only makes a wait stricter);
+//   * K / V no longer pass through registers into LDS: their LDS images are only needed by the dQ phase, so they are LDS-DMA'd at the
+//     top of the head and land under the dK / dV phase, which needs just this wave's own 32 key rows -- those arrive as MFMA
+//     fragments straight from global memory (prefetched during the previous head's dQ phase: the 32 registers the raw rows used to
+//     occupy), no LDS write pass, no LDS read for them;
+//   * per head the queue of a wave is  [K,V DMA 16] dKdV-phase [dK,dV stores 8] wait(8) | [Q,dO DMA 8][lse,D 2][K,V fragments 8]
+//     dQ-phase [dQ stores 4] | next head: wait(4).
+// everything this wave loaded for the head that starts has landed; N younger operations (stores) may still be in flight.  The
+// destinations are "+v" operands: no consumer moves above the wait, and the compiler cannot assume their old contents.
+template <int N> DEVFN void bwd_wait_head(bf16x8 (&k)[4], bf16x8 (&v)[4], float& a, float& b) {
+  asm volatile("s_waitcnt vmcnt(%10)" : "+v"(k[0]), "+v"(k[1]), "+v"(k[2]), "+v"(k[3]), "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(a), "+v"(b)
+               : "n"(N) : "memory");
+}
+#if ATST_ATTN_ABL & 8
+constexpr int BWD_ST_DKV = 0, BWD_ST_DQ = 0;         // experiment build without stores
+#else
+constexpr int BWD_ST_DKV = 8, BWD_ST_DQ = 4;         // store instructions of store_row64 x 2 / x 1 (16 B per lane each: cannot be fewer)
+#endif
+
+__global__ __launch_bounds__(512, 2) void attn_bwd256_kernel(AttnArgs p, const float* __restrict__ Dg) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int NP = 256;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), hi = lane >> 5, l31 = lane & 31;
+  const int H = p.H, C = H * HD;
+  const size_t ld = 3 * (size_t)C;
+  const int s = blockIdx.x;
+  bf16* sQ = reinterpret_cast<bf16*>(smem_raw);
+  bf16* sK = sQ + B256_MAT; bf16* sV = sK + B256_MAT; bf16* sDO = sV + B256_MAT;
+  float* sLse = reinterpret_cast<float*>(sDO + B256_MAT);
+  float* sD = sLse + NP;
+  const bf16* qkv = p.qkv + (size_t)s * NP * ld;
+  const bf16* dob = p.d_o + (size_t)s * NP * C;
+  const int valid = p.valid[s];
+  const int ntile = (valid + 31) / 32 < 8 ? (valid + 31) / 32 : 8;
+  const float scale = 0.125f;
+  const int k0 = wid * 32;                                          // this wave's key rows (dK / dV phase) = its query rows (dQ phase)
+
+  // LDS-DMA map: instruction i of a wave covers rows 32 wid + 8 i .. + 8 (128-B rows), lane = (row, physical chunk); the same map
+  // serves Q, K, V (columns 0, C, 2C of the qkv row) and dO
+  int dq_off[4], ddo_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wid * 32 + i * 8 + (lane >> 3), c = (lane & 7) ^ b256_key(row);
+    dq_off[i] = row * (int)ld + c * 8;
+    ddo_off[i] = row * C + c * 8;
+  }
+  const unsigned lQ = lds_addr(sQ) + wid * 4096, lK = lds_addr(sK) + wid * 4096, lV = lds_addr(sV) + wid * 4096, lDO = lds_addr(sDO) + wid * 4096;
+  auto dma_qdo = [&](int h) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      glds16_asm(qkv + dq_off[i] + h * HD, lQ + i * 1024);
+      glds16_asm(dob + ddo_off[i] + h * HD, lDO + i * 1024);
+    }
+  };
+  auto dma_kv = [&](int h) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      glds16_asm(qkv + dq_off[i] + C + h * HD, lK + i * 1024);
+      glds16_asm(qkv + dq_off[i] + 2 * C + h * HD, lV + i * 1024);
+    }
+  };
+  // next head's operands that live in registers: this wave's own K / V rows as MFMA fragments (row k0 + l31, logical chunk 2 ks + hi)
+  // and one lse / D value per thread (threads >= 256 re-load row tid - 256: every wave issues the same number of loads)
+  bf16x8 kfn[4], vfn[4];
+  float plse, pd;
+  const bf16* kv_src = qkv + (size_t)(k0 + l31) * ld + C + hi * 8;
+  auto load_regs = [&](int h) {
+    gload4_asm(plse, p.lse + ((size_t)s * H + h) * NP + (tid & 255));
+    gload4_asm(pd, Dg + ((size_t)s * H + h) * NP + (tid & 255));
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      gload16_asm(kfn[ks], kv_src + h * HD + ks * 16);
+      gload16_asm(vfn[ks], kv_src + C + h * HD + ks * 16);
+    }
+  };
+  // lane-only parts of the swizzled fragment addresses (row blocks are multiples of 16 rows, so the permutation key of a
+  // fragment row depends on the lane alone); the block / tile offsets are added as constants by the reads
+  int rofs[4], tofs[2][2];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) rofs[ks] = l31 * HD + (((ks * 2 + hi) ^ b256_key(l31)) << 3);
+  {
+    const int a = lane & 15, g = lane >> 4;
+    const int lrow = 4 * (g >> 1) + (a >> 2), lcol = (g & 1) * 16 + 4 * (a & 3);
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+      for (int half = 0; half < 2; ++half)
+        tofs[cc][half] = (lrow + 8 * half) * HD + (((cc * 4 + (lcol >> 3)) ^ b256_key(lrow + 8 * half)) << 3) + (lcol & 7);
+  }
+  auto rfrag = [&](const bf16* X, int row0, int ks) { return ld_frag(X + row0 * HD + rofs[ks]); };          // rows row0 + l31
+  auto tfrag = [&](const bf16* X, int r0, int cc) {                                                          // X^T fragment
+    union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+    u.s.a = lds_tr4(X + r0 * HD + tofs[cc][0]); u.s.b = lds_tr4(X + r0 * HD + tofs[cc][1]);
+    return u.v;
+  };
+  const float c1 = scale * LOG2E;
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  unsigned mbits = 0;                                               // padded keys of the last key tile (dQ phase), one bit per accumulator register
+#pragma unroll
+  for (int r = 0; r < 16; ++r) mbits |= ((ntile - 1) * 32 + crow32(r, hi) >= valid ? 1u : 0u) << r;
+  asm volatile("" : "+v"(mbits));
+  // The loop is ROTATED: iteration h = -1 only issues the loads of head 0.  The register-destination loads (kfn, vfn, plse, pd) then have
+  // ONE definition site (load_regs below) and ONE wait site (bwd_wait_head): with a peeled prologue the compiler merged the two
+  // definitions through register copies at the loop's back edge -- copies that read the destination registers while the loads may
+  // still be in flight (nothing interlocks a VGPR read against an outstanding VMEM load; an asm load counts as complete at its
+  // statement).  Checked in the ISA after every change to this kernel (tools/check_attn_bwd_isa.py).
+  for (int h = -1; h < H; ++h) {
+    bf16x8 kf[4], vf[4];
+    if (h >= 0) {
+    // Q, dO images (LDS-DMA) and this wave's K / V fragments, lse, D of head h have landed; only the previous head's dQ stores are
+    // younger (head 0: nothing is, so everything is waited for -- by a statement without register operands)
+    if (h == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bwd_wait_head<BWD_ST_DQ>(kfn, vfn, plse, pd);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { kf[ks] = kfn[ks]; vf[ks] = vfn[ks]; }
+    if (tid < NP) { sLse[tid] = -plse * LOG2E; sD[tid] = pd; }         // exponent offset of P = exp2(c1 s - lse log2 e)
+    __syncthreads();                                               // everyone's share of Q / dO is in place, nobody reads the previous head's K / V any more
+    dma_kv(h);                                                     // K, V images of this head: needed by the dQ phase only
+    // ---------------- dK, dV : this wave owns keys [32 wid, 32 wid + 32)
+    {
+      bf16* dkrow = p.dqkv + ((size_t)s * NP + k0 + l31) * ld + C + h * HD;
+      bf16* dvrow = dkrow + C;
+      f32x16 dk0, dk1, dv0, dv1; zero16(dk0); zero16(dk1); zero16(dv0); zero16(dv1);
+      if (k0 < valid) {
+        const float kbias = (k0 + l31 >= valid) ? -3.0e38f : 0.f;  // padded key: P = 0 (reference: exp(-10000 + ...) == 0 in fp32)
+        for (int i = 0; i < 8; ++i) {
+          f32x16 sc, dp;
+#if ATST_ATTN_ABL & 16
+          sc = zero; dp = zero; asm volatile("" : "+v"(sc), "+v"(dp));
+#else
+          sc = mfma32(rfrag(sQ, i * 32, 0), kf[0], zero);
+          dp = mfma32(rfrag(sDO, i * 32, 0), vf[0], zero);
+#pragma unroll
+          for (int ks = 1; ks < 4; ++ks) {
+            sc = mfma32(rfrag(sQ, i * 32, ks), kf[ks], sc);
+            dp = mfma32(rfrag(sDO, i * 32, ks), vf[ks], dp);
+          }
+#endif
+          float pv[16], ds[16];                                    // ds without the softmax scale: applied once to dK at the end
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(sLse + i * 32 + 8 * g + 4 * hi);
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(sD + i * 32 + 8 * g + 4 * hi);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int r = 4 * g + e;
+#if ATST_ATTN_ABL & 1
+              const float pr = sc[r];
+#else
+              const float pr = fast_exp2(fmaf(sc[r], c1, l4[e]) + kbias);
+#endif
+              pv[r] = pr;
+              ds[r] = pr * (dp[r] - d4[e]);
+            }
+          }
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            bf16x8 pf = pack8(pv + 8 * t), dsf = pack8(ds + 8 * t);
+#if ATST_ATTN_ABL & 2
+            asm volatile("" :: "v"(pf), "v"(dsf));
+#else
+            dv0 = mfma32(tfrag(sDO, i * 32 + 16 * t, 0), pf, dv0);
+            dv1 = mfma32(tfrag(sDO, i * 32 + 16 * t, 1), pf, dv1);
+            dk0 = mfma32(tfrag(sQ, i * 32 + 16 * t, 0), dsf, dk0);
+            dk1 = mfma32(tfrag(sQ, i * 32 + 16 * t, 1), dsf, dk1);
+#endif
+          }
+        }
+      }
+#if ATST_ATTN_ABL & 8
+      asm volatile("" :: "v"(dk0), "v"(dk1), "v"(dv0), "v"(dv1));
+#else
+      store_row64(dkrow, dk0, dk1, scale, hi);
+      store_row64(dvrow, dv0, dv1, 1.0f, hi);
+#endif
+    }
+    }                                                              // h >= 0
+    // ---------------- dQ : this wave owns queries [32 wid, 32 wid + 32)
+    {
+      const int q0 = k0;
+      bf16x8 qf[4], dof[4];
+      float Dq = 0.f, nlse = 0.f;
+      if (h >= 0) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          qf[ks] = rfrag(sQ, q0, ks);
+          dof[ks] = rfrag(sDO, q0, ks);
+        }
+        Dq = sD[q0 + l31]; nlse = sLse[q0 + l31];
+      }
+      // my K / V pieces have landed (the dK / dV stores behind them may still be in flight); with the barrier: everyone's have, and
+      // every wave holds its query rows, so the Q / dO images can take the next head
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(BWD_ST_DKV) : "memory");
+      if (h + 1 < H) {
+        dma_qdo(h + 1);
+        load_regs(h + 1);
+      }
+      if (h < 0) continue;                                         // the rotated iteration: loads of head 0 issued, nothing to compute
+      f32x16 dq0, dq1; zero16(dq0); zero16(dq1);
+      for (int j = 0; j < ((ATST_ATTN_ABL & 4) ? 0 : ntile); ++j) {
+        f32x16 sc, dp;
+        sc = mfma32(rfrag(sK, j * 32, 0), qf[0], zero);
+        dp = mfma32(rfrag(sV, j * 32, 0), dof[0], zero);
+#pragma unroll
+        for (int ks = 1; ks < 4; ++ks) {
+          sc = mfma32(rfrag(sK, j * 32, ks), qf[ks], sc);
+          dp = mfma32(rfrag(sV, j * 32, ks), dof[ks], dp);
+        }
+        float ds[16];
+        const unsigned mb = j == ntile - 1 ? mbits : 0u;           // only the last key tile can hold padded keys
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+#if ATST_ATTN_ABL & 1
+          float pr = sc[r];
+#else
+          float pr = fast_exp2(fmaf(sc[r], c1, nlse));
+#endif
+          if ((mb >> r) & 1u) pr = 0.f;
+          ds[r] = pr * (dp[r] - Dq);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const bf16x8 dsf = pack8(ds + 8 * t);
+          dq0 = mfma32(tfrag(sK, j * 32 + 16 * t, 0), dsf, dq0);
+          dq1 = mfma32(tfrag(sK, j * 32 + 16 * t, 1), dsf, dq1);
+        }
+      }
+      bf16* dqrow = p.dqkv + ((size_t)s * NP + q0 + l31) * ld + h * HD;
+#if ATST_ATTN_ABL & 8
+      asm volatile("" :: "v"(dq0), "v"(dq1));
+#else
+      store_row64(dqrow, dq0, dq1, scale, hi);
+#endif
+    }
+    // (the barrier at the top of the next head separates this head's last K / V reads from the next K / V DMA)
+  }
+}
+
 template <int NP> int fwd_lds() { return Geo<NP>::G * 2 * Geo<NP>::LDS_MAT * 2; }
 template <int NP> int dkv_lds() { return Geo<NP>::G * (2 * Geo<NP>::LDS_MAT * 2 + 2 * NP * 4); }
 
@@ -902,7 +1168,7 @@ int launch_bwd(const AttnArgs& a, hipStream_t st) {
 }
 }  // namespace
 
-int g_bwd256 = 1;          // merged per-sequence backward kernel for NP = 256 (tuning hook 402/403)
+int g_bwd256 = 1;          // merged per-sequence backward kernel for NP = 256: 1 = hand-scheduled transfers (round 4), 3 = round-3 kernel, 0 = two kernels (tuning hooks 403 / 405 / 402)
 int g_fwd256 = 2;          // NP = 256 forward: 2 = two-pass softmax + LDS-DMA head loop, 1 = online-softmax head loop, 0 = per-(sequence, head) kernel (tuning hooks 404 / 401 / 400)
 void atst_attn_set_variant(int v) { if (v == 4) g_fwd256 = 2; else if (v >= 2) g_bwd256 = v - 2; else g_fwd256 = v; }
 
@@ -947,12 +1213,15 @@ int atst_attn_bwd(const AttnArgs& a, hipStream_t st) {
     if (!done) {
       hipError_t e = hipFuncSetAttribute((const void*)attn_bwd256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, B256_LDS);
       if (e != hipSuccess) return (int)e;
+      e = hipFuncSetAttribute((const void*)attn_bwd256_r3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, B256_LDS);
+      if (e != hipSuccess) return (int)e;
       done = true;
     }
     const long rows = (long)a.S * 256;
     hipLaunchKernelGGL(attn_rowdot_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, a.d_o, (const bf16*)a.o, a.dscratch, a.S, a.H, 256);
     ProfScope ps(PK_ATTN_BWD_DKV, 14.0 * a.S * a.H * 256.0 * 256.0 * HD, st, 16.0 * a.S * a.H * 256.0 * HD);
-    hipLaunchKernelGGL(attn_bwd256_kernel, dim3(a.S), dim3(512), B256_LDS, st, a, (const float*)a.dscratch);
+    if (g_bwd256 == 3) hipLaunchKernelGGL(attn_bwd256_r3_kernel, dim3(a.S), dim3(512), B256_LDS, st, a, (const float*)a.dscratch);
+    else hipLaunchKernelGGL(attn_bwd256_kernel, dim3(a.S), dim3(512), B256_LDS, st, a, (const float*)a.dscratch);
     return (int)hipGetLastError();
   }
   switch (a.NP) {

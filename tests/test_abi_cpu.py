@@ -56,3 +56,16 @@ def test_no_oracle_import_in_product_code():
             if f.endswith(".py"):
                 src = open(os.path.join(d, f)).read()
                 assert "oracle" not in src, f"{f} must not reference the test-only oracle"
+
+
+def test_attention_kernels_isa_audit():
+    """The NP = 256 attention kernels issue their next-head loads as inline assembly and wait by hand (csrc/attention.hip); the audit
+    re-compiles the file and checks in the ISA that no compiler copy / spill touches an in-flight destination register, that nothing
+    spills, and that the store counts behind the hand-written vmcnt waits hold (tools/check_attn_bwd_isa.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not available")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_attn_bwd_isa.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
