@@ -663,230 +663,18 @@ __global__ void attn_rowdot_kernel(const bf16* __restrict__ d_o, const bf16* __r
 #ifndef ATST_ATTN_ABL
 #define ATST_ATTN_ABL 0
 #endif
-__global__ __launch_bounds__(512, 2) void attn_bwd256_r3_kernel(AttnArgs p, const float* __restrict__ Dg) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  constexpr int NP = 256;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hi = lane >> 5, l31 = lane & 31;
-  const int H = p.H, C = H * HD;
-  const size_t ld = 3 * (size_t)C;
-  const int s = blockIdx.x;
-  bf16* sQ = reinterpret_cast<bf16*>(smem_raw);
-  bf16* sK = sQ + B256_MAT; bf16* sV = sK + B256_MAT; bf16* sDO = sV + B256_MAT;
-  float* sLse = reinterpret_cast<float*>(sDO + B256_MAT);
-  float* sD = sLse + NP;
-  const bf16* qkv = p.qkv + (size_t)s * NP * ld;
-  const bf16* dob = p.d_o + (size_t)s * NP * C;
-  const int valid = p.valid[s];
-  const int ntile = (valid + 31) / 32 < 8 ? (valid + 31) / 32 : 8;
-  const float scale = 0.125f;
-
-  // next head: Q and dO go HBM -> LDS by global_load_lds during the dQ phase (their LDS images are dead once every wave
-  // has taken its own query rows into registers); K and V, which the dQ phase still reads, are prefetched into registers
-  // (8 x 16 B per thread) and written to LDS at the top of the next head ; lse / D one float per thread
-  typedef const void __attribute__((address_space(1))) * gptr_t;
-  typedef void __attribute__((address_space(3))) * lptr_t;
-  bf16x8 pb[8];
-  float plse = 0.f, pd = 0.f;
-  // staging map: thread t moves chunk (t & 7) of rows (t >> 3) + 64 j, j = 0..3, of each of the four matrices; the
-  // permutation key of those rows is the same for every j (64 j >> 1 is a multiple of 8)
-  const int srow = tid >> 3, sk = (tid & 7) * 8;
-  const int sofs = srow * HD + (((tid & 7) ^ b256_key(srow)) << 3);
-  // LDS-DMA map: instruction i of a wave covers rows 32 wid + 8 i .. + 8 (128-B rows), lane = (row, physical chunk)
-  int dq_off[4], ddo_off[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = wid * 32 + i * 8 + (lane >> 3), c = (lane & 7) ^ b256_key(row);
-    dq_off[i] = row * (int)ld + c * 8;
-    ddo_off[i] = row * C + c * 8;
-  }
-  auto dma_qdo = [&](int h) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      __builtin_amdgcn_global_load_lds((gptr_t)(qkv + dq_off[i] + h * HD), (lptr_t)(reinterpret_cast<char*>(sQ) + (wid * 4 + i) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(dob + ddo_off[i] + h * HD), (lptr_t)(reinterpret_cast<char*>(sDO) + (wid * 4 + i) * 1024), 16, 0, 0);
-    }
-  };
-  auto load_aux = [&](int h) {
-    if (tid < NP) { plse = p.lse[((size_t)s * H + h) * NP + tid]; pd = Dg[((size_t)s * H + h) * NP + tid]; }
-  };
-  auto load_kv = [&](int h) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      pb[j] = ld_frag(qkv + (size_t)(srow + 64 * j) * ld + C + h * HD + sk);
-      pb[4 + j] = ld_frag(qkv + (size_t)(srow + 64 * j) * ld + 2 * C + h * HD + sk);
-    }
-  };
-  auto store_lds = [&]() {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      *reinterpret_cast<bf16x8*>(sK + sofs + 64 * j * HD) = pb[j];
-      *reinterpret_cast<bf16x8*>(sV + sofs + 64 * j * HD) = pb[4 + j];
-    }
-    if (tid < NP) { sLse[tid] = -plse * LOG2E; sD[tid] = pd; }       // exponent offset of P = exp2(c1 s - lse log2 e)
-  };
-  // lane-only parts of the swizzled fragment addresses (row blocks are multiples of 16 rows, so the permutation key of a
-  // fragment row depends on the lane alone); the block / tile offsets are added as constants by the reads
-  int rofs[4], tofs[2][2];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) rofs[ks] = l31 * HD + (((ks * 2 + hi) ^ b256_key(l31)) << 3);
-  {
-    const int a = lane & 15, g = lane >> 4;
-    const int lrow = 4 * (g >> 1) + (a >> 2), lcol = (g & 1) * 16 + 4 * (a & 3);
-#pragma unroll
-    for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-      for (int half = 0; half < 2; ++half)
-        tofs[cc][half] = (lrow + 8 * half) * HD + (((cc * 4 + (lcol >> 3)) ^ b256_key(lrow + 8 * half)) << 3) + (lcol & 7);
-  }
-  auto rfrag = [&](const bf16* X, int row0, int ks) { return ld_frag(X + row0 * HD + rofs[ks]); };          // rows row0 + l31
-  auto tfrag = [&](const bf16* X, int r0, int cc) {                                                          // X^T fragment
-    union { struct { s16x4 a, b; } s; bf16x8 v; } u;
-    u.s.a = lds_tr4(X + r0 * HD + tofs[cc][0]); u.s.b = lds_tr4(X + r0 * HD + tofs[cc][1]);
-    return u.v;
-  };
-  const float c1 = scale * LOG2E;
-  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  unsigned mbits = 0;                                               // padded keys of the last key tile (dQ phase), one bit per accumulator register
-#pragma unroll
-  for (int r = 0; r < 16; ++r) mbits |= ((ntile - 1) * 32 + crow32(r, hi) >= valid ? 1u : 0u) << r;
-  asm volatile("" : "+v"(mbits));
-  dma_qdo(0);
-  load_aux(0);
-  load_kv(0);
-  for (int h = 0; h < H; ++h) {
-    store_lds();                                                   // K, V, lse, D of head h (waits for their loads -- and, in order, for the Q / dO DMA issued before them)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    // ---------------- dK, dV : this wave owns keys [32 wid, 32 wid + 32)
-    {
-      const int k0 = wid * 32;
-      bf16* dkrow = p.dqkv + ((size_t)s * NP + k0 + l31) * ld + C + h * HD;
-      bf16* dvrow = dkrow + C;
-      f32x16 dk0, dk1, dv0, dv1; zero16(dk0); zero16(dk1); zero16(dv0); zero16(dv1);
-      if (k0 < valid) {
-        bf16x8 kf[4], vf[4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          kf[ks] = rfrag(sK, k0, ks);
-          vf[ks] = rfrag(sV, k0, ks);
-        }
-        const float kbias = (k0 + l31 >= valid) ? -3.0e38f : 0.f;  // padded key: P = 0 (reference: exp(-10000 + ...) == 0 in fp32)
-        for (int i = 0; i < 8; ++i) {
-          f32x16 sc, dp;
-#if ATST_ATTN_ABL & 16
-          sc = zero; dp = zero; asm volatile("" : "+v"(sc), "+v"(dp));
-#else
-          sc = mfma32(rfrag(sQ, i * 32, 0), kf[0], zero);
-          dp = mfma32(rfrag(sDO, i * 32, 0), vf[0], zero);
-#pragma unroll
-          for (int ks = 1; ks < 4; ++ks) {
-            sc = mfma32(rfrag(sQ, i * 32, ks), kf[ks], sc);
-            dp = mfma32(rfrag(sDO, i * 32, ks), vf[ks], dp);
-          }
-#endif
-          float pv[16], ds[16];                                    // ds without the softmax scale: applied once to dK at the end
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const f32x4 l4 = *reinterpret_cast<const f32x4*>(sLse + i * 32 + 8 * g + 4 * hi);
-            const f32x4 d4 = *reinterpret_cast<const f32x4*>(sD + i * 32 + 8 * g + 4 * hi);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int r = 4 * g + e;
-#if ATST_ATTN_ABL & 1
-              const float pr = sc[r];
-#else
-              const float pr = fast_exp2(fmaf(sc[r], c1, l4[e]) + kbias);
-#endif
-              pv[r] = pr;
-              ds[r] = pr * (dp[r] - d4[e]);
-            }
-          }
-#pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            bf16x8 pf = pack8(pv + 8 * t), dsf = pack8(ds + 8 * t);
-#if ATST_ATTN_ABL & 2
-            asm volatile("" :: "v"(pf), "v"(dsf));
-#else
-            dv0 = mfma32(tfrag(sDO, i * 32 + 16 * t, 0), pf, dv0);
-            dv1 = mfma32(tfrag(sDO, i * 32 + 16 * t, 1), pf, dv1);
-            dk0 = mfma32(tfrag(sQ, i * 32 + 16 * t, 0), dsf, dk0);
-            dk1 = mfma32(tfrag(sQ, i * 32 + 16 * t, 1), dsf, dk1);
-#endif
-          }
-        }
-      }
-#if ATST_ATTN_ABL & 8
-      asm volatile("" :: "v"(dk0), "v"(dk1), "v"(dv0), "v"(dv1));
-#else
-      store_row64(dkrow, dk0, dk1, scale, hi);
-      store_row64(dvrow, dv0, dv1, 1.0f, hi);
-#endif
-    }
-    // ---------------- dQ : this wave owns queries [32 wid, 32 wid + 32)
-    {
-      const int q0 = wid * 32;
-      bf16x8 qf[4], dof[4];
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        qf[ks] = rfrag(sQ, q0, ks);
-        dof[ks] = rfrag(sDO, q0, ks);
-      }
-      const float Dq = sD[q0 + l31], nlse = sLse[q0 + l31];
-      if (h + 1 < H) {                                             // every wave holds its query rows: the Q / dO images can be overwritten
-        __syncthreads();
-        dma_qdo(h + 1);
-        load_aux(h + 1);
-        load_kv(h + 1);
-      }
-      f32x16 dq0, dq1; zero16(dq0); zero16(dq1);
-      for (int j = 0; j < ((ATST_ATTN_ABL & 4) ? 0 : ntile); ++j) {
-        f32x16 sc, dp;
-        sc = mfma32(rfrag(sK, j * 32, 0), qf[0], zero);
-        dp = mfma32(rfrag(sV, j * 32, 0), dof[0], zero);
-#pragma unroll
-        for (int ks = 1; ks < 4; ++ks) {
-          sc = mfma32(rfrag(sK, j * 32, ks), qf[ks], sc);
-          dp = mfma32(rfrag(sV, j * 32, ks), dof[ks], dp);
-        }
-        float ds[16];
-        const unsigned mb = j == ntile - 1 ? mbits : 0u;           // only the last key tile can hold padded keys
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-#if ATST_ATTN_ABL & 1
-          float pr = sc[r];
-#else
-          float pr = fast_exp2(fmaf(sc[r], c1, nlse));
-#endif
-          if ((mb >> r) & 1u) pr = 0.f;
-          ds[r] = pr * (dp[r] - Dq);
-        }
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const bf16x8 dsf = pack8(ds + 8 * t);
-          dq0 = mfma32(tfrag(sK, j * 32 + 16 * t, 0), dsf, dq0);
-          dq1 = mfma32(tfrag(sK, j * 32 + 16 * t, 1), dsf, dq1);
-        }
-      }
-      bf16* dqrow = p.dqkv + ((size_t)s * NP + q0 + l31) * ld + h * HD;
-#if ATST_ATTN_ABL & 8
-      asm volatile("" :: "v"(dq0), "v"(dq1));
-#else
-      store_row64(dqrow, dq0, dq1, scale, hi);
-#endif
-    }
-    __syncthreads();                                               // everyone is done with this head's LDS image
-  }
-}
-
-
-// ---- round 4: the same backward with every asynchronous transfer issued and waited for BY HAND ----------------------------------
+// ---- round 4: every asynchronous transfer issued and waited for BY HAND ---------------------------------------------------------
 // What the ablation of the round-3 kernel showed (tools/attn_ablate.sh, profiles/r04_attn_ablate.txt): removing the global stores alone
-// took 67 of 300 us off -- the stores were not overlapped with anything.  The ISA says why: hipcc's waitcnt insertion put
-// `s_waitcnt vmcnt(0)` (a) between the register prefetch loads of the next head, right behind the dK / dV stores and the LDS-DMA issue,
-// (b) in front of the first transposing LDS read of the dQ loop (it treats the builtin as a reader of every LDS-DMA in flight) and
-// (c) at the top of every head -- vmcnt retires in order, so each of them also waited for the stores just issued to be acknowledged by
-// HBM, and for the next head's operands to land before the current head went on: nothing was prefetched, every head paid two store
-// drains and one full load latency.  Here:
+// took 67 of 300 us off, the softmax arithmetic 32, each group of products 50-65 -- the parts add up, little overlaps.  One suspect was
+// in the ISA: hipcc's waitcnt insertion had put `s_waitcnt vmcnt(0)` (a) between the register prefetch loads of the next head, right
+// behind the dK / dV stores and the LDS-DMA issue, (b) in front of the first transposing LDS read of the dQ loop (it treats the
+// builtin as a reader of every LDS-DMA in flight) and (c) at the top of every head -- vmcnt retires in order, so each of them also
+// waited for the stores just issued to be acknowledged, and for the next head's operands to land before the current head went on.
+// This version removes all of them (checked in the ISA: tools/check_attn_bwd_isa.py) and frees the 56 B of scratch the round-3 kernel
+// spilled (245 registers instead of 256) -- and measures 307 vs 310 us (profiles/r04_attn_time.txt): the drains were not the cost.  What
+// is: the row-per-lane stores themselves (32-B pieces of 128-B lines, ~60 us = the store bandwidth of the chip at that
+// granularity) and, in the product loops, the LDS-read latency in front of every MFMA (no register left to read a block ahead).
+// Kept because it is the cleaner schedule (no spills, exact waits), not because it is faster.  Here:
 //   * every load is inline assembly (LDS-DMA: glds16_asm ; register loads: gload16_asm), invisible to the compiler's scoreboard, so it
 //     inserts no wait; the waits are written below as exact `vmcnt(N)` counts, N = the number of STORE instructions issued behind the
 //     loads being waited for (vmcnt counts loads and stores in issue order; more stores than counted only makes a wait stricter);
@@ -1014,6 +802,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd256_kernel(AttnArgs p, const f
       f32x16 dk0, dk1, dv0, dv1; zero16(dk0); zero16(dk1); zero16(dv0); zero16(dv1);
       if (k0 < valid) {
         const float kbias = (k0 + l31 >= valid) ? -3.0e38f : 0.f;  // padded key: P = 0 (reference: exp(-10000 + ...) == 0 in fp32)
+        const bool padded = k0 + 32 > valid;                       // wave-uniform: only the block that straddles `valid` needs the bias
+        // (Software-pipelining this loop -- S / dP of block i + 1, or dV / dK of block i - 1, next to the softmax arithmetic of block i -- was
+        // measured in round 4: the extra live operands spill (104 / 36 B of scratch at 256 registers) and hipcc keeps the 16 MFMAs of a
+        // block together whatever sched_group_barrier asks for; the loop is bound by exposed LDS-read latency -- every MFMA waits for
+        // a fragment read issued right in front of it, there is no register left to read a block ahead.  profiles/r04_attn_ablate.txt)
         for (int i = 0; i < 8; ++i) {
           f32x16 sc, dp;
 #if ATST_ATTN_ABL & 16
@@ -1038,7 +831,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd256_kernel(AttnArgs p, const f
 #if ATST_ATTN_ABL & 1
               const float pr = sc[r];
 #else
-              const float pr = fast_exp2(fmaf(sc[r], c1, l4[e]) + kbias);
+              float arg = fmaf(sc[r], c1, l4[e]);
+              if (padded) arg += kbias;
+              const float pr = fast_exp2(arg);
 #endif
               pv[r] = pr;
               ds[r] = pr * (dp[r] - d4[e]);
@@ -1168,7 +963,7 @@ int launch_bwd(const AttnArgs& a, hipStream_t st) {
 }
 }  // namespace
 
-int g_bwd256 = 1;          // merged per-sequence backward kernel for NP = 256: 1 = hand-scheduled transfers (round 4), 3 = round-3 kernel, 0 = two kernels (tuning hooks 403 / 405 / 402)
+int g_bwd256 = 1;          // merged per-sequence backward kernel for NP = 256 (tuning hook 402/403); the round-3 version of it (compiler-scheduled transfers) is in git history: 310 vs 307 us, profiles/r04_attn_time.txt
 int g_fwd256 = 2;          // NP = 256 forward: 2 = two-pass softmax + LDS-DMA head loop, 1 = online-softmax head loop, 0 = per-(sequence, head) kernel (tuning hooks 404 / 401 / 400)
 void atst_attn_set_variant(int v) { if (v == 4) g_fwd256 = 2; else if (v >= 2) g_bwd256 = v - 2; else g_fwd256 = v; }
 
@@ -1213,15 +1008,12 @@ int atst_attn_bwd(const AttnArgs& a, hipStream_t st) {
     if (!done) {
       hipError_t e = hipFuncSetAttribute((const void*)attn_bwd256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, B256_LDS);
       if (e != hipSuccess) return (int)e;
-      e = hipFuncSetAttribute((const void*)attn_bwd256_r3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, B256_LDS);
-      if (e != hipSuccess) return (int)e;
       done = true;
     }
     const long rows = (long)a.S * 256;
     hipLaunchKernelGGL(attn_rowdot_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, a.d_o, (const bf16*)a.o, a.dscratch, a.S, a.H, 256);
     ProfScope ps(PK_ATTN_BWD_DKV, 14.0 * a.S * a.H * 256.0 * 256.0 * HD, st, 16.0 * a.S * a.H * 256.0 * HD);
-    if (g_bwd256 == 3) hipLaunchKernelGGL(attn_bwd256_r3_kernel, dim3(a.S), dim3(512), B256_LDS, st, a, (const float*)a.dscratch);
-    else hipLaunchKernelGGL(attn_bwd256_kernel, dim3(a.S), dim3(512), B256_LDS, st, a, (const float*)a.dscratch);
+    hipLaunchKernelGGL(attn_bwd256_kernel, dim3(a.S), dim3(512), B256_LDS, st, a, (const float*)a.dscratch);
     return (int)hipGetLastError();
   }
   switch (a.NP) {

@@ -21,9 +21,3 @@ fwd = lambda: hip.call("atst_attention_fwd", hip.ptr(qkv), hip.ptr(valid), hip.p
 bwd = lambda: hip.call("atst_attention_bwd", hip.ptr(qkv), hip.ptr(valid), hip.ptr(o), hip.ptr(lse), hip.ptr(d_o), hip.ptr(dqkv), hip.ptr(scr), S, H, NP, hip.stream())
 fwd(); bwd()
 print(f"attention fwd {med(fwd):7.1f} us   bwd (row-dot + merged kernel) {med(bwd):7.1f} us", flush=True)
-if os.environ.get("AB"):                         # hooks 403 / 405: hand-scheduled transfers (round 4) / the round-3 backward kernel, taking turns
-    for rnd in range(3):
-        for v, name in ((3, "round-4"), (5, "round-3")):
-            lib.atst_tune_gemm_variant(400 + v)
-            print(f"  bwd {name}: {med(bwd):7.1f} us", flush=True)
-    lib.atst_tune_gemm_variant(403)
