@@ -82,6 +82,43 @@ DEVFN void store_row64(bf16* row, const f32x16& t0, const f32x16& t1, float mul,
   }
 }
 
+// Full-line stores of a 32-row x 64-column bf16 tile held as two C-layout accumulators (row = lane & 31; t0: columns 0..31, t1: 32..63):
+// the tile is transposed through a wave-private 4 KB LDS region (16-B chunks XOR-permuted by the row: conflict-free both ways) so that
+// every store instruction writes 8 complete 128-B lines instead of 32-B pieces of 32 different lines (store_row64: the row-per-lane
+// pattern costs the NP = 256 kernels the full store bandwidth of the chip at that granularity, profiles/r04_attn_ablate.txt).
+DEVFN void store_tile64_staged(bf16* g00 /* global address of (row 0, column 0) */, size_t ld /* elements between rows */, const f32x16& t0,
+                               const f32x16& t1, float mul, char* stage /* 4 KB, this wave's */, int lane) {
+  const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const f32x16& v = t == 0 ? t0 : t1;
+    unsigned P[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      P[g][0] = pack2(v[4 * g] * mul, v[4 * g + 1] * mul);
+      P[g][1] = pack2(v[4 * g + 2] * mul, v[4 * g + 3] * mul);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int w = 0; w < 2; ++w) {
+        auto r = __builtin_amdgcn_permlane32_swap(P[k][w], P[k + 2][w], false, false);   // P[k].upper <-> P[k+2].lower
+        P[k][w] = r[0]; P[k + 2][w] = r[1];
+      }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {                                 // columns t * 32 + 16 hi + 8 k .. + 7 = chunk 4 t + 2 hi + k of row l31
+      const u32x4 o = {P[k][0], P[k][1], P[k + 2][0], P[k + 2][1]};
+      *reinterpret_cast<u32x4*>(stage + l31 * 128 + (((4 * t + 2 * hi + k) ^ (l31 & 7)) << 4)) = o;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {                                   // instruction j: rows 8 j .. 8 j + 7, lane = (row, chunk): 8 lanes per 128-B line
+    const int row = 8 * j + (lane >> 3), c = lane & 7;
+    const u32x4 o = *reinterpret_cast<const u32x4*>(stage + row * 128 + ((c ^ (row & 7)) << 4));
+    *reinterpret_cast<u32x4*>(g00 + (size_t)row * ld + c * 8) = o;
+  }
+}
+
 DEVFN void zero16(f32x16& a) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) a[r] = 0.f;
@@ -422,7 +459,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256v2_kernel(AttnArgs p) {
 #ifdef ATST_ABLATE_ATTN_STORE
     if (rs == 12345.678f)                                           // experiment builds: no output stores
 #endif
-    store_row64(orow, o0, o1, inv, hi);
+    store_row64(orow, o0, o1, inv, hi);                            // (full-line stores through an LDS transposition buffer, as in the backward: 60 B of scratch at 256 registers -- the score strip is the register file)
     if (hi == 0) p.lse[((size_t)s * H + h) * NP + q0 + l31] = mx * 0.125f + __logf(rs);
   }
 }
@@ -785,6 +822,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd256_kernel(AttnArgs p, const f
   // statement).  Checked in the ISA after every change to this kernel (tools/check_attn_bwd_isa.py).
   for (int h = -1; h < H; ++h) {
     bf16x8 kf[4], vf[4];
+    f32x16 dk0, dk1, dv0, dv1; zero16(dk0); zero16(dk1); zero16(dv0); zero16(dv1);
     if (h >= 0) {
     // Q, dO images (LDS-DMA) and this wave's K / V fragments, lse, D of head h have landed; only the previous head's dQ stores are
     // younger (head 0: nothing is, so everything is waited for -- by a statement without register operands)
@@ -797,9 +835,6 @@ __global__ __launch_bounds__(512, 2) void attn_bwd256_kernel(AttnArgs p, const f
     dma_kv(h);                                                     // K, V images of this head: needed by the dQ phase only
     // ---------------- dK, dV : this wave owns keys [32 wid, 32 wid + 32)
     {
-      bf16* dkrow = p.dqkv + ((size_t)s * NP + k0 + l31) * ld + C + h * HD;
-      bf16* dvrow = dkrow + C;
-      f32x16 dk0, dk1, dv0, dv1; zero16(dk0); zero16(dk1); zero16(dv0); zero16(dv1);
       if (k0 < valid) {
         const float kbias = (k0 + l31 >= valid) ? -3.0e38f : 0.f;  // padded key: P = 0 (reference: exp(-10000 + ...) == 0 in fp32)
         const bool padded = k0 + 32 > valid;                       // wave-uniform: only the block that straddles `valid` needs the bias
@@ -853,12 +888,6 @@ __global__ __launch_bounds__(512, 2) void attn_bwd256_kernel(AttnArgs p, const f
           }
         }
       }
-#if ATST_ATTN_ABL & 8
-      asm volatile("" :: "v"(dk0), "v"(dk1), "v"(dv0), "v"(dv1));
-#else
-      store_row64(dkrow, dk0, dk1, scale, hi);
-      store_row64(dvrow, dv0, dv1, 1.0f, hi);
-#endif
     }
     }                                                              // h >= 0
     // ---------------- dQ : this wave owns queries [32 wid, 32 wid + 32)
@@ -874,9 +903,20 @@ __global__ __launch_bounds__(512, 2) void attn_bwd256_kernel(AttnArgs p, const f
         }
         Dq = sD[q0 + l31]; nlse = sLse[q0 + l31];
       }
-      // my K / V pieces have landed (the dK / dV stores behind them may still be in flight); with the barrier: everyone's have, and
-      // every wave holds its query rows, so the Q / dO images can take the next head
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(BWD_ST_DKV) : "memory");
+      // my K / V pieces have landed (issued a whole dK / dV phase ago: nothing younger is in flight); with the barrier: everyone's have,
+      // and every wave holds its query rows, so the Q / dO images are dead: this wave's 32 rows of each first serve as the transposition
+      // buffers of its dK / dV tiles (full-line stores), then take the next head's Q / dO (this wave's own LDS-DMA share: wave-private)
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (h >= 0) {
+#if ATST_ATTN_ABL & 8
+        asm volatile("" :: "v"(dk0), "v"(dk1), "v"(dv0), "v"(dv1));
+#else
+        bf16* dk00 = p.dqkv + ((size_t)s * NP + k0) * ld + C + h * HD;
+        store_tile64_staged(dk00, ld, dk0, dk1, scale, reinterpret_cast<char*>(sQ) + wid * 4096, lane);
+        store_tile64_staged(dk00 + C, ld, dv0, dv1, 1.0f, reinterpret_cast<char*>(sDO) + wid * 4096, lane);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the buffers have been read back: the DMA below may overwrite them
+#endif
+      }
       if (h + 1 < H) {
         dma_qdo(h + 1);
         load_regs(h + 1);
