@@ -912,8 +912,13 @@ __global__ __launch_bounds__(512, 2) void attn_bwd256_kernel(AttnArgs p, const f
         asm volatile("" :: "v"(dk0), "v"(dk1), "v"(dv0), "v"(dv1));
 #else
         bf16* dk00 = p.dqkv + ((size_t)s * NP + k0) * ld + C + h * HD;
-        store_tile64_staged(dk00, ld, dk0, dk1, scale, reinterpret_cast<char*>(sQ) + wid * 4096, lane);
-        store_tile64_staged(dk00 + C, ld, dv0, dv1, 1.0f, reinterpret_cast<char*>(sDO) + wid * 4096, lane);
+        if (p.row_stores) {                                        // tuning hook 406: the round-3 row-per-lane stores (A/B only)
+          store_row64(dk00 + (size_t)l31 * ld, dk0, dk1, scale, hi);
+          store_row64(dk00 + (size_t)l31 * ld + C, dv0, dv1, 1.0f, hi);
+        } else {
+          store_tile64_staged(dk00, ld, dk0, dk1, scale, reinterpret_cast<char*>(sQ) + wid * 4096, lane);
+          store_tile64_staged(dk00 + C, ld, dv0, dv1, 1.0f, reinterpret_cast<char*>(sDO) + wid * 4096, lane);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the buffers have been read back: the DMA below may overwrite them
 #endif
       }
@@ -1005,7 +1010,8 @@ int launch_bwd(const AttnArgs& a, hipStream_t st) {
 
 int g_bwd256 = 1;          // merged per-sequence backward kernel for NP = 256 (tuning hook 402/403); the round-3 version of it (compiler-scheduled transfers) is in git history: 310 vs 307 us, profiles/r04_attn_time.txt
 int g_fwd256 = 2;          // NP = 256 forward: 2 = two-pass softmax + LDS-DMA head loop, 1 = online-softmax head loop, 0 = per-(sequence, head) kernel (tuning hooks 404 / 401 / 400)
-void atst_attn_set_variant(int v) { if (v == 4) g_fwd256 = 2; else if (v >= 2) g_bwd256 = v - 2; else g_fwd256 = v; }
+int g_bwd_row_stores = 0;  // 406 / 407: NP = 256 backward dK / dV stores row-per-lane (A/B) / LDS-transposed full lines (default)
+void atst_attn_set_variant(int v) { if (v == 6 || v == 7) g_bwd_row_stores = v == 6; else if (v == 4) g_fwd256 = 2; else if (v >= 2) g_bwd256 = v - 2; else g_fwd256 = v; }
 
 int atst_attn_fwd(const AttnArgs& a, hipStream_t st) {
   if (a.S <= 0) return ATST_OK;
@@ -1053,7 +1059,8 @@ int atst_attn_bwd(const AttnArgs& a, hipStream_t st) {
     const long rows = (long)a.S * 256;
     hipLaunchKernelGGL(attn_rowdot_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, a.d_o, (const bf16*)a.o, a.dscratch, a.S, a.H, 256);
     ProfScope ps(PK_ATTN_BWD_DKV, 14.0 * a.S * a.H * 256.0 * 256.0 * HD, st, 16.0 * a.S * a.H * 256.0 * HD);
-    hipLaunchKernelGGL(attn_bwd256_kernel, dim3(a.S), dim3(512), B256_LDS, st, a, (const float*)a.dscratch);
+    AttnArgs a2 = a; a2.row_stores = g_bwd_row_stores;
+    hipLaunchKernelGGL(attn_bwd256_kernel, dim3(a.S), dim3(512), B256_LDS, st, a2, (const float*)a.dscratch);
     return (int)hipGetLastError();
   }
   switch (a.NP) {

@@ -130,12 +130,24 @@ DEVFN float gelu_grad_bf16dst(float x) {
 #endif
 }
 
+// fp8 forward saturation accounting: the activation scales of the e4m3 forward are constants (csrc/engine.hip ACT_SCALE); a value
+// beyond +-448 / scale is clipped.  Every quantising kernel counts the elements it clipped (n per lane, summed over the wave, one atomic
+// per wave that clipped anything) into the counter of its encoder pass (atst_encoder_t.f8_sat): a run whose activations outgrow the
+// fixed scales is reported instead of degrading silently (round-2 / round-3 ADVICE).
+DEVFN void f8_sat_add(unsigned* counter, unsigned n_clipped_lane);
+
 // XCD-aware, bijective remap of a 1-D grid: block b runs on XCD b%8 (observed, speed only); give every XCD a
 // contiguous chunk of logical ids so that neighbouring tiles share one L2.
 DEVFN int xcd_remap(int bid, int nblk) {
   const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, loc = bid >> 3;
   const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + loc;
+}
+
+DEVFN void f8_sat_add(unsigned* counter, unsigned n) {
+  if (!counter) return;
+  const float tot = wave_sum((float)n);                            // <= 64 * a few hundred: exact in fp32
+  if (tot > 0.f && (threadIdx.x & 63) == 0) atomicAdd(counter, (unsigned)tot);
 }
 
 // ---- MFMA fragment helpers (layouts verified on hardware by tools/probes/probe_isa.hip) ------------------------------

@@ -92,11 +92,13 @@ DEVFN void epilogue8(const GemmArgs& p, int row, int col, f32x4 v0, f32x4 v1, co
     st_bf16(p.C2, idx, g0, g1);                                    // activation a
     if (p.q8) {                                                    // fp8 forward: e4m3 copy of the SAME bf16 values for the fc2 GEMM
       const float s = p.q8_scale;
-      auto c = [&](float a_) { return __builtin_amdgcn_fmed3f(bf2f(f2bf(a_)) * s, -448.f, 448.f); };
+      unsigned nclip = 0;                                          // elements beyond +-448 / scale (fixed activation scale: reported, see f8_sat_add)
+      auto c = [&](float a_) { const float t = bf2f(f2bf(a_)) * s; nclip += fabsf(t) > 448.f ? 1u : 0u; return __builtin_amdgcn_fmed3f(t, -448.f, 448.f); };
       int lo = __builtin_amdgcn_cvt_pk_fp8_f32(c(g0[0]), c(g0[1]), 0, false); lo = __builtin_amdgcn_cvt_pk_fp8_f32(c(g0[2]), c(g0[3]), lo, true);
       int hi_w = __builtin_amdgcn_cvt_pk_fp8_f32(c(g1[0]), c(g1[1]), 0, false); hi_w = __builtin_amdgcn_cvt_pk_fp8_f32(c(g1[2]), c(g1[3]), hi_w, true);
       typedef int v2i_ __attribute__((ext_vector_type(2)));
       *reinterpret_cast<v2i_*>(p.q8 + idx) = v2i_{lo, hi_w};
+      if (nclip && p.q8_sat) atomicAdd(p.q8_sat, nclip);           // rare path: per-lane atomics only when something was clipped
     }
   } else if constexpr (EPI == EPI_RESID) {
     st_f32(p.C, idx, x.a0 + x.s * (v0 + b0), x.a1 + x.s * (v1 + b1));

@@ -27,6 +27,7 @@ struct GemmArgs {
   // statistics of the forward in ln_mean / ln_rstd, affine weight in ln_gamma.
   const float* lnb_x; bf16* lnb_g; float* lnb_dgamma; float* lnb_dbeta; float* lnb_dbias_up;
   uint8_t* q8; float q8_scale;       // EPI_BIAS_GELU: optional e4m3 copy of the activation * q8_scale (A operand of the fp8 fc2 GEMM)
+  unsigned* q8_sat;                  // EPI_BIAS_GELU: counter of the elements of that copy clipped at +-448 (or null)
   float dq_mul;                      // fp8 GEMMs: host factor on top of *dq (1 / activation scale); 0 is read as 1
   const float* dq_div;               // fp8 GEMMs: optional device scalar the accumulators are DIVIDED by (delayed-scaling quantisation scale of A)
   const float* q8_scale_ptr;         // EPI_DGELU: device scale of the optional e4m3 copy (q8) of the output; amax of the output -> q8_amax
@@ -50,7 +51,7 @@ int atst_gemm_tn_group(const WgradArgs* items, int n, hipStream_t st);   // inde
 
 // LayerNorm (eps 1e-6), C in {384, 768}
 int atst_ln_fwd(const float* x, const float* gamma, const float* beta, bf16* y, float* mean, float* rstd, int M, int C, hipStream_t st,
-                uint8_t* y8 = nullptr, float s8 = 1.0f);   // y8: optional e4m3 copy of y * s8 (fp8 forward)
+                uint8_t* y8 = nullptr, float s8 = 1.0f, unsigned* sat = nullptr);   // y8: optional e4m3 copy of y * s8 (fp8 forward) ; sat: clipped-element counter
 int atst_ln_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, int M, int C, hipStream_t st);   // fp32 output, no statistics (inference taps)
 struct LnBwdArgs {
   const bf16* dy;                    // [M,C] gradient wrt the LN output
@@ -76,6 +77,7 @@ struct AttnArgs {
   bf16* dqkv;                        // bwd out [S*NP, 3*C]
   float* dscratch;                   // bwd scratch [S, H, NP] fp32 (rowsum(dO*O)); null -> two-kernel backward
   int S, H, NP;
+  int row_stores;                    // tuning hook (NP = 256 backward): 1 = row-per-lane dK / dV stores instead of the LDS-transposed full-line ones
   int stride;                        // rows between consecutive sequences in qkv / o / d_o / dqkv (0 = NP).  stride < NP: sequences are PACKED --
                                      // the NP - stride rows that complete a sequence's last 32-row tile belong to the next sequence and are treated
                                      // as absent (read as zeros, never written).  NP < 256 kernels only.
@@ -115,7 +117,7 @@ int atst_byol_loss(const float* student, const float* teacher, int B, int ncrops
                    float* stats, hipStream_t st);
 
 // fp8 (OCP e4m3) operand preparation for the ATST-base forward GEMMs (BASELINE.json configs[4])
-int atst_quant_fp8(const bf16* x, size_t n, float scale, uint8_t* y, hipStream_t st);               // y = e4m3(clamp(x * scale, +-448))
+int atst_quant_fp8(const bf16* x, size_t n, float scale, uint8_t* y, hipStream_t st, unsigned* sat = nullptr);   // y = e4m3(clamp(x * scale, +-448)) ; sat += clipped elements
 // every tensor of `table` (device int32 [n][2] = {element offset, numel}, 256-aligned) of a flat fp32 buffer -> e4m3 at the same
 // offsets with a per-tensor scale 448 / amax; dq[t] = amax / 448 (the factor that undoes it).  amax: device scratch [n].
 int atst_quant_fp8_dyn(const bf16* x, size_t n, const float* scale /* device */, uint8_t* y /* or null: amax only */, float* amax /* device, atomicMax */, hipStream_t st);

@@ -113,18 +113,20 @@ int atst_transpose_bf16(const bf16* src, int rows, int cols, bf16* dst, hipStrea
 
 // ---- fp8 (OCP e4m3) operand preparation ----------------------------------------------------------------------------------
 namespace {
-__global__ void quant_fp8_kernel(const bf16* __restrict__ x, size_t n8, float scale, unsigned* __restrict__ y) {
+__global__ void quant_fp8_kernel(const bf16* __restrict__ x, size_t n8, float scale, unsigned* __restrict__ y, unsigned* __restrict__ sat) {
+  unsigned nclip = 0;
   // 8 bf16 in (16 B), 8 e4m3 out (8 B) per thread per iteration
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
     const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + i * 8);
     float f[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) f[e] = __builtin_amdgcn_fmed3f(bf2f(v[e]) * scale, -448.f, 448.f);
+    for (int e = 0; e < 8; ++e) { const float t = bf2f(v[e]) * scale; nclip += fabsf(t) > 448.f ? 1u : 0u; f[e] = __builtin_amdgcn_fmed3f(t, -448.f, 448.f); }
     int lo = 0, hi = 0;
     lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false); lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
     hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false); hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
     y[i * 2] = (unsigned)lo; y[i * 2 + 1] = (unsigned)hi;
   }
+  f8_sat_add(sat, nclip);
 }
 __global__ void amax_batch_kernel(const float* __restrict__ p, const int* __restrict__ table, float* __restrict__ amax) {
   const int t = blockIdx.y;
@@ -210,11 +212,11 @@ int atst_quant_bf16_table_fp8(const bf16* p16, const int* table, int n, const fl
   hipLaunchKernelGGL(quant_bf16_table_kernel, dim3(32, n), dim3(256), 0, st, p16, table, dq, p8);
   return (int)hipGetLastError();
 }
-int atst_quant_fp8(const bf16* x, size_t n, float scale, uint8_t* y, hipStream_t st) {
+int atst_quant_fp8(const bf16* x, size_t n, float scale, uint8_t* y, hipStream_t st, unsigned* sat) {
   if (n == 0) return ATST_OK;
   if (n % 8) return ATST_EINVAL;
   int grid = (int)((n / 8 + 255) / 256); if (grid > 8192) grid = 8192;
-  hipLaunchKernelGGL(quant_fp8_kernel, dim3(grid), dim3(256), 0, st, x, n / 8, scale, reinterpret_cast<unsigned*>(y));
+  hipLaunchKernelGGL(quant_fp8_kernel, dim3(grid), dim3(256), 0, st, x, n / 8, scale, reinterpret_cast<unsigned*>(y), sat);
   return (int)hipGetLastError();
 }
 int atst_quant_weights_fp8(const float* p32, const int* table, int n, uint8_t* p8, float* dq, float* amax, hipStream_t st) {

@@ -177,6 +177,7 @@ class EncoderPass:
         if eng.fp8 and not self.precise:
             e.fp8 = 1
             e.p8, e.w_dq = (eng.p8.data_ptr(), eng.dq_s.data_ptr()) if net == "student" else (eng.t8.data_ptr(), eng.dq_t.data_ptr())
+            e.f8_sat = eng.f8_sat[0 if net == "student" else 1:].data_ptr()
             if net == "student" and train:
                 e.p8t, e.g8_scale, e.g8_amax = eng.p8t.data_ptr(), eng.g8_scale.data_ptr(), eng.g8_amax.data_ptr()
         e.ws, e.ws_bytes = self.ws.buf.data_ptr(), nbytes
@@ -468,6 +469,9 @@ class AtstEngine:
             self._f8_table = torch.tensor(rows, dtype=torch.int32, device=dev).contiguous()
             self.p8, self.t8 = z(L.n_student, torch.uint8), z(L.n_teacher, torch.uint8)
             self.dq_s, self.dq_t, self._f8_amax = z(len(rows)), z(len(rows)), z(len(rows))
+            # clipped-element counters of the fixed forward activation scales, [student, teacher] (atst_encoder_t.f8_sat): never reset by
+            # the step, read on demand (fp8_saturation()) -- a host read-back, so not once per step
+            self.f8_sat = z(2, torch.int32)
             # fp8 dgrad (d = 768): e4m3 copy of the transposed weight shadows + delayed-scaling state of the four gradient operands
             # of every block ([depth][4]: g -> fc2, du -> fc1, g2 -> proj, dqkv -> qkv).  fp8_bwd_state: 0 off, 1 recording, 2 on.
             self.p8t = z(L.n_student, torch.uint8)
@@ -860,6 +864,17 @@ class AtstEngine:
             hip.call("atst_fp8_update_scales", hip.ptr(win), hip.ptr(self.g8_scale), win.numel(), float(self.fp8_margin), hip.stream())
             self.g8_amax.zero_()
             self.fp8_bwd_state = 2
+
+    def fp8_saturation(self, reset: bool = False) -> Dict[str, int]:
+        """Activation elements clipped at +-448 by the e4m3 forward since the last reset, per network.  The forward scales are constants
+        (csrc/engine.hip ACT_SCALE: LayerNorm / attention outputs beyond +-56, GELU outputs beyond +-112 saturate); a non-zero count
+        says the run has outgrown them.  Synchronises (one 8-byte read-back): call it at logging cadence, not per step."""
+        if not self.fp8:
+            return {"student": 0, "teacher": 0}
+        v = self.f8_sat.tolist()
+        if reset:
+            self.f8_sat.zero_()
+        return {"student": int(v[0]), "teacher": int(v[1])}
 
     def fp8_state(self) -> Optional[dict]:
         """Delayed-scaling state of the fp8 dgrad path (optimizer state: saved with the moments, see trainer.save_checkpoint)."""

@@ -45,7 +45,8 @@ class Encoder(C.Structure):
                 ("mel", C.c_void_p), ("valid", C.c_void_p), ("rowflag", C.c_void_p), ("dp_scale", C.c_void_p),
                 ("ws", C.c_void_p), ("ws_bytes", C.c_size_t), ("tap", C.c_void_p), ("tap_first", C.c_int),
                 ("p8", C.c_void_p), ("w_dq", C.c_void_p), ("fp8", C.c_int), ("patch_h", C.c_int), ("patch_w", C.c_int),
-                ("p8t", C.c_void_p), ("g8_scale", C.c_void_p), ("g8_amax", C.c_void_p), ("fp8_bwd", C.c_int), ("row_stride", C.c_int)]
+                ("p8t", C.c_void_p), ("g8_scale", C.c_void_p), ("g8_amax", C.c_void_p), ("fp8_bwd", C.c_int), ("row_stride", C.c_int),
+                ("f8_sat", C.c_void_p)]
 
 
 _SIGS = {

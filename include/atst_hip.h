@@ -200,6 +200,10 @@ typedef struct {
    * 0 = NP.  n_tok + use_cls <= row_stride < NP packs the sequences (NP < 256 only): 1 s views are 26 tokens in tiles of 32, and the
    * GEMM / LayerNorm / weight-gradient kernels then run over S * row_stride rows.  The workspace is sized for NP either way.      */
   int row_stride;
+  /* fp8 forward: device counter (or NULL) that every activation-quantising kernel of the pass adds its number of CLIPPED elements to --
+   * the activation scales are constants (8 for LayerNorm / attention outputs, 4 behind GELU: |x| > 56 / 112 saturates at +-448); the
+   * caller clears and reads it (AtstEngine.fp8_saturation()).  A non-zero count means the fixed scales no longer fit the run.      */
+  uint32_t* f8_sat;
 } atst_encoder_t;
 
 size_t atst_encoder_ws_bytes(int S, int NP, int C, int H, int depth, int train, int fp8 /* = atst_encoder_t.fp8: also carve the e4m3 operand copies */);

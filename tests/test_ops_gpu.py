@@ -548,3 +548,85 @@ def test_fp8_dgrad_step_base():
     eng.optimizer_step(1e-3, 0.04, 0.99)
     l1 = float(eng.forward(mels, lens)[0]); eng.backward()
     assert math.isfinite(l1) and torch.isfinite(eng.p32).all()
+
+
+def test_configs4_base_fp8_hires_as_one_thing():
+    """BASELINE.json configs[4] with every piece switched on TOGETHER: ATST-base (d = 768, depth 2 here), 10 s @ 32 kHz through the HIP
+    front end with 128 mel bands, one patch row of 128 x 8 (the reference parameterises n_mels / patch_h / patch_w together:
+    methods/atstframe/train.py:15,50-51, transform.py:14-17), e4m3 forward GEMMs and e4m3 fc2 / fc1 / proj dgrad GEMMs with delayed
+    scaling -- against the oracle evaluated the same way (log_mel(sample_rate=32000, n_mels=128), emulate_bf16 + emulate_fp8 +
+    emulate_fp8_dgrad on HIP's quantisation grid, HIP's ReLU gates).  Tolerances: those of the separate tests of each piece."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from parity_helpers import oracle_grads
+    from audiossl_amd.engine import AtstEngine
+    from audiossl_amd.frontend import LogMelFrontend
+    depth, B, sr = 2, 6, 32000
+    W = O.recipe_weights("base", depth=depth, seed=17, patch_h=128, patch_w=8)
+    eng = AtstEngine("base", depth=depth, drop_path_rate=0.0, fp8=True, patch_h=128, patch_w=8)
+    eng.load_weights(W)
+    wave = O.recipe_wave(B, 11 * sr, seed=5)
+    views = [wave[:, :10 * sr].contiguous(), wave[:, sr // 2:sr // 2 + 10 * sr].contiguous()]
+    fe = LogMelFrontend(1024, sr=sr, n_mels=128)
+    mels = [fe(v.to(DEV)) for v in views]
+    mels_c = [O.log_mel(v, 1024, n_mels=128, sample_rate=sr) for v in views]
+    assert mels[0].shape == (B, 1, 128, 2001)
+    dmel = max(float((a.cpu() - b).abs().max()) for a, b in zip(mels, mels_c))
+    assert dmel < 2e-3, dmel                                               # the front-end tolerance of tests/test_frontend_gpu.py
+    lens = [torch.full((B,), 2001), torch.tensor([2001, 1801, 1283, 2001, 999, 2001])]
+    ep = eng._pass("student", 2 * B, 2001, True, 0)
+    assert ep.n_tok == 250 and ep.NP == 256 and eng.fp8_bwd_state == 1
+    fwd = lambda Wl: O.atst_forward(Wl, mels_c, lens, "base", 2, depth=depth, drop_path_rate=0.0)
+    loss1 = float(eng.forward(mels, lens)[0])
+    gates = {f"student.{w}.": (eng.heads[f"student.{w}"].saved[4][:, :4096].float() > 0).cpu() for w in ("projector", "predictor")}
+    cls = eng._student_groups[0][0].out.float().view(2 * B, 256, 768)[:, 0].cpu()
+    with torch.no_grad(), O.emulate_bf16(), O.emulate_fp8():
+        cls_o = O.encoder_forward(W, "student.encoder.", torch.cat(mels_c), torch.cat(lens), "base", depth=depth, drop_path_rate=0.0)
+    e_cls = relerr(cls, cls_o)
+    eng.backward()                                                         # recording step (bf16 dgrad)
+    sc = eng.g8_scale.view(depth, 4).clone()
+    site = {0: "mlp.fc2.weight", 1: "mlp.fc1.weight", 2: "attn.proj.weight"}
+    inject = {f"student.encoder.blocks.{i}.{nm}": float(sc[i, k]) for i in range(depth) for k, nm in site.items()}
+    assert eng.fp8_bwd_state == 2 and min(inject.values()) > 1.0
+    loss2 = float(eng.forward(mels, lens)[0]); eng.backward()              # e4m3 dgrad step, same weights and inputs
+    g = eng.g32.clone()
+    lo, go = oracle_grads(W, fwd, True, gates, ctxs=(O.emulate_fp8(), O.emulate_fp8_dgrad(inject)))
+    num = den = 0.0
+    worst = ("", 0.0)
+    for name, (off, shape) in eng.layout.entries.items():
+        n = math.prod(shape)
+        if name not in go or float(go[name].norm()) == 0.0 or name in ("encoder.pos_embed", "encoder.norm.bias"):
+            continue
+        r = relerr(g[off:off + n].cpu(), go[name].reshape(-1))
+        num += r * n; den += n
+        if r > worst[1]:
+            worst = (name, r)
+    print(f"\n[configs[4] base fp8 hires depth {depth}] mel max|d| {dmel:.1e}; CLS vs fp8-emulating oracle {e_cls:.3e}; loss {loss2:.5f} (oracle {lo:.5f}); "
+          f"gradients mean {num / den:.3e} worst {worst[0]} {worst[1]:.3e}")
+    assert loss1 == loss2 and abs(loss2 - lo) < 5e-2
+    assert e_cls < 5.5e-2                                                  # test_fp8_encoder_forward_and_step_base
+    assert num / den < 9e-2 and worst[1] < 0.2                             # test_fp8_dgrad_step_base
+    eng.optimizer_step(1e-3, 0.04, 0.99)
+    assert torch.isfinite(eng.p32).all() and torch.isfinite(eng.g32).all()
+
+
+def test_fp8_forward_saturation_counter():
+    """The e4m3 forward uses FIXED activation scales (csrc/engine.hip ACT_SCALE = 8 / 4 behind GELU: |x| > 56 / 112 clips at +-448).  Every
+    quantising kernel counts what it clipped into atst_encoder_t.f8_sat (AtstEngine.fp8_saturation()): zero on the recipe weights, and
+    non-zero -- for the student only -- once a student LayerNorm gain pushes its output beyond +-56."""
+    from audiossl_amd.engine import AtstEngine
+    depth, B = 1, 2
+    W = O.recipe_weights("base", depth=depth, seed=7)
+    mels = [O.recipe_mel(B, 1001, seed=1).to(DEV), O.recipe_mel(B, 1001, seed=2).to(DEV)]
+    lens = [torch.full((B,), 1001)] * 2
+    eng = AtstEngine("base", depth=depth, drop_path_rate=0.0, fp8=True)
+    eng.load_weights(W)
+    eng.forward(mels, lens)
+    assert eng.fp8_saturation() == {"student": 0, "teacher": 0}
+    W2 = {k: v.clone() for k, v in W.items()}
+    W2["student.encoder.blocks.0.norm1.weight"] *= 40.0                      # LayerNorm output ~ N(0, 40^2): far beyond +-56
+    eng.load_weights(W2)
+    loss = eng.forward(mels, lens)[0]
+    sat = eng.fp8_saturation(reset=True)
+    print(f"\n[fp8 saturation] clipped elements: {sat}; loss {float(loss):.4f}")
+    assert sat["student"] > 1000 and sat["teacher"] == 0 and math.isfinite(float(loss))
+    assert eng.fp8_saturation() == {"student": 0, "teacher": 0}               # reset

@@ -21,3 +21,9 @@ fwd = lambda: hip.call("atst_attention_fwd", hip.ptr(qkv), hip.ptr(valid), hip.p
 bwd = lambda: hip.call("atst_attention_bwd", hip.ptr(qkv), hip.ptr(valid), hip.ptr(o), hip.ptr(lse), hip.ptr(d_o), hip.ptr(dqkv), hip.ptr(scr), S, H, NP, hip.stream())
 fwd(); bwd()
 print(f"attention fwd {med(fwd):7.1f} us   bwd (row-dot + merged kernel) {med(bwd):7.1f} us", flush=True)
+if os.environ.get("AB"):                         # hooks 407 / 406: LDS-transposed full-line dK / dV stores (default) / row-per-lane stores, taking turns
+    for rnd in range(3):
+        for v, name in ((7, "full-line"), (6, "row-per-lane")):
+            lib.atst_tune_gemm_variant(400 + v)
+            print(f"  bwd dK/dV stores {name}: {med(bwd):7.1f} us", flush=True)
+    lib.atst_tune_gemm_variant(407)
