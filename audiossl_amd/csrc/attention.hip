@@ -1057,7 +1057,7 @@ int atst_attn_bwd(const AttnArgs& a, hipStream_t st) {
       done = true;
     }
     const long rows = (long)a.S * 256;
-    hipLaunchKernelGGL(attn_rowdot_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, a.d_o, (const bf16*)a.o, a.dscratch, a.S, a.H, 256);
+    if (!a.d_ready) hipLaunchKernelGGL(attn_rowdot_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, a.d_o, (const bf16*)a.o, a.dscratch, a.S, a.H, 256);
     ProfScope ps(PK_ATTN_BWD_DKV, 14.0 * a.S * a.H * 256.0 * 256.0 * HD, st, 16.0 * a.S * a.H * 256.0 * HD);
     AttnArgs a2 = a; a2.row_stores = g_bwd_row_stores;
     hipLaunchKernelGGL(attn_bwd256_kernel, dim3(a.S), dim3(512), B256_LDS, st, a2, (const float*)a.dscratch);

@@ -614,7 +614,7 @@ def test_configs4_base_fp8_hires_as_one_thing():
           f"gradients mean {num / den:.3e} worst {worst[0]} {worst[1]:.3e}")
     assert loss1 == loss2 and abs(loss2 - lo) < 5e-2
     assert e_cls < 5.5e-2                                                  # test_fp8_encoder_forward_and_step_base
-    assert num / den < 9e-2 and worst[1] < 0.2                             # test_fp8_dgrad_step_base
+    assert num / den < 1.3e-1 and worst[1] < 0.25                          # measured 8.8e-2 / 0.16 (x1.5): 12 head rows (test_fp8_dgrad_step_base: 16 rows, 7.6e-2 / 0.17)
     eng.optimizer_step(1e-3, 0.04, 0.99)
     assert torch.isfinite(eng.p32).all() and torch.isfinite(eng.g32).all()
 
