@@ -6,6 +6,8 @@
 #include "kernels.h"
 #include "../../include/atst_hip.h"
 
+extern int g_rowdot_fused;            // attention.hip (tuning hook 408 / 409)
+
 namespace {
 
 struct LayerWs {
@@ -321,7 +323,7 @@ static int encoder_bwd_range(const atst_encoder_t* e, int lo, int hi, bool head,
     // ---- attention branch: x_mid = x_in + s1 * (proj(attn(LN1(x_in))) + bp) ; w.g = s1 * d(x_mid)
     // NP = 256: the proj dgrad GEMM's epilogue also leaves D = rowsum(d_o * o) per (sequence, head, query) in w.dscr -- the row-dot
     // pass of the attention backward, which otherwise re-reads d_o and o in a kernel of its own
-    const bool fuse_rowdot = NP == 256;
+    const bool fuse_rowdot = NP == 256 && g_rowdot_fused;
     {
       GemmArgs a{};
       a.M = M; a.N = C; a.K = C; a.lda = C; a.ldb = C; a.epi = EPI_BF16; a.C = w.d_o; a.ldc = C; a.rows_per_seq = 1;

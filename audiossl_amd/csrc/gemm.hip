@@ -93,10 +93,12 @@ DEVFN void epilogue8(const GemmArgs& p, int row, int col, f32x4 v0, f32x4 v1, co
 #pragma unroll
       for (int e = 0; e < 4; ++e) d += bf2f(f2bf(c0[e])) * bf2f(ov[e]) + bf2f(f2bf(c1[e])) * bf2f(ov[4 + e]);
       d += dpp_mov<0xB1>(d); d += dpp_mov<0x4E>(d); d += dpp_mov<0x141>(d);
-      if ((threadIdx.x & 7) == 0) {
-        const int sq = row / p.rows_per_seq, q = row - sq * p.rows_per_seq;
-        p.rd_out[((size_t)sq * p.rd_heads + (col >> 6)) * p.rows_per_seq + q] = d;
-      }
+      // all 8 lanes of the group store the (same) sum to the same address.  Not `if (lane % 8 == 0)`: in the 128-row instantiation
+      // (128 registers, spills) hipcc folded that inner branch into `s_and_b64 exec` without its own save and placed a spill RELOAD in
+      // the join block, in front of the exec restore -- 7 of 8 lanes went on with a stale register that is later used as an address
+      // (memory fault at M < 2048; found with tests/test_ops_gpu.py::test_gemm_rowdot_epilogue).
+      const int sq = row / p.rows_per_seq, q = row - sq * p.rows_per_seq;
+      p.rd_out[((size_t)sq * p.rd_heads + ((col & ~63) >> 6)) * p.rows_per_seq + q] = d;
     }
   } else if constexpr (EPI == EPI_F32) {
     st_f32(p.C, idx, v0 + b0, v1 + b1);

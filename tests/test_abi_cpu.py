@@ -69,3 +69,16 @@ def test_attention_kernels_isa_audit():
         pytest.skip("hipcc not available")
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_attn_bwd_isa.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_no_spill_reload_under_a_narrowed_exec_mask():
+    """Round 4: in the 128-row GEMM instantiation hipcc folded an inner `if (lane % 8 == 0)` into `s_and_b64 exec` and put a spill reload in
+    the join block in front of the exec restore -- 7 of 8 lanes continued with a stale address register (memory fault).  The source no
+    longer has that branch; this scans the ISA of every kernel for the pattern (tools/check_exec_reload.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not available")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_exec_reload.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
