@@ -45,15 +45,6 @@ int atst_gemm_nt_resid_ln_bf16(const uint16_t* A, const uint16_t* B, int M, int 
   return atst_gemm_nt(a, ST(stream));
 }
 
-int atst_gemm_nt_rowdot_bf16(const uint16_t* dY, const uint16_t* Wt, int M, int N, int K, uint16_t* d_o, const uint16_t* o, float* D,
-                             int rows_per_seq, int heads, void* stream) {
-  if (!dY || !Wt || !d_o || !o || !D || rows_per_seq <= 0 || heads <= 0 || N != heads * 64 || M % rows_per_seq) return ATST_EINVAL;
-  GemmArgs a{};
-  a.A = CBF(dY); a.B = CBF(Wt); a.M = M; a.N = N; a.K = K; a.lda = K; a.ldb = K; a.epi = EPI_BF16; a.C = d_o; a.ldc = N;
-  a.rows_per_seq = rows_per_seq; a.rd_o = CBF(o); a.rd_out = D; a.rd_heads = heads;
-  return atst_gemm_nt(a, ST(stream));
-}
-
 int atst_gemm_nt_lnbwd_bf16(const uint16_t* dY, const uint16_t* Wt, int M, int K, const float* x, const float* mean, const float* rstd,
                             const float* gamma, const float* dres, float* dx, uint16_t* g, const float* row_scale, int rows_per_seq,
                             float* dgamma, float* dbeta, float* dbias_up, void* stream) {

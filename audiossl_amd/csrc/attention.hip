@@ -1010,9 +1010,8 @@ int launch_bwd(const AttnArgs& a, hipStream_t st) {
 
 int g_bwd256 = 1;          // merged per-sequence backward kernel for NP = 256 (tuning hook 402/403); the round-3 version of it (compiler-scheduled transfers) is in git history: 310 vs 307 us, profiles/r04_attn_time.txt
 int g_fwd256 = 2;          // NP = 256 forward: 2 = two-pass softmax + LDS-DMA head loop, 1 = online-softmax head loop, 0 = per-(sequence, head) kernel (tuning hooks 404 / 401 / 400)
-int g_rowdot_fused = 1;    // 409 / 408: rowsum(dO * O) from the proj dgrad GEMM's epilogue (default) / from attn_rowdot_kernel (read by engine.hip)
 int g_bwd_row_stores = 0;  // 406 / 407: NP = 256 backward dK / dV stores row-per-lane (A/B) / LDS-transposed full lines (default)
-void atst_attn_set_variant(int v) { if (v == 8 || v == 9) g_rowdot_fused = v == 9; else if (v == 6 || v == 7) g_bwd_row_stores = v == 6; else if (v == 4) g_fwd256 = 2; else if (v >= 2) g_bwd256 = v - 2; else g_fwd256 = v; }
+void atst_attn_set_variant(int v) { if (v == 6 || v == 7) g_bwd_row_stores = v == 6; else if (v == 4) g_fwd256 = 2; else if (v >= 2) g_bwd256 = v - 2; else g_fwd256 = v; }
 
 int atst_attn_fwd(const AttnArgs& a, hipStream_t st) {
   if (a.S <= 0) return ATST_OK;
@@ -1058,7 +1057,7 @@ int atst_attn_bwd(const AttnArgs& a, hipStream_t st) {
       done = true;
     }
     const long rows = (long)a.S * 256;
-    if (!a.d_ready) hipLaunchKernelGGL(attn_rowdot_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, a.d_o, (const bf16*)a.o, a.dscratch, a.S, a.H, 256);
+    hipLaunchKernelGGL(attn_rowdot_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, a.d_o, (const bf16*)a.o, a.dscratch, a.S, a.H, 256);
     ProfScope ps(PK_ATTN_BWD_DKV, 14.0 * a.S * a.H * 256.0 * 256.0 * HD, st, 16.0 * a.S * a.H * 256.0 * HD);
     AttnArgs a2 = a; a2.row_stores = g_bwd_row_stores;
     hipLaunchKernelGGL(attn_bwd256_kernel, dim3(a.S), dim3(512), B256_LDS, st, a2, (const float*)a.dscratch);

@@ -6,8 +6,6 @@
 #include "kernels.h"
 #include "../../include/atst_hip.h"
 
-extern int g_rowdot_fused;            // attention.hip (tuning hook 408 / 409)
-
 namespace {
 
 struct LayerWs {
@@ -321,24 +319,11 @@ static int encoder_bwd_range(const atst_encoder_t* e, int lo, int hi, bool head,
       float* t = cur; cur = oth; oth = t;
     }
     // ---- attention branch: x_mid = x_in + s1 * (proj(attn(LN1(x_in))) + bp) ; w.g = s1 * d(x_mid)
-    // NP = 256: the proj dgrad GEMM's epilogue also leaves D = rowsum(d_o * o) per (sequence, head, query) in w.dscr -- the row-dot
-    // pass of the attention backward, which otherwise re-reads d_o and o in a kernel of its own
-    const bool fuse_rowdot = NP == 256 && g_rowdot_fused;
-    {
-      GemmArgs a{};
-      a.M = M; a.N = C; a.K = C; a.lda = C; a.ldb = C; a.epi = EPI_BF16; a.C = w.d_o; a.ldc = C; a.rows_per_seq = 1;
-      if (use8) {
-        a.A = reinterpret_cast<const bf16*>(w.g28); a.B = reinterpret_cast<const bf16*>(e->p8t + lo_.proj_w);
-        a.fp8 = 1; a.dq = e->w_dq + 4 * i + 1; a.dq_mul = 1.0f; a.dq_div = gs8(i, 2);
-      } else {
-        a.A = w.g2; a.B = qt + lo_.proj_w;
-      }
-      if (fuse_rowdot) { a.rd_o = l.o; a.rd_out = w.dscr; a.rd_heads = e->H; a.rows_per_seq = NP; }
-      RUN(atst_gemm_nt(a, st));
-    }
+    if (use8) RUN(gemm8_bwd(w.g28, e->p8t + lo_.proj_w, M, C, C, EPI_BF16, w.d_o, st, e->w_dq + 4 * i + 1, gs8(i, 2)));
+    else RUN(gemm(w.g2, qt + lo_.proj_w, M, C, C, EPI_BF16, w.d_o, st));
     AttnArgs at{};
     at.qkv = l.qkv; at.valid = e->valid; at.o = l.o; at.lse = l.lse; at.d_o = w.d_o; at.dqkv = w.dqkv; at.dscratch = w.dscr;
-    at.S = S; at.H = e->H; at.NP = NP; at.stride = RS; at.d_ready = fuse_rowdot ? 1 : 0;
+    at.S = S; at.H = e->H; at.NP = NP; at.stride = RS;
     RUN(atst_attn_bwd(at, st));
     {
       WgradArgs wg[4] = {};

@@ -46,9 +46,7 @@ DEVFN void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: 
 template <int EPI, bool SCALE = true>
 DEVFN void epi_fetch8(const GemmArgs& p, int row, int col, EpiAux& x) {
   const size_t idx = (size_t)row * p.ldc + col;
-  if constexpr (EPI == EPI_BF16) {
-    if (p.rd_o) x.a0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p.rd_o + idx));   // 8 bf16 of the attention output (fused row-dot)
-  } else if constexpr (EPI == EPI_RESID) {
+  if constexpr (EPI == EPI_RESID) {
     x.a0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p.resid + idx));
     x.a1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p.resid + idx + 4));
     if constexpr (SCALE) x.s = p.row_scale ? p.row_scale[row / p.rows_per_seq] : 1.0f;   // else: the caller supplies it
@@ -83,23 +81,6 @@ DEVFN void epilogue8(const GemmArgs& p, int row, int col, f32x4 v0, f32x4 v1, co
   };
   if constexpr (EPI == EPI_BF16) {
     st_bf16(p.C, idx, v0 + b0, v1 + b1);
-    if (p.rd_o) {
-      // fused rowsum(dO * O) of the attention backward: this thread's 8 columns, then the 8 threads that cover the head's 64 columns
-      // (8 consecutive lanes in every kernel's slot map) through DPP: quad xor 1, quad xor 2, half-row mirror.  Same numbers as
-      // attn_rowdot_kernel: the products of the bf16 values that are stored.
-      const bf16x8 ov = __builtin_bit_cast(bf16x8, x.a0);
-      const f32x4 c0 = v0 + b0, c1 = v1 + b1;
-      float d = 0.f;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) d += bf2f(f2bf(c0[e])) * bf2f(ov[e]) + bf2f(f2bf(c1[e])) * bf2f(ov[4 + e]);
-      d += dpp_mov<0xB1>(d); d += dpp_mov<0x4E>(d); d += dpp_mov<0x141>(d);
-      // all 8 lanes of the group store the (same) sum to the same address.  Not `if (lane % 8 == 0)`: in the 128-row instantiation
-      // (128 registers, spills) hipcc folded that inner branch into `s_and_b64 exec` without its own save and placed a spill RELOAD in
-      // the join block, in front of the exec restore -- 7 of 8 lanes went on with a stale register that is later used as an address
-      // (memory fault at M < 2048; found with tests/test_ops_gpu.py::test_gemm_rowdot_epilogue).
-      const int sq = row / p.rows_per_seq, q = row - sq * p.rows_per_seq;
-      p.rd_out[((size_t)sq * p.rd_heads + ((col & ~63) >> 6)) * p.rows_per_seq + q] = d;
-    }
   } else if constexpr (EPI == EPI_F32) {
     st_f32(p.C, idx, v0 + b0, v1 + b1);
   } else if constexpr (EPI == EPI_BIAS_GELU) {
@@ -1547,7 +1528,7 @@ template <int EPI>
 double nt_bytes(const GemmArgs& a) {
   const double mn = (double)a.M * a.N;
   double b = 2.0 * a.K * ((double)a.M + a.N);
-  if (EPI == EPI_BF16) b += 2.0 * mn + (a.rd_o ? 2.0 * mn : 0.0);
+  if (EPI == EPI_BF16) b += 2.0 * mn;
   if (EPI == EPI_F32) b += 4.0 * mn;
   if (EPI == EPI_BIAS_GELU) b += 2.0 * mn + (a.C ? 2.0 * mn : 0.0);            // a always, u only when it is saved (training)
   if (EPI == EPI_RESID) b += 8.0 * mn + (a.ln_out ? 2.0 * mn : 0.0);

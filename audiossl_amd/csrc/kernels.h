@@ -35,10 +35,6 @@ struct GemmArgs {
   const float* dq;                   // fp8 GEMMs: device scalar multiplied into the accumulators (1 / (scale_A * scale_B)); null = 1
   int fp8;                           // operands are OCP e4m3 bytes (K, lda, ldb in elements = bytes); MX-scaled MFMA, unit block scales
   int skew;                          // only read by tools/experiments/gemm_r02_variants.hip (start-up skew experiment)
-  // EPI_BF16, proj dgrad in front of the NP = 256 attention backward: also D[s, h, q] = sum over the head's 64 columns of C[row, :] * rd_o[row, :]
-  // (C = d_o as stored, i.e. bf16-rounded; rd_o = the attention output o; row = s * rows_per_seq + q) -> rd_out [S, rd_heads, rows_per_seq] fp32:
-  // the `rowsum(dO * O)` of the softmax backward, which cost a kernel of its own that re-read both tensors (attn_rowdot_kernel)
-  const bf16* rd_o; float* rd_out; int rd_heads;
 };
 int atst_gemm_nt(const GemmArgs& a, hipStream_t st);
 void atst_gemm_nt_set_variant(int v);     // tuning hook: -1 auto, 0/1/2 fixed tile configuration
@@ -81,7 +77,6 @@ struct AttnArgs {
   bf16* dqkv;                        // bwd out [S*NP, 3*C]
   float* dscratch;                   // bwd scratch [S, H, NP] fp32 (rowsum(dO*O)); null -> two-kernel backward
   int S, H, NP;
-  int d_ready;                       // backward, NP = 256: dscratch already holds rowsum(dO * O) (written by the proj dgrad GEMM's epilogue): skip the row-dot kernel
   int row_stores;                    // tuning hook (NP = 256 backward): 1 = row-per-lane dK / dV stores instead of the LDS-transposed full-line ones
   int stride;                        // rows between consecutive sequences in qkv / o / d_o / dqkv (0 = NP).  stride < NP: sequences are PACKED --
                                      // the NP - stride rows that complete a sequence's last 32-row tile belong to the next sequence and are treated

@@ -95,50 +95,37 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x,
   }
 }
 
-// gradient of the token-embedding stage.  block = token n (x) sequence slice ; thread = 4 columns (16-B loads, 8-B stores) of every
-// second sequence of the slice (blockDim.y = 2), four sequences in flight per thread.  (Round 3: 2 columns per thread, one 8-B load in
-// flight: 2.1 TB/s, 142 us per 512 x 256 tokens.)
+// gradient of the token-embedding stage.  block = token n (x) sequence slice ; thread = 2 columns.
 __global__ void token_grad_kernel(const float* __restrict__ dx0, const uint8_t* __restrict__ rowflag, int S, int NP,
                                   int n_tok, int C, int use_cls, float* dcls, float* dpos, float* dbias, float* dmask,
                                   bf16* __restrict__ g0) {
-  const int n = blockIdx.x, c = threadIdx.x * 4;
+  const int n = blockIdx.x, c = threadIdx.x * 2;
+  if (c >= C) return;
   const int s_per = (S + gridDim.y - 1) / gridDim.y;
   const int s_begin = blockIdx.y * s_per;
   const int s_end = s_begin + s_per < S ? s_begin + s_per : S;
   const bool is_cls = use_cls && n == 0;
   const bool is_patch = use_cls ? (n >= 1 && n <= n_tok) : (n < n_tok);
-  f32x4 all = {0.f, 0.f, 0.f, 0.f}, un = all, mk = all;
-  constexpr int U = 4;
-  for (int s0 = s_begin + threadIdx.y; s0 < s_end; s0 += 2 * U) {
-    f32x4 v[U]; bool live[U], masked[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int s = s0 + 2 * u;
-      live[u] = s < s_end;
-      const size_t row = (size_t)(live[u] ? s : s_begin) * NP + n;
-      v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dx0 + row * C + c));
-      masked[u] = rowflag && rowflag[row];
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (!live[u]) continue;
-      const size_t row = (size_t)(s0 + 2 * u) * NP + n;
-      all += v[u];
-      bf16x4 o;
-      if (masked[u]) mk += v[u]; else un += v[u];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = f2bf((masked[u] || !is_patch) ? 0.f : v[u][e]);
-      *reinterpret_cast<bf16x4*>(g0 + row * C + c) = o;
-    }
+  float all0 = 0.f, all1 = 0.f, un0 = 0.f, un1 = 0.f, mk0 = 0.f, mk1 = 0.f;
+  for (int s = s_begin; s < s_end; ++s) {
+    const size_t row = (size_t)s * NP + n;
+    const f32x2 v = *reinterpret_cast<const f32x2*>(dx0 + row * C + c);
+    const bool masked = rowflag && rowflag[row];
+    all0 += v[0]; all1 += v[1];
+    bf16x2 o;
+    if (masked) { mk0 += v[0]; mk1 += v[1]; o[0] = f2bf(0.f); o[1] = f2bf(0.f); }
+    else { un0 += v[0]; un1 += v[1]; o[0] = f2bf(v[0]); o[1] = f2bf(v[1]); }
+    if (!is_patch) { o[0] = f2bf(0.f); o[1] = f2bf(0.f); }
+    *reinterpret_cast<bf16x2*>(g0 + row * C + c) = o;
   }
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    if (is_cls) atomicAdd(dcls + c + e, all[e]);
-    if (is_cls || is_patch) atomicAdd(dpos + (size_t)(use_cls ? n : n + 1) * C + c + e, all[e]);
-    if (is_patch) {
-      atomicAdd(dbias + c + e, un[e]);
-      if (dmask && rowflag) atomicAdd(dmask + c + e, mk[e]);
-    }
+  if (is_cls) { atomicAdd(dcls + c, all0); atomicAdd(dcls + c + 1, all1); }
+  if (is_cls || is_patch) {
+    const int pi = use_cls ? n : n + 1;
+    atomicAdd(dpos + (size_t)pi * C + c, all0); atomicAdd(dpos + (size_t)pi * C + c + 1, all1);
+  }
+  if (is_patch) {
+    atomicAdd(dbias + c, un0); atomicAdd(dbias + c + 1, un1);
+    if (dmask && rowflag) { atomicAdd(dmask + c, mk0); atomicAdd(dmask + c + 1, mk1); }
   }
 }
 }  // namespace
@@ -187,7 +174,7 @@ int atst_token_grad(const float* dx0, const uint8_t* rowflag, int S, int NP, int
                     float* dcls, float* dpos, float* dbias, float* dmask, bf16* g0, hipStream_t st) {
   if (S <= 0) return ATST_OK;
   int gy = S / 32; if (gy < 1) gy = 1; if (gy > 16) gy = 16;
-  hipLaunchKernelGGL(token_grad_kernel, dim3(NP, gy), dim3(C / 4, 2), 0, st, dx0, rowflag, S, NP, n_tok, C, use_cls,
+  hipLaunchKernelGGL(token_grad_kernel, dim3(NP, gy), dim3(C / 2), 0, st, dx0, rowflag, S, NP, n_tok, C, use_cls,
                      dcls, dpos, dbias, dmask, g0);
   return (int)hipGetLastError();
 }

@@ -330,7 +330,7 @@ def main():
                           "optimizer": "HF-AdamW + EMA teacher (fused)", "drop_path": 0.1},
                "flops_per_clip_G": round(fpc / 1e9, 2), "step_tflops": round(value * fpc / 1e12, 2),
                "mfma_roofline_frac_step": round(value * fpc / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
-               "loss": round(loss_val, 5), "roofline": roof, "kernels": kernels[:8]}
+               "loss": round(loss_val, 5), "roofline": roof, "kernels": kernels[:16]}
         if step_hbm:
             tbs = step_hbm["traffic_bytes_per_step"] / (dt / args.steps) / 1e12
             step_hbm.update({"TB_per_s": round(tbs, 3), "frac_of_8TBs_peak": round(tbs / (PEAK_HBM_GBS / 1e3), 4)})

@@ -72,13 +72,6 @@ int atst_gemm_nt_resid_ln_bf16(const uint16_t* A, const uint16_t* B, int M, int 
 int atst_gemm_nt_lnbwd_bf16(const uint16_t* dY, const uint16_t* Wt, int M, int K, const float* x, const float* mean, const float* rstd,
                             const float* gamma, const float* dres, float* dx, uint16_t* g, const float* row_scale, int rows_per_seq,
                             float* dgamma, float* dbeta, float* dbias_up, void* stream);
-/* proj dgrad GEMM in front of the attention backward, with the softmax backward's row term as part of its epilogue:
- *   d_o = bf16(dY[M,K] Wt[N,K]^T)  [M,N], N = heads * 64 ;  D[s, h, q] = sum over head h's 64 columns of d_o[row, :] * o[row, :]  (fp32,
- *   products of the stored bf16 values), row = s * rows_per_seq + q, D is [M / rows_per_seq, heads, rows_per_seq].
- * Replaces atst_gemm_nt_bf16(EPI_BF16) + the row-dot pass of atst_attention_bwd: autograd of `softmax(q k^T) v` then `proj`,
- * audiossl/modules/transformer.py:109-121 (Attention.forward).                                                              */
-int atst_gemm_nt_rowdot_bf16(const uint16_t* dY, const uint16_t* Wt, int M, int N, int K, uint16_t* d_o, const uint16_t* o, float* D,
-                             int rows_per_seq, int heads, void* stream);
 /* The same GEMM on OCP e4m3 operands (A8 [M,K], B8 [N,K] bytes; N % 384 == 0, K % 64 == 0) with v_mfma_scale_f32_32x32x64_f8f6f4:
  * C = epilogue(dq_mul * (*dq) * A8 B8^T); epilogues BF16 / F32 / BIAS_GELU / RESID.  north_star "fp8 MFMA QKV/MLP GEMMs".      */
 int atst_gemm_nt_fp8(const uint8_t* A8, const uint8_t* B8, int M, int N, int K, int lda, int ldb, int epi, void* C, int ldc,
