@@ -344,7 +344,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256v2_kernel(AttnArgs p) {
   typedef const void __attribute__((address_space(1))) * gptr_t;
   typedef void __attribute__((address_space(3))) * lptr_t;
   constexpr int NP = 256;
-  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), hi = lane >> 5, l31 = lane & 31;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hi = lane >> 5, l31 = lane & 31;
   const int H = p.H, C = H * HD;
   const size_t ld = 3 * (size_t)C;
   const int s = blockIdx.x;
@@ -362,19 +362,18 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256v2_kernel(AttnArgs p) {
     offK[i] = row * (int)ld + C + (pc ^ ((row >> 1) & 7)) * 8;
     offV[i] = row * (int)ld + 2 * C + (pc ^ (((row >> 1) & 1) << 2)) * 8;
   }
-  const unsigned lbase = lds_addr(smem_raw) + wid * 4096;
   auto issue = [&](int h) {
-    const unsigned buf = lbase + (h & 1) * F2_BUF;
+    char* buf = smem_raw + (h & 1) * F2_BUF;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      glds16_asm(base + offK[i] + h * HD, buf + i * 1024);
-      glds16_asm(base + offV[i] + h * HD, buf + F2_MAT + i * 1024);
+      __builtin_amdgcn_global_load_lds((gptr_t)(base + offK[i] + h * HD), (lptr_t)(buf + (wid * 4 + i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(base + offV[i] + h * HD), (lptr_t)(buf + F2_MAT + (wid * 4 + i) * 1024), 16, 0, 0);
     }
   };
   bf16x8 qn[4];
   auto qload = [&](int h) {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) gload16_asm(qn[ks], base + (size_t)(q0 + l31) * ld + h * HD + ks * 16 + hi * 8);
+    for (int ks = 0; ks < 4; ++ks) qn[ks] = ld_frag(base + (size_t)(q0 + l31) * ld + h * HD + ks * 16 + hi * 8);
   };
   // lane-only parts of the swizzled fragment addresses (tile offsets are compile-time constants added by the reads)
   int kofs[4], vofs[2];
@@ -398,20 +397,16 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256v2_kernel(AttnArgs p) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) mbits |= ((ntile - 1) * 32 + crow32(r, hi) >= valid ? 1u : 0u) << r;
   asm volatile("" : "+v"(mbits));
-  // Rotated loop (iteration -1 only issues head 0's transfers): ONE definition site and ONE wait site for the asm-loaded Q fragments,
-  // see attn_bwd256_kernel.  Behind the transfers of head h a wave issues the 4 output-row stores (+ the lse store) of head h - 1:
-  // vmcnt(4) at the top leaves those in flight instead of draining them in front of every head (round 3: vmcnt(0)).
-  for (int h = -1; h < H; ++h) {
+  // (Round 4 also ran this kernel with its transfers as inline assembly and an exact vmcnt(4) at the top of every head, like the backward:
+  // +1.2 ... 1.6 us per launch inside the step, profiles/r04_ab_*: the compiler-tracked form stays.)
+  issue(0);
+  qload(0);
+  for (int h = 0; h < H; ++h) {
     bf16x8 qf[4];
-    if (h >= 0) {
-      if (h == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      asm volatile("s_waitcnt vmcnt(4)" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]) :: "memory");
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) qf[ks] = qn[ks];
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // head h landed everywhere; buffer (h+1)&1 no longer read
-    }
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = qn[ks];
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // head h landed everywhere; buffer (h+1)&1 no longer read
     if (h + 1 < H) { issue(h + 1); qload(h + 1); }
-    if (h < 0) continue;
     const char* sK = smem_raw + (h & 1) * F2_BUF;
     const char* sV = sK + F2_MAT;
     // pass 1: the wave's 32 x 256 score strip (raw q.k, scale folded into the exponent) and its row maximum

@@ -655,12 +655,12 @@ class AtstEngine:
         """[depth,2,S] fp32 factors keep/keep_prob.  keep (0/1, [depth,2,S]) may be injected for parity tests; otherwise
         drawn like the reference: floor(keep_prob + U[0,1)) per sample, per branch (modules/transformer.py:48-56)."""
         rates = self._dpr_rates
-        if keep is None:
+        if keep is None:                                            # drawn here: floor(1 - 0 + U[0, 1)) = 1 at rate 0 by itself
             keep = torch.floor((1.0 - rates) + torch.rand(self.depth, 2, S, device=self.device))
-        else:
-            keep = keep.to(self.device, torch.float32)
-        # a block whose rate is 0 (block 0 of the linspace schedule) never drops in the reference, whatever was drawn: drop_path()
-        # returns its input when drop_prob == 0 (modules/transformer.py:49-50)
+            return (keep / (1.0 - rates)).contiguous()
+        keep = keep.to(self.device, torch.float32)
+        # injected decisions: a block whose rate is 0 (block 0 of the linspace schedule) never drops in the reference, whatever was
+        # drawn -- drop_path() returns its input when drop_prob == 0 (modules/transformer.py:49-50)
         return torch.where(rates > 0, keep / (1.0 - rates), torch.ones_like(keep)).contiguous()
 
     def _valid(self, lengths: torch.Tensor, use_cls: int, n_max: int = 1 << 30) -> torch.Tensor:
