@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round measurement pass on the GPU box: bench lines, rocprofv3 kernel stats of the default bench command, PMC traffic passes.
 # usage (inside gpurun): bash tools/round_measure.sh <tag>
-tag=${1:-r03}
+tag=${1:-r04}
 head=${2:-$(cat tools/.head 2>/dev/null || echo unknown)}      # the GPU box has no .git: pass HEAD as $2 (or write tools/.head before the call)
 out=gpurun_out/$tag
 mkdir -p $out
@@ -13,6 +13,12 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o f -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile > /dev/null 2> $out/pmc_fetch.err
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o w -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile > /dev/null 2> $out/pmc_write.err
 python tools/traffic_from_pmc.py $out/pmc_fetch $out/pmc_write $out/traffic_clip6.json clip6 "$head" 3
+# extra data points: ATST-base bf16 / fp8 / fp8 at the configs[4] input geometry ; the fp32 parity mode next to bf16 at the same batch
+timeout 300 python bench.py --arch base --workload clip2 --no-cpu-baseline > $out/bench_base_clip2.json 2> $out/bench_base.err
+timeout 300 python bench.py --arch base --workload clip2 --dtype fp8 --no-cpu-baseline > $out/bench_base_fp8_clip2.json 2>> $out/bench_base.err
+timeout 300 python bench.py --arch base --workload clip2 --dtype fp8 --hires --no-cpu-baseline > $out/bench_base_fp8_hires_clip2.json 2>> $out/bench_base.err
+timeout 600 python bench.py --precise --workload clip2 --batch 64 --steps 8 --warmup 2 --no-cpu-baseline > $out/bench_precise_clip2_b64.json 2> $out/bench_precise.err
+timeout 300 python bench.py --workload clip2 --batch 64 --steps 40 --no-cpu-baseline --no-profile > $out/bench_bf16_clip2_b64.json 2>> $out/bench_precise.err
 find $out -name "*_kernel_stats.csv" | head; cat $out/bench_clip6.json | cut -c1-400
 # the raw per-dispatch counter CSVs are large: keep only the summary json in the merge-back
 rm -rf $out/pmc_fetch $out/pmc_write
