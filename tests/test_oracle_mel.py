@@ -3,6 +3,7 @@ from /root/reference and from this image, so this part of the oracle is PARITY U
 (a) an independent numpy restatement of the STFT (rfft of reflect-padded, Hann-windowed frames) and of the filterbank
 formulas, and (b) the self-consistency probes recorded in SURVEY.md Appendix A.1 (sine -> mel bin 21, 42.16 dB)."""
 import numpy as np
+import pytest
 import torch
 
 from oracle import atst_oracle as O
@@ -69,3 +70,30 @@ def test_block_mask_properties():
         runs = np.diff(np.flatnonzero(np.diff(np.concatenate(([0], m.astype(int), [0])))))[::2]
         assert runs.min() >= 5 or m[-5:].any()                                  # spans of length 5 (may merge / clip at the end)
         assert 0.35 < m.mean() < 0.66                                           # overlap => realised ratio below 0.65
+
+
+def test_log_mel_vs_third_party_audio_utils():
+    """A THIRD-PARTY cross-check that is present in the image: transformers.audio_utils (Hugging Face's numpy port of the torchaudio /
+    librosa front ends -- `mel_filter_bank(norm=None, mel_scale="htk")` documents itself as torchaudio.functional.melscale_fbanks,
+    `spectrogram(center=True, pad_mode="reflect", power=2)` as torchaudio's Spectrogram, `power_to_db(db_range)` as AmplitudeToDB(top_db)).
+    It is not torchaudio, so the row stays "parity unpinned" in the strict sense, but it is code this repo did not
+    write: filterbank, STFT power and dB stage of the oracle agree with it, for both recipes' windows and for the 32 kHz / 128-band geometry."""
+    A = pytest.importorskip("transformers.audio_utils")
+    for sr, n_mels, win in ((16000, 64, 1024), (16000, 64, 640), (32000, 128, 1024)):
+        fb_hf = A.mel_filter_bank(num_frequency_bins=513, num_mel_filters=n_mels, min_frequency=60.0, max_frequency=7800.0, sampling_rate=sr,
+                                  norm=None, mel_scale="htk")
+        fb = O.mel_filterbank(n_mels=n_mels, sample_rate=sr).numpy()
+        assert fb_hf.shape == fb.shape and np.abs(fb_hf - fb).max() < 2e-5, (sr, n_mels, np.abs(fb_hf - fb).max())   # fp32 (torchaudio op order) vs float64: 4e-6 / 1e-5
+        rng = np.random.default_rng(sr + win)
+        t = np.arange(sr) / sr
+        wave = (0.1 * rng.standard_normal(sr) + 0.3 * np.sin(2 * np.pi * 440.0 * t) * (0.5 + 0.5 * np.sin(2 * np.pi * 3.0 * t))).astype(np.float32)
+        n = np.arange(win)
+        window = np.zeros(1024); left = (1024 - win) // 2
+        window[left:left + win] = 0.5 - 0.5 * np.cos(2 * np.pi * n / win)                # periodic Hann(win), centred in the 1024-point frame (torch.stft)
+        spec = A.spectrogram(wave.astype(np.float64), window, frame_length=1024, hop_length=160, fft_length=1024, power=2.0, center=True,
+                             pad_mode="reflect", mel_filters=fb_hf, mel_floor=1e-10, dtype=np.float64)       # [n_mels, T]
+        db = A.power_to_db(spec, reference=1.0, min_value=1e-10, db_range=80.0)
+        want = (db - O.DB_MIN) / (O.DB_MAX - O.DB_MIN) * 2 - 1
+        got = O.log_mel(torch.from_numpy(wave)[None], win, n_mels=n_mels, sample_rate=sr)[0, 0].numpy()
+        assert got.shape == want.shape, (got.shape, want.shape)
+        assert np.abs(got - want).max() < 2e-4, (sr, n_mels, win, np.abs(got - want).max())
