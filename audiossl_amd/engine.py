@@ -456,7 +456,7 @@ class AtstEngine:
         # per-tensor scaled, refreshed with the bf16 shadows; the backward and everything saved for it stay bf16
         self.fp8 = bool(fp8)
         # parity mode: training passes run on the fp32 / split-bf16 twin of the encoder (csrc/engine_hp.hip), everything else
-        # (view grouping, heads -- already split-bf16 --, loss, optimizer, EMA) is this same engine.  ~30x slower: small shapes.
+        # (view grouping, heads -- already split-bf16 --, loss, optimizer, EMA) is this same engine.  17x slower (bench.py --precise).
         self.precise = bool(precise)
         if self.precise and self.fp8:
             raise hip.HipError("precise=True is the fp32 parity mode; it excludes fp8")
