@@ -27,7 +27,8 @@ enum { ATST_EPI_BF16 = 0, ATST_EPI_F32 = 1, ATST_EPI_BIAS_GELU = 2, ATST_EPI_RES
 
 int atst_version(void);
 /* Tuning hooks for A/B measurements (tools/gemm_bench.py, env ATST_TUNE=a,b,... read by audiossl_amd/hip.py); defaults are the
- * measured best.
+ * measured best.  These are PROCESS-GLOBAL test knobs (plain ints inside the library, read at launch time, no locking): set them from one
+ * thread, before the launches they are meant for, and restore the default afterwards (the tests do).  Nothing in the product path calls this.
  *   -1 auto | 0..3 force a 128x128 / 256x128 nt tile config | 4 force the row-384 tile
  *   105/106 wgrad 192x384 LDS-DMA tile off/on        110+r wgrad grid = r rounds of resident blocks (128x128 tile)
  *   120/121/122 192x384 wgrad schedule: all waves issue behind the hand-off / wave rows staggered (default) / 32-row stages in a 4-deep ring
@@ -37,6 +38,8 @@ int atst_version(void);
  *   350/351 apply the tall / 4-wave kernels from M = 8192 (default) / from any M (parity tests of those kernels at small M)
  *   360/361 4-wave kernels for launches of <= 1.5 rounds of 256x384 tiles off/on
  *   400/401/404 NP=256 attention forward: per-head / online / two-pass      402/403 merged NP=256 attention backward off/on
+ *   130/131 grouped wgrad: round-3 block order / (problem, split) groups packed onto XCDs (default)
+ *   406/407 NP=256 attention backward dK / dV stores: row-per-lane / LDS-transposed full lines (default)
  * The measured-and-rejected GEMM variants of round 2 (64-deep ring stages, ping-pong main loop, register epilogue, start-up
  * skew, phase tracers) are not part of this library: tools/experiments/gemm_r02_variants.hip (ATST_GEMM_VARIANTS=1 build).          */
 int atst_tune_gemm_variant(int v);
