@@ -60,6 +60,11 @@ DEVFN int reflect(int i, int n) { i = i < 0 ? -i : i; return i >= n ? 2 * (n - 1
 // MAXLEN LDS reads at immediate offsets + FMAs; MAXLEN = 0: generic per-lane loop for longer filters.  Round 3 ran that loop for
 // every frame -- 39 iterations of a dependent global load (a 64-line gather, band-major table) + LDS read + FMA that the compiler
 // cannot pipeline across a per-lane trip count: ~40 % of the kernel (tools/mel_probe.py).
+// Experiment builds (tools/mel_ablate.sh): ATST_MEL_ABL bit 0 = no waveform loads (constant input), 1 = no FFT passes 2 and 3, 2 = no real-transform
+// un-pack / power, 3 = no filterbank products, 4 = no log10, 5 = no output stores.
+#ifndef ATST_MEL_ABL
+#define ATST_MEL_ABL 0
+#endif
 #ifndef ATST_MEL_OCC
 #define ATST_MEL_OCC 2                 // waves per SIMD the register allocation is held to.  3 (what the 54 KB of LDS would allow) spills 7 registers: 1170 vs 1069 us per 512 clips (profiles/r04_mel_probe.txt)
 #endif
@@ -92,7 +97,9 @@ __global__ __launch_bounds__(256, ATST_MEL_OCC) void stft_mel_db_kernel(const fl
     for (int i = lane; i < 7 + MAXLEN; i += 64) pw[wid][NBIN + i] = 0.f;
   }
   // twiddles of the two twiddled passes depend on the lane only: fetched once per block, not once per frame
-  float2 tw8[8], tw64[8];
+  float2 tw8[8], tw64[8], tw1k[9];
+#pragma unroll
+  for (int j = 0; j < 9; ++j) tw1k[j] = g_tw1024[lane + 64 * j <= 512 ? lane + 64 * j : 512];
   f32x2 win[8];                                                    // this lane's 16 window taps
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
@@ -107,7 +114,13 @@ __global__ __launch_bounds__(256, ATST_MEL_OCC) void stft_mel_db_kernel(const fl
     int t = t0 + fl; if (t >= T) t = T - 1;             // duplicates are computed but never stored
     const int base = t * HOPS - NFFT / 2;
     float2 u[8];
+#if ATST_MEL_ABL & 1
+#pragma unroll
+    for (int r = 0; r < 8; ++r) u[r] = make_float2(win[r][0] * (float)(t + r), win[r][1]);
+    if (false) {
+#else
     if (base >= 0 && base + NFFT <= n_samples && ((reinterpret_cast<size_t>(w + base) & 7) == 0)) {   // interior frame, 8-B aligned: vector loads
+#endif
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         const f32x2 x2 = *reinterpret_cast<const f32x2*>(w + base + 2 * (lane + 64 * r));
@@ -124,6 +137,7 @@ __global__ __launch_bounds__(256, ATST_MEL_OCC) void stft_mel_db_kernel(const fl
 #pragma unroll
     for (int r = 0; r < 8; ++r) fa[wid][lane * 9 + r] = u[r];             // pa(lane * 8 + r)
     wave_sync();
+#if !(ATST_MEL_ABL & 2)
     {                                                   // pass p = 8
       const int k = lane & 7, j = (lane - k) * 8 + k;
 #pragma unroll
@@ -141,27 +155,40 @@ __global__ __launch_bounds__(256, ATST_MEL_OCC) void stft_mel_db_kernel(const fl
       for (int r = 0; r < 8; ++r) fa[wid][lane + 64 * r] = u[r];
     }
     wave_sync();
-    for (int k = lane; k <= 512; k += 64) {             // un-pack the real transform, power spectrum
-      const float2 zk = fa[wid][k & 511];
-      float2 zc = fa[wid][(512 - k) & 511]; zc.y = -zc.y;
-      const float2 e = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y + zc.y));
-      const float2 d = csub(zk, zc);
-      const float2 o = make_float2(0.5f * d.y, -0.5f * d.x);      // d / (2i)
-      const float2 x = cadd(e, cmul(g_tw1024[k], o));
-      pw[wid][k] = x.x * x.x + x.y * x.y;
+#endif
+    // un-pack the real transform, power spectrum: bins k = lane + 64 j.  The twiddles of a lane's nine bins are frame-invariant and sit in
+    // registers (tw1k): fetched inside the loop they were nine dependent global loads per frame, 300 of the kernel's 1075 us (profiles/r04_mel_ablate.txt)
+#pragma unroll
+    for (int j = 0; j < ((ATST_MEL_ABL & 4) ? 0 : 9); ++j) {
+      const int k = lane + 64 * j;
+      if (k <= 512) {
+        const float2 zk = fa[wid][k & 511];
+        float2 zc = fa[wid][(512 - k) & 511]; zc.y = -zc.y;
+        const float2 e = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y + zc.y));
+        const float2 d = csub(zk, zc);
+        const float2 o = make_float2(0.5f * d.y, -0.5f * d.x);      // d / (2i)
+        const float2 x = cadd(e, cmul(tw1k[j], o));
+        pw[wid][k] = x.x * x.x + x.y * x.y;
+      }
     }
     wave_sync();
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       float mel = 0.f;
-      if constexpr (MAXLEN > 0) {
+      if constexpr (MAXLEN > 0 && !(ATST_MEL_ABL & 8)) {
         const float* pp = &pw[wid][m_start[b]];
 #pragma unroll
         for (int q = 0; q < MAXLEN; ++q) mel = fmaf(fw[b][q], pp[q], mel);     // same summation order as the loop
-      } else {
+      } else if (!(ATST_MEL_ABL & 8)) {
         for (int q = 0; q < m_len[b]; ++q) mel += fbw[q * NMEL + lane + 64 * b] * pw[wid][m_start[b] + q];
+      } else {
+        mel = pw[wid][m_start[b]] + fw[b][0];
       }
+#if ATST_MEL_ABL & 16
+      const float db = mel;
+#else
       const float db = 10.0f * log10f(fmaxf(mel, 1e-10f));
+#endif
       dbb[lane + 64 * b][fl] = db;
       if (t0 + fl < T) vmax = fmaxf(vmax, db);
     }
@@ -174,7 +201,7 @@ __global__ __launch_bounds__(256, ATST_MEL_OCC) void stft_mel_db_kernel(const fl
     atomicMax(clipmax + clip, __float_as_uint(m));
   }
   float* o = out + (size_t)clip * NMEL * T;
-  for (int i = tid; i < NMEL * FPB; i += 256) {
+  for (int i = tid; i < ((ATST_MEL_ABL & 32) ? 1 : NMEL * FPB); i += 256) {
     const int m = i / FPB, f = i % FPB;
     if (t0 + f < T) o[(size_t)m * T + t0 + f] = dbb[m][f];
   }
@@ -239,7 +266,11 @@ int atst_mel_frontend(const float* wave, int n_clips, int n_samples, int wave_ld
 #define MEL_LAUNCH(NB_, ML_) hipLaunchKernelGGL((stft_mel_db_kernel<NB_, ML_>), dim3((T + FPB - 1) / FPB, n_clips), dim3(256), 0, st, wave, wave_ld, \
                                                 n_samples, T, window, fb_weights, fb_start, fb_len, fb_maxlen, out, clipmax)
   if (n_mels == 64) {                                 // 16 kHz / 64 bands: longest filter 39 bins
+#ifdef ATST_MEL_FORCE_LOOP
+    MEL_LAUNCH(1, 0);
+#else
     if (fb_maxlen <= 40) MEL_LAUNCH(1, 40); else MEL_LAUNCH(1, 0);
+#endif
   } else {                                            // 32 kHz / 128 bands: 10 bins ; 16 kHz / 128 bands: ~20
     if (fb_maxlen <= 16) MEL_LAUNCH(2, 16); else if (fb_maxlen <= 40) MEL_LAUNCH(2, 40); else MEL_LAUNCH(2, 0);
   }
