@@ -85,11 +85,14 @@ int gemm(const bf16* A, const bf16* B, int M, int N, int K, int epi, void* C, hi
 constexpr float ACT_SCALE = 8.0f, ACT_SCALE_GELU = 4.0f;   // LayerNorm / attention outputs stay within +-56, GELU outputs within +-112
 int gemm8(const uint8_t* A8, const uint8_t* B8, int M, int N, int K, int epi, void* C, hipStream_t st, const float* w_dq, float act_scale,
           const float* bias = nullptr, const float* resid = nullptr, const float* row_scale = nullptr, int rps = 1, void* C2 = nullptr,
-          uint8_t* q8 = nullptr, float q8_scale = 1.0f, unsigned* q8_sat = nullptr) {
+          uint8_t* q8 = nullptr, float q8_scale = 1.0f, unsigned* q8_sat = nullptr, const float* act_scale_dev = nullptr,
+          const float* q8_scale_dev = nullptr, float* q8_amax = nullptr) {
   GemmArgs a{};
   a.A = reinterpret_cast<const bf16*>(A8); a.B = reinterpret_cast<const bf16*>(B8); a.M = M; a.N = N; a.K = K; a.lda = K; a.ldb = K;
   a.epi = epi; a.C = C; a.ldc = N; a.C2 = C2; a.bias = bias; a.resid = resid; a.row_scale = row_scale; a.rows_per_seq = rps;
   a.fp8 = 1; a.dq = w_dq; a.dq_mul = 1.0f / act_scale; a.q8 = q8; a.q8_scale = q8_scale; a.q8_sat = q8_sat;
+  if (act_scale_dev) { a.dq_mul = 1.0f; a.dq_div = act_scale_dev; }   // running activation scale of the A operand (device scalar)
+  a.q8_scale_ptr = q8_scale_dev; a.q8_amax = q8_amax;                // scale / amax of the e4m3 copy this epilogue writes (GELU output)
   return atst_gemm_nt(a, st);
 }
 // dgrad GEMM (N == 384) whose epilogue is the backward of the LayerNorm in front of the differentiated Linear:
@@ -189,18 +192,24 @@ extern "C" int atst_encoder_fwd(const atst_encoder_t* e, void* stream) {
       const size_t MC = (size_t)M * C;
       // the e4m3 operand copies come out of the producing kernels (LayerNorm, GELU epilogue); only the attention output
       // is quantised by a pass of its own
-      unsigned* sat = e->f8_sat;                      // clipped-element counter of the fixed activation scales (or null)
-      RUN(atst_ln_fwd(w.x[2 * i], p + lo.ln1_w, p + lo.ln1_b, l.h1, l.mean1, l.rstd1, M, C, st, w.q8a, ACT_SCALE, sat));
-      RUN(gemm8(w.q8a, q8 + lo.qkv_w, M, 3 * C, C, EPI_BF16, l.qkv, st, dq + 0, ACT_SCALE));
+      unsigned* sat = e->f8_sat;                      // clipped-element counter (or null)
+      // activation scales: site k of block i (0: LN1 out -> qkv, 1: attention out -> proj, 2: LN2 out -> fc1, 3: GELU out -> fc2).  With
+      // f8_act_scale / f8_act_amax ([depth][4] device floats) the scale is the caller's running (delayed) one and this pass records max |x|
+      // of every site; without them the constants ACT_SCALE / ACT_SCALE_GELU.
+      auto scp = [&](int k) -> const float* { return e->f8_act_scale ? e->f8_act_scale + 4 * i + k : nullptr; };
+      auto amp = [&](int k) -> float* { return e->f8_act_amax ? e->f8_act_amax + 4 * i + k : nullptr; };
+      RUN(atst_ln_fwd(w.x[2 * i], p + lo.ln1_w, p + lo.ln1_b, l.h1, l.mean1, l.rstd1, M, C, st, w.q8a, ACT_SCALE, sat, scp(0), amp(0)));
+      RUN(gemm8(w.q8a, q8 + lo.qkv_w, M, 3 * C, C, EPI_BF16, l.qkv, st, dq + 0, ACT_SCALE, nullptr, nullptr, nullptr, 1, nullptr, nullptr, 1.0f, nullptr, scp(0)));
       AttnArgs at{};
       at.qkv = l.qkv; at.valid = e->valid; at.o = l.o; at.lse = l.lse; at.S = S; at.H = e->H; at.NP = NP; at.stride = RS;
       RUN(atst_attn_fwd(at, st));
-      RUN(atst_quant_fp8(l.o, MC, ACT_SCALE, w.q8a, st, sat));
-      RUN(gemm8(w.q8a, q8 + lo.proj_w, M, C, C, EPI_RESID, w.x[2 * i + 1], st, dq + 1, ACT_SCALE, p + lo.proj_b, w.x[2 * i], s1, RS));
-      RUN(atst_ln_fwd(w.x[2 * i + 1], p + lo.ln2_w, p + lo.ln2_b, l.h2, l.mean2, l.rstd2, M, C, st, w.q8a, ACT_SCALE, sat));
+      if (scp(1)) RUN(atst_quant_fp8_dyn(l.o, MC, scp(1), w.q8a, amp(1), st, sat));
+      else RUN(atst_quant_fp8(l.o, MC, ACT_SCALE, w.q8a, st, sat));
+      RUN(gemm8(w.q8a, q8 + lo.proj_w, M, C, C, EPI_RESID, w.x[2 * i + 1], st, dq + 1, ACT_SCALE, p + lo.proj_b, w.x[2 * i], s1, RS, nullptr, nullptr, 1.0f, nullptr, scp(1)));
+      RUN(atst_ln_fwd(w.x[2 * i + 1], p + lo.ln2_w, p + lo.ln2_b, l.h2, l.mean2, l.rstd2, M, C, st, w.q8a, ACT_SCALE, sat, scp(2), amp(2)));
       RUN(gemm8(w.q8a, q8 + lo.fc1_w, M, 4 * C, C, EPI_BIAS_GELU, e->train ? l.u : nullptr, st, dq + 2, ACT_SCALE, p + lo.fc1_b, nullptr, nullptr, 1, l.a,
-                w.q8b, ACT_SCALE_GELU, sat));
-      RUN(gemm8(w.q8b, q8 + lo.fc2_w, M, C, 4 * C, EPI_RESID, w.x[2 * i + 2], st, dq + 3, ACT_SCALE_GELU, p + lo.fc2_b, w.x[2 * i + 1], s2, RS));
+                w.q8b, ACT_SCALE_GELU, sat, scp(2), scp(3), amp(3)));
+      RUN(gemm8(w.q8b, q8 + lo.fc2_w, M, C, 4 * C, EPI_RESID, w.x[2 * i + 2], st, dq + 3, ACT_SCALE_GELU, p + lo.fc2_b, w.x[2 * i + 1], s2, RS, nullptr, nullptr, 1.0f, nullptr, scp(3)));
     } else {
       if (i == 0 || !fuse_ln) RUN(atst_ln_fwd(w.x[2 * i], p + lo.ln1_w, p + lo.ln1_b, l.h1, l.mean1, l.rstd1, M, C, st));
       RUN(gemm(l.h1, q + lo.qkv_w, M, 3 * C, C, EPI_BF16, l.qkv, st));

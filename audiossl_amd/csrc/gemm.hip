@@ -91,7 +91,7 @@ DEVFN void epilogue8(const GemmArgs& p, int row, int col, f32x4 v0, f32x4 v1, co
     for (int e = 0; e < 4; ++e) { g0[e] = gelu_bf16dst(v0[e]); g1[e] = gelu_bf16dst(v1[e]); }
     st_bf16(p.C2, idx, g0, g1);                                    // activation a
     if (p.q8) {                                                    // fp8 forward: e4m3 copy of the SAME bf16 values for the fc2 GEMM
-      const float s = p.q8_scale;
+      const float s = p.q8_scale_ptr ? *p.q8_scale_ptr : p.q8_scale;   // running (delayed) activation scale, or the constant
       unsigned nclip = 0;                                          // elements beyond +-448 / scale (fixed activation scale: reported, see f8_sat_add)
       auto c = [&](float a_) { const float t = bf2f(f2bf(a_)) * s; nclip += fabsf(t) > 448.f ? 1u : 0u; return __builtin_amdgcn_fmed3f(t, -448.f, 448.f); };
       int lo = __builtin_amdgcn_cvt_pk_fp8_f32(c(g0[0]), c(g0[1]), 0, false); lo = __builtin_amdgcn_cvt_pk_fp8_f32(c(g0[2]), c(g0[3]), lo, true);
@@ -99,6 +99,7 @@ DEVFN void epilogue8(const GemmArgs& p, int row, int col, f32x4 v0, f32x4 v1, co
       typedef int v2i_ __attribute__((ext_vector_type(2)));
       *reinterpret_cast<v2i_*>(p.q8 + idx) = v2i_{lo, hi_w};
       if (nclip && p.q8_sat) atomicAdd(p.q8_sat, nclip);           // rare path: per-lane atomics only when something was clipped
+      w0 = g0; w1 = g1;                                            // for the running amax of this site (row-384 kernel)
     }
   } else if constexpr (EPI == EPI_RESID) {
     st_f32(p.C, idx, x.a0 + x.s * (v0 + b0), x.a1 + x.s * (v1 + b1));
@@ -800,13 +801,13 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
           epilogue8<EPI>(p, row, n0 + c8, *reinterpret_cast<const f32x4*>(sC + rl * CLD2 + (c8 >> 1)), *reinterpret_cast<const f32x4*>(sC + rl * CLD2 + PLANE1 + (c8 >> 1)),
                          *reinterpret_cast<const f32x4*>(sBias + (c8 >> 1)), *reinterpret_cast<const f32x4*>(sBias + PLANE1 + (c8 >> 1)), aux[i], w0, w1);
         }
-        if constexpr (EPI == EPI_DGELU) {
-          if (p.q8_amax) {
+        if constexpr (EPI == EPI_DGELU || EPI == EPI_BIAS_GELU) {
+          if (p.q8_amax) {                                         // dGELU: max |du| ; fc1 + GELU (fp8 forward): max |a| -- the next step's scale of this site
 #pragma unroll
             for (int e = 0; e < 4; ++e) omax = fmaxf(omax, fmaxf(fabsf(w0[e]), fabsf(w1[e])));
           }
-          csr[i][0] += w0; csr[i][1] += w1;                        // rows beyond M contribute zeros
         }
+        if constexpr (EPI == EPI_DGELU) { csr[i][0] += w0; csr[i][1] += w1; }   // rows beyond M contribute zeros
       }
     }
     if (part < NPART - 1) lds_barrier();
@@ -830,6 +831,12 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
       }
     }
     if (p.q8_amax) {
+      omax = wave_max(omax);
+      if (lane == 0 && omax > 0.f) atomicMax(reinterpret_cast<unsigned*>(p.q8_amax), __float_as_uint(omax));
+    }
+  }
+  if constexpr (EPI == EPI_BIAS_GELU) {
+    if (p.q8 && p.q8_amax) {
       omax = wave_max(omax);
       if (lane == 0 && omax > 0.f) atomicMax(reinterpret_cast<unsigned*>(p.q8_amax), __float_as_uint(omax));
     }

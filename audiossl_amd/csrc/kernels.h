@@ -51,7 +51,8 @@ int atst_gemm_tn_group(const WgradArgs* items, int n, hipStream_t st);   // inde
 
 // LayerNorm (eps 1e-6), C in {384, 768}
 int atst_ln_fwd(const float* x, const float* gamma, const float* beta, bf16* y, float* mean, float* rstd, int M, int C, hipStream_t st,
-                uint8_t* y8 = nullptr, float s8 = 1.0f, unsigned* sat = nullptr);   // y8: optional e4m3 copy of y * s8 (fp8 forward) ; sat: clipped-element counter
+                uint8_t* y8 = nullptr, float s8 = 1.0f, unsigned* sat = nullptr, const float* s8p = nullptr, float* amax8 = nullptr);
+                // y8: optional e4m3 copy of y * scale (fp8 forward), scale = *s8p (device, delayed scaling) or s8 ; sat: clipped-element counter ; amax8: max |y| (atomicMax)
 int atst_ln_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, int M, int C, hipStream_t st);   // fp32 output, no statistics (inference taps)
 struct LnBwdArgs {
   const bf16* dy;                    // [M,C] gradient wrt the LN output
@@ -120,7 +121,8 @@ int atst_byol_loss(const float* student, const float* teacher, int B, int ncrops
 int atst_quant_fp8(const bf16* x, size_t n, float scale, uint8_t* y, hipStream_t st, unsigned* sat = nullptr);   // y = e4m3(clamp(x * scale, +-448)) ; sat += clipped elements
 // every tensor of `table` (device int32 [n][2] = {element offset, numel}, 256-aligned) of a flat fp32 buffer -> e4m3 at the same
 // offsets with a per-tensor scale 448 / amax; dq[t] = amax / 448 (the factor that undoes it).  amax: device scratch [n].
-int atst_quant_fp8_dyn(const bf16* x, size_t n, const float* scale /* device */, uint8_t* y /* or null: amax only */, float* amax /* device, atomicMax */, hipStream_t st);
+int atst_quant_fp8_dyn(const bf16* x, size_t n, const float* scale /* device */, uint8_t* y /* or null: amax only */, float* amax /* device, atomicMax */, hipStream_t st,
+                       unsigned* sat = nullptr /* clipped-element counter */);
 int atst_fp8_update_scales(float* amax, float* scale, int n, float margin, hipStream_t st);
 int atst_quant_bf16_table_fp8(const bf16* p16, const int* table, int n, const float* dq, uint8_t* p8, hipStream_t st);
 int atst_quant_weights_fp8(const float* p32, const int* table, int n, uint8_t* p8, float* dq, float* amax, hipStream_t st);

@@ -32,7 +32,10 @@ template <int VPT, typename OUT = bf16>   // values per lane = C / 64 ; OUT = bf
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, OUT* __restrict__ y,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out, int M,
-                                                     uint8_t* __restrict__ y8 = nullptr, float s8 = 1.0f, unsigned* __restrict__ sat = nullptr) {
+                                                     uint8_t* __restrict__ y8 = nullptr, float s8c = 1.0f, unsigned* __restrict__ sat = nullptr,
+                                                     const float* __restrict__ s8p = nullptr, float* __restrict__ amax8 = nullptr) {
+  const float s8 = s8p ? *s8p : s8c;                              // fp8 forward: running (delayed) activation scale, or the constant
+  float rmax = 0.f;
   using MP = LnMap<VPT>; constexpr int C = VPT * 64, W = MP::W, CH = MP::CH;
   typedef typename VecOf<W>::f fvec; typedef typename VecOf<W>::h hvec;
   const int lane = threadIdx.x & 63;
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         if (y8) {
           st_fp8<W>(y8 + (size_t)row * C + MP::col(i, lane), r, s8);   // fp8 forward: e4m3 copy of the SAME bf16 values (the next GEMM's A operand)
 #pragma unroll
-          for (int e = 0; e < W; ++e) nclip += fabsf(r[e] * s8) > 448.f ? 1u : 0u;
+          for (int e = 0; e < W; ++e) { nclip += fabsf(r[e] * s8) > 448.f ? 1u : 0u; rmax = fmaxf(rmax, fabsf(r[e])); }
         }
       } else {
         fvec of;
@@ -87,7 +90,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     }
     if (lane == 0 && mean_out) { mean_out[row] = mu; rstd_out[row] = rs; }
   }
-  if constexpr (sizeof(OUT) == 2) { if (y8) f8_sat_add(sat, nclip); }
+  if constexpr (sizeof(OUT) == 2) {
+    if (y8) {
+      f8_sat_add(sat, nclip);
+      if (amax8) { rmax = wave_max(rmax); if (lane == 0 && rmax > 0.f) atomicMax(reinterpret_cast<unsigned*>(amax8), __float_as_uint(rmax)); }
+    }
+  }
 }
 
 template <int VPT>
@@ -169,11 +177,11 @@ int ln_grid(int M) { int b = (M + 3) / 4; return b < 2048 ? b : 2048; }
 }  // namespace
 
 int atst_ln_fwd(const float* x, const float* gamma, const float* beta, bf16* y, float* mean, float* rstd, int M, int C, hipStream_t st,
-                uint8_t* y8, float s8, unsigned* sat) {
+                uint8_t* y8, float s8, unsigned* sat, const float* s8p, float* amax8) {
   if (M <= 0) return ATST_OK;
   ProfScope ps(PK_LN_FWD, (double)M * C * (y8 ? 7.0 : 6.0), st);      // read fp32, write bf16 (+ e4m3)
-  if (C == 384) hipLaunchKernelGGL(ln_fwd_kernel<6>, dim3(ln_grid(M)), dim3(256), 0, st, x, gamma, beta, y, mean, rstd, M, y8, s8, sat);
-  else if (C == 768) hipLaunchKernelGGL(ln_fwd_kernel<12>, dim3(ln_grid(M)), dim3(256), 0, st, x, gamma, beta, y, mean, rstd, M, y8, s8, sat);
+  if (C == 384) hipLaunchKernelGGL(ln_fwd_kernel<6>, dim3(ln_grid(M)), dim3(256), 0, st, x, gamma, beta, y, mean, rstd, M, y8, s8, sat, s8p, amax8);
+  else if (C == 768) hipLaunchKernelGGL(ln_fwd_kernel<12>, dim3(ln_grid(M)), dim3(256), 0, st, x, gamma, beta, y, mean, rstd, M, y8, s8, sat, s8p, amax8);
   else return ATST_EINVAL;
   return (int)hipGetLastError();
 }

@@ -155,14 +155,15 @@ __global__ void quant_weights_kernel(const float* __restrict__ p, const int* __r
 // Gradient operands of the fp8 dgrad GEMMs (delayed scaling): y = e4m3(clamp(x * *scale)) when y != null, and
 // *amax = max(*amax, max |x|) (float bits of a non-negative value order like unsigned) for the NEXT step's scale.
 __global__ void quant_fp8_dyn_kernel(const bf16* __restrict__ x, size_t n8, const float* __restrict__ scale, unsigned* __restrict__ y,
-                                     unsigned* __restrict__ amax) {
+                                     unsigned* __restrict__ amax, unsigned* __restrict__ sat) {
   const float sc = scale ? *scale : 1.0f;
   float m = 0.f;
+  unsigned nclip = 0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
     const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + i * 8);
     float f[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { const float t = bf2f(v[e]); m = fmaxf(m, fabsf(t)); f[e] = __builtin_amdgcn_fmed3f(t * sc, -448.f, 448.f); }
+    for (int e = 0; e < 8; ++e) { const float t = bf2f(v[e]); m = fmaxf(m, fabsf(t)); nclip += fabsf(t * sc) > 448.f ? 1u : 0u; f[e] = __builtin_amdgcn_fmed3f(t * sc, -448.f, 448.f); }
     if (y) {
       int lo = 0, hi = 0;
       lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false); lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
@@ -172,6 +173,7 @@ __global__ void quant_fp8_dyn_kernel(const bf16* __restrict__ x, size_t n8, cons
   }
   m = wave_max(m);
   if (amax && (threadIdx.x & 63) == 0 && m > 0.f) atomicMax(amax, __float_as_uint(m));
+  if (y) f8_sat_add(sat, nclip);
 }
 // after a backward: scale[i] = 448 / (margin * amax[i]) for the next step (unchanged where nothing was observed), amax[i] = 0
 __global__ void fp8_update_scales_kernel(float* __restrict__ amax, float* __restrict__ scale, int n, float margin) {
@@ -195,11 +197,11 @@ __global__ void quant_bf16_table_kernel(const bf16* __restrict__ p, const int* _
   }
 }
 
-int atst_quant_fp8_dyn(const bf16* x, size_t n, const float* scale, uint8_t* y, float* amax, hipStream_t st) {
+int atst_quant_fp8_dyn(const bf16* x, size_t n, const float* scale, uint8_t* y, float* amax, hipStream_t st, unsigned* sat) {
   if (n == 0) return ATST_OK;
   if (n % 8) return ATST_EINVAL;
   int grid = (int)((n / 8 + 255) / 256); if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(quant_fp8_dyn_kernel, dim3(grid), dim3(256), 0, st, x, n / 8, scale, reinterpret_cast<unsigned*>(y), reinterpret_cast<unsigned*>(amax));
+  hipLaunchKernelGGL(quant_fp8_dyn_kernel, dim3(grid), dim3(256), 0, st, x, n / 8, scale, reinterpret_cast<unsigned*>(y), reinterpret_cast<unsigned*>(amax), sat);
   return (int)hipGetLastError();
 }
 int atst_fp8_update_scales(float* amax, float* scale, int n, float margin, hipStream_t st) {

@@ -138,7 +138,7 @@ def pad_tokens(n: int) -> int:
 class EncoderPass:
     """One encoder invocation geometry (S sequences of one mel width) with its activation workspace."""
 
-    def __init__(self, eng: "AtstEngine", net: str, S: int, width: int, train: bool, precise: bool = False):
+    def __init__(self, eng: "AtstEngine", net: str, S: int, width: int, train: bool, precise: bool = False, record_amax: bool = False):
         self.eng, self.net, self.S, self.width, self.train = eng, net, S, width, train
         self.precise = bool(precise)                     # fp32 / split-bf16 twin of the encoder (csrc/engine_hp.hip): parity mode
         cfg = eng.cfg
@@ -177,7 +177,13 @@ class EncoderPass:
         if eng.fp8 and not self.precise:
             e.fp8 = 1
             e.p8, e.w_dq = (eng.p8.data_ptr(), eng.dq_s.data_ptr()) if net == "student" else (eng.t8.data_ptr(), eng.dq_t.data_ptr())
-            e.f8_sat = eng.f8_sat[0 if net == "student" else 1:].data_ptr()
+            k = 0 if net == "student" else 1
+            e.f8_sat = eng.f8_sat[k:].data_ptr()
+            # running activation scales of the e4m3 forward (delayed scaling): every pass quantises with them; the passes of a training
+            # step also record this step's amax (inference passes do not touch the state)
+            e.f8_act_scale = eng.f8a_scale[k].data_ptr()
+            if record_amax:
+                e.f8_act_amax = eng.f8a_amax[k].data_ptr()
             if net == "student" and train:
                 e.p8t, e.g8_scale, e.g8_amax = eng.p8t.data_ptr(), eng.g8_scale.data_ptr(), eng.g8_amax.data_ptr()
         e.ws, e.ws_bytes = self.ws.buf.data_ptr(), nbytes
@@ -472,6 +478,11 @@ class AtstEngine:
             # clipped-element counters of the fixed forward activation scales, [student, teacher] (atst_encoder_t.f8_sat): never reset by
             # the step, read on demand (fp8_saturation()) -- a host read-back, so not once per step
             self.f8_sat = z(2, torch.int32)
+            # forward activation sites, [student | teacher][depth][4] (LN1 out, attention out, LN2 out, GELU out): running scale
+            # 448 / (margin * max amax over the window), initialised to the constants of round 2 / 3 (8, 8, 8, 4); amax of the current step
+            self.f8a_scale = torch.tensor([8.0, 8.0, 8.0, 4.0], device=dev).repeat(2, self.depth).contiguous()
+            self.f8a_amax = z(2 * 4 * self.depth).view(2, 4 * self.depth)
+            self.f8a_hist = None                                     # [FP8_HISTORY, 2, 4 depth], allocated with the dgrad window below
             # fp8 dgrad (d = 768): e4m3 copy of the transposed weight shadows + delayed-scaling state of the four gradient operands
             # of every block ([depth][4]: g -> fc2, du -> fc1, g2 -> proj, dqkv -> qkv).  fp8_bwd_state: 0 off, 1 recording, 2 on.
             self.p8t = z(L.n_student, torch.uint8)
@@ -484,6 +495,7 @@ class AtstEngine:
             # over the ranks so that every replica quantises on the same grid.
             self.FP8_HISTORY = 16
             self.g8_hist, self._g8_hist_k = z(self.FP8_HISTORY * 4 * self.depth).view(self.FP8_HISTORY, 4 * self.depth), 0
+            self.f8a_hist, self._f8a_hist_k = z(self.FP8_HISTORY * 8 * self.depth).view(self.FP8_HISTORY, 2, 4 * self.depth), 0
         self.bn_buffers: Dict[str, Dict[str, torch.Tensor]] = {}
         for key in ("student.projector", "student.predictor", "teacher.projector"):
             self.bn_buffers[key] = dict(running_mean=z(HEAD_HIDDEN), running_var=torch.ones(HEAD_HIDDEN, device=dev),
@@ -635,7 +647,7 @@ class AtstEngine:
     def _pass(self, net: str, S: int, width: int, train: bool, slot: int) -> EncoderPass:
         key = (net, S, width, train, slot)
         if key not in self._passes:
-            self._passes[key] = EncoderPass(self, net, S, width, train, precise=self.precise)
+            self._passes[key] = EncoderPass(self, net, S, width, train, precise=self.precise, record_amax=True)
         return self._passes[key]
 
     def inference_pass(self, net: str, S: int, width: int, keep: int = 4) -> EncoderPass:
@@ -787,6 +799,7 @@ class AtstEngine:
         stats, ns, ntc = parallel.allreduce_monitor_sums(self._stats, float(s_out.shape[0]), float(t_out.shape[0]))
         self._student_groups = groups
         self.last_outputs = (s_out, t_out)
+        self._fp8_after_forward()
         return loss, parallel.feature_std(stats[0], stats[1], ns), parallel.feature_std(stats[2], stats[3], ntc)
 
     def backward(self, grad_scale=1.0, zero_grad: bool = True):
@@ -865,6 +878,20 @@ class AtstEngine:
             self.g8_amax.zero_()
             self.fp8_bwd_state = 2
 
+    def _fp8_after_forward(self):
+        """Delayed scaling of the e4m3 forward: the amax every activation site recorded in this step's passes (student groups share
+        their sites, the teacher has its own) enters a 16-step window; the next step quantises with 448 / (margin * window max).  Sites
+        that saw nothing keep their scale.  MAX-reduced over the ranks (replicas quantise on one grid)."""
+        if not self.fp8 or self.f8a_hist is None:
+            return
+        if parallel._collective():
+            dist.all_reduce(self.f8a_amax, op=dist.ReduceOp.MAX)
+        self.f8a_hist[self._f8a_hist_k % self.FP8_HISTORY].copy_(self.f8a_amax)
+        self._f8a_hist_k += 1
+        win = self.f8a_hist.max(dim=0).values.contiguous()
+        hip.call("atst_fp8_update_scales", hip.ptr(win), hip.ptr(self.f8a_scale), win.numel(), float(self.fp8_margin), hip.stream())
+        self.f8a_amax.zero_()
+
     def fp8_saturation(self, reset: bool = False) -> Dict[str, int]:
         """Activation elements clipped at +-448 by the e4m3 forward since the last reset, per network.  The forward scales are constants
         (csrc/engine.hip ACT_SCALE: LayerNorm / attention outputs beyond +-56, GELU outputs beyond +-112 saturate); a non-zero count
@@ -880,13 +907,16 @@ class AtstEngine:
         """Delayed-scaling state of the fp8 dgrad path (optimizer state: saved with the moments, see trainer.save_checkpoint)."""
         if not (self.fp8 and getattr(self, "fp8_bwd_state", 0)):
             return None
-        return {"g8_scale": self.g8_scale.cpu(), "g8_hist": self.g8_hist.cpu(), "hist_k": int(self._g8_hist_k), "state": int(self.fp8_bwd_state)}
+        return {"g8_scale": self.g8_scale.cpu(), "g8_hist": self.g8_hist.cpu(), "hist_k": int(self._g8_hist_k), "state": int(self.fp8_bwd_state),
+                "f8a_scale": self.f8a_scale.cpu(), "f8a_hist": self.f8a_hist.cpu(), "f8a_hist_k": int(self._f8a_hist_k)}
 
     def load_fp8_state(self, st: Optional[dict]):
         if not st or not (self.fp8 and getattr(self, "fp8_bwd_state", 0)):
             return
         self.g8_scale.copy_(st["g8_scale"]); self.g8_hist.copy_(st["g8_hist"])
         self._g8_hist_k, self.fp8_bwd_state = int(st["hist_k"]), int(st["state"])
+        if "f8a_scale" in st:
+            self.f8a_scale.copy_(st["f8a_scale"]); self.f8a_hist.copy_(st["f8a_hist"]); self._f8a_hist_k = int(st["f8a_hist_k"])
 
     def _reduce_async(self, a: int, b: int):
         """Sum g32[a:b] over ranks on the communication stream, ordered after everything enqueued so far."""
@@ -908,15 +938,16 @@ class AtstEngine:
         if optimizer_state:
             bufs += [self.m32, self.v32]
         if f8:
-            bufs += [self.g8_scale, self.g8_hist]
+            bufs += [self.g8_scale, self.g8_hist, self.f8a_scale, self.f8a_hist]
         for t in bufs:
             dist.broadcast(t, 0)
         if optimizer_state:
-            step = torch.tensor([self.opt_step, self._g8_hist_k if f8 else 0, self.fp8_bwd_state if f8 else 0], dtype=torch.int64, device=self.device)
+            step = torch.tensor([self.opt_step, self._g8_hist_k if f8 else 0, self.fp8_bwd_state if f8 else 0, self._f8a_hist_k if f8 else 0],
+                                dtype=torch.int64, device=self.device)
             dist.broadcast(step, 0)
             self.opt_step = int(step[0].item())
             if f8:
-                self._g8_hist_k, self.fp8_bwd_state = int(step[1].item()), int(step[2].item())
+                self._g8_hist_k, self.fp8_bwd_state, self._f8a_hist_k = int(step[1].item()), int(step[2].item()), int(step[3].item())
         self.sync_shadows(force=True)
 
     def allreduce_grads(self):

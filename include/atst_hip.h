@@ -207,6 +207,11 @@ typedef struct {
    * the activation scales are constants (8 for LayerNorm / attention outputs, 4 behind GELU: |x| > 56 / 112 saturates at +-448); the
    * caller clears and reads it (AtstEngine.fp8_saturation()).  A non-zero count means the fixed scales no longer fit the run.      */
   uint32_t* f8_sat;
+  /* fp8 forward, running (delayed) activation scales: [depth][4] device floats each, site k of block i = 0: LayerNorm-1 output (qkv GEMM),
+   * 1: attention output (proj), 2: LayerNorm-2 output (fc1), 3: GELU output (fc2).  f8_act_scale (or NULL = the constants 8, 8, 8, 4) is what
+   * the producing kernels quantise with and the consuming GEMMs divide by; f8_act_amax (or NULL) receives max |x| of every site of this pass
+   * (atomicMax) -- the caller turns it into the next step's scales (atst_fp8_update_scales; AtstEngine: 448 / (2 * max over 16 steps)).    */
+  const float* f8_act_scale; float* f8_act_amax;
 } atst_encoder_t;
 
 size_t atst_encoder_ws_bytes(int S, int NP, int C, int H, int depth, int train, int fp8 /* = atst_encoder_t.fp8: also carve the e4m3 operand copies */);

@@ -149,6 +149,7 @@ class _HeadLinear(torch.autograd.Function):         # forward ~exact (split-bf16
 
 
 _FP8 = False
+_FP8_ACT = {}
 FP8_ACT_SCALE, FP8_ACT_SCALE_GELU = 8.0, 4.0        # csrc/engine.hip ACT_SCALE / ACT_SCALE_GELU
 
 
@@ -157,17 +158,20 @@ class emulate_fp8:
     operands -- activations x fixed scale, weights x 448 / amax per tensor, both saturated at +-448 -- exactly like the HIP
     fp8 path (csrc/engine.hip gemm8, csrc/optim.hip quant kernels); gradients flow as if the bf16 operands had been used."""
 
-    def __init__(self, on: bool = True):
-        self.on = on
+    def __init__(self, on: bool = True, act_scales=None):
+        """act_scales: optional {weight key: scale of that Linear's INPUT activation} -- the running (delayed) scales of a later step
+        (AtstEngine.f8a_scale); sites not listed use the constants FP8_ACT_SCALE / FP8_ACT_SCALE_GELU (= the first step)."""
+        self.on, self.act_scales = on, dict(act_scales or {})
 
     def __enter__(self):
-        global _FP8
-        self.prev, _FP8 = _FP8, self.on
+        global _FP8, _FP8_ACT
+        self.prev, _FP8 = (_FP8, _FP8_ACT), self.on
+        _FP8_ACT = self.act_scales
         return self
 
     def __exit__(self, *a):
-        global _FP8
-        _FP8 = self.prev
+        global _FP8, _FP8_ACT
+        _FP8, _FP8_ACT = self.prev
 
 
 def _q8(x: Tensor, scale) -> Tensor:
@@ -230,7 +234,7 @@ def _linear(x: Tensor, W: Weights, key: str, b: Optional[Tensor], act_scale: flo
     """F.linear on the (bf16-shadow when emulating) weight W[key], or its e4m3-forward version inside emulate_fp8()."""
     if not _FP8:
         return F.linear(x, _w(W, key), b)
-    y = _Fp8Linear.apply(x, _w(W, key), W[key].detach(), act_scale, key)
+    y = _Fp8Linear.apply(x, _w(W, key), W[key].detach(), _FP8_ACT.get(key, act_scale), key)
     return y if b is None else y + b
 
 

@@ -471,6 +471,14 @@ def test_fp8_dynamic_quantiser_and_scale_update():
     assert float(sc2[1]) == 1.0 and float(amax2.abs().max()) == 0.0          # nothing observed at site 1: scale unchanged
 
 
+def _act_scales(eng):
+    """{weight key: running activation scale of that Linear's input} for both networks, as the NEXT forward of `eng` will use them."""
+    names = ("attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight")
+    sc = eng.f8a_scale.cpu()
+    return {f"{net}.encoder.blocks.{i}.{nm}": float(sc[k, 4 * i + j]) for k, net in enumerate(("student", "teacher")) for i in range(eng.depth)
+            for j, nm in enumerate(names)}
+
+
 def test_fp8_dgrad_step_base():
     """BASELINE.json configs[4]: ATST-base with e4m3 forward AND fc2 / fc1 / proj dgrad GEMMs (qkv dgrad and weight gradients on bf16
     operands).  Delayed scaling: the first backward records the amax of every gradient operand and runs in bf16, every later one
@@ -497,6 +505,8 @@ def test_fp8_dgrad_step_base():
     eng.backward()                                                # step 1: bf16 dgrad, amax recorded
     g_first = eng.g32.clone()
     sc = eng.g8_scale.view(depth, 4).clone()
+    act2 = _act_scales(eng)                                       # forward activation scales of step 2 (running amax of step 1)
+    assert all(v > 1.0 for v in act2.values()) and any(abs(v - 8.0) > 1e-3 for v in act2.values())
     assert eng.fp8_bwd_state == 2 and float(sc[:, :3].min()) > 1.0 and float(eng.g8_amax.abs().max()) == 0.0   # sites g, du, g2 (qkv dgrad stays bf16)
     fwd = lambda Wl: O.atst_forward(Wl, mels_c, lens, "base", 2, depth=depth, drop_path_rate=0.0)
     rec = O.emulate_fp8_dgrad(None)
@@ -513,7 +523,7 @@ def test_fp8_dgrad_step_base():
     eng.forward(mels, lens); eng.backward()                       # same weights, same inputs: now e4m3 dgrad operands
     g_fp8 = eng.g32.clone()
     assert torch.isfinite(g_fp8).all()
-    _, o_fp8 = oracle_grads(W, fwd, True, gates, ctxs=(O.emulate_fp8(), O.emulate_fp8_dgrad(inject)))
+    _, o_fp8 = oracle_grads(W, fwd, True, gates, ctxs=(O.emulate_fp8(act_scales=act2), O.emulate_fp8_dgrad(inject)))
 
     def table(get_a, get_b):
         worst, num, den = ("", 0.0), 0.0, 0.0
@@ -597,9 +607,10 @@ def test_configs4_base_fp8_hires_as_one_thing():
     site = {0: "mlp.fc2.weight", 1: "mlp.fc1.weight", 2: "attn.proj.weight"}
     inject = {f"student.encoder.blocks.{i}.{nm}": float(sc[i, k]) for i in range(depth) for k, nm in site.items()}
     assert eng.fp8_bwd_state == 2 and min(inject.values()) > 1.0
+    act2 = _act_scales(eng)                                                # the running forward scales step 2 quantises with
     loss2 = float(eng.forward(mels, lens)[0]); eng.backward()              # e4m3 dgrad step, same weights and inputs
     g = eng.g32.clone()
-    lo, go = oracle_grads(W, fwd, True, gates, ctxs=(O.emulate_fp8(), O.emulate_fp8_dgrad(inject)))
+    lo, go = oracle_grads(W, fwd, True, gates, ctxs=(O.emulate_fp8(act_scales=act2), O.emulate_fp8_dgrad(inject)))
     num = den = 0.0
     worst = ("", 0.0)
     for name, (off, shape) in eng.layout.entries.items():
@@ -612,17 +623,18 @@ def test_configs4_base_fp8_hires_as_one_thing():
             worst = (name, r)
     print(f"\n[configs[4] base fp8 hires depth {depth}] mel max|d| {dmel:.1e}; CLS vs fp8-emulating oracle {e_cls:.3e}; loss {loss2:.5f} (oracle {lo:.5f}); "
           f"gradients mean {num / den:.3e} worst {worst[0]} {worst[1]:.3e}")
-    assert loss1 == loss2 and abs(loss2 - lo) < 5e-2
+    assert abs(loss1 - loss2) < 2e-2 and abs(loss2 - lo) < 5e-2            # step 2 quantises its activations on the adapted grid
     assert e_cls < 5.5e-2                                                  # test_fp8_encoder_forward_and_step_base
     assert num / den < 1.3e-1 and worst[1] < 0.25                          # measured 8.8e-2 / 0.16 (x1.5): 12 head rows (test_fp8_dgrad_step_base: 16 rows, 7.6e-2 / 0.17)
     eng.optimizer_step(1e-3, 0.04, 0.99)
     assert torch.isfinite(eng.p32).all() and torch.isfinite(eng.g32).all()
 
 
-def test_fp8_forward_saturation_counter():
-    """The e4m3 forward uses FIXED activation scales (csrc/engine.hip ACT_SCALE = 8 / 4 behind GELU: |x| > 56 / 112 clips at +-448).  Every
-    quantising kernel counts what it clipped into atst_encoder_t.f8_sat (AtstEngine.fp8_saturation()): zero on the recipe weights, and
-    non-zero -- for the student only -- once a student LayerNorm gain pushes its output beyond +-56."""
+def test_fp8_forward_saturation_counter_and_running_scales():
+    """The e4m3 forward starts from the activation scales of rounds 2 / 3 (8; 4 behind GELU: |x| > 56 / 112 clips at +-448) and adapts them:
+    every site records its amax, the next step quantises with 448 / (2 * max over the window) (atst_encoder_t.f8_act_scale / f8_act_amax).
+    Every quantising kernel counts what it clipped (f8_sat, AtstEngine.fp8_saturation()).  Zero on the recipe weights; with a student
+    LayerNorm gain of 40 the FIRST forward clips (student only) and the second -- on the adapted scales -- does not."""
     from audiossl_amd.engine import AtstEngine
     depth, B = 1, 2
     W = O.recipe_weights("base", depth=depth, seed=7)
@@ -630,13 +642,18 @@ def test_fp8_forward_saturation_counter():
     lens = [torch.full((B,), 1001)] * 2
     eng = AtstEngine("base", depth=depth, drop_path_rate=0.0, fp8=True)
     eng.load_weights(W)
+    assert torch.equal(eng.f8a_scale.cpu(), torch.tensor([8.0, 8.0, 8.0, 4.0]).repeat(2, depth))
     eng.forward(mels, lens)
     assert eng.fp8_saturation() == {"student": 0, "teacher": 0}
+    sc1 = eng.f8a_scale.clone()
+    assert float(eng.f8a_amax.abs().max()) == 0.0 and bool((sc1 > 1.0).all()) and not torch.equal(sc1.cpu(), torch.tensor([8.0, 8.0, 8.0, 4.0]).repeat(2, depth))
     W2 = {k: v.clone() for k, v in W.items()}
-    W2["student.encoder.blocks.0.norm1.weight"] *= 40.0                      # LayerNorm output ~ N(0, 40^2): far beyond +-56
+    W2["student.encoder.blocks.0.norm1.weight"] *= 40.0                      # LayerNorm output ~ N(0, 40^2): far beyond the range of any scale seen so far
     eng.load_weights(W2)
     loss = eng.forward(mels, lens)[0]
     sat = eng.fp8_saturation(reset=True)
-    print(f"\n[fp8 saturation] clipped elements: {sat}; loss {float(loss):.4f}")
+    print(f"\n[fp8 saturation] clipped elements: {sat}; loss {float(loss):.4f}; LN1 site scale {float(sc1[0, 0]):.2f} -> {float(eng.f8a_scale[0, 0]):.3f}")
     assert sat["student"] > 1000 and sat["teacher"] == 0 and math.isfinite(float(loss))
-    assert eng.fp8_saturation() == {"student": 0, "teacher": 0}               # reset
+    assert float(eng.f8a_scale[0, 0]) < 0.2 * float(sc1[0, 0])                # the window max now holds the large amax
+    eng.forward(mels, lens)
+    assert eng.fp8_saturation() == {"student": 0, "teacher": 0}               # adapted: nothing clips any more
