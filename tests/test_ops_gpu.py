@@ -505,7 +505,7 @@ def test_fp8_dgrad_step_base():
     eng.backward()                                                # step 1: bf16 dgrad, amax recorded
     g_first = eng.g32.clone()
     sc = eng.g8_scale.view(depth, 4).clone()
-    act2 = _act_scales(eng)                                       # forward activation scales of step 2 (running amax of step 1)
+    act2, act2_dev = _act_scales(eng), eng.f8a_scale.clone()      # forward activation scales of step 2 (running amax of step 1)
     assert all(v > 1.0 for v in act2.values()) and any(abs(v - 8.0) > 1e-3 for v in act2.values())
     assert eng.fp8_bwd_state == 2 and float(sc[:, :3].min()) > 1.0 and float(eng.g8_amax.abs().max()) == 0.0   # sites g, du, g2 (qkv dgrad stays bf16)
     fwd = lambda Wl: O.atst_forward(Wl, mels_c, lens, "base", 2, depth=depth, drop_path_rate=0.0)
@@ -526,6 +526,12 @@ def test_fp8_dgrad_step_base():
     g_fp8 = eng.g32.clone()
     assert torch.isfinite(g_fp8).all()
     _, o_fp8 = oracle_grads(W, fwd, True, gates2, ctxs=(O.emulate_fp8(act_scales=act2), O.emulate_fp8_dgrad(inject)))
+    # the same forward once more (activation scales put back to what step 2 used: bit-identical forward, same gates) with the dgrad on bf16
+    # operands (recording mode): isolates what the e4m3 gradient operands change
+    eng.f8a_scale.copy_(act2_dev); eng.fp8_bwd_state = 1
+    eng.forward(mels, lens); eng.backward()
+    g_bf = eng.g32.clone()
+    _, o_bf = oracle_grads(W, fwd, True, gates2, ctxs=(O.emulate_fp8(act_scales=act2), O.emulate_fp8_dgrad(None)))
 
     def table(get_a, get_b):
         worst, num, den = ("", 0.0), 0.0, 0.0
@@ -543,11 +549,11 @@ def test_fp8_dgrad_step_base():
     or_of = lambda o: (lambda name, off, n: o[name].reshape(-1) if name in o else None)
     m1, w1 = table(hip_of(g_first), or_of(o_first))
     m2, w2 = table(hip_of(g_fp8), or_of(o_fp8))
-    m3, w3 = table(hip_of(g_fp8), hip_of(g_first))
-    mo, wo = table(lambda name, off, n: o_fp8[name].reshape(-1) if name in o_fp8 else torch.zeros(n), or_of(o_first))
+    m3, w3 = table(hip_of(g_fp8), hip_of(g_bf))
+    mo, wo = table(lambda name, off, n: o_fp8[name].reshape(-1) if name in o_fp8 else torch.zeros(n), or_of(o_bf))
     print(f"\n[fp8 base depth {depth}] HIP vs oracle, bf16 dgrad (fp8 forward): mean {m1:.3e} worst {w1[0]} {w1[1]:.3e}")
     print(f"[fp8 base depth {depth}] HIP vs oracle, e4m3 dgrad:               mean {m2:.3e} worst {w2[0]} {w2[1]:.3e}")
-    print(f"[fp8 base depth {depth}] HIP e4m3 dgrad vs HIP bf16 dgrad:        mean {m3:.3e} worst {w3[0]} {w3[1]:.3e}   (oracle's own: mean {mo:.3e} worst {wo[1]:.3e})")
+    print(f"[fp8 base depth {depth}] HIP e4m3 dgrad vs HIP bf16 dgrad (same fwd): mean {m3:.3e} worst {w3[0]} {w3[1]:.3e}   (oracle's own: mean {mo:.3e} worst {wo[1]:.3e})")
     # e4m3 is a 6-12 % staircase: a 2e-3 difference between two realisations of an operand moves ~2 % of its elements to the neighbouring code
     # (forward: test_fp8_encoder_forward_and_step_base measures 3.6e-2 on the features), and the gradient inherits the forward's difference
     assert m1 < 9e-2 and m2 < 9e-2 and w2[1] < 0.2, (m1, m2, w2)
@@ -556,7 +562,7 @@ def test_fp8_dgrad_step_base():
     assert abs(m3 - mo) < 0.6 * max(m3, mo)                       # HIP moves by about as much as the oracle predicts when the dgrad goes e4m3
     # predictor / projector weight gradients do not pass through any encoder dgrad GEMM: unchanged up to atomics order
     off, shape = eng.layout.entries["predictor.3.weight"]
-    assert relerr(g_fp8[off:off + math.prod(shape)], g_first[off:off + math.prod(shape)]) < 1e-5
+    assert relerr(g_fp8[off:off + math.prod(shape)], g_bf[off:off + math.prod(shape)]) < 1e-5
     eng.optimizer_step(1e-3, 0.04, 0.99)
     l1 = float(eng.forward(mels, lens)[0]); eng.backward()
     assert math.isfinite(l1) and torch.isfinite(eng.p32).all()
