@@ -82,7 +82,7 @@ int gemm(const bf16* A, const bf16* B, int M, int N, int K, int epi, void* C, hi
   return atst_gemm_nt(a, st);
 }
 // e4m3 forward GEMM: A8 [M,K] (activation copy, scale act_scale), B8 [N,K] (weight shadow, per-tensor scale in *w_dq)
-constexpr float ACT_SCALE = 8.0f, ACT_SCALE_GELU = 4.0f;   // LayerNorm / attention outputs stay within +-56, GELU outputs within +-112
+constexpr float ACT_SCALE = 8.0f, ACT_SCALE_GELU = 4.0f;   // activation scales when the caller passes no running ones (f8_act_scale == NULL): +-56 / +-112 fit
 int gemm8(const uint8_t* A8, const uint8_t* B8, int M, int N, int K, int epi, void* C, hipStream_t st, const float* w_dq, float act_scale,
           const float* bias = nullptr, const float* resid = nullptr, const float* row_scale = nullptr, int rps = 1, void* C2 = nullptr,
           uint8_t* q8 = nullptr, float q8_scale = 1.0f, unsigned* q8_sat = nullptr, const float* act_scale_dev = nullptr,
