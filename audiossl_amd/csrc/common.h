@@ -15,6 +15,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32;
 
+#ifndef ATST_AMAX_SLOTS           // = include/atst_hip.h
+#define ATST_AMAX_SLOTS 16
+#define ATST_AMAX_SLOT_STRIDE 64
+#define ATST_AMAX_SITE_STRIDE (ATST_AMAX_SLOTS * ATST_AMAX_SLOT_STRIDE)
+#endif
 #define ATST_OK 0
 #define ATST_EINVAL 1001        // bad argument (shape not supported by the compiled kernels)
 
@@ -142,6 +147,16 @@ DEVFN int xcd_remap(int bid, int nblk) {
   const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, loc = bid >> 3;
   const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + loc;
+}
+
+// Running max |x| of a quantisation site (delayed scaling).  A site is NOT one float: atomics on one address serialise at L2 (~5 ns each), and a
+// launch posts one per wave -- 32 k for a full-size fc1 + GELU GEMM, which cost that launch +190 us (and the LayerNorm kernel +34 us for 8 k).  A
+// site is ATST_AMAX_SLOTS floats, 256 B apart (ATST_AMAX_SITE_STRIDE floats in all); a wave posts into the slot its `key` selects and the
+// consumer takes the max over the slots.  Non-negative floats order like their bit patterns.
+constexpr int AMAX_SLOTS = ATST_AMAX_SLOTS, AMAX_SLOT_STRIDE = ATST_AMAX_SLOT_STRIDE, AMAX_SITE_STRIDE = ATST_AMAX_SITE_STRIDE;
+DEVFN void amax_post(float* site, float wave_max_value, int lane, unsigned key) {
+  if (lane == 0 && wave_max_value > 0.f)
+    atomicMax(reinterpret_cast<unsigned*>(site + (key % AMAX_SLOTS) * AMAX_SLOT_STRIDE), __float_as_uint(wave_max_value));
 }
 
 DEVFN void f8_sat_add(unsigned* counter, unsigned n) {

@@ -197,7 +197,7 @@ extern "C" int atst_encoder_fwd(const atst_encoder_t* e, void* stream) {
       // f8_act_scale / f8_act_amax ([depth][4] device floats) the scale is the caller's running (delayed) one and this pass records max |x|
       // of every site; without them the constants ACT_SCALE / ACT_SCALE_GELU.
       auto scp = [&](int k) -> const float* { return e->f8_act_scale ? e->f8_act_scale + 4 * i + k : nullptr; };
-      auto amp = [&](int k) -> float* { return e->f8_act_amax ? e->f8_act_amax + 4 * i + k : nullptr; };
+      auto amp = [&](int k) -> float* { return e->f8_act_amax ? e->f8_act_amax + (size_t)(4 * i + k) * AMAX_SITE_STRIDE : nullptr; };
       RUN(atst_ln_fwd(w.x[2 * i], p + lo.ln1_w, p + lo.ln1_b, l.h1, l.mean1, l.rstd1, M, C, st, w.q8a, ACT_SCALE, sat, scp(0), amp(0)));
       RUN(gemm8(w.q8a, q8 + lo.qkv_w, M, 3 * C, C, EPI_BF16, l.qkv, st, dq + 0, ACT_SCALE, nullptr, nullptr, nullptr, 1, nullptr, nullptr, 1.0f, nullptr, scp(0)));
       AttnArgs at{};
@@ -287,7 +287,7 @@ static int encoder_bwd_range(const atst_encoder_t* e, int lo, int hi, bool head,
   const bool rec8 = e->fp8 && e->fp8_bwd >= 1 && e->g8_amax && !fuse_lnb;
   const bool use8 = rec8 && e->fp8_bwd >= 2 && e->p8t && e->g8_scale && e->w_dq;
   auto gs8 = [&](int layer, int k) -> const float* { return use8 ? e->g8_scale + 4 * layer + k : nullptr; };
-  auto ga8 = [&](int layer, int k) -> float* { return rec8 ? e->g8_amax + 4 * layer + k : nullptr; };
+  auto ga8 = [&](int layer, int k) -> float* { return rec8 ? e->g8_amax + (size_t)(4 * layer + k) * AMAX_SITE_STRIDE : nullptr; };
   float* cur = w.dxA; float* oth = w.dxB;
   if (head) {
     LnBwdArgs a{};

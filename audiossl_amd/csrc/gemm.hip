@@ -91,15 +91,21 @@ DEVFN void epilogue8(const GemmArgs& p, int row, int col, f32x4 v0, f32x4 v1, co
     for (int e = 0; e < 4; ++e) { g0[e] = gelu_bf16dst(v0[e]); g1[e] = gelu_bf16dst(v1[e]); }
     st_bf16(p.C2, idx, g0, g1);                                    // activation a
     if (p.q8) {                                                    // fp8 forward: e4m3 copy of the SAME bf16 values for the fc2 GEMM
-      const float s = p.q8_scale_ptr ? *p.q8_scale_ptr : p.q8_scale;   // running (delayed) activation scale, or the constant
-      unsigned nclip = 0;                                          // elements beyond +-448 / scale (fixed activation scale: reported, see f8_sat_add)
-      auto c = [&](float a_) { const float t = bf2f(f2bf(a_)) * s; nclip += fabsf(t) > 448.f ? 1u : 0u; return __builtin_amdgcn_fmed3f(t, -448.f, 448.f); };
+      const float s = x.s;                                         // running (delayed) activation scale, or the constant: the caller read it once
+      auto c = [&](float a_) { return __builtin_amdgcn_fmed3f(bf2f(f2bf(a_)) * s, -448.f, 448.f); };
       int lo = __builtin_amdgcn_cvt_pk_fp8_f32(c(g0[0]), c(g0[1]), 0, false); lo = __builtin_amdgcn_cvt_pk_fp8_f32(c(g0[2]), c(g0[3]), lo, true);
       int hi_w = __builtin_amdgcn_cvt_pk_fp8_f32(c(g1[0]), c(g1[1]), 0, false); hi_w = __builtin_amdgcn_cvt_pk_fp8_f32(c(g1[2]), c(g1[3]), hi_w, true);
       typedef int v2i_ __attribute__((ext_vector_type(2)));
       *reinterpret_cast<v2i_*>(p.q8 + idx) = v2i_{lo, hi_w};
-      if (nclip && p.q8_sat) atomicAdd(p.q8_sat, nclip);           // rare path: per-lane atomics only when something was clipped
-      w0 = g0; w1 = g1;                                            // for the running amax of this site (row-384 kernel)
+      // elements beyond +-448 / scale are clipped: counted (f8_sat), but only on the rare path where the slot's largest value is one of them
+      const float m8 = fmaxf(fmaxf(fmaxf(fabsf(g0[0]), fabsf(g0[1])), fmaxf(fabsf(g0[2]), fabsf(g0[3]))), fmaxf(fmaxf(fabsf(g1[0]), fabsf(g1[1])), fmaxf(fabsf(g1[2]), fabsf(g1[3]))));
+      if (m8 * s > 447.f && p.q8_sat) {                            // (bf16 rounding of g can only move a value across 448 / s by 2^-8 relative: 447 is a safe trigger)
+        unsigned nclip = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) nclip += (fabsf(bf2f(f2bf(g0[e])) * s) > 448.f ? 1u : 0u) + (fabsf(bf2f(f2bf(g1[e])) * s) > 448.f ? 1u : 0u);
+        if (nclip) atomicAdd(p.q8_sat, nclip);
+      }
+      w0 = f32x4{m8, 0.f, 0.f, 0.f}; w1 = f32x4{0.f, 0.f, 0.f, 0.f};   // for the running amax of this site (row-384 kernel)
     }
   } else if constexpr (EPI == EPI_RESID) {
     st_f32(p.C, idx, x.a0 + x.s * (v0 + b0), x.a1 + x.s * (v1 + b1));
@@ -298,6 +304,7 @@ __global__ __launch_bounds__((NtGeo<BMT, NSTG, WTM>::THREADS), (NtGeo<BMT, NSTG,
 namespace row384 {
 constexpr int BNR = 384, WAVES = 8, THREADS = 512, CLD = BNR + 4;
 constexpr int CLD2 = 448, PLANE1 = 208;       // staging layout of the 8-column-slot epilogues (see the staging loop)
+constexpr int TR_PITCH = 208;                  // transposed-accumulator epilogue: bytes per staged row of a wave's strip (96 bf16 + 16 B)
 template <int MI> struct Geo {
   static constexpr int BMR = 64 * MI, ROWB = BK * 2, A_BYTES = BMR * ROWB, BB = BNR * ROWB, STAGE = A_BYTES + BB;   // 32 / 40 KB
   static constexpr int NSTG = MI == 4 ? 3 : 2;
@@ -517,8 +524,13 @@ DEVFN void lnb_flush(const GemmArgs& p, const LnbCols& cs, float* red, int tid) 
 // v_mfma_scale_f32_32x32x64_f8f6f4 per accumulator (unit block scales; twice the bf16 MFMA rate) instead of two
 // 32x32x16 bf16 MFMAs: half the matrix-pipe time AND half the operand bytes per FLOP.  p.dq undoes the per-tensor scales.
 // LN (EPI_RESID only): the epilogue also produces the LayerNorm of the new residual row (the next sub-layer's pre-LN).
-template <int EPI, int MI, bool LN = false, bool F8 = false>
+// TR (EPI_BF16 only): the MFMA operands are swapped, so an accumulator block holds C^T: a lane owns ONE row of the block and four consecutive
+// columns per register quad.  The epilogue then needs no fp32 staging and no block barrier: a quad is packed to 8 B of bf16, a wave writes its
+// 32 x 96 block row to a PRIVATE staging strip (12 ds_write_b64 instead of 96 ds_write_b32), reads it back as 16-B pieces of 192-B row segments and
+// stores them; the eight waves drift apart and overlap each other's LDS and store phases.
+template <int EPI, int MI, bool LN = false, bool F8 = false, bool TR = false>
 __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(GemmArgs p) {
+  static_assert(!TR || (EPI == EPI_BF16 && !LN), "transposed accumulators: store-only bf16 epilogue");
   using namespace row384;
   using RG = row384::Geo<MI>;
   constexpr int BMR = RG::BMR, A_BYTES = RG::A_BYTES, STAGE = RG::STAGE, NSTG = RG::NSTG, ROWB = RG::ROWB;
@@ -565,6 +577,12 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
     for (int j = 0; j < 3; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float* sBiasT = reinterpret_cast<float*>(smem_raw + NSTG * STAGE);   // TR: bias of the block's 384 columns, behind the ring
+  if constexpr (TR) {                                              // the oldest load of every wave: landed (and barrier-published) long before the epilogue
+    if (wid < BNR / 64) {
+      if (p.bias) lds_fill64(p.bias + n0 + wid * 64 + lane, sBiasT + wid * 64); else sBiasT[wid * 64 + lane] = 0.f;
+    }
+  }
 
   const int nk = p.K / BK;
   const int xr = swz_key(l31);                                     // every fragment row is l31 plus a multiple of 32
@@ -605,7 +623,8 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
         const v8i_ a8 = frag(st + offA + mi * 32 * ROWB);
 #pragma unroll
         for (int ni = 0; ni < 3; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8[ni], acc[mi][ni], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+          acc[mi][ni] = TR ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b8[ni], a8, acc[mi][ni], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F)
+                           : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8[ni], acc[mi][ni], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
         if (ILV && ISSUE) {                                      // 5 loads over 4 slots
           __builtin_amdgcn_sched_barrier(0);
           issue_one(kt + NSTG - 1, slot); ++slot;
@@ -626,7 +645,7 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
-        for (int ni = 0; ni < 3; ++ni) acc[mi][ni] = mfma32(af[mi], bf[ni], acc[mi][ni]);
+        for (int ni = 0; ni < 3; ++ni) acc[mi][ni] = TR ? mfma32(bf[ni], af[mi], acc[mi][ni]) : mfma32(af[mi], bf[ni], acc[mi][ni]);
         if (ILV && ISSUE && slot < LOADS_PER_TILE) {
           __builtin_amdgcn_sched_barrier(0);
           issue_one(kt + NSTG - 1, slot);
@@ -654,6 +673,36 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
     tile(kt, std::false_type{});
   }
   asm volatile("s_barrier" ::: "memory");
+
+  if constexpr (TR) {
+    constexpr int TP = row384::TR_PITCH;
+    char* stg = smem_raw + wid * (32 * TP);                       // this wave's strip: 32 rows x 96 bf16 (+ pad)
+    const float dq = F8 ? (p.dq ? *p.dq : 1.0f) * (p.dq_mul != 0.f ? p.dq_mul : 1.0f) / (p.dq_div ? *p.dq_div : 1.0f) : 1.0f;
+    bf16* cw = reinterpret_cast<bf16*>(p.C) + n0 + wn * 96;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+      for (int ni = 0; ni < 3; ++ni)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int c4 = ni * 32 + 8 * g + 4 * hi;                // my four columns of this quad inside the wave's 96
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(sBiasT + wn * 96 + c4);
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (F8 ? acc[mi][ni][4 * g + e] * dq : acc[mi][ni][4 * g + e]) + b4[e];
+          *reinterpret_cast<u32x2*>(stg + l31 * TP + c4 * 2) = pack_bf16x4(v);
+        }
+      // LDS operations of one wave execute in order: the reads below see the writes above, the next block row's writes follow the reads
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const int idx = j * 64 + lane, r = idx / 12, c = idx - r * 12;
+        const u32x4 w = *reinterpret_cast<const u32x4*>(stg + r * TP + c * 16);
+        const int row = m0 + wm * 32 * MI + mi * 32 + r;
+        if (row < p.M) __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(cw + (size_t)row * p.ldc + c * 8));
+      }
+    }
+    return;
+  }
 
   // Epilogue: the fp32 tile goes through LDS 32 rows at a time so that every global access is a 16-B piece of a full
   // 384-column row.  Part (mi, h) takes 16 rows of accumulator block mi from EVERY wave (two 16-row groups, one per
@@ -730,6 +779,9 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
   for (int i = 0; i < (EPI == EPI_DGELU ? SLOTS : 1); ++i) { csr[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; csr[i][1] = csr[i][0]; }
   float q8s = 1.0f, omax = 0.f;                                   // EPI_DGELU: scale of the e4m3 copy of du ; running max |du| (next step's scale)
   if constexpr (EPI == EPI_DGELU) { if (p.q8 && p.q8_scale_ptr) q8s = *p.q8_scale_ptr; }
+  // fc1 + GELU (fp8 forward): the running scale of the e4m3 copy is read ONCE here -- read per slot inside epilogue8 it is a load in the
+  // middle of a part's stores (loads and stores retire through one counter)
+  if constexpr (EPI == EPI_BIAS_GELU) { if (p.q8) q8s = p.q8_scale_ptr ? *p.q8_scale_ptr : p.q8_scale; }
   LnbCols lcs;
   if constexpr (lnbwd) {
 #pragma unroll
@@ -797,7 +849,7 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
         f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = w0;
         if (row < p.M) {
           if constexpr (EPI == EPI_RESID) aux[i].s = sScale[trow];
-          if constexpr (EPI == EPI_DGELU) aux[i].s = q8s;
+          if constexpr (EPI == EPI_DGELU || EPI == EPI_BIAS_GELU) aux[i].s = q8s;
           epilogue8<EPI>(p, row, n0 + c8, *reinterpret_cast<const f32x4*>(sC + rl * CLD2 + (c8 >> 1)), *reinterpret_cast<const f32x4*>(sC + rl * CLD2 + PLANE1 + (c8 >> 1)),
                          *reinterpret_cast<const f32x4*>(sBias + (c8 >> 1)), *reinterpret_cast<const f32x4*>(sBias + PLANE1 + (c8 >> 1)), aux[i], w0, w1);
         }
@@ -830,16 +882,10 @@ __global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(
         atomicAdd(p.colsum + n0 + tid, t);
       }
     }
-    if (p.q8_amax) {
-      omax = wave_max(omax);
-      if (lane == 0 && omax > 0.f) atomicMax(reinterpret_cast<unsigned*>(p.q8_amax), __float_as_uint(omax));
-    }
+    if (p.q8_amax) amax_post(p.q8_amax, wave_max(omax), lane, blockIdx.x * WAVES + wid);
   }
   if constexpr (EPI == EPI_BIAS_GELU) {
-    if (p.q8 && p.q8_amax) {
-      omax = wave_max(omax);
-      if (lane == 0 && omax > 0.f) atomicMax(reinterpret_cast<unsigned*>(p.q8_amax), __float_as_uint(omax));
-    }
+    if (p.q8 && p.q8_amax) amax_post(p.q8_amax, wave_max(omax), lane, blockIdx.x * WAVES + wid);
   }
   if constexpr (lnbwd) lnb_flush<WAVES>(p, lcs, sC, tid);        // 9,216 floats of the staging area, behind a barrier
   if constexpr (fused_ln) {                                       // row statistics of the whole tile: two store instructions per wave instead of two per row
@@ -1529,6 +1575,7 @@ int g_dgelu_row384 = 2;     // 306/307/308: dGELU GEMM on the 256x384 tile never
 int g_w4_mode = 0;          // 330 + m: 4-wave two-blocks-per-CU kernels: 0 only for small grids ; 2 = 256x192 (plain epilogues) + 128x384 (row-wise) everywhere ; 3 = 256x192 for the plain epilogues only
 int g_w4_min_m = 8192;      // 350/351: apply the tall / 4-wave kernels from M = 8192 / from any M (parity tests run small shapes)
 int g_w4_auto = 1;          // 360/361: 4-wave kernels for launches of <= 1.5 rounds of 256 x 384 tiles
+int g_bf16_tr = 0;          // 370/371: store-only bf16 epilogue from transposed accumulators (wave-private staging, no block barrier): measured 1-10 % slower
 
 // Algorithmic HBM bytes of one nt GEMM: both operands once, every epilogue input once, every output once.
 template <int EPI>
@@ -1560,18 +1607,18 @@ int launch_nt_cfg(const GemmArgs& a, hipStream_t st) {
   hipLaunchKernelGGL((gemm_nt_kernel<EPI, BMT, NSTG, WTM>), dim3(nblk), dim3(G::THREADS), G::LDS, st, a);
   return (int)hipGetLastError();
 }
-template <int EPI, int MI, bool LN, bool F8 = false>
+template <int EPI, int MI, bool LN, bool F8 = false, bool TR = false>
 int launch_nt_row384_cfg(const GemmArgs& a, hipStream_t st) {
   using RG = row384::Geo<MI>;
-  constexpr int LDS = row384::lds_bytes<MI, EPI, LN>();
+  constexpr int LDS = TR ? RG::NSTG * RG::STAGE + row384::BNR * 4 : row384::lds_bytes<MI, EPI, LN>();
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_row384_kernel<EPI, MI, LN, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_row384_kernel<EPI, MI, LN, F8, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
   const int nblk = ((a.M + RG::BMR - 1) / RG::BMR) * (a.N / row384::BNR);
-  hipLaunchKernelGGL((gemm_nt_row384_kernel<EPI, MI, LN, F8>), dim3(nblk), dim3(row384::THREADS), LDS, st, a);
+  hipLaunchKernelGGL((gemm_nt_row384_kernel<EPI, MI, LN, F8, TR>), dim3(nblk), dim3(row384::THREADS), LDS, st, a);
   return (int)hipGetLastError();
 }
 template <int EPI, int WM, bool LN>
@@ -1594,6 +1641,7 @@ int launch_nt_row384(const GemmArgs& a, hipStream_t st) {
   if (a.fp8) {                                                    // e4m3 operands seen as byte pairs: K, lda, ldb are already halved
     if constexpr (EPI == EPI_BF16 || EPI == EPI_BIAS_GELU || EPI == EPI_RESID || EPI == EPI_F32 || EPI == EPI_DGELU) {
       ProfScope ps(prof_kind<EPI>(), 4.0 * a.M * a.N * a.K, st, nt_bytes<EPI>(a));
+      if constexpr (EPI == EPI_BF16) { if (g_bf16_tr) return launch_nt_row384_cfg<EPI, 4, false, true, true>(a, st); }
       return launch_nt_row384_cfg<EPI, 4, false, true>(a, st);
     } else {
       return ATST_EINVAL;
@@ -1624,6 +1672,9 @@ int launch_nt_row384(const GemmArgs& a, hipStream_t st) {
   if constexpr (EPI == EPI_RESID) {
     if (a.ln_out) return tall ? launch_nt_row384_cfg<EPI, 4, true>(a, st) : launch_nt_row384_cfg<EPI, 2, true>(a, st);
   }
+  if constexpr (EPI == EPI_BF16) {
+    if (g_bf16_tr) return tall ? launch_nt_row384_cfg<EPI, 4, false, false, true>(a, st) : launch_nt_row384_cfg<EPI, 2, false, false, true>(a, st);
+  }
   return tall ? launch_nt_row384_cfg<EPI, 4, false>(a, st) : launch_nt_row384_cfg<EPI, 2, false>(a, st);
 }
 template <int EPI>
@@ -1649,7 +1700,8 @@ int launch_nt(const GemmArgs& a, hipStream_t st) {
 }  // namespace
 
 void atst_gemm_nt_set_variant(int v) {
-  if (v >= 360) g_w4_auto = v - 360;
+  if (v >= 370) g_bf16_tr = v - 370;
+  else if (v >= 360) g_w4_auto = v - 360;
   else if (v >= 350) g_w4_min_m = v == 351 ? 1 : 8192;
   else if (v >= 330) g_w4_mode = v - 330;
   else if (v >= 306) g_dgelu_row384 = v - 306;
@@ -1677,6 +1729,7 @@ int atst_gemm_nt(const GemmArgs& a0, hipStream_t st) {
     return ATST_EINVAL;
   }
   if (a.M <= 0 || a.N % BN || a.K % BK || a.lda % 8 || a.ldb % 8) return ATST_EINVAL;
+  if (a.q8) return ATST_EINVAL;                                   // e4m3 copies of an output are written by the e4m3 GEMMs only (row-384 epilogues own the scale plumbing)
   switch (a.epi) {
     case EPI_BF16: return launch_nt<EPI_BF16>(a, st);
     case EPI_F32: return launch_nt<EPI_F32>(a, st);

@@ -79,7 +79,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         if (y8) {
           st_fp8<W>(y8 + (size_t)row * C + MP::col(i, lane), r, s8);   // fp8 forward: e4m3 copy of the SAME bf16 values (the next GEMM's A operand)
 #pragma unroll
-          for (int e = 0; e < W; ++e) { nclip += fabsf(r[e] * s8) > 448.f ? 1u : 0u; rmax = fmaxf(rmax, fabsf(r[e])); }
+          float cm = 0.f;
+#pragma unroll
+          for (int e = 0; e < W; ++e) cm = fmaxf(cm, fabsf(r[e]));
+          rmax = fmaxf(rmax, cm);
+          if (cm * s8 > 448.f) {                                     // rare: something of this chunk was clipped -- count exactly
+#pragma unroll
+            for (int e = 0; e < W; ++e) nclip += fabsf(r[e] * s8) > 448.f ? 1u : 0u;
+          }
         }
       } else {
         fvec of;
@@ -93,7 +100,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   if constexpr (sizeof(OUT) == 2) {
     if (y8) {
       f8_sat_add(sat, nclip);
-      if (amax8) { rmax = wave_max(rmax); if (lane == 0 && rmax > 0.f) atomicMax(reinterpret_cast<unsigned*>(amax8), __float_as_uint(rmax)); }
+      if (amax8) amax_post(amax8, wave_max(rmax), lane, wave);
     }
   }
 }
@@ -153,10 +160,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs p) {
       if (p.g8) st_fp8<W>(p.g8 + base + MP::col(i, lane), r, s8);   // e4m3 copy of the SAME bf16 values (A operand of the fp8 dgrad GEMM)
     }
   }
-  if (p.g_amax) {
-    gmax = wave_max(gmax);
-    if (lane == 0 && gmax > 0.f) atomicMax(reinterpret_cast<unsigned*>(p.g_amax), __float_as_uint(gmax));
-  }
+  if (p.g_amax) amax_post(p.g_amax, wave_max(gmax), lane, blockIdx.x * 4 + wid);
   // block reduction of the three column accumulators, then one atomic per column per block
 #pragma unroll
   for (int i = 0; i < VPT; ++i) {

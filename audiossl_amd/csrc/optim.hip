@@ -155,7 +155,7 @@ __global__ void quant_weights_kernel(const float* __restrict__ p, const int* __r
 // Gradient operands of the fp8 dgrad GEMMs (delayed scaling): y = e4m3(clamp(x * *scale)) when y != null, and
 // *amax = max(*amax, max |x|) (float bits of a non-negative value order like unsigned) for the NEXT step's scale.
 __global__ void quant_fp8_dyn_kernel(const bf16* __restrict__ x, size_t n8, const float* __restrict__ scale, unsigned* __restrict__ y,
-                                     unsigned* __restrict__ amax, unsigned* __restrict__ sat) {
+                                     float* __restrict__ amax, unsigned* __restrict__ sat) {
   const float sc = scale ? *scale : 1.0f;
   float m = 0.f;
   unsigned nclip = 0;
@@ -163,7 +163,14 @@ __global__ void quant_fp8_dyn_kernel(const bf16* __restrict__ x, size_t n8, cons
     const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + i * 8);
     float f[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { const float t = bf2f(v[e]); m = fmaxf(m, fabsf(t)); nclip += fabsf(t * sc) > 448.f ? 1u : 0u; f[e] = __builtin_amdgcn_fmed3f(t * sc, -448.f, 448.f); }
+    float cm = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float t = bf2f(v[e]); cm = fmaxf(cm, fabsf(t)); f[e] = __builtin_amdgcn_fmed3f(t * sc, -448.f, 448.f); }
+    m = fmaxf(m, cm);
+    if (cm * sc > 448.f) {                                           // rare: count what was clipped
+#pragma unroll
+      for (int e = 0; e < 8; ++e) nclip += fabsf(bf2f(v[e]) * sc) > 448.f ? 1u : 0u;
+    }
     if (y) {
       int lo = 0, hi = 0;
       lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false); lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
@@ -171,8 +178,7 @@ __global__ void quant_fp8_dyn_kernel(const bf16* __restrict__ x, size_t n8, cons
       y[i * 2] = (unsigned)lo; y[i * 2 + 1] = (unsigned)hi;
     }
   }
-  m = wave_max(m);
-  if (amax && (threadIdx.x & 63) == 0 && m > 0.f) atomicMax(amax, __float_as_uint(m));
+  if (amax) amax_post(amax, wave_max(m), threadIdx.x & 63, blockIdx.x * 4 + (threadIdx.x >> 6));   // amax: a SITE (AMAX_SITE_STRIDE floats)
   if (y) f8_sat_add(sat, nclip);
 }
 // after a backward: scale[i] = 448 / (margin * amax[i]) for the next step (unchanged where nothing was observed), amax[i] = 0
@@ -201,7 +207,7 @@ int atst_quant_fp8_dyn(const bf16* x, size_t n, const float* scale, uint8_t* y, 
   if (n == 0) return ATST_OK;
   if (n % 8) return ATST_EINVAL;
   int grid = (int)((n / 8 + 255) / 256); if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(quant_fp8_dyn_kernel, dim3(grid), dim3(256), 0, st, x, n / 8, scale, reinterpret_cast<unsigned*>(y), reinterpret_cast<unsigned*>(amax), sat);
+  hipLaunchKernelGGL(quant_fp8_dyn_kernel, dim3(grid), dim3(256), 0, st, x, n / 8, scale, reinterpret_cast<unsigned*>(y), amax, sat);
   return (int)hipGetLastError();
 }
 int atst_fp8_update_scales(float* amax, float* scale, int n, float margin, hipStream_t st) {

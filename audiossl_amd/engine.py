@@ -183,9 +183,9 @@ class EncoderPass:
             # step also record this step's amax (inference passes do not touch the state)
             e.f8_act_scale = eng.f8a_scale[k].data_ptr()
             if record_amax:
-                e.f8_act_amax = eng.f8a_amax[k].data_ptr()
+                e.f8_act_amax = eng.f8a_amax_sites[k].data_ptr()
             if net == "student" and train:
-                e.p8t, e.g8_scale, e.g8_amax = eng.p8t.data_ptr(), eng.g8_scale.data_ptr(), eng.g8_amax.data_ptr()
+                e.p8t, e.g8_scale, e.g8_amax = eng.p8t.data_ptr(), eng.g8_scale.data_ptr(), eng.g8_amax_sites.data_ptr()
         e.ws, e.ws_bytes = self.ws.buf.data_ptr(), nbytes
         self.e = e
         if self.precise:
@@ -482,11 +482,15 @@ class AtstEngine:
             # 448 / (margin * max amax over the window), initialised to the constants of round 2 / 3 (8, 8, 8, 4); amax of the current step
             self.f8a_scale = torch.tensor([8.0, 8.0, 8.0, 4.0], device=dev).repeat(2, self.depth).contiguous()
             self.f8a_amax = z(2 * 4 * self.depth).view(2, 4 * self.depth)
+            # what the kernels post into: a site is AMAX_SITE_STRIDE floats (16 slots 256 B apart -- same-address atomics serialise at L2, and a
+            # launch posts one per wave); reduced to f8a_amax / g8_amax once per step
+            self.f8a_amax_sites = z(2 * 4 * self.depth * hip.AMAX_SITE_STRIDE).view(2, 4 * self.depth, hip.AMAX_SITE_STRIDE)
             self.f8a_hist = None                                     # [FP8_HISTORY, 2, 4 depth], allocated with the dgrad window below
             # fp8 dgrad (d = 768): e4m3 copy of the transposed weight shadows + delayed-scaling state of the four gradient operands
             # of every block ([depth][4]: g -> fc2, du -> fc1, g2 -> proj, dqkv -> qkv).  fp8_bwd_state: 0 off, 1 recording, 2 on.
             self.p8t = z(L.n_student, torch.uint8)
             self.g8_scale, self.g8_amax = torch.ones(4 * self.depth, device=dev), z(4 * self.depth)
+            self.g8_amax_sites = z(4 * self.depth * hip.AMAX_SITE_STRIDE).view(4 * self.depth, hip.AMAX_SITE_STRIDE)
             self.fp8_bwd_state = 1 if (self.cfg["embed_dim"] == 768 and os.environ.get("ATST_FP8_BWD", "1") != "0") else 0
             self.fp8_margin = 2.0
             # amax HISTORY: the scale of a site is 448 / (margin * max amax over the last FP8_HISTORY steps), so one quiet step does not
@@ -869,6 +873,8 @@ class AtstEngine:
         """Delayed scaling: this step's amax of every gradient operand becomes the next step's quantisation scale (448 / (margin amax));
         the first backward only records (bf16 dgrad), every later one runs the dgrad GEMMs on e4m3 operands."""
         if self.fp8 and getattr(self, "fp8_bwd_state", 0):
+            torch.amax(self.g8_amax_sites, dim=-1, out=self.g8_amax)
+            self.g8_amax_sites.zero_()
             if parallel._collective():
                 dist.all_reduce(self.g8_amax, op=dist.ReduceOp.MAX)            # 4 * depth floats: every rank derives the same scales
             self.g8_hist[self._g8_hist_k % self.FP8_HISTORY].copy_(self.g8_amax)
@@ -884,6 +890,8 @@ class AtstEngine:
         that saw nothing keep their scale.  MAX-reduced over the ranks (replicas quantise on one grid)."""
         if not self.fp8 or self.f8a_hist is None:
             return
+        torch.amax(self.f8a_amax_sites, dim=-1, out=self.f8a_amax)
+        self.f8a_amax_sites.zero_()
         if parallel._collective():
             dist.all_reduce(self.f8a_amax, op=dist.ReduceOp.MAX)
         self.f8a_hist[self._f8a_hist_k % self.FP8_HISTORY].copy_(self.f8a_amax)

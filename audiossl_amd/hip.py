@@ -18,6 +18,8 @@ if os.environ.get("ATST_LIB_TAG"):          # experiment builds side by side (au
 ATST_MAX_DEPTH = 24
 
 EPI_BF16, EPI_F32, EPI_BIAS_GELU, EPI_RESID, EPI_DGELU, EPI_PATCH, EPI_LNBWD = range(7)
+AMAX_SLOTS, AMAX_SLOT_STRIDE = 16, 64                 # include/atst_hip.h ATST_AMAX_*: a running-amax site is 16 slots, 256 B apart
+AMAX_SITE_STRIDE = AMAX_SLOTS * AMAX_SLOT_STRIDE
 
 
 class HipError(RuntimeError):

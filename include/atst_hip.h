@@ -15,6 +15,15 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* A running-amax SITE (delayed fp8 scaling) is not one float: same-address atomics serialise at L2 and a launch posts one per wave.  Every
+ * `amax` argument below that is filled by atomicMax points at ATST_AMAX_SITE_STRIDE floats per site, of which ATST_AMAX_SLOTS (256 B apart) are
+ * used; the site's value is the max over its slots (AtstEngine reduces them once per step), and the caller clears all of them.          */
+#ifndef ATST_AMAX_SLOTS
+#define ATST_AMAX_SLOTS 16
+#define ATST_AMAX_SLOT_STRIDE 64
+#define ATST_AMAX_SITE_STRIDE (ATST_AMAX_SLOTS * ATST_AMAX_SLOT_STRIDE)
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -84,8 +93,9 @@ int atst_gemm_nt_fp8(const uint8_t* A8, const uint8_t* B8, int M, int N, int K, 
 int atst_quant_fp8_bf16(const uint16_t* x, size_t n, float scale, uint8_t* y, void* stream);
 /* per-tensor-scaled e4m3 shadows of n tensors of a flat fp32 buffer: table int32 [n][2] = {element offset, numel};
  * dq[t] = amax_t / 448; amax = device scratch [n]                                                                             */
-/* fp8 dgrad support: y = e4m3(clamp(x * *scale)) (y may be NULL: record only) and *amax = max(*amax, max |x|) ; scale[i] = 448 / (margin
- * amax[i]) then amax[i] = 0 ; e4m3 copy of the transposed bf16 weight shadows with the forward copies' per-tensor factors dq.       */
+/* fp8 dgrad support: y = e4m3(clamp(x * *scale)) (y may be NULL: record only) and max |x| posted into the amax SITE (see ATST_AMAX_SLOTS:
+ * ATST_AMAX_SITE_STRIDE floats) ; update_scales works on REDUCED values, one float per site: scale[i] = 448 / (margin amax[i]) then
+ * amax[i] = 0 ; e4m3 copy of the transposed bf16 weight shadows with the forward copies' per-tensor factors dq.                      */
 int atst_quant_fp8_dyn_bf16(const uint16_t* x, size_t n, const float* scale, uint8_t* y, float* amax, void* stream);
 int atst_fp8_update_scales(float* amax, float* scale, int n, float margin, void* stream);
 int atst_quant_bf16_table_fp8(const uint16_t* p16, const int32_t* table, int n, const float* dq, uint8_t* p8, void* stream);
@@ -194,7 +204,8 @@ typedef struct {
    * n_tok = width / patch_w, the patch-embedding weight is [C, patch_h * patch_w] (a multiple of 256, <= 1024).          */
   int patch_h, patch_w;
   /* fp8 dgrad (C = 768, fp8 != 0): p8t = e4m3 copy of the TRANSPOSED weight shadows (same offsets / per-tensor factors as p8);
-   * g8_scale / g8_amax = [depth][4] device floats, one per gradient operand (g into fc2, du into fc1, g2 into proj, dqkv into qkv):
+   * g8_scale = [depth][4] device floats, g8_amax = [depth][4] amax SITES (ATST_AMAX_SITE_STRIDE floats each), one per gradient operand
+   * (g into fc2, du into fc1, g2 into proj, dqkv into qkv):
    * the operand is quantised with g8_scale (delayed scaling: derived from the previous step's amax by atst_fp8_update_scales) and this
    * step's max |x| is recorded in g8_amax.  fp8_bwd: 0 = bf16 backward, 1 = bf16 backward + amax recording (first step), 2 = fp8 dgrad.
    * Weight gradients always use the bf16 operands.                                                                          */
@@ -207,7 +218,8 @@ typedef struct {
    * the activation scales are constants (8 for LayerNorm / attention outputs, 4 behind GELU: |x| > 56 / 112 saturates at +-448); the
    * caller clears and reads it (AtstEngine.fp8_saturation()).  A non-zero count means the fixed scales no longer fit the run.      */
   uint32_t* f8_sat;
-  /* fp8 forward, running (delayed) activation scales: [depth][4] device floats each, site k of block i = 0: LayerNorm-1 output (qkv GEMM),
+  /* fp8 forward, running (delayed) activation scales: f8_act_scale [depth][4] device floats, f8_act_amax [depth][4] amax SITES
+   * (ATST_AMAX_SITE_STRIDE floats each); site k of block i = 0: LayerNorm-1 output (qkv GEMM),
    * 1: attention output (proj), 2: LayerNorm-2 output (fc1), 3: GELU output (fc2).  f8_act_scale (or NULL = the constants 8, 8, 8, 4) is what
    * the producing kernels quantise with and the consuming GEMMs divide by; f8_act_amax (or NULL) receives max |x| of every site of this pass
    * (atomicMax) -- the caller turns it into the next step's scales (atst_fp8_update_scales; AtstEngine: 448 / (2 * max over 16 steps)).    */

@@ -66,6 +66,26 @@ def test_gemm_nt_plain(M, N, K):
     assert relerr(outb.float(), ref + bias) < 4e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 384, 256), (1027, 1152, 384), (8192 + 77, 1152, 384), (8192, 384, 1536), (16384 + 130, 2304, 768)])
+@pytest.mark.parametrize("has_bias", [True, False])
+def test_gemm_nt_bf16_transposed_epilogue_same_bits(M, N, K, has_bias):
+    """The store-only bf16 epilogue from transposed accumulators (hook 371) writes exactly what the staged fp32 epilogue (370, default) writes:
+    same MFMA sums, same bias add, same rounding -- on 128- and 256-row tiles, ragged last tiles, with and without a bias."""
+    A, B = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2))
+    bias = rnd(N, seed=3) if has_bias else None
+    outs = []
+    try:
+        for hook in (370, 371):
+            hip.load().atst_tune_gemm_variant(hook)
+            o, _ = gemm_nt(A, B, hip.EPI_BF16, torch.bfloat16, bias=bias)
+            outs.append(o)
+    finally:
+        hip.load().atst_tune_gemm_variant(370)
+    ref = A.float() @ B.float().t() + (bias if has_bias else 0.0)
+    assert relerr(outs[1].float(), ref) < 4e-3
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("M", [640, 8192 + 64])                     # 128-row tiles / 256-row tiles with a ragged last tile
 def test_gemm_nt_epilogues(M):
     N, K, rps = 384, 128, 64
@@ -457,15 +477,17 @@ def test_fp8_dynamic_quantiser_and_scale_update():
     n = 8 * 4099
     x = bf(rnd(n, scale=3e-4, seed=3))
     scale = torch.tensor([448.0 / (2.0 * 1.2e-3)], device=DEV)
-    amax = torch.zeros(1, device=DEV)
+    amax = torch.zeros(hip.AMAX_SITE_STRIDE, device=DEV)                 # one amax SITE: 16 slots, 256 B apart (include/atst_hip.h)
     y = torch.empty(n, dtype=torch.uint8, device=DEV)
     hip.call("atst_quant_fp8_dyn_bf16", hip.ptr(x), n, hip.ptr(scale), hip.ptr(y), hip.ptr(amax), hip.stream())
-    assert float(amax) == float(x.float().abs().max())
+    assert float(amax.max()) == float(x.float().abs().max())
+    assert int((amax.view(hip.AMAX_SLOTS, hip.AMAX_SLOT_STRIDE)[:, 1:] != 0).sum()) == 0 and int((amax != 0).sum()) > 1   # spread over the slots, nothing between them
     want = torch.clamp(x.float() * scale, -448, 448).to(torch.float8_e4m3fn)
     assert torch.equal(y.view(torch.float8_e4m3fn).float(), want.float())
     # record-only mode leaves no output and still tracks amax; the update turns amax into the next scale and clears it
-    amax2 = torch.zeros(2, device=DEV); sc2 = torch.ones(2, device=DEV)
-    hip.call("atst_quant_fp8_dyn_bf16", hip.ptr(x), n, None, None, hip.ptr(amax2), hip.stream())
+    sites = torch.zeros(2, hip.AMAX_SITE_STRIDE, device=DEV); sc2 = torch.ones(2, device=DEV)
+    hip.call("atst_quant_fp8_dyn_bf16", hip.ptr(x), n, None, None, hip.ptr(sites), hip.stream())
+    amax2 = sites.amax(dim=-1).contiguous()                             # the reduced value of every site is what the scale update consumes
     hip.call("atst_fp8_update_scales", hip.ptr(amax2), hip.ptr(sc2), 2, 2.0, hip.stream())
     assert abs(float(sc2[0]) - 448.0 / (2.0 * float(x.float().abs().max()))) < 1e-3 * float(sc2[0])
     assert float(sc2[1]) == 1.0 and float(amax2.abs().max()) == 0.0          # nothing observed at site 1: scale unchanged
