@@ -78,7 +78,6 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         *reinterpret_cast<hvec*>(yr + MP::col(i, lane)) = ob;
         if (y8) {
           st_fp8<W>(y8 + (size_t)row * C + MP::col(i, lane), r, s8);   // fp8 forward: e4m3 copy of the SAME bf16 values (the next GEMM's A operand)
-#pragma unroll
           float cm = 0.f;
 #pragma unroll
           for (int e = 0; e < W; ++e) cm = fmaxf(cm, fabsf(r[e]));
