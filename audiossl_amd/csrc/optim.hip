@@ -162,7 +162,6 @@ __global__ void quant_fp8_dyn_kernel(const bf16* __restrict__ x, size_t n8, cons
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
     const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + i * 8);
     float f[8];
-#pragma unroll
     float cm = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) { const float t = bf2f(v[e]); cm = fmaxf(cm, fabsf(t)); f[e] = __builtin_amdgcn_fmed3f(t * sc, -448.f, 448.f); }
