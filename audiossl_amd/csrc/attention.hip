@@ -55,6 +55,9 @@ DEVFN float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 // owned by lane & 31).  A lane holds 4-element groups {8g + 4 hi .. +3}; v_permlane32_swap trades groups between the
 // two half-waves so that every lane ends up with two complete 8-element (16-B) pieces per tile: 4 dwordx4 stores per
 // row instead of 8 dwordx2 (the row-per-lane store tail is issue-bound: -18 % on the forward kernel).
+#ifndef ATST_ATTN_NT              // build-time A/B of the store cache policy: bit 0 row-per-lane stores (store_row64), bit 1 full-line stores (store_tile64_staged)
+#define ATST_ATTN_NT 0
+#endif
 DEVFN unsigned pack2(float a, float b) { bf16x2 t; t[0] = f2bf(a); t[1] = f2bf(b); return __builtin_bit_cast(unsigned, t); }
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 DEVFN void store_row64(bf16* row, const f32x16& t0, const f32x16& t1, float mul, int hi) {
@@ -77,7 +80,8 @@ DEVFN void store_row64(bf16* row, const f32x16& t0, const f32x16& t1, float mul,
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       u32x4 o = {P[k][0], P[k][1], P[k + 2][0], P[k + 2][1]};
-      *reinterpret_cast<u32x4*>(row + t * 32 + 16 * hi + 8 * k) = o;
+      if constexpr (ATST_ATTN_NT & 1) __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(row + t * 32 + 16 * hi + 8 * k));
+      else *reinterpret_cast<u32x4*>(row + t * 32 + 16 * hi + 8 * k) = o;
     }
   }
 }
@@ -115,7 +119,8 @@ DEVFN void store_tile64_staged(bf16* g00 /* global address of (row 0, column 0) 
   for (int j = 0; j < 4; ++j) {                                   // instruction j: rows 8 j .. 8 j + 7, lane = (row, chunk): 8 lanes per 128-B line
     const int row = 8 * j + (lane >> 3), c = lane & 7;
     const u32x4 o = *reinterpret_cast<const u32x4*>(stage + row * 128 + ((c ^ (row & 7)) << 4));
-    *reinterpret_cast<u32x4*>(g00 + (size_t)row * ld + c * 8) = o;
+    if constexpr (ATST_ATTN_NT & 2) __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(g00 + (size_t)row * ld + c * 8));
+    else *reinterpret_cast<u32x4*>(g00 + (size_t)row * ld + c * 8) = o;
   }
 }
 

@@ -39,6 +39,13 @@ constexpr int C_LD = BN + 4;                   // fp32 epilogue staging tile [12
 // waited on without also waiting for that store to be acknowledged by L2, so a load -> store -> load -> store sequence
 // costs one full memory round trip per store (measured: that was ~half of every GEMM's time).
 struct EpiAux { f32x4 a0, a1; float s; };
+// Cache policy of the epilogue traffic (build-time A/B: ATST_EXTRA_FLAGS=-DATST_NT=<mask>): bit 0 bf16 stores of epilogue8, bit 1 its fp32
+// stores, bit 2 the fp32 row stores of the row-wise epilogues, bit 3 the epilogue loads, bit 4 the bf16 rows of the row-wise epilogues -- non-temporal when set.
+#ifndef ATST_NT
+#define ATST_NT 15
+#endif
+template <int BIT, class T> DEVFN void st_pol(const T& v, T* dst) { if constexpr ((ATST_NT >> BIT) & 1) __builtin_nontemporal_store(v, dst); else *dst = v; }
+template <int BIT, class T> DEVFN T ld_pol(const T* src) { if constexpr ((ATST_NT >> BIT) & 1) return __builtin_nontemporal_load(src); else return *src; }
 
 // Block barrier for LDS hand-offs inside the epilogues.  __syncthreads() also drains vmcnt (workgroup-scope fence): every part
 // would then wait for the acknowledgement of the global stores it has just issued and for the LDS-DMA refills in flight.
@@ -47,11 +54,11 @@ template <int EPI, bool SCALE = true>
 DEVFN void epi_fetch8(const GemmArgs& p, int row, int col, EpiAux& x) {
   const size_t idx = (size_t)row * p.ldc + col;
   if constexpr (EPI == EPI_RESID) {
-    x.a0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p.resid + idx));
-    x.a1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p.resid + idx + 4));
+    x.a0 = ld_pol<3>(reinterpret_cast<const f32x4*>(p.resid + idx));
+    x.a1 = ld_pol<3>(reinterpret_cast<const f32x4*>(p.resid + idx + 4));
     if constexpr (SCALE) x.s = p.row_scale ? p.row_scale[row / p.rows_per_seq] : 1.0f;   // else: the caller supplies it
   } else if constexpr (EPI == EPI_DGELU) {
-    x.a0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p.U + idx));       // 8 bf16 pre-activations
+    x.a0 = ld_pol<3>(reinterpret_cast<const f32x4*>(p.U + idx));       // 8 bf16 pre-activations
   } else if constexpr (EPI == EPI_PATCH) {
     const int tok = row % p.rows_per_seq;
     x.a0 = *reinterpret_cast<const f32x4*>(p.table + (size_t)tok * p.N + col);
@@ -73,11 +80,11 @@ DEVFN void epilogue8(const GemmArgs& p, int row, int col, f32x4 v0, f32x4 v1, co
   auto st_bf16 = [](void* base, size_t i, const f32x4& lo, const f32x4& hi4) {
     const float t[8] = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
     const bf16x8 o = pack8(t);
-    __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(base) + i));   // streamed once: keep L2 for operands
+    st_pol<0>(o, reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(base) + i));                      // streamed once: keep L2 for operands
   };
   auto st_f32 = [](void* base, size_t i, const f32x4& lo, const f32x4& hi4) {
-    __builtin_nontemporal_store(lo, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + i));
-    __builtin_nontemporal_store(hi4, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + i + 4));
+    st_pol<1>(lo, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + i));
+    st_pol<1>(hi4, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + i + 4));
   };
   if constexpr (EPI == EPI_BF16) {
     st_bf16(p.C, idx, v0 + b0, v1 + b1);
@@ -396,8 +403,8 @@ DEVFN void st_bf16_row(bf16* rowp, const float* v /* [12]: columns 128 j + 4 li 
   recv[0] = __builtin_amdgcn_update_dpp(0u, send[0], 0xB1, 0xF, 0xF, true);
   recv[1] = __builtin_amdgcn_update_dpp(0u, send[1], 0xB1, 0xF, 0xF, true);
   const u32x4 wide = odd ? u32x4{recv[0], recv[1], c1[0], c1[1]} : u32x4{c0[0], c0[1], recv[0], recv[1]};
-  *reinterpret_cast<u32x4*>(rowp + (odd ? 128 + 4 * (li - 1) : 4 * li)) = wide;
-  *reinterpret_cast<u32x2*>(rowp + 256 + 4 * li) = c2;
+  st_pol<4>(wide, reinterpret_cast<u32x4*>(rowp + (odd ? 128 + 4 * (li - 1) : 4 * li)));
+  st_pol<4>(c2, reinterpret_cast<u32x2*>(rowp + 256 + 4 * li));
 }
 // residual + LayerNorm forward of the new row: x_new = resid + s (acc + bias) -> fp32 stream ; h = LN(x_new) -> bf16 operand
 // of the next GEMM ; row statistics saved for the LayerNorm backward.  ref: Block.forward, audiossl/modules/transformer.py:136-150.
@@ -410,7 +417,7 @@ DEVFN void lnf_row(const GemmArgs& p, int row, const float* sRow, const float* s
     const int col = j * 128 + li * 4;
     const f32x4 a4 = *reinterpret_cast<const f32x4*>(sRow + col), b4 = *reinterpret_cast<const f32x4*>(sBias + col);
     const f32x4 o = rv[j] + sc * (a4 + b4);
-    __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (size_t)row * 384 + col));
+    st_pol<2>(o, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (size_t)row * 384 + col));
 #pragma unroll
     for (int e = 0; e < 4; ++e) { v[4 * j + e] = o[e]; sum += o[e]; }
   }
@@ -490,7 +497,7 @@ DEVFN void lnb_row(const GemmArgs& p, int row, bool live, const float* sRow, con
       o[e] = live ? r4[e] + rs * (d4[e] * g4[e] - c1 - xh * c2) : 0.f;
       gs[4 * j + e] = o[e] * sc;
     }
-    if (live) __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (size_t)row * 384 + col));
+    if (live) st_pol<2>(o, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (size_t)row * 384 + col));
     lnb_fold4(cs.du + 2 * j, gs + 4 * j);
   }
   if (p.lnb_g) {                                                   // every lane takes part in the DPP exchange; dead rows do not store
