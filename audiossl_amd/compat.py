@@ -33,6 +33,8 @@ ALIASES: Dict[str, str] = {
 }
 _installed: List[str] = []          # sys.modules keys this module created (aliases and stand-in parents)
 _saved: Dict[str, types.ModuleType] = {}   # entries that were displaced
+_MISSING = object()
+_parent_attrs: List[tuple] = []     # (parent module, attribute, previous value or _MISSING): what install set on REAL parent packages
 
 
 def _ensure_parent(name: str) -> types.ModuleType:
@@ -41,7 +43,12 @@ def _ensure_parent(name: str) -> types.ModuleType:
         return sys.modules[name]
     try:
         return importlib.import_module(name)           # aliases are registered first: a parent's __init__ that imports them gets ours
-    except Exception:                                   # noqa: BLE001 - not installed, or its own imports are missing here
+    except ModuleNotFoundError as e:
+        # only "this package (or the distribution above it) is not installed" turns into a stand-in; a genuine error inside an installed
+        # audiossl -- a missing optional dependency of its __init__, a syntax error -- propagates instead of being hidden behind an empty
+        # package that would also make its siblings unimportable
+        if e.name is None or not (name == e.name or name.startswith(e.name + ".")):
+            raise
         sys.modules.pop(name, None)
         pkg = types.ModuleType(name)
         pkg.__path__ = []                               # a package with nothing of its own to find
@@ -68,7 +75,9 @@ def install_as_audiossl(verbose: bool = False) -> Dict[str, types.ModuleType]:
         for i in range(1, len(parts)):
             parent = _ensure_parent(".".join(parts[:i]))
             child = ".".join(parts[:i + 1])
-            if child in sys.modules:
+            if child in sys.modules and getattr(parent, parts[i], _MISSING) is not sys.modules[child]:
+                if parent.__name__ not in _installed:   # a real package: remember what uninstall() has to put back
+                    _parent_attrs.append((parent, parts[i], getattr(parent, parts[i], _MISSING)))
                 setattr(parent, parts[i], sys.modules[child])
     if verbose:
         for up, mod in out.items():
@@ -77,7 +86,14 @@ def install_as_audiossl(verbose: bool = False) -> Dict[str, types.ModuleType]:
 
 
 def uninstall() -> None:
-    """Undo install_as_audiossl(): drop the aliases and stand-ins, restore displaced modules."""
+    """Undo install_as_audiossl(): drop the aliases and stand-ins, restore displaced modules and the attributes of real parent packages."""
+    for parent, attr, old in reversed(_parent_attrs):
+        if old is _MISSING:
+            if hasattr(parent, attr):
+                delattr(parent, attr)
+        else:
+            setattr(parent, attr, old)
+    _parent_attrs.clear()
     for name in reversed(_installed):
         sys.modules.pop(name, None)
     _installed.clear()

@@ -101,3 +101,37 @@ def test_aliases_without_any_distribution():
         print("ok")
     """)
     assert "ok" in out
+
+
+def test_genuine_import_error_in_the_distribution_is_not_hidden(tmp_path):
+    # an installed audiossl whose methods/atst/__init__ needs a dependency that is missing here: install_as_audiossl() must surface that
+    # error, not replace the package by an empty stand-in (which would also make its siblings, e.g. .downstream, unimportable); and
+    # uninstall() takes the attributes it set on REAL parent packages away again
+    _tree(str(tmp_path), {
+        "audiossl/__init__.py": "",
+        "audiossl/methods/__init__.py": "",
+        "audiossl/methods/atst/__init__.py": "import a_dependency_that_is_not_installed_here\n",
+        "audiossl/methods/atst/model.py": "class ATSTLightningModule:\n    decoy = True\n",
+    })
+    out = _run("""
+        import audiossl_amd
+        try:
+            audiossl_amd.install_as_audiossl()
+            raise SystemExit("the distribution's own ImportError was swallowed")
+        except ModuleNotFoundError as e:
+            assert e.name == "a_dependency_that_is_not_installed_here", e.name
+        print("ok")
+    """, str(tmp_path))
+    assert "ok" in out
+    _tree(str(tmp_path), {"audiossl/methods/atst/__init__.py": ""})
+    out = _run("""
+        import sys, audiossl_amd
+        import audiossl.methods.atst as real
+        assert not hasattr(real, "transform")
+        audiossl_amd.install_as_audiossl()
+        assert real.transform.__name__ == "audiossl_amd.methods.atst.transform" and real.model.__name__ == "audiossl_amd.methods.atst.model"
+        audiossl_amd.compat.uninstall()
+        assert not hasattr(real, "transform") and not hasattr(real, "model")           # nothing of ours left on the real package
+        print("ok")
+    """, str(tmp_path))
+    assert "ok" in out
