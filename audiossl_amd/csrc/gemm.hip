@@ -162,8 +162,12 @@ __global__ __launch_bounds__((NtGeo<BMT, NSTG, WTM>::THREADS), (NtGeo<BMT, NSTG,
 
   const int ntn = p.N / BN;
   const int ntm = (p.M + BMT - 1) / BMT;
-  const int id = xcd_remap(blockIdx.x, ntm * ntn);
+  // split-K (EPI_F32 only, p.ksplit > 1): blocks [s ntm ntn, (s + 1) ntm ntn) work on k-tiles [s kchunk, (s + 1) kchunk) of every output tile
+  const int ksp = (EPI == EPI_F32 && p.ksplit > 1) ? p.ksplit : 1;
+  const int ks_id = ksp > 1 ? (int)blockIdx.x / (ntm * ntn) : 0;
+  const int id = xcd_remap(ksp > 1 ? (int)blockIdx.x % (ntm * ntn) : (int)blockIdx.x, ntm * ntn);
   const int m0 = (id / ntn) * BMT, n0 = (id % ntn) * BN;
+  const int nk_all = p.K / BK, kchunk = (nk_all + ksp - 1) / ksp, kt_first = ks_id * kchunk;
 
   // Operand tiles go HBM/L2 -> LDS directly (global_load_lds, 16 B per lane, 1 KiB = 16 rows per wave-instruction, no
   // staging registers), NSTG-1 K-tiles ahead of the MFMAs.  LDS rows are 64 B; chunk c of row r is stored at chunk
@@ -179,12 +183,12 @@ __global__ __launch_bounds__((NtGeo<BMT, NSTG, WTM>::THREADS), (NtGeo<BMT, NSTG,
   for (int j = 0; j < G::A_IPW; ++j) {
     const int row = (wid * G::A_IPW + j) * 16 + lrow;
     int ra = m0 + row; ra = ra < p.M ? ra : p.M - 1;              // clamp: rows >= M are never stored
-    srcA[j] = p.A + (size_t)ra * p.lda + (lchunk ^ ((row >> 2) & 3)) * 8;
+    srcA[j] = p.A + (size_t)ra * p.lda + (lchunk ^ ((row >> 2) & 3)) * 8 + kt_first * BK;
   }
 #pragma unroll
   for (int j = 0; j < NB_PER_WAVE; ++j) {
     const int row = (wid * NB_PER_WAVE + j) * 16 + lrow;
-    srcB[j] = p.B + (size_t)(n0 + row) * p.ldb + (lchunk ^ ((row >> 2) & 3)) * 8;
+    srcB[j] = p.B + (size_t)(n0 + row) * p.ldb + (lchunk ^ ((row >> 2) & 3)) * 8 + kt_first * BK;
   }
   constexpr int LOADS_PER_TILE = G::A_IPW + NB_PER_WAVE;          // per wave, in issue order
   auto issue = [&](int kt) {
@@ -205,7 +209,7 @@ __global__ __launch_bounds__((NtGeo<BMT, NSTG, WTM>::THREADS), (NtGeo<BMT, NSTG,
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = p.K / BK;
+  const int nk = nk_all - kt_first < kchunk ? (nk_all - kt_first > 0 ? nk_all - kt_first : 0) : kchunk;
   const int xr = (l31 >> 2) & 3;                                  // swizzle key of this lane's fragment rows
   const int offA = (wm * WTM + l31) * 64, offB = G::A_BYTES + (wn * 64 + l31) * 64;
 #pragma unroll
@@ -249,6 +253,7 @@ __global__ __launch_bounds__((NtGeo<BMT, NSTG, WTM>::THREADS), (NtGeo<BMT, NSTG,
   const int c8 = (tid & 15) * 8, rr = tid >> 4;
   f32x4 bias0, bias1;
   epi_bias8(p, n0 + c8, bias0, bias1);
+  if (ks_id > 0) { bias0 = f32x4{0.f, 0.f, 0.f, 0.f}; bias1 = bias0; }   // split-K: the bias enters once
   f32x4 csum0 = {0.f, 0.f, 0.f, 0.f}, csum1 = csum0;              // EPI_DGELU: column sums of du = fc1 bias gradient
 #pragma unroll
   for (int part = 0; part < BMT / 64; ++part) {
@@ -278,6 +283,17 @@ __global__ __launch_bounds__((NtGeo<BMT, NSTG, WTM>::THREADS), (NtGeo<BMT, NSTG,
       const int rl = pass * RPP + rr, row = m0 + part * 64 + rl;
       if (row < p.M) {
         f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = w0;
+        if (EPI == EPI_F32 && ksp > 1) {                              // partial sums of this K range: fp32 atomics into the zeroed output
+          // lane-contiguous columns (16 lanes = 64 B of one row per instruction): an atomic instruction costs by the lines it touches --
+          // 8 consecutive columns per lane (16 lines per instruction) ran at 32 G atomics/s, a tenth of what the weight gradients reach
+          float* dst = reinterpret_cast<float*>(p.C) + (size_t)row * p.ldc + n0;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int col = (tid & 15) + 16 * e;
+            atomicAdd(dst + col, sC[rl * C_LD + col] + (ks_id == 0 && p.bias ? p.bias[n0 + col] : 0.f));
+          }
+          continue;
+        }
         epilogue8<EPI>(p, row, n0 + c8, *reinterpret_cast<const f32x4*>(sC + rl * C_LD + c8),
                        *reinterpret_cast<const f32x4*>(sC + rl * C_LD + c8 + 4), bias0, bias1, aux[pass], w0, w1);
         if constexpr (EPI == EPI_DGELU) { csum0 += w0; csum1 += w1; }
@@ -1582,6 +1598,7 @@ int g_dgelu_row384 = 2;     // 306/307/308: dGELU GEMM on the 256x384 tile never
 int g_w4_mode = 0;          // 330 + m: 4-wave two-blocks-per-CU kernels: 0 only for small grids ; 2 = 256x192 (plain epilogues) + 128x384 (row-wise) everywhere ; 3 = 256x192 for the plain epilogues only
 int g_w4_min_m = 8192;      // 350/351: apply the tall / 4-wave kernels from M = 8192 / from any M (parity tests run small shapes)
 int g_w4_auto = 1;          // 360/361: 4-wave kernels for launches of <= 1.5 rounds of 256 x 384 tiles
+int g_f32_splitk = 1;       // 380/381: split-K for fp32-output GEMMs with <= 64 output tiles and K >= 2048
 int g_bf16_tr = 0;          // 370/371: store-only bf16 epilogue from transposed accumulators (wave-private staging, no block barrier): measured 1-10 % slower
 
 // Algorithmic HBM bytes of one nt GEMM: both operands once, every epilogue input once, every output once.
@@ -1609,7 +1626,7 @@ int launch_nt_cfg(const GemmArgs& a, hipStream_t st) {
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  const int nblk = ((a.M + BMT - 1) / BMT) * (a.N / BN);
+  const int nblk = ((a.M + BMT - 1) / BMT) * (a.N / BN) * (EPI == EPI_F32 && a.ksplit > 1 ? a.ksplit : 1);
   ProfScope ps(prof_kind<EPI>(), 2.0 * a.M * a.N * a.K, st, nt_bytes<EPI>(a));
   hipLaunchKernelGGL((gemm_nt_kernel<EPI, BMT, NSTG, WTM>), dim3(nblk), dim3(G::THREADS), G::LDS, st, a);
   return (int)hipGetLastError();
@@ -1695,6 +1712,21 @@ int launch_nt(const GemmArgs& a, hipStream_t st) {
       if constexpr (EPI == EPI_RESID) return launch_nt_row384<EPI>(a, st);
     }
     int v = g_nt_variant;
+    if constexpr (EPI == EPI_F32) {
+      // A handful of output tiles with a long K (the head Linears: 1536 x 256 x 12288 = 24 tiles of 384 k-tiles, 103 us on 24 CUs): split K
+      // over the idle CUs, partial sums by fp32 atomics into a zeroed output (the summation order then varies run to run at the 1e-7 level,
+      // like the weight gradients').  >= 16 k-tiles per split so that a block still amortises its ring start-up.
+      const int tiles = ((a.M + 127) / 128) * (a.N / BN), nk = a.K / BK;
+      if (g_f32_splitk && v < 0 && tiles <= 64 && nk >= 64 && a.ldc == a.N) {
+        int ks = 256 / tiles; if (ks > nk / 16) ks = nk / 16;
+        if (ks > 1) {
+          GemmArgs b = a; b.ksplit = ks;
+          hipError_t e = hipMemsetAsync(a.C, 0, sizeof(float) * (size_t)a.M * a.N, st);
+          if (e != hipSuccess) return (int)e;
+          return launch_nt_cfg<EPI, 128, 3, 64>(b, st);
+        }
+      }
+    }
     if ((v == 4 || (v < 0 && g_row384_auto)) && a.N % 384 == 0 && (EPI != EPI_DGELU || g_dgelu_row384 == 1 || (g_dgelu_row384 == 2 && a.K >= 768))) return launch_nt_row384<EPI>(a, st);
     if (v < 0) v = (EPI == EPI_F32 && a.M >= 16384) ? 3          // ATST-Frame head Linears (83 k rows): 256x128 tile, -13 %
                  : a.K <= 512 ? 0 : 1;
@@ -1707,7 +1739,8 @@ int launch_nt(const GemmArgs& a, hipStream_t st) {
 }  // namespace
 
 void atst_gemm_nt_set_variant(int v) {
-  if (v >= 370) g_bf16_tr = v - 370;
+  if (v >= 380) g_f32_splitk = v - 380;
+  else if (v >= 370) g_bf16_tr = v - 370;
   else if (v >= 360) g_w4_auto = v - 360;
   else if (v >= 350) g_w4_min_m = v == 351 ? 1 : 8192;
   else if (v >= 330) g_w4_mode = v - 330;

@@ -66,6 +66,29 @@ def test_gemm_nt_plain(M, N, K):
     assert relerr(outb.float(), ref + bias) < 4e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(1536, 256, 12288), (512, 256, 12288), (1536, 384, 4096), (200, 128, 2048 + 32)])
+def test_gemm_nt_f32_split_k(M, N, K):
+    """fp32-output GEMMs with a handful of output tiles and a long K (the second head Linear: 24 tiles x 384 k-tiles) split K over the idle CUs
+    and sum the partials with fp32 atomics into a zeroed output: same result as the single-block-per-tile path (hook 380) to fp32 summation
+    order, bias added exactly once, ragged last K chunk and rows beyond M untouched."""
+    A, B = bf(rnd(M, K, seed=1, scale=0.3)), bf(rnd(N, K, seed=2, scale=0.3))
+    bias = rnd(N, seed=3)
+    ref = A.double() @ B.double().t() + bias.double()
+    outs = []
+    try:
+        for hook in (380, 381):
+            hip.load().atst_tune_gemm_variant(hook)
+            pad = torch.full((M + 3, N), 7.0, device=DEV)                          # rows beyond M must stay as they are
+            hip.call("atst_gemm_nt_bf16", hip.ptr(A), hip.ptr(B), M, N, K, K, K, hip.EPI_F32, hip.ptr(pad), N, None, hip.ptr(bias), None, None, 1,
+                     None, None, None, None, None, hip.stream())
+            assert float((pad[M:] - 7.0).abs().max()) == 0.0
+            outs.append(pad[:M].clone())
+    finally:
+        hip.load().atst_tune_gemm_variant(381)
+    assert relerr(outs[0].double(), ref) < 2e-6 and relerr(outs[1].double(), ref) < 2e-6
+    assert relerr(outs[1], outs[0]) < 1e-6
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 384, 256), (1027, 1152, 384), (8192 + 77, 1152, 384), (8192, 384, 1536), (16384 + 130, 2304, 768)])
 @pytest.mark.parametrize("has_bias", [True, False])
 def test_gemm_nt_bf16_transposed_epilogue_same_bits(M, N, K, has_bias):
