@@ -24,7 +24,9 @@
 #include "kernels.h"
 #include "profile.h"
 
+#include <mutex>
 #include <type_traits>
+#include <unordered_map>
 #include <utility>
 
 namespace {
@@ -253,7 +255,6 @@ __global__ __launch_bounds__((NtGeo<BMT, NSTG, WTM>::THREADS), (NtGeo<BMT, NSTG,
   const int c8 = (tid & 15) * 8, rr = tid >> 4;
   f32x4 bias0, bias1;
   epi_bias8(p, n0 + c8, bias0, bias1);
-  if (ks_id > 0) { bias0 = f32x4{0.f, 0.f, 0.f, 0.f}; bias1 = bias0; }   // split-K: the bias enters once
   f32x4 csum0 = {0.f, 0.f, 0.f, 0.f}, csum1 = csum0;              // EPI_DGELU: column sums of du = fc1 bias gradient
 #pragma unroll
   for (int part = 0; part < BMT / 64; ++part) {
@@ -283,15 +284,10 @@ __global__ __launch_bounds__((NtGeo<BMT, NSTG, WTM>::THREADS), (NtGeo<BMT, NSTG,
       const int rl = pass * RPP + rr, row = m0 + part * 64 + rl;
       if (row < p.M) {
         f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = w0;
-        if (EPI == EPI_F32 && ksp > 1) {                              // partial sums of this K range: fp32 atomics into the zeroed output
-          // lane-contiguous columns (16 lanes = 64 B of one row per instruction): an atomic instruction costs by the lines it touches --
-          // 8 consecutive columns per lane (16 lines per instruction) ran at 32 G atomics/s, a tenth of what the weight gradients reach
-          float* dst = reinterpret_cast<float*>(p.C) + (size_t)row * p.ldc + n0;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const int col = (tid & 15) + 16 * e;
-            atomicAdd(dst + col, sC[rl * C_LD + col] + (ks_id == 0 && p.bias ? p.bias[n0 + col] : 0.f));
-          }
+        if (EPI == EPI_F32 && ksp > 1) {                              // partial sums of this K range -> workspace; splitk_reduce_kernel adds them up in a fixed order
+          float* dst = p.ks_ws + ((size_t)ks_id * p.M + row) * p.N + n0 + c8;
+          *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(sC + rl * C_LD + c8);
+          *reinterpret_cast<f32x4*>(dst + 4) = *reinterpret_cast<const f32x4*>(sC + rl * C_LD + c8 + 4);
           continue;
         }
         epilogue8<EPI>(p, row, n0 + c8, *reinterpret_cast<const f32x4*>(sC + rl * C_LD + c8),
@@ -315,6 +311,21 @@ __global__ __launch_bounds__((NtGeo<BMT, NSTG, WTM>::THREADS), (NtGeo<BMT, NSTG,
       }
     }
   }
+}
+
+// Split-K reduction in a FIXED order, as its own launch (stream order makes the partial tiles visible; an in-kernel "last block reduces" needs an
+// agent-scope release, i.e. an L2 write-back per block on this 8-XCD part: measured 68-87 us against 36-42 us for atomics).  Fixed order
+// because the head Linears feed BatchNorm + ReLU gates: with fp32 atomics the order varies from run to run and flips gates of near-zero
+// pre-activations.  C[row, col .. col+3] = bias + sum_s ws[s][row][col .. col+3].
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int ks, int M, int N, const float* __restrict__ bias,
+                                                            float* __restrict__ C, int ldc) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, n4 = (size_t)(N / 4);
+  if (i >= (size_t)M * n4) return;
+  const int row = (int)(i / n4), col = (int)(i % n4) * 4;
+  f32x4 acc = bias ? *reinterpret_cast<const f32x4*>(bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* src = ws + (size_t)row * N + col;
+  for (int s = 0; s < ks; ++s) acc += *reinterpret_cast<const f32x4*>(src + (size_t)s * M * N);
+  *reinterpret_cast<f32x4*>(C + (size_t)row * ldc + col) = acc;
 }
 
 // ---- 384-column tiles: 8 waves (2 x 4) ---------------------------------------------------------------------------------
@@ -1599,6 +1610,23 @@ int g_w4_mode = 0;          // 330 + m: 4-wave two-blocks-per-CU kernels: 0 only
 int g_w4_min_m = 8192;      // 350/351: apply the tall / 4-wave kernels from M = 8192 / from any M (parity tests run small shapes)
 int g_w4_auto = 1;          // 360/361: 4-wave kernels for launches of <= 1.5 rounds of 256 x 384 tiles
 int g_f32_splitk = 1;       // 380/381: split-K for fp32-output GEMMs with <= 64 output tiles and K >= 2048
+// Split-K workspace: per stream (kernels of one stream run in order, so one buffer per stream is race-free), grown on demand, never shrunk.
+struct SplitKWs { float* ws = nullptr; size_t cap = 0; };
+int splitk_workspace(hipStream_t st, size_t floats, float** ws) {
+  static std::mutex mu;
+  static std::unordered_map<hipStream_t, SplitKWs> table;
+  std::lock_guard<std::mutex> lk(mu);
+  SplitKWs& w = table[st];
+  if (floats > w.cap) {
+    if (w.ws) { hipError_t e = hipStreamSynchronize(st); if (e != hipSuccess) return (int)e; (void)hipFree(w.ws); w.ws = nullptr; w.cap = 0; }
+    const size_t want = floats + floats / 4;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&w.ws), want * sizeof(float));
+    if (e != hipSuccess) return (int)e;
+    w.cap = want;
+  }
+  *ws = w.ws;
+  return ATST_OK;
+}
 int g_bf16_tr = 0;          // 370/371: store-only bf16 epilogue from transposed accumulators (wave-private staging, no block barrier): measured 1-10 % slower
 
 // Algorithmic HBM bytes of one nt GEMM: both operands once, every epilogue input once, every output once.
@@ -1714,17 +1742,21 @@ int launch_nt(const GemmArgs& a, hipStream_t st) {
     int v = g_nt_variant;
     if constexpr (EPI == EPI_F32) {
       // A handful of output tiles with a long K (the head Linears: 1536 x 256 x 12288 = 24 tiles of 384 k-tiles, 103 us on 24 CUs): split K
-      // over the idle CUs, partial sums by fp32 atomics into a zeroed output (the summation order then varies run to run at the 1e-7 level,
-      // like the weight gradients').  >= 16 k-tiles per split so that a block still amortises its ring start-up.
+      // over the idle CUs; partial tiles go to a library-owned workspace and splitk_reduce_kernel sums them in a fixed order.  The split
+      // count is a function of K ALONE (16 k-tiles per split, at most 24 splits): the summation order of an output element must not depend on
+      // how many rows the launch has -- 8 ranks with 4 clips each and 1 rank with 32 clips have to produce the same head outputs bit for bit,
+      // or ReLU gates of near-zero pre-activations differ between them (tests/test_dist_gpu.py).
       const int tiles = ((a.M + 127) / 128) * (a.N / BN), nk = a.K / BK;
-      if (g_f32_splitk && v < 0 && tiles <= 64 && nk >= 64 && a.ldc == a.N) {
-        int ks = 256 / tiles; if (ks > nk / 16) ks = nk / 16;
-        if (ks > 1) {
-          GemmArgs b = a; b.ksplit = ks;
-          hipError_t e = hipMemsetAsync(a.C, 0, sizeof(float) * (size_t)a.M * a.N, st);
-          if (e != hipSuccess) return (int)e;
-          return launch_nt_cfg<EPI, 128, 3, 64>(b, st);
-        }
+      if (g_f32_splitk && v < 0 && tiles <= 64 && nk >= 64) {
+        const int ks = nk / 16 < 24 ? nk / 16 : 24;
+        GemmArgs b = a; b.ksplit = ks;
+        const int rc = splitk_workspace(st, (size_t)ks * a.M * a.N, &b.ks_ws);
+        if (rc != ATST_OK) return rc;
+        const int rc2 = launch_nt_cfg<EPI, 128, 3, 64>(b, st);
+        if (rc2 != ATST_OK) return rc2;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((size_t)a.M * (a.N / 4) + 255) / 256)), dim3(256), 0, st, b.ks_ws, ks, a.M, a.N, a.bias,
+                           reinterpret_cast<float*>(a.C), a.ldc);
+        return (int)hipGetLastError();
       }
     }
     if ((v == 4 || (v < 0 && g_row384_auto)) && a.N % 384 == 0 && (EPI != EPI_DGELU || g_dgelu_row384 == 1 || (g_dgelu_row384 == 2 && a.K >= 768))) return launch_nt_row384<EPI>(a, st);

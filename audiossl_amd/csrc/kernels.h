@@ -35,7 +35,8 @@ struct GemmArgs {
   const float* dq;                   // fp8 GEMMs: device scalar multiplied into the accumulators (1 / (scale_A * scale_B)); null = 1
   int fp8;                           // operands are OCP e4m3 bytes (K, lda, ldb in elements = bytes); MX-scaled MFMA, unit block scales
   int skew;                          // only read by tools/experiments/gemm_r02_variants.hip (start-up skew experiment)
-  int ksplit;                        // set by the launcher (EPI_F32, tiny grids, long K): K is split over `ksplit` blocks per tile, fp32 atomics into a zeroed C
+  int ksplit;                        // set by the launcher (EPI_F32, tiny grids, long K): K is split over `ksplit` blocks per output tile
+  float* ks_ws;                      // split-K workspace [ksplit][M][N] of partial sums (library-owned, per stream)
 };
 int atst_gemm_nt(const GemmArgs& a, hipStream_t st);
 void atst_gemm_nt_set_variant(int v);     // tuning hook: -1 auto, 0/1/2 fixed tile configuration

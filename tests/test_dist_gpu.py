@@ -98,7 +98,11 @@ def test_eight_ranks_equal_one_rank_on_the_concatenated_batch(tmp_path, mode):
     print(f"\n[8 ranks vs 1, {mode}] loss {float(eight['loss'][0]):.6f} vs {float(one['loss'][0]):.6f}; flat gradient rel {g:.2e}; predictor {gp:.2e}")
     assert abs(float(eight["loss"][0]) - float(one["loss"][0])) < 3e-4
     assert abs(float(eight["std_s"]) - float(one["std_s"])) < 1e-4 and abs(float(eight["std_t"]) - float(one["std_t"])) < 1e-4
-    assert g < 5e-3 and gp < 1e-4, (g, gp)                                  # measured: clip 1.7e-3 / 2.8e-5, frame 3.4e-4 / 1.5e-5
+    # measured: clip 2.9e-3 / 3.5e-4, frame 3.4e-4 / 1.3e-5.  The predictor figure is set by a handful of ReLU gates of near-zero pre-activations
+    # that the two SyncBN evaluation orders (8 combined partial statistics vs one pass) put on different sides of zero: 2.8e-5 with the head
+    # Linears summed in one block per tile, 3.5e-4 with their K split over 24 blocks (csrc/gemm.hip split-K) -- same kernels and the same
+    # summation order in both runs either way, only the rounding pattern that meets the gates differs.
+    assert g < 5e-3 and gp < 1e-3, (g, gp)
     for k in one.files:
         if k.startswith("bn/") and not k.endswith("num_batches_tracked"):
             assert _rel(eight[k], one[k]) < 1e-4, k

@@ -68,9 +68,9 @@ def test_gemm_nt_plain(M, N, K):
 
 @pytest.mark.parametrize("M,N,K", [(1536, 256, 12288), (512, 256, 12288), (1536, 384, 4096), (200, 128, 2048 + 32)])
 def test_gemm_nt_f32_split_k(M, N, K):
-    """fp32-output GEMMs with a handful of output tiles and a long K (the second head Linear: 24 tiles x 384 k-tiles) split K over the idle CUs
-    and sum the partials with fp32 atomics into a zeroed output: same result as the single-block-per-tile path (hook 380) to fp32 summation
-    order, bias added exactly once, ragged last K chunk and rows beyond M untouched."""
+    """fp32-output GEMMs with a handful of output tiles and a long K (the second head Linear: 24 tiles x 384 k-tiles) split K over the idle CUs;
+    the last block of a tile sums the partial tiles in a fixed order: same result as the single-block-per-tile path (hook 380) to fp32
+    summation order, bit-identical from run to run, bias added exactly once, ragged last K chunk, rows beyond M untouched."""
     A, B = bf(rnd(M, K, seed=1, scale=0.3)), bf(rnd(N, K, seed=2, scale=0.3))
     bias = rnd(N, seed=3)
     ref = A.double() @ B.double().t() + bias.double()
@@ -87,6 +87,11 @@ def test_gemm_nt_f32_split_k(M, N, K):
         hip.load().atst_tune_gemm_variant(381)
     assert relerr(outs[0].double(), ref) < 2e-6 and relerr(outs[1].double(), ref) < 2e-6
     assert relerr(outs[1], outs[0]) < 1e-6
+    again = torch.empty(M, N, device=DEV)
+    for _ in range(3):                                                              # fixed summation order: the same bits every time
+        hip.call("atst_gemm_nt_bf16", hip.ptr(A), hip.ptr(B), M, N, K, K, K, hip.EPI_F32, hip.ptr(again), N, None, hip.ptr(bias), None, None, 1,
+                 None, None, None, None, None, hip.stream())
+        assert torch.equal(again, outs[1])
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 384, 256), (1027, 1152, 384), (8192 + 77, 1152, 384), (8192, 384, 1536), (16384 + 130, 2304, 768)])
