@@ -169,6 +169,10 @@ int atst_log_mixup_exp_f32(const float* x, const float* bank, const int32_t* zid
 int atst_bn_stats_f32(const float* h, int R, int N, float* mean, float* m2, float* scratch, void* stream) {
   return atst_bn_stats(h, R, N, mean, m2, scratch, ST(stream));
 }
+int atst_bn_finish_f32(const float* mean, const float* m2, float count, const float* count_dev, float momentum, float eps,
+                       float* running_mean, float* running_var, int64_t* num_batches_tracked, float* rstd, int n, void* stream) {
+  return atst_bn_finish(mean, m2, count, count_dev, momentum, eps, running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked), rstd, n, ST(stream));
+}
 int atst_bn_apply_relu_bf16(const float* h, const float* mean, const float* rstd, const float* gamma, const float* beta,
                             int R, int N, uint16_t* y, void* stream) {
   return atst_bn_apply_relu(h, mean, rstd, gamma, beta, R, N, BF(y), ST(stream));

@@ -562,8 +562,11 @@ DEVFN void lnb_flush(const GemmArgs& p, const LnbCols& cs, float* red, int tid) 
 // columns per register quad.  The epilogue then needs no fp32 staging and no block barrier: a quad is packed to 8 B of bf16, a wave writes its
 // 32 x 96 block row to a PRIVATE staging strip (12 ds_write_b64 instead of 96 ds_write_b32), reads it back as 16-B pieces of 192-B row segments and
 // stores them; the eight waves drift apart and overlap each other's LDS and store phases.
+#ifndef ATST_MI2_WPS           // waves per SIMD the 128-row instantiation is compiled for: 4 = two blocks per CU (128 registers), 2 = one (256, no spills)
+#define ATST_MI2_WPS 4
+#endif
 template <int EPI, int MI, bool LN = false, bool F8 = false, bool TR = false>
-__global__ __launch_bounds__(512, (MI == 2 ? 4 : 2)) void gemm_nt_row384_kernel(GemmArgs p) {
+__global__ __launch_bounds__(512, (MI == 2 ? ATST_MI2_WPS : 2)) void gemm_nt_row384_kernel(GemmArgs p) {
   static_assert(!TR || (EPI == EPI_BF16 && !LN), "transposed accumulators: store-only bf16 epilogue");
   using namespace row384;
   using RG = row384::Geo<MI>;

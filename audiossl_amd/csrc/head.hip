@@ -34,6 +34,24 @@ __global__ void bn_finalize_kernel(const float* __restrict__ part, int gy, int N
   for (int y = 0; y < gy; ++y) a += part[(size_t)y * N + i];
   out[i] = a * scale;
 }
+// what nn.BatchNorm1d(train) does with the batch statistics besides normalising, in one launch (it was eight element-wise torch kernels
+// per head, 24 launches per step): rstd = rsqrt(M2 / count + eps) ; running_mean <- (1 - mom) running_mean + mom mean ;
+// running_var <- (1 - mom) running_var + mom M2 / max(count - 1, 1) ; num_batches_tracked += 1.  count: the python float of a single
+// rank, or a device scalar across ranks (never read back).  ref: torch.nn.BatchNorm1d inside build_mlp, audiossl/models/atst/byol.py:13-16.
+__global__ void bn_finish_kernel(const float* __restrict__ mean, const float* __restrict__ m2, float count, const float* __restrict__ count_dev,
+                                 float momentum, float eps, float* __restrict__ running_mean, float* __restrict__ running_var,
+                                 long long* __restrict__ num_batches, float* __restrict__ rstd, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && num_batches) *num_batches += 1;
+  if (i >= n) return;
+  const float cnt = count_dev ? *count_dev : count;
+  const float q = m2[i];
+  rstd[i] = 1.0f / sqrtf(q / cnt + eps);
+  if (running_mean) {
+    running_mean[i] = running_mean[i] * (1.0f - momentum) + momentum * mean[i];
+    running_var[i] = running_var[i] * (1.0f - momentum) + momentum * (q / fmaxf(cnt - 1.0f, 1.0f));
+  }
+}
 __global__ void bn_apply_relu_kernel(const float* __restrict__ h, const float* __restrict__ mean, const float* __restrict__ rstd,
                                      const float* __restrict__ gamma, const float* __restrict__ beta, size_t total, int N,
                                      bf16* __restrict__ y) {
@@ -185,6 +203,13 @@ int atst_bn_stats(const float* h, int R, int N, float* mean, float* m2, float* s
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((N + 255) / 256), dim3(256), 0, st, (const float*)scratch, gy, N, 1.0f / R, mean);
   hipLaunchKernelGGL(bn_col_kernel<1>, dim3(N / 64, gy), dim3(256), 0, st, h, R, N, (const float*)mean, scratch);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((N + 255) / 256), dim3(256), 0, st, (const float*)scratch, gy, N, 1.0f, m2);
+  return (int)hipGetLastError();
+}
+int atst_bn_finish(const float* mean, const float* m2, float count, const float* count_dev, float momentum, float eps, float* running_mean,
+                   float* running_var, long long* num_batches, float* rstd, int n, hipStream_t st) {
+  if (n <= 0 || !mean || !m2 || !rstd || (running_mean && !running_var)) return ATST_EINVAL;
+  hipLaunchKernelGGL(bn_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, st, mean, m2, count, count_dev, momentum, eps, running_mean, running_var,
+                     num_batches, rstd, n);
   return (int)hipGetLastError();
 }
 int atst_bn_apply_relu(const float* h, const float* mean, const float* rstd, const float* gamma, const float* beta,

@@ -102,6 +102,8 @@ int atst_token_grad(const float* dx0, const uint8_t* rowflag, int S, int NP, int
 // heads
 #define ATST_BN_ROW_BLOCKS 32
 int atst_bn_stats(const float* h, int R, int N, float* mean, float* m2, float* scratch /* [ATST_BN_ROW_BLOCKS * N] */, hipStream_t st);
+int atst_bn_finish(const float* mean, const float* m2, float count, const float* count_dev, float momentum, float eps, float* running_mean,
+                   float* running_var, long long* num_batches, float* rstd, int n, hipStream_t st);
 int atst_bn_apply_relu(const float* h, const float* mean, const float* rstd, const float* gamma, const float* beta,
                        int R, int N, bf16* y, hipStream_t st);
 int atst_bn_apply_relu_split3(const float* h, const float* mean, const float* rstd, const float* gamma, const float* beta,

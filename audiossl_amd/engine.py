@@ -287,14 +287,13 @@ class HeadPass:
         x16, h = self._pending
         self._pending = None
         R, dev, st = h.shape[0], h.device, hip.stream()
-        var = m2 / count
-        rstd = torch.rsqrt(var + BN_EPS)
         bn = eng.bn_buffers[f"{self.net}.{self.which}"]
-        with torch.no_grad():
-            bn["running_mean"].mul_(1 - BN_MOMENTUM).add_(mean, alpha=BN_MOMENTUM)
-            unb = m2 / torch.clamp(count - 1.0, min=1.0) if isinstance(count, torch.Tensor) else m2 / max(count - 1.0, 1.0)
-            bn["running_var"].mul_(1 - BN_MOMENTUM).add_(unb, alpha=BN_MOMENTUM)
-            bn["num_batches_tracked"] += 1
+        rstd = torch.empty(HEAD_HIDDEN, device=dev)
+        on_dev = isinstance(count, torch.Tensor)
+        cdev = count.to(torch.float32).contiguous() if on_dev else None        # named: must outlive the launch call
+        # rstd + running statistics + num_batches_tracked in one launch (nn.BatchNorm1d(train), models/atst/byol.py:13-16)
+        hip.call("atst_bn_finish_f32", hip.ptr(mean), hip.ptr(m2), 0.0 if on_dev else float(count), hip.ptr(cdev), BN_MOMENTUM, BN_EPS,
+                 hip.ptr(bn["running_mean"]), hip.ptr(bn["running_var"]), hip.ptr(bn["num_batches_tracked"]), hip.ptr(rstd), HEAD_HIDDEN, st)
         # second Linear also in split-bf16: its output feeds the next head's BatchNorm+ReLU gates
         y3 = torch.empty(R, 3 * HEAD_HIDDEN, dtype=torch.bfloat16, device=dev)
         hip.call("atst_bn_apply_relu_split3_bf16", hip.ptr(h), hip.ptr(mean), hip.ptr(rstd), hip.ptr(self._w("1.weight", f32=True)),

@@ -138,6 +138,11 @@ int atst_transpose_bf16_batch(const uint16_t* src_base, uint16_t* dst_base, cons
 
 /* build_mlp's BatchNorm1d(train)+ReLU: audiossl/models/atst/byol.py:13-16                                            */
 int atst_bn_stats_f32(const float* h, int R, int N, float* mean, float* m2, float* scratch /* [32 * N] row-block partials: fixed-order (run-to-run reproducible) reduction */, void* stream);
+/* the rest of BatchNorm1d(train) on the (global) batch statistics, one launch: rstd = rsqrt(M2 / count + eps); running_mean / running_var
+ * (unbiased: M2 / max(count - 1, 1)) momentum update in place (NULL = leave them); *num_batches_tracked += 1 (NULL = skip).  count_dev != NULL
+ * overrides `count` with a device scalar (the cross-rank row count, never read back).                                                */
+int atst_bn_finish_f32(const float* mean, const float* m2, float count, const float* count_dev, float momentum, float eps,
+                       float* running_mean, float* running_var, int64_t* num_batches_tracked, float* rstd, int n, void* stream);
 int atst_bn_apply_relu_bf16(const float* h, const float* mean, const float* rstd, const float* gamma, const float* beta,
                             int R, int N, uint16_t* y, void* stream);
 /* same, output as split-bf16 operand [R, 3N] = [hi | lo | hi] for the following Linear */

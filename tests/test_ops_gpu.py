@@ -354,6 +354,32 @@ def test_rows_colsum_transpose():
     assert torch.equal(t, src.t().contiguous())
 
 
+def test_bn_finish_matches_torch_batchnorm():
+    """atst_bn_finish_f32 = what nn.BatchNorm1d(train) does with the batch statistics besides normalising (rstd, running_mean / running_var with
+    the unbiased variance, num_batches_tracked), with the row count as a host float and as a device scalar (cross-rank count)."""
+    R, N = 300, 4096
+    h = rnd(R, N, seed=1) * 2 + 0.5
+    bn = torch.nn.BatchNorm1d(N).to(DEV).train()
+    with torch.no_grad():
+        bn.running_mean.copy_(rnd(N, seed=2)); bn.running_var.copy_(rnd(N, seed=3).abs() + 0.5)
+    rm, rv, nb = bn.running_mean.clone(), bn.running_var.clone(), bn.num_batches_tracked.clone()
+    bn(h)
+    mean, m2 = torch.empty(N, device=DEV), torch.empty(N, device=DEV)
+    scratch = torch.empty(32 * N, device=DEV)
+    hip.call("atst_bn_stats_f32", hip.ptr(h), R, N, hip.ptr(mean), hip.ptr(m2), hip.ptr(scratch), hip.stream())
+    for count_dev in (None, torch.tensor(float(R), device=DEV)):
+        rm2, rv2, nb2, rstd = rm.clone(), rv.clone(), nb.clone(), torch.empty(N, device=DEV)
+        hip.call("atst_bn_finish_f32", hip.ptr(mean), hip.ptr(m2), float(R) if count_dev is None else 0.0, hip.ptr(count_dev), 0.1, 1e-5,
+                 hip.ptr(rm2), hip.ptr(rv2), hip.ptr(nb2), hip.ptr(rstd), N, hip.stream())
+        assert relerr(rstd, torch.rsqrt(h.var(0, unbiased=False) + 1e-5)) < 1e-6
+        assert relerr(rm2, bn.running_mean) < 1e-6 and relerr(rv2, bn.running_var) < 1e-6
+        assert int(nb2) == int(bn.num_batches_tracked) == int(nb) + 1
+    # statistics only (inference-style use): running buffers untouched
+    rstd = torch.empty(N, device=DEV)
+    hip.call("atst_bn_finish_f32", hip.ptr(mean), hip.ptr(m2), float(R), None, 0.1, 1e-5, None, None, None, hip.ptr(rstd), N, hip.stream())
+    assert relerr(rstd, torch.rsqrt(h.var(0, unbiased=False) + 1e-5)) < 1e-6
+
+
 def test_bn_relu_head():
     R, N = 300, 4096
     h = rnd(R, N, seed=1) * 2 + 0.5
