@@ -21,36 +21,67 @@ constexpr int NFFT = 1024, HOPS = 160, NBIN = 513;
 constexpr int FPB = 32;                       // frames per block (8 per wave)
 constexpr float DB_MIN = -79.6482f, DB_MAX = 50.6842f, TOP_DB = 80.0f, DB_BIAS = 200.0f;
 
-__device__ float2 g_tw512[512];               // exp(-2 pi i j / 512)
-__device__ float2 g_tw1024[NBIN];             // exp(-2 pi i k / 1024), k <= 512
+__device__ f32x2 g_tw512[512];               // exp(-2 pi i j / 512)
+__device__ f32x2 g_tw1024[NBIN];             // exp(-2 pi i k / 1024), k <= 512
 
-DEVFN float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-DEVFN float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-DEVFN float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-DEVFN float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }          // a * (-i)
+// Complex numbers are 2-vectors so that every operation is ONE packed instruction (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 with the
+// swizzles and sign flips in their op_sel / neg modifiers).  Written on HIP's float2 struct the same arithmetic went through LLVM's SLP
+// vectoriser, which built each complex product from two packed FMAs (sum and difference) and stitched the halves together with v_mov:
+// 177 moves in a kernel that is bound by VALU issue.
+typedef f32x2 cpx;
+DEVFN cpx mk(float re, float im) { return cpx{re, im}; }
+DEVFN cpx cmul(cpx a, cpx b) { return __builtin_elementwise_fma(a.yy, cpx{-b.y, b.x}, a.xx * b); }   // (ax bx - ay by, ax by + ay bx)
+DEVFN cpx rot90(cpx b) { return cpx{-b.y, b.x}; }                          // i b
+DEVFN cpx cmul_r(cpx a, cpx b, cpx ib) { return __builtin_elementwise_fma(a.yy, ib, a.xx * b); }   // a * b with i b supplied (frame-invariant twiddles)
+DEVFN cpx cadd(cpx a, cpx b) { return a + b; }
+DEVFN cpx csub(cpx a, cpx b) { return a - b; }
+DEVFN cpx mul_mi(cpx a) { return cpx{a.y, -a.x}; }                          // a * (-i)
 
 // 8-point DFT, natural-order in / natural-order out (three radix-2 layers)
-DEVFN void dft8(float2* u) {
+DEVFN void dft8(cpx* u) {
   const float s = 0.70710678118654752f;
-  float2 a[8];
+  cpx a[8];
 #pragma unroll
   for (int i = 0; i < 4; ++i) { a[i] = cadd(u[i], u[i + 4]); a[i + 4] = csub(u[i], u[i + 4]); }
-  a[5] = cmul(a[5], make_float2(s, -s));
+  a[5] = (a[5] + mul_mi(a[5])) * s;                                        // a5 * (s, -s)
   a[6] = mul_mi(a[6]);
-  a[7] = cmul(a[7], make_float2(-s, -s));
-  float2 b[8];
+  a[7] = (mul_mi(a[7]) - a[7]) * s;                                        // a7 * (-s, -s)
+  cpx b[8];
 #pragma unroll
   for (int h = 0; h < 8; h += 4) {
     b[h] = cadd(a[h], a[h + 2]); b[h + 2] = csub(a[h], a[h + 2]);
     b[h + 1] = cadd(a[h + 1], a[h + 3]); b[h + 3] = mul_mi(csub(a[h + 1], a[h + 3]));
   }
-  float2 c[8];
+  cpx c[8];
 #pragma unroll
   for (int h = 0; h < 8; h += 4) {
     c[h] = cadd(b[h], b[h + 1]); c[h + 1] = csub(b[h], b[h + 1]);
     c[h + 2] = cadd(b[h + 2], b[h + 3]); c[h + 3] = csub(b[h + 2], b[h + 3]);
   }
   u[0] = c[0]; u[1] = c[4]; u[2] = c[2]; u[3] = c[6]; u[4] = c[1]; u[5] = c[5]; u[6] = c[3]; u[7] = c[7];
+}
+// the same transform with the outputs left where the last layer produces them: v[j] is natural output BREV8(j); the callers store v[j] at
+// the address of output BREV8(j), a compile-time index.
+DEVFN constexpr int BREV8(int j) { return ((j & 1) << 2) | (j & 2) | ((j & 4) >> 2); }
+DEVFN void dft8_brev(cpx* u) {
+  const float s = 0.70710678118654752f;
+  cpx a[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { a[i] = cadd(u[i], u[i + 4]); a[i + 4] = csub(u[i], u[i + 4]); }
+  a[5] = (a[5] + mul_mi(a[5])) * s;
+  a[6] = mul_mi(a[6]);
+  a[7] = (mul_mi(a[7]) - a[7]) * s;
+  cpx b[8];
+#pragma unroll
+  for (int h = 0; h < 8; h += 4) {
+    b[h] = cadd(a[h], a[h + 2]); b[h + 2] = csub(a[h], a[h + 2]);
+    b[h + 1] = cadd(a[h + 1], a[h + 3]); b[h + 3] = mul_mi(csub(a[h + 1], a[h + 3]));
+  }
+#pragma unroll
+  for (int h = 0; h < 8; h += 4) {
+    u[h] = cadd(b[h], b[h + 1]); u[h + 1] = csub(b[h], b[h + 1]);
+    u[h + 2] = cadd(b[h + 2], b[h + 3]); u[h + 3] = csub(b[h + 2], b[h + 3]);
+  }
 }
 
 DEVFN int reflect(int i, int n) { i = i < 0 ? -i : i; return i >= n ? 2 * (n - 1) - i : i; }
@@ -65,6 +96,9 @@ DEVFN int reflect(int i, int n) { i = i < 0 ? -i : i; return i >= n ? 2 * (n - 1
 #ifndef ATST_MEL_ABL
 #define ATST_MEL_ABL 0
 #endif
+#ifndef ATST_MEL_TWO_BUFFERS
+#define ATST_MEL_TWO_BUFFERS 0
+#endif
 #ifndef ATST_MEL_OCC
 #define ATST_MEL_OCC 2                 // waves per SIMD the register allocation is held to.  3 (what the 54 KB of LDS would allow) spills 7 registers: 1170 vs 1069 us per 512 clips (profiles/r04_mel_probe.txt)
 #endif
@@ -75,8 +109,15 @@ __global__ __launch_bounds__(256, ATST_MEL_OCC) void stft_mel_db_kernel(const fl
                                                           int fb_maxlen, float* __restrict__ out, unsigned int* __restrict__ clipmax) {
   // padded indices: pa(i) = i + i/8 (the radix-8 pass writes 8 consecutive points per lane: 64-B lane stride otherwise,
   // 8-way bank conflicts), pb(i) = i + 8 (i/64) (the second pass scatters groups of 8 lanes 512 B apart)
-  __shared__ float2 fa[4][576];
-  __shared__ float2 fb[4][576];
+  // ONE transform buffer per wave, the three passes work in place: a wave's LDS instructions execute in order, so the reads of a pass (one
+  // instruction for all 64 lanes) are served before the writes that follow them.  (Two buffers made the block 54 KB of LDS = two blocks per
+  // CU whatever the register budget; 36 KB allows four.)
+  __shared__ cpx fa[4][576];
+#if ATST_MEL_TWO_BUFFERS
+  __shared__ cpx fb[4][576];
+#else
+  cpx (*fb)[576] = fa;
+#endif
   __shared__ float pw[4][NBIN + 7 + MAXLEN];                        // the tail is read (with zero weights) by bands whose filter is shorter than MAXLEN: kept zero
   constexpr int NMEL = 64 * NB;
   __shared__ float dbb[NMEL][FPB + 1];
@@ -97,13 +138,14 @@ __global__ __launch_bounds__(256, ATST_MEL_OCC) void stft_mel_db_kernel(const fl
     for (int i = lane; i < 7 + MAXLEN; i += 64) pw[wid][NBIN + i] = 0.f;
   }
   // twiddles of the two twiddled passes depend on the lane only: fetched once per block, not once per frame
-  float2 tw8[8], tw64[8], tw1k[9];
+  cpx tw8[8], tw64[8], tw1k[9], tw8r[8], tw64r[8], tw1kr[9];      // ...r: i * twiddle, so that a complex product is two packed instructions with no sign flip
 #pragma unroll
-  for (int j = 0; j < 9; ++j) tw1k[j] = g_tw1024[lane + 64 * j <= 512 ? lane + 64 * j : 512];
+  for (int j = 0; j < 9; ++j) { tw1k[j] = g_tw1024[lane + 64 * j <= 512 ? lane + 64 * j : 512]; tw1kr[j] = rot90(tw1k[j]); asm volatile("" : "+v"(tw1kr[j])); }   // opaque: not re-derived (one v_xor) at every use
   f32x2 win[8];                                                    // this lane's 16 window taps
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
-    tw8[r] = g_tw512[(lane & 7) * r * 8]; tw64[r] = g_tw512[lane * r];
+    tw8[r] = g_tw512[(lane & 7) * r * 8]; tw64[r] = g_tw512[lane * r]; tw8r[r] = rot90(tw8[r]); tw64r[r] = rot90(tw64[r]);
+    asm volatile("" : "+v"(tw8r[r]), "+v"(tw64r[r]));
     win[r] = *reinterpret_cast<const f32x2*>(window + 2 * (lane + 64 * r));
   }
   // every wave transforms its own frame in its own LDS arrays: the passes only need the wave's LDS writes to be visible
@@ -113,10 +155,10 @@ __global__ __launch_bounds__(256, ATST_MEL_OCC) void stft_mel_db_kernel(const fl
     const int fl = fi * 4 + wid;                       // frame within block
     int t = t0 + fl; if (t >= T) t = T - 1;             // duplicates are computed but never stored
     const int base = t * HOPS - NFFT / 2;
-    float2 u[8];
+    cpx u[8];
 #if ATST_MEL_ABL & 1
 #pragma unroll
-    for (int r = 0; r < 8; ++r) u[r] = make_float2(win[r][0] * (float)(t + r), win[r][1]);
+    for (int r = 0; r < 8; ++r) u[r] = mk(win[r][0] * (float)(t + r), win[r][1]);
     if (false) {
 #else
     if (base >= 0 && base + NFFT <= n_samples && ((reinterpret_cast<size_t>(w + base) & 7) == 0)) {   // interior frame, 8-B aligned: vector loads
@@ -124,35 +166,35 @@ __global__ __launch_bounds__(256, ATST_MEL_OCC) void stft_mel_db_kernel(const fl
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         const f32x2 x2 = *reinterpret_cast<const f32x2*>(w + base + 2 * (lane + 64 * r));
-        u[r] = make_float2(x2[0] * win[r][0], x2[1] * win[r][1]);
+        u[r] = x2 * win[r];
       }
     } else {                                                       // frames that reach into the reflect padding
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         const int j0 = 2 * (lane + 64 * r);
-        u[r] = make_float2(w[reflect(base + j0, n_samples)] * win[r][0], w[reflect(base + j0 + 1, n_samples)] * win[r][1]);
+        u[r] = mk(w[reflect(base + j0, n_samples)], w[reflect(base + j0 + 1, n_samples)]) * win[r];
       }
     }
-    dft8(u);                                            // pass p = 1 : no twiddles, out index lane*8 + r
+    dft8_brev(u);                                       // pass p = 1 : no twiddles, out index lane*8 + r
 #pragma unroll
-    for (int r = 0; r < 8; ++r) fa[wid][lane * 9 + r] = u[r];             // pa(lane * 8 + r)
+    for (int r = 0; r < 8; ++r) fa[wid][lane * 9 + BREV8(r)] = u[r];      // pa(lane * 8 + r)
     wave_sync();
 #if !(ATST_MEL_ABL & 2)
     {                                                   // pass p = 8
       const int k = lane & 7, j = (lane - k) * 8 + k;
 #pragma unroll
-      for (int r = 0; r < 8; ++r) u[r] = cmul(fa[wid][lane + (lane >> 3) + 72 * r], tw8[r]);   // pa(lane + 64 r)
-      dft8(u);
+      for (int r = 0; r < 8; ++r) u[r] = cmul_r(fa[wid][lane + (lane >> 3) + 72 * r], tw8[r], tw8r[r]);   // pa(lane + 64 r)
+      dft8_brev(u);
 #pragma unroll
-      for (int r = 0; r < 8; ++r) fb[wid][j + r * 8 + (lane >> 3) * 8] = u[r];                 // pb(j + 8 r), j + 8 r < 64 (lane >> 3) + 64
+      for (int r = 0; r < 8; ++r) fb[wid][j + BREV8(r) * 8 + (lane >> 3) * 8] = u[r];          // pb(j + 8 r), j + 8 r < 64 (lane >> 3) + 64
     }
     wave_sync();
     {                                                   // pass p = 64
 #pragma unroll
-      for (int r = 0; r < 8; ++r) u[r] = cmul(fb[wid][lane + 72 * r], tw64[r]);                // pb(lane + 64 r)
-      dft8(u);
+      for (int r = 0; r < 8; ++r) u[r] = cmul_r(fb[wid][lane + 72 * r], tw64[r], tw64r[r]);                // pb(lane + 64 r)
+      dft8_brev(u);
 #pragma unroll
-      for (int r = 0; r < 8; ++r) fa[wid][lane + 64 * r] = u[r];
+      for (int r = 0; r < 8; ++r) fa[wid][lane + 64 * BREV8(r)] = u[r];
     }
     wave_sync();
 #endif
@@ -162,12 +204,11 @@ __global__ __launch_bounds__(256, ATST_MEL_OCC) void stft_mel_db_kernel(const fl
     for (int j = 0; j < ((ATST_MEL_ABL & 4) ? 0 : 9); ++j) {
       const int k = lane + 64 * j;
       if (k <= 512) {
-        const float2 zk = fa[wid][k & 511];
-        float2 zc = fa[wid][(512 - k) & 511]; zc.y = -zc.y;
-        const float2 e = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y + zc.y));
-        const float2 d = csub(zk, zc);
-        const float2 o = make_float2(0.5f * d.y, -0.5f * d.x);      // d / (2i)
-        const float2 x = cadd(e, cmul(tw1k[j], o));
+        const cpx zk = fa[wid][k & 511];
+        cpx zc = fa[wid][(512 - k) & 511]; zc.y = -zc.y;
+        const cpx e = (zk + zc) * 0.5f;
+        const cpx o = mul_mi(zk - zc) * 0.5f;                       // d / (2i)
+        const cpx x = cadd(e, cmul_r(o, tw1k[j], tw1kr[j]));
         pw[wid][k] = x.x * x.x + x.y * x.y;
       }
     }
@@ -221,8 +262,8 @@ __global__ void db_finalize_kernel(float* __restrict__ x, const unsigned int* __
 // sincos, rounded to fp32 exactly like the host tables used to be): no hipMemcpyToSymbol, so no entry point synchronises.
 __global__ void twiddle_init_kernel() {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < 512) { const double a = -2.0 * M_PI * i / 512.0; g_tw512[i] = make_float2((float)cos(a), (float)sin(a)); }
-  if (i < NBIN) { const double a = -2.0 * M_PI * i / 1024.0; g_tw1024[i] = make_float2((float)cos(a), (float)sin(a)); }
+  if (i < 512) { const double a = -2.0 * M_PI * i / 512.0; g_tw512[i] = f32x2{(float)cos(a), (float)sin(a)}; }
+  if (i < NBIN) { const double a = -2.0 * M_PI * i / 1024.0; g_tw1024[i] = f32x2{(float)cos(a), (float)sin(a)}; }
 }
 // One fill per DEVICE (the __device__ tables are per device), and a launch on any OTHER stream first waits for the event
 // recorded behind that fill -- a second front-end call on a side stream must not read tables that are still being written.
