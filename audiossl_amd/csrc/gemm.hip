@@ -154,8 +154,11 @@ template <int BMT, int NSTG, int WTM> struct NtGeo {
   static constexpr int WPS = BLOCKS_PER_CU * WAVES / 4 > 8 ? 8 : BLOCKS_PER_CU * WAVES / 4;   // waves per SIMD to plan for
 };
 
-template <int EPI, int BMT, int NSTG, int WTM>
+// KS: split-K instantiation (EPI_F32 only) -- a template parameter so that every other instantiation compiles to exactly what it was without it
+// (as a run-time branch it cost the 256 x 128 tile of the ATST-Frame heads 10 %).
+template <int EPI, int BMT, int NSTG, int WTM, bool KS = false>
 __global__ __launch_bounds__((NtGeo<BMT, NSTG, WTM>::THREADS), (NtGeo<BMT, NSTG, WTM>::WPS)) void gemm_nt_kernel(GemmArgs p) {
+  static_assert(!KS || EPI == EPI_F32, "split-K: fp32 output only");
   using G = NtGeo<BMT, NSTG, WTM>;
   constexpr int MI = G::MI;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -165,7 +168,7 @@ __global__ __launch_bounds__((NtGeo<BMT, NSTG, WTM>::THREADS), (NtGeo<BMT, NSTG,
   const int ntn = p.N / BN;
   const int ntm = (p.M + BMT - 1) / BMT;
   // split-K (EPI_F32 only, p.ksplit > 1): blocks [s ntm ntn, (s + 1) ntm ntn) work on k-tiles [s kchunk, (s + 1) kchunk) of every output tile
-  const int ksp = (EPI == EPI_F32 && p.ksplit > 1) ? p.ksplit : 1;
+  const int ksp = KS ? p.ksplit : 1;
   const int ks_id = ksp > 1 ? (int)blockIdx.x / (ntm * ntn) : 0;
   const int id = xcd_remap(ksp > 1 ? (int)blockIdx.x % (ntm * ntn) : (int)blockIdx.x, ntm * ntn);
   const int m0 = (id / ntn) * BMT, n0 = (id % ntn) * BN;
@@ -284,7 +287,7 @@ __global__ __launch_bounds__((NtGeo<BMT, NSTG, WTM>::THREADS), (NtGeo<BMT, NSTG,
       const int rl = pass * RPP + rr, row = m0 + part * 64 + rl;
       if (row < p.M) {
         f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = w0;
-        if (EPI == EPI_F32 && ksp > 1) {                              // partial sums of this K range -> workspace; splitk_reduce_kernel adds them up in a fixed order
+        if constexpr (KS) {                                           // partial sums of this K range -> workspace; splitk_reduce_kernel adds them up in a fixed order
           float* dst = p.ks_ws + ((size_t)ks_id * p.M + row) * p.N + n0 + c8;
           *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(sC + rl * C_LD + c8);
           *reinterpret_cast<f32x4*>(dst + 4) = *reinterpret_cast<const f32x4*>(sC + rl * C_LD + c8 + 4);
@@ -1648,18 +1651,18 @@ double nt_bytes(const GemmArgs& a) {
 }
 template <int EPI> constexpr int prof_kind() { return EPI == EPI_LNBWD ? PK_GEMM_NT6 : PK_GEMM_NT0 + EPI; }
 
-template <int EPI, int BMT, int NSTG, int WTM>
+template <int EPI, int BMT, int NSTG, int WTM, bool KS = false>
 int launch_nt_cfg(const GemmArgs& a, hipStream_t st) {
   using G = NtGeo<BMT, NSTG, WTM>;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, BMT, NSTG, WTM>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, BMT, NSTG, WTM, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  const int nblk = ((a.M + BMT - 1) / BMT) * (a.N / BN) * (EPI == EPI_F32 && a.ksplit > 1 ? a.ksplit : 1);
+  const int nblk = ((a.M + BMT - 1) / BMT) * (a.N / BN) * (KS ? a.ksplit : 1);
   ProfScope ps(prof_kind<EPI>(), 2.0 * a.M * a.N * a.K, st, nt_bytes<EPI>(a));
-  hipLaunchKernelGGL((gemm_nt_kernel<EPI, BMT, NSTG, WTM>), dim3(nblk), dim3(G::THREADS), G::LDS, st, a);
+  hipLaunchKernelGGL((gemm_nt_kernel<EPI, BMT, NSTG, WTM, KS>), dim3(nblk), dim3(G::THREADS), G::LDS, st, a);
   return (int)hipGetLastError();
 }
 template <int EPI, int MI, bool LN, bool F8 = false, bool TR = false>
@@ -1755,7 +1758,7 @@ int launch_nt(const GemmArgs& a, hipStream_t st) {
         GemmArgs b = a; b.ksplit = ks;
         const int rc = splitk_workspace(st, (size_t)ks * a.M * a.N, &b.ks_ws);
         if (rc != ATST_OK) return rc;
-        const int rc2 = launch_nt_cfg<EPI, 128, 3, 64>(b, st);
+        const int rc2 = launch_nt_cfg<EPI, 128, 3, 64, true>(b, st);
         if (rc2 != ATST_OK) return rc2;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((size_t)a.M * (a.N / 4) + 255) / 256)), dim3(256), 0, st, b.ks_ws, ks, a.M, a.N, a.bias,
                            reinterpret_cast<float*>(a.C), a.ldc);
