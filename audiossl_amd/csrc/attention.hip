@@ -654,6 +654,142 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Backward, NP = 32 (the 1 s local views: 26 tokens, packed), ONE wave per (sequence, head) pair doing both halves.  The two-kernel path reads
+// Q, K, V twice, dO three times and O twice from memory (each kernel stages its own pair of matrices and fetches the other pair as fragments);
+// here Q, K, V, dO are staged once (18 KB per pair, wave-private), O is read once for D = rowsum(dO * O), and the 32 x 32 score tile is simply
+// computed in both orientations (S for dK / dV: lane = key ; S^T for dQ: lane = query) -- 16 extra MFMAs cost nothing next to a second pass
+// over memory and a second launch.
+__global__ __launch_bounds__(256) void attn_bwd32_kernel(AttnArgs p) {
+  constexpr int NP = 32, MAT = NP * A_LD;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+  const int C = p.H * HD;
+  const size_t ld = 3 * (size_t)C;
+  const int pair = blockIdx.x * 4 + wid;
+  if (pair >= p.S * p.H) return;                                  // wave-private LDS, no block barrier below
+  const int s = pair / p.H, h = pair % p.H;
+  constexpr int PAIR_BYTES = 4 * MAT * 2 + 2 * NP * 4;
+  char* pb = smem_raw + wid * PAIR_BYTES;
+  bf16* sQ = reinterpret_cast<bf16*>(pb);
+  bf16* sDO = sQ + MAT; bf16* sK = sDO + MAT; bf16* sV = sK + MAT;
+  float* sLse = reinterpret_cast<float*>(sV + MAT);
+  float* sD = sLse + NP;
+  const int RS = p.stride > 0 ? p.stride : NP;
+  const bf16* base = p.qkv + (size_t)s * RS * ld + h * HD;
+  const bf16* dobase = p.d_o + (size_t)s * RS * C + h * HD;
+  const bf16* obase = p.o + (size_t)s * RS * C + h * HD;
+  stage_rows<NP>(sQ, base, ld, lane, 64, RS);
+  stage_rows<NP>(sK, base + C, ld, lane, 64, RS);
+  stage_rows<NP>(sV, base + 2 * C, ld, lane, 64, RS);
+  stage_rows<NP>(sDO, dobase, (size_t)C, lane, 64, RS);
+  {                                                               // D[q]: half a row per lane (lane = q + 32 half), folded by one swap
+    const int q = l31;
+    float d = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bf16x8 a = ld_frag_if(q < RS, dobase + (size_t)q * C + (hi * 4 + k) * 8), b = ld_frag_if(q < RS, obase + (size_t)q * C + (hi * 4 + k) * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d += bf2f(a[e]) * bf2f(b[e]);
+    }
+    d = pair32_sum(d);
+    if (hi == 0) { sD[q] = d; sLse[q] = p.lse[((size_t)s * p.H + h) * NP + q]; }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // this wave's staging is complete (LDS operations of a wave execute in order)
+  __builtin_amdgcn_wave_barrier();
+  const int valid = p.valid[s];
+  const float scale = 0.125f;
+  const bool live = l31 < RS;
+  // ---- dK, dV: lane = key l31
+  {
+    bf16* dkrow = p.dqkv + ((size_t)s * RS + l31) * ld + C + h * HD;
+    bf16* dvrow = dkrow + C;
+    f32x16 dk0, dk1, dv0, dv1; zero16(dk0); zero16(dk1); zero16(dv0); zero16(dv1);
+    if (valid > 0) {
+      const float kbias = (l31 >= valid) ? MASK_NEG : 0.f;
+      f32x16 sc, dp; zero16(sc); zero16(dp);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        sc = mfma32(ld_frag(sQ + l31 * A_LD + hi * 8 + ks * 16), ld_frag(sK + l31 * A_LD + hi * 8 + ks * 16), sc);      // S[q, kv]
+        dp = mfma32(ld_frag(sDO + l31 * A_LD + hi * 8 + ks * 16), ld_frag(sV + l31 * A_LD + hi * 8 + ks * 16), dp);     // dP[q, kv]
+      }
+      float pv[16], ds[16];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(sLse + 8 * g + 4 * hi);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(sD + 8 * g + 4 * hi);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          const float pr = fast_exp2((sc[r] * scale + kbias - l4[e]) * LOG2E);
+          pv[r] = pr;
+          ds[r] = pr * (dp[r] - d4[e]) * scale;
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const bf16x8 pf = pack8(pv + 8 * t), dsf = pack8(ds + 8 * t);
+        dv0 = mfma32(ld_frag_tr(sDO, A_LD, 16 * t, 0, lane), pf, dv0);
+        dv1 = mfma32(ld_frag_tr(sDO, A_LD, 16 * t, 32, lane), pf, dv1);
+        dk0 = mfma32(ld_frag_tr(sQ, A_LD, 16 * t, 0, lane), dsf, dk0);
+        dk1 = mfma32(ld_frag_tr(sQ, A_LD, 16 * t, 32, lane), dsf, dk1);
+      }
+    }
+    if (live) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 a, b, c, d;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a[e] = f2bf(dk0[4 * g + e]); b[e] = f2bf(dk1[4 * g + e]);
+          c[e] = f2bf(dv0[4 * g + e]); d[e] = f2bf(dv1[4 * g + e]);
+        }
+        *reinterpret_cast<bf16x4*>(dkrow + 8 * g + 4 * hi) = a;
+        *reinterpret_cast<bf16x4*>(dkrow + 32 + 8 * g + 4 * hi) = b;
+        *reinterpret_cast<bf16x4*>(dvrow + 8 * g + 4 * hi) = c;
+        *reinterpret_cast<bf16x4*>(dvrow + 32 + 8 * g + 4 * hi) = d;
+      }
+    }
+  }
+  // ---- dQ: lane = query l31 (S^T[kv, q], as attn_bwd_dq_kernel)
+  {
+    const float D = sD[l31], lse = sLse[l31];
+    f32x16 dq0, dq1; zero16(dq0); zero16(dq1);
+    if (valid > 0) {
+      f32x16 sc, dp; zero16(sc); zero16(dp);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        sc = mfma32(ld_frag(sK + l31 * A_LD + hi * 8 + ks * 16), ld_frag(sQ + l31 * A_LD + hi * 8 + ks * 16), sc);      // S^T[kv, q]
+        dp = mfma32(ld_frag(sV + l31 * A_LD + hi * 8 + ks * 16), ld_frag(sDO + l31 * A_LD + hi * 8 + ks * 16), dp);     // dP^T[kv, q]
+      }
+      float ds[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kv = crow32(r, hi);
+        const float pr = fast_exp2((sc[r] * scale + (kv >= valid ? MASK_NEG : 0.f) - lse) * LOG2E);
+        ds[r] = pr * (dp[r] - D) * scale;
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const bf16x8 dsf = pack8(ds + 8 * t);
+        dq0 = mfma32(ld_frag_tr(sK, A_LD, 16 * t, 0, lane), dsf, dq0);
+        dq1 = mfma32(ld_frag_tr(sK, A_LD, 16 * t, 32, lane), dsf, dq1);
+      }
+    }
+    bf16* dqrow = p.dqkv + ((size_t)s * RS + l31) * ld + h * HD;
+    if (live) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 a, b;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] = f2bf(dq0[4 * g + e]); b[e] = f2bf(dq1[4 * g + e]); }
+        *reinterpret_cast<bf16x4*>(dqrow + 8 * g + 4 * hi) = a;
+        *reinterpret_cast<bf16x4*>(dqrow + 32 + 8 * g + 4 * hi) = b;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Backward, NP = 256, one block (8 waves) per SEQUENCE looping over its heads.  Q, K, V, dO of the current head are all
 // LDS-resident (4 x 36 KB) so that both halves of the backward -- dK/dV (wave = 32 keys) and dQ (wave = 32 queries) --
 // read every operand on-chip after ONE staging pass (the two-kernel version stages Q,dO and K,V separately and re-reads
@@ -1010,8 +1146,9 @@ int launch_bwd(const AttnArgs& a, hipStream_t st) {
 
 int g_bwd256 = 1;          // merged per-sequence backward kernel for NP = 256 (tuning hook 402/403); the round-3 version of it (compiler-scheduled transfers) is in git history: 310 vs 307 us, profiles/r04_attn_time.txt
 int g_fwd256 = 2;          // NP = 256 forward: 2 = two-pass softmax + LDS-DMA head loop, 1 = online-softmax head loop, 0 = per-(sequence, head) kernel (tuning hooks 404 / 401 / 400)
+int g_bwd32 = 1;           // 408 / 409: NP = 32 backward as two kernels (A/B) / one fused kernel (default)
 int g_bwd_row_stores = 0;  // 406 / 407: NP = 256 backward dK / dV stores row-per-lane (A/B) / LDS-transposed full lines (default)
-void atst_attn_set_variant(int v) { if (v == 6 || v == 7) g_bwd_row_stores = v == 6; else if (v == 4) g_fwd256 = 2; else if (v >= 2) g_bwd256 = v - 2; else g_fwd256 = v; }
+void atst_attn_set_variant(int v) { if (v == 8 || v == 9) g_bwd32 = v == 9; else if (v == 6 || v == 7) g_bwd_row_stores = v == 6; else if (v == 4) g_fwd256 = 2; else if (v >= 2) g_bwd256 = v - 2; else g_fwd256 = v; }
 
 int atst_attn_fwd(const AttnArgs& a, hipStream_t st) {
   if (a.S <= 0) return ATST_OK;
@@ -1061,6 +1198,18 @@ int atst_attn_bwd(const AttnArgs& a, hipStream_t st) {
     ProfScope ps(PK_ATTN_BWD_DKV, 14.0 * a.S * a.H * 256.0 * 256.0 * HD, st, 16.0 * a.S * a.H * 256.0 * HD);
     AttnArgs a2 = a; a2.row_stores = g_bwd_row_stores;
     hipLaunchKernelGGL(attn_bwd256_kernel, dim3(a.S), dim3(512), B256_LDS, st, a2, (const float*)a.dscratch);
+    return (int)hipGetLastError();
+  }
+  if (a.NP == 32 && g_bwd32) {                                     // one wave per (sequence, head): both halves from one staging pass
+    constexpr int LDS32 = 4 * (4 * 32 * A_LD * 2 + 2 * 32 * 4);
+    static bool done32 = false;
+    if (!done32) {
+      hipError_t e = hipFuncSetAttribute((const void*)attn_bwd32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS32);
+      if (e != hipSuccess) return (int)e;
+      done32 = true;
+    }
+    ProfScope ps(PK_ATTN_BWD_DKV, 18.0 * a.S * a.H * 32.0 * 32.0 * HD, st, 16.0 * a.S * a.H * 32.0 * HD);
+    hipLaunchKernelGGL(attn_bwd32_kernel, dim3((a.S * a.H + 3) / 4), dim3(256), LDS32, st, a);
     return (int)hipGetLastError();
   }
   switch (a.NP) {

@@ -313,6 +313,14 @@ def test_attention(NP, valid):
         # keys beyond `valid` receive exactly zero gradient
         inval = (rowvalid == 0).reshape(-1)
         assert float(got[inval][:, 1:].abs().max()) == 0.0 if inval.any() else True
+    if NP == 32:                                                        # fused one-wave-per-pair backward (default, hook 409) against the two-kernel path (408)
+        try:
+            hip.load().atst_tune_gemm_variant(408)
+            two = torch.full_like(qkv, float("nan"))
+            hip.call("atst_attention_bwd", hip.ptr(qkv), hip.ptr(vt), hip.ptr(o), hip.ptr(lse), hip.ptr(d_o), hip.ptr(two), None, S, H, NP, hip.stream())
+        finally:
+            hip.load().atst_tune_gemm_variant(409)
+        assert relerr(dqkv.float(), two.float()) < 2e-3                 # same math, D summed in a different order
 
 
 def test_patchify_bit_exact():
