@@ -186,3 +186,34 @@ def test_cnn_patch_embed_layout_matches_reference_names():
     Ll = E.FlatLayout("small", None, True, "Linear")
     assert L.entries["encoder.patch_embed.proj.weight"][0] == Ll.entries["encoder.patch_embed.patch_embed.weight"][0]
     assert L.n_student == Ll.n_student
+
+
+def test_block_mask_against_the_hf_port_of_fairseq_compute_mask_indices():
+    """fairseq is absent, so the block-mask sampler is a restatement of its published algorithm ("parity unpinned").  An independent
+    cross-check: transformers' wav2vec2 `_compute_mask_indices` is a third-party port of the same fairseq function (static spans, overlap
+    allowed).  Its start range is one longer than fairseq's (S - L + 1 against S - L), so the draws are not comparable bit for bit; what must
+    agree: the span COUNT for the same numpy seed (both take it from the first uniform draw: int(p S / L + u), min_masks), that every
+    maximal run is built from spans of length L, and the distribution of the masked fraction (mean over 2000 draws within 1 %)."""
+    import numpy as np
+    from transformers.models.wav2vec2.modeling_wav2vec2 import _compute_mask_indices
+    from audiossl_amd.methods.atstframe.random_mask import block_mask
+    S, p, L = 250, 0.65, 5
+    frac_mine, frac_hf = [], []
+    for seed in range(2000):
+        np.random.seed(seed)
+        u = np.random.rand()
+        n_spans = max(2, int(p * S / L + u))
+        np.random.seed(seed)
+        mine = block_mask(S, p, L, min_masks=2)
+        np.random.seed(seed)
+        hf = _compute_mask_indices((1, S), p, L, min_masks=2)[0]
+        assert mine.dtype == bool and mine.shape == (S,) and hf.shape == (S,)
+        # both are unions of n_spans spans of length L: between L (all coincide) and n_spans * L masked frames, never a run shorter than L
+        for m in (mine, hf):
+            assert L <= int(m.sum()) <= n_spans * L
+            runs = np.diff(np.flatnonzero(np.diff(np.concatenate([[0], m.astype(np.int8), [0]])) != 0))[::2]
+            assert runs.min() >= L or (m[-1] and runs[-1] < L)              # only HF's clamp at the last frame can cut a run short
+        assert not mine[S - 1] or mine[S - L:].all()                        # fairseq's start range ends at S - L - 1: frame S - 1 is only ever the tail of a full span
+        frac_mine.append(mine.mean()); frac_hf.append(hf.mean())
+    assert abs(np.mean(frac_mine) - np.mean(frac_hf)) < 0.01 * np.mean(frac_hf), (np.mean(frac_mine), np.mean(frac_hf))
+    assert abs(np.std(frac_mine) - np.std(frac_hf)) < 0.15 * np.std(frac_hf)
