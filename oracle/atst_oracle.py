@@ -11,7 +11,10 @@ Pinning status (see DESIGN.md section "Oracle"):
   * mel front end (torchaudio), block-mask sampler (fairseq), HF-AdamW (transformers<5): the arithmetic
     lives in third-party packages that are absent from /root/reference and from this image ->
     "parity unpinned" for those three; they follow the published algorithms and are
-    pinned only by known-answer tests (tests/test_oracle_mel.py).
+    pinned only by known-answer tests (tests/test_oracle_mel.py) and by cross-checks against independent third-party
+    implementations that ARE in the image: transformers.audio_utils (mel), transformers' wav2vec2 _compute_mask_indices
+    (a port of the fairseq sampler), torch.optim.AdamW (up to HF-AdamW's two documented differences) --
+    tests/test_oracle_mel.py, tests/test_host_logic_cpu.py.
 
 All ``ref:`` citations are relative to the upstream repository root.
 """

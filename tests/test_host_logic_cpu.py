@@ -217,3 +217,26 @@ def test_block_mask_against_the_hf_port_of_fairseq_compute_mask_indices():
         frac_mine.append(mine.mean()); frac_hf.append(hf.mean())
     assert abs(np.mean(frac_mine) - np.mean(frac_hf)) < 0.01 * np.mean(frac_hf), (np.mean(frac_mine), np.mean(frac_hf))
     assert abs(np.std(frac_mine) - np.std(frac_hf)) < 0.15 * np.std(frac_hf)
+
+
+def test_hf_adamw_restatement_against_torch_adamw():
+    """transformers < 5's AdamW is gone from the image ("parity unpinned": oracle.hf_adamw_step follows its published algorithm).  Independent
+    cross-check against torch.optim.AdamW, which differs from it in exactly two documented ways: (a) eps is added to sqrt(v) BEFORE the bias
+    correction in HF (an effective eps / sqrt(1 - beta2^t)), (b) HF decays the weights after the Adam update, torch before.  With gradients
+    bounded away from zero both effects are second order: over 6 steps the two trajectories must agree to 1e-6 while the parameters move by 6e-3,
+    and with wd = 0 and eps -> 0 they must agree to fp32 rounding."""
+    import torch
+    from oracle import atst_oracle as O
+    g = torch.Generator().manual_seed(0)
+    p0 = torch.randn(4096, generator=g)
+    grads = [torch.sign(torch.randn(4096, generator=g)) * (0.5 + torch.randn(4096, generator=g).abs()) for _ in range(6)]
+    for lr, wd, eps, tol in ((1e-3, 0.04, 1e-6, 1e-6), (1e-3, 0.0, 1e-12, 2e-7)):
+        p = p0.clone(); m = torch.zeros_like(p); v = torch.zeros_like(p)
+        q = torch.nn.Parameter(p0.clone())
+        opt = torch.optim.AdamW([q], lr=lr, betas=(0.9, 0.999), eps=eps, weight_decay=wd)
+        for t, gr in enumerate(grads, 1):
+            O.hf_adamw_step(p, gr, m, v, t, lr, wd, eps=eps)
+            q.grad = gr.clone(); opt.step()
+        moved = float((p - p0).abs().max())
+        diff = float((p - q.detach()).abs().max())
+        assert moved > 5e-3 and diff < tol, (lr, wd, eps, moved, diff)
