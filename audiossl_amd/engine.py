@@ -531,6 +531,10 @@ class AtstEngine:
         self._student_groups = None
         self._grads_summed = False
         self.overlap_teacher = False     # side-stream teacher pass: measured no gain (full-chip kernels serialise), off by default
+        # Two independent chains next to each other wherever one of them cannot fill the chip: the student's local-view groups (M = 26624: 208
+        # blocks on 256 CUs, one 4-wave block each) run their forward beside the TEACHER pass (side stream) and their backward beside the
+        # global-view group's backward.  Same box, same call: 4905-4921 -> 5142-5163 clips/s (+4.9 %).  ATST_OVERLAP_LT=0 switches it off (A/B).
+        self.overlap_local_teacher = os.environ.get("ATST_OVERLAP_LT", "1") != "0"
         self._side = torch.cuda.Stream(device=self.device)
         self._comm = torch.cuda.Stream(device=self.device)     # gradient all-reduce underneath the backward pass
         self.overlap_comm = True
@@ -714,7 +718,7 @@ class AtstEngine:
         s_idx, n_idx = sel.nonzero(as_tuple=True)                                         # row-major (b, n) order
         return (s_idx * NP + n_idx).to(torch.int32).contiguous(), rowflag
 
-    def _run_net(self, net: str, mels, lengths, masks, mask_input: bool, keep, train: bool):
+    def _run_net(self, net: str, mels, lengths, masks, mask_input: bool, keep, train: bool, after_group=None):
         """MultiCropWrapper.forward: encoder per width-group -> rows for the head (view-major).
         ref: audiossl/models/atst/byol.py:103-121 ; methods/atstframe/byol.py:118-138."""
         feats, groups = [], []
@@ -745,6 +749,8 @@ class AtstEngine:
                 hip.call("atst_gather_rows_bf16", hip.ptr(out16), hip.ptr(rows), rows.numel(), self.cfg["embed_dim"], hip.ptr(f), hip.stream())
             feats.append(f)
             groups.append((ep, rows))
+            if after_group is not None:
+                after_group(gi)
         return torch.cat(feats) if len(feats) > 1 else feats[0], groups
 
     def forward(self, mels: List[torch.Tensor], lengths: List[torch.Tensor], masks: Optional[List[torch.Tensor]] = None,
@@ -762,15 +768,30 @@ class AtstEngine:
         # The teacher pass has no data dependence on the student pass: it can run on a second HIP stream (measured: no gain,
         # full-chip kernels serialise; off by default).
         main = torch.cuda.current_stream()
+        lt = self.overlap_local_teacher and not self.overlap_teacher and not self.frame and len(mels) > 2
         if self.overlap_teacher:
             self._side.wait_stream(main)
             with torch.cuda.stream(self._side):
                 tf, _ = self._run_net("teacher", mels[t_sl], lengths[t_sl], sub(masks, t_sl), False, keep_teacher, False)
                 t_out = self.heads["teacher.projector"].forward(tf, False)
+        elif lt:
+            t_out = None
+            box = {}
+
+            def teacher_next_to_local(gi):                     # called after the student's group gi has been enqueued on the main stream
+                if gi == 0:
+                    self._side.wait_stream(main)               # the teacher starts when the student's global-view group is done ...
+                    with torch.cuda.stream(self._side):        # ... and runs while the main stream works through the local-view groups
+                        box["tf"], _ = self._run_net("teacher", mels[t_sl], lengths[t_sl], sub(masks, t_sl), False, keep_teacher, False)
+            sf, groups = self._run_net("student", mels[s_sl], lengths[s_sl], sub(masks, s_sl), True, keep_student, train, after_group=teacher_next_to_local)
+            main.wait_stream(self._side)
+            tf = box["tf"]
+            tf.record_stream(main)
         else:
             tf, _ = self._run_net("teacher", mels[t_sl], lengths[t_sl], sub(masks, t_sl), False, keep_teacher, False)
             t_out = None
-        sf, groups = self._run_net("student", mels[s_sl], lengths[s_sl], sub(masks, s_sl), True, keep_student, train)
+        if not lt:
+            sf, groups = self._run_net("student", mels[s_sl], lengths[s_sl], sub(masks, s_sl), True, keep_student, train)
         if t_out is None:
             # the two projectors' BatchNorm statistics do not depend on each other: ONE cross-rank exchange for both
             # (2 forward SyncBN collectives per step instead of 3; the predictor's needs the student projector's output)
@@ -833,17 +854,34 @@ class AtstEngine:
         if overlap:
             self._reduce_async(L.entries["projector.0.weight"][0], L.n_student)
             self._async_reduce = True
+        # The small (local-view) groups' backward on the side stream NEXT TO the large group's: their launches leave CUs idle, and every
+        # gradient accumulation is an fp32 atomic (weight gradients, bias / LayerNorm column sums, token stage), so the two chains can run
+        # concurrently.  The side stream is joined before the first encoder bucket is reduced (or at the end).
+        main = torch.cuda.current_stream()
+        side_bwd = self.overlap_local_teacher and len(order) > 1 and not self.precise and not self.frame
+        joined = not side_bwd
+        keep_alive = []
         for k, gi in enumerate(order):
             ep, rows = groups[gi]
             n = rows.numel()
-            ep.dout.zero_()
+            last = k == len(order) - 1
             src = df[offs[gi]:offs[gi] + n].contiguous()           # named: must outlive the launch call
+            if side_bwd and not last:
+                if k == 0:
+                    self._side.wait_stream(main)                   # df is final on the main stream
+                keep_alive.append(src)
+                with torch.cuda.stream(self._side):
+                    ep.dout.zero_()
+                    hip.call("atst_scatter_rows_bf16", hip.ptr(src), hip.ptr(rows), n, self.cfg["embed_dim"], hip.ptr(ep.dout), hip.stream())
+                    ep.backward()
+                continue
+            ep.dout.zero_()
             if ep.precise:
                 ep.dout.index_copy_(0, rows.long(), src)
             else:
                 hip.call("atst_scatter_rows_bf16", hip.ptr(src), hip.ptr(rows), n, self.cfg["embed_dim"],
                          hip.ptr(ep.dout), hip.stream())
-            if overlap and k == len(order) - 1:
+            if overlap and last:
                 cuts = self.bucket_cuts()                                               # depth ... 0
                 top = L.entries["projector.0.weight"][0]
                 for hi, lo in zip(cuts[:-1], cuts[1:]):
@@ -852,10 +890,17 @@ class AtstEngine:
                     ep.backward_range(lo, hi)
                     a = 0 if lo == 0 else L.entries[f"encoder.blocks.{lo}.norm1.weight"][0]
                     # LN1 backward of block lo adds the fc2 bias gradient of block lo-1 (below the cut: reduced later)
+                    if not joined:
+                        main.wait_stream(self._side)               # every group has passed this slice only once the side chain is done
+                        joined = True
                     self._reduce_async(a, top)
                     top = a
             else:
                 ep.backward()
+        if not joined:
+            main.wait_stream(self._side)
+        for t in keep_alive:
+            t.record_stream(self._side)
         self._fp8_after_backward()
 
     def bucket_cuts(self) -> List[int]:
