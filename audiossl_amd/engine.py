@@ -530,7 +530,7 @@ class AtstEngine:
         self._stats = torch.zeros(4, HEAD_OUT, device=dev)
         self._student_groups = None
         self._grads_summed = False
-        self.overlap_teacher = False     # side-stream teacher pass: measured no gain (full-chip kernels serialise), off by default
+        self.overlap_teacher = os.environ.get("ATST_OVERLAP_T", "0") == "1"     # side-stream teacher pass next to the WHOLE student pass: measured no gain (full-chip kernels serialise), off by default
         # Two independent chains next to each other wherever one of them cannot fill the chip: the student's local-view groups (M = 26624: 208
         # blocks on 256 CUs, one 4-wave block each) run their forward beside the TEACHER pass (side stream) and their backward beside the
         # global-view group's backward.  Same box, same call: 4905-4921 -> 5142-5163 clips/s (+4.9 %).  ATST_OVERLAP_LT=0 switches it off (A/B).
