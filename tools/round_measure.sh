@@ -10,6 +10,8 @@ timeout 600 python bench.py > $out/bench_clip6.json 2> $out/bench_clip6.err
 timeout 300 python bench.py --workload clip2 --no-cpu-baseline > $out/bench_clip2.json 2> $out/bench_clip2.err
 timeout 300 python bench.py --workload frame --no-cpu-baseline > $out/bench_frame.json 2> $out/bench_frame.err
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o clip6 -- python3 bench.py > $out/bench_clip6_under_rocprof.json 2> $out/prof.err
+# the same command with the second stream off (ATST_OVERLAP_LT=0): per-kernel durations without the time a launch shares the chip with the other chain
+ATST_OVERLAP_LT=0 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_excl -o clip6_exclusive -- python3 bench.py --no-cpu-baseline > $out/bench_clip6_exclusive_under_rocprof.json 2> $out/prof_excl.err
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o f -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile > /dev/null 2> $out/pmc_fetch.err
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o w -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile > /dev/null 2> $out/pmc_write.err
 python tools/traffic_from_pmc.py $out/pmc_fetch $out/pmc_write $out/traffic_clip6.json clip6 "$head" 3
@@ -22,4 +24,4 @@ timeout 300 python bench.py --workload clip2 --batch 64 --steps 40 --no-cpu-base
 find $out -name "*_kernel_stats.csv" | head; cat $out/bench_clip6.json | cut -c1-400
 # the raw per-dispatch counter CSVs are large: keep only the summary json in the merge-back
 rm -rf $out/pmc_fetch $out/pmc_write
-find $out/prof -type f ! -name "*_kernel_stats.csv" -delete
+find $out/prof $out/prof_excl -type f ! -name "*_kernel_stats.csv" -delete
