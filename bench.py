@@ -134,8 +134,9 @@ def main():
                          "sr / n_mels / patch_h / patch_w parameters) -> 2001 frames, 250 patches of 1024 values; use with --arch base --dtype fp8")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--profile-stride", type=int, default=7,
-                    help="HIP events around every n-th launch of each kernel kind (1 = all: costs ~6 %% of the step)")
+    ap.add_argument("--profile-stride", type=int, default=17,
+                    help="HIP events around every n-th launch of each kernel kind (1 = all: costs ~6 %% of the step; 7: ~1.2 %%, events fence the overlap of "
+                         "consecutive kernels and of the two streams; a prime, so that the samples walk through the 12 / 24 / 48 launches a kind has per step)")
     ap.add_argument("--overlap", action="store_true", help="run the teacher pass on a second HIP stream")
     ap.add_argument("--backend", default=os.environ.get("ATST_DIST_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (one rank per GPU); gloo = test transport, lets several ranks share one GPU")
