@@ -245,6 +245,9 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     lib.atst_profile_enable(0)
+    if os.environ.get("ATST_BENCH_MEM"):        # soak runs: allocator state after the timed region (stderr; not part of the JSON contract)
+        print(f"[bench] rank {rank}: max allocated {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB, reserved {torch.cuda.memory_reserved() / 2**30:.2f} GiB",
+              file=sys.stderr, flush=True)
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if dist.is_initialized():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
