@@ -292,6 +292,50 @@ def test_head_and_loss_backward_given_same_features():
         assert rel(got, v.grad.numpy()) < 1.5e-2, k
 
 
+def test_two_stream_step_equals_one_stream_step():
+    """The local-view groups run beside the teacher pass (forward) and beside the global-view group's backward on a second HIP stream
+    (AtstEngine.overlap_local_teacher, default on).  Same weights, same inputs, same DropPath decisions, stream on / off: the forward is made of
+    the same launches in a different interleaving -- loss, head outputs and BatchNorm buffers must be bit-identical --, the gradients differ only
+    by the order of their fp32 atomics (measured 2e-7 of the gradient norm).  6 crops, B = 8, three steps (optimizer + EMA in between)."""
+    B, widths = 8, [1001, 1001, 101, 101, 101, 101]
+    W = O.recipe_weights("small", depth=3, seed=21)
+    gen = torch.Generator().manual_seed(5)
+    keep_t = [(torch.rand(3, 2, 2 * B, generator=gen) > 0.1).float()]
+    keep_s = [(torch.rand(3, 2, 2 * B, generator=gen) > 0.1).float(), (torch.rand(3, 2, 4 * B, generator=gen) > 0.1).float()]
+    for k in keep_t + keep_s:
+        k[0] = 1.0                                              # block 0 never drops (rate 0)
+    runs = {}
+    for on in (False, True):
+        eng = AtstEngine("small", depth=3, ncrops=6, drop_path_rate=0.1)
+        eng.overlap_local_teacher = on
+        eng.load_weights(W)
+        rec = []
+        for step in range(3):
+            mels = [O.recipe_mel(B, w, seed=100 * step + i).cuda() for i, w in enumerate(widths)]
+            lens = [torch.full((B,), w) for w in widths]
+            loss, _, _ = eng.forward(mels, lens, None, keep_t, keep_s)
+            eng.backward()
+            rec.append((float(loss), eng.last_outputs[0].clone(), eng.last_outputs[1].clone(), eng.g32.clone()))
+            if step == 0:
+                bn_first = {k: {b: t.clone() for b, t in v.items()} for k, v in eng.bn_buffers.items()}
+            eng.optimizer_step(1e-3, 0.04, 0.99)
+        torch.cuda.synchronize()
+        runs[on] = (rec, eng.p32.clone(), eng.t32.clone(), bn_first)
+    (r0, p0, t0, bn0), (r1, p1, t1, bn1) = runs[False], runs[True]
+    l0, s0, to0, g0 = r0[0]
+    l1, s1, to1, g1 = r1[0]
+    assert l0 == l1 and torch.equal(s0, s1) and torch.equal(to0, to1)              # step 1: identical weights -> identical forward, bit for bit
+    e = float((g0 - g1).norm() / g0.norm())
+    print(f"\n[two streams vs one] step-1 loss {l0:.6f} == {l1:.6f}; gradient rel diff {e:.2e}; losses {[r[0] for r in r0]} / {[r[0] for r in r1]}")
+    assert e < 2e-5
+    for k in bn0:                                                                    # BatchNorm buffers after the first forward: same launches, same bits
+        for b in bn0[k]:
+            assert torch.equal(bn0[k][b], bn1[k][b]), (k, b)
+    for (la, *_), (lb, *_) in zip(r0[1:], r1[1:]):
+        assert abs(la - lb) < 2e-3                                                   # later steps: Adam turns the 1e-7 gradient noise into O(lr) parameter noise
+    assert float((p0 - p1).abs().max()) < 2.5e-3 * 3 and float((t0 - t1).abs().max()) < 1e-3
+
+
 @pytest.mark.parametrize("name", ["clip_small_2views_b64", "clip_small_2views_b16", "clip_small_2views",
                                   "clip_small_2views_nodrop", "clip_small_6crops"])
 def test_clip_step_vs_reference_golden(name):
