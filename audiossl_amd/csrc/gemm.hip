@@ -12,11 +12,15 @@
 //                           whole rows: the residual epilogue also produces the next LayerNorm (forward) and the dgrad
 //                           epilogue runs the LayerNorm backward (EPI_LNBWD).  e4m3 operands: same ring, MX-scaled MFMA.
 //   gemm_nt_w4_kernel       the same wave tile (128x96) in 4-wave blocks, two per CU, for launches of <= 1.5 rounds
-//   gemm_nt_kernel          128x128 / 256x128 tiles for N % 384 != 0 (heads) and the K = 384 dGELU GEMM
+//   gemm_nt_kernel          128x128 / 256x128 tiles for N % 384 != 0 (heads) and the K = 384 dGELU GEMM; <.., KS = true>: split-K for fp32
+//                           outputs with a handful of tiles and a long K (head Linears), partial tiles summed in a fixed order by
+//                           splitk_reduce_kernel
 //   gemm_tn_tall[_group]_kernel  192x384 weight-gradient tile, the four gradients of a block in one launch
 //   gemm_tn_kernel          128x128 weight-gradient tile for the remaining shapes
 // Measured-and-rejected variants (ping-pong main loop, register epilogue, 64-deep stages, phase skew, split loaders, phase
-// tracers, ablation switches) live in tools/experiments/ (gemm_r02_variants.hip ; wgrad_schedule_variants.patch), not here.
+// tracers, ablation switches) live in tools/experiments/ (gemm_r02_variants.hip ; wgrad_schedule_variants.patch), not here.  One
+// rejected variant of round 4 stays, behind hook 371, because a test keeps it bit-identical to the shipped path: the store-only bf16
+// epilogue from transposed accumulators (template parameter TR of gemm_nt_row384_kernel; 1-10 % slower).
 // Reference math being accelerated: nn.Linear in audiossl/modules/transformer.py:109,119,87-90 and
 // audiossl/models/atst/audio_transformer.py:63,69 ; audiossl/models/atst/byol.py:13 ; LayerNorm backward of
 // audiossl/modules/transformer.py:128,132,144-146.
