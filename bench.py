@@ -135,8 +135,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--profile-stride", type=int, default=17,
-                    help="HIP events around every n-th launch of each kernel kind (1 = all: costs ~6 %% of the step; 7: ~1.2 %%, events fence the overlap of "
-                         "consecutive kernels and of the two streams; a prime, so that the samples walk through the 12 / 24 / 48 launches a kind has per step)")
+                    help="HIP events around one launch in n of each kernel kind, a hashed subset of the launch indices (1 = all: costs ~6 %% of the step; 7: ~0.6 %%; "
+                         "17: ~0.3 %% -- events fence the overlap of consecutive kernels and of the two streams)")
     ap.add_argument("--overlap", action="store_true", help="run the teacher pass on a second HIP stream")
     ap.add_argument("--backend", default=os.environ.get("ATST_DIST_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (one rank per GPU); gloo = test transport, lets several ranks share one GPU")
@@ -304,7 +304,7 @@ def main():
             peak = PEAK_BF16_TFLOPS if d["bound"] == "mfma" else PEAK_HBM_GBS
             roof = {"bound": d["bound"], "kernel": d["kernel"], "achieved": d["achieved"], "peak": peak, "unit": d["unit"],
                     "frac": round(d["achieved"] / peak, 4), "traffic": None, "algorithmic_bytes_per_launch": d["bytes_per_launch"],
-                    "avg_launch_us": d["avg_us"], "launches": d["launches"], "timed_every_nth_launch": args.profile_stride,
+                    "avg_launch_us": d["avg_us"], "launches": d["launches"], "timed_one_launch_in": args.profile_stride,
                     "share_of_timed_kernel_ms": round(d["total_ms"] / sum(r["total_ms"] for r in kernels), 3)}
             if "tflops" in d:
                 roof["tflops"], roof["flop_per_byte"] = d["tflops"], d["flop_per_byte"]
