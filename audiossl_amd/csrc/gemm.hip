@@ -48,7 +48,7 @@ struct EpiAux { f32x4 a0, a1; float s; };
 // Cache policy of the epilogue traffic (build-time A/B: ATST_EXTRA_FLAGS=-DATST_NT=<mask>): bit 0 bf16 stores of epilogue8, bit 1 its fp32
 // stores, bit 2 the fp32 row stores of the row-wise epilogues, bit 3 the epilogue loads, bit 4 the bf16 rows of the row-wise epilogues -- non-temporal when set.
 #ifndef ATST_NT
-#define ATST_NT 15
+#define ATST_NT 127            // bits 5 / 6: the GELU activation a / the plain bf16 GEMM outputs on their own (A/B builds: profiles/r04_cache_policy_ab.txt)
 #endif
 template <int BIT, class T> DEVFN void st_pol(const T& v, T* dst) { if constexpr ((ATST_NT >> BIT) & 1) __builtin_nontemporal_store(v, dst); else *dst = v; }
 template <int BIT, class T> DEVFN T ld_pol(const T* src) { if constexpr ((ATST_NT >> BIT) & 1) return __builtin_nontemporal_load(src); else return *src; }
@@ -88,12 +88,17 @@ DEVFN void epilogue8(const GemmArgs& p, int row, int col, f32x4 v0, f32x4 v1, co
     const bf16x8 o = pack8(t);
     st_pol<0>(o, reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(base) + i));                      // streamed once: keep L2 for operands
   };
+  auto st_bf16_b = [](void* base, size_t i, const f32x4& lo, const f32x4& hi4, auto bit) {           // the same with its own policy bit (A/B builds)
+    const float t[8] = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+    const bf16x8 o = pack8(t);
+    st_pol<decltype(bit)::value>(o, reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(base) + i));
+  };
   auto st_f32 = [](void* base, size_t i, const f32x4& lo, const f32x4& hi4) {
     st_pol<1>(lo, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + i));
     st_pol<1>(hi4, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + i + 4));
   };
   if constexpr (EPI == EPI_BF16) {
-    st_bf16(p.C, idx, v0 + b0, v1 + b1);
+    st_bf16_b(p.C, idx, v0 + b0, v1 + b1, std::integral_constant<int, 6>{});    // bit 6: plain-bf16 GEMM outputs (qkv, dgrads)
   } else if constexpr (EPI == EPI_F32) {
     st_f32(p.C, idx, v0 + b0, v1 + b1);
   } else if constexpr (EPI == EPI_BIAS_GELU) {
@@ -102,7 +107,7 @@ DEVFN void epilogue8(const GemmArgs& p, int row, int col, f32x4 v0, f32x4 v1, co
     f32x4 g0, g1;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { g0[e] = gelu_bf16dst(v0[e]); g1[e] = gelu_bf16dst(v1[e]); }
-    st_bf16(p.C2, idx, g0, g1);                                    // activation a
+    st_bf16_b(p.C2, idx, g0, g1, std::integral_constant<int, 5>{});    // activation a (bit 5: the next GEMM reads it whole)
     if (p.q8) {                                                    // fp8 forward: e4m3 copy of the SAME bf16 values for the fc2 GEMM
       const float s = x.s;                                         // running (delayed) activation scale, or the constant: the caller read it once
       auto c = [&](float a_) { return __builtin_amdgcn_fmed3f(bf2f(f2bf(a_)) * s, -448.f, 448.f); };
