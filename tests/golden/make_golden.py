@@ -398,8 +398,93 @@ def gen_aug(name="aug_byol_a"):
     save(name, **out)
 
 
+def gen_base_encoder_grad(name="base_depth3_encoder_grad"):
+    """ATST-base geometry pinned to the reference: the encoder class AST_base builds (audio_transformer.py:371-374:
+    embed_dim 768, 12 heads, 64 x 4 patches, qkv_bias False, LayerNorm eps 1e-6) at depth 3, ragged lengths, DropPath 0.1 recorded;
+    per-block activations (sampled), CLS, and the gradient of the smooth objective L = sum(CLS * R)."""
+    depth, S = 3, 6
+    torch.manual_seed(3)
+    enc = AST(depth=depth, embed_dim=768, num_heads=12, patch_h=64, patch_w=4, qkv_bias=False,
+              norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), drop_path_rate=0.1)
+    W = O.recipe_weights("base", depth=depth, seed=31)
+    enc.load_state_dict({k[len("student.encoder."):]: v for k, v in W.items() if k.startswith("student.encoder.")})
+    enc.train()
+    mel = O.recipe_mel(S, 1001, seed=33)
+    length = torch.tensor([1001, 1001, 777, 640, 1001, 405])
+    R = torch.from_numpy(np.random.default_rng(35).standard_normal((S, 768)).astype(np.float32))
+    rates = [x.item() for x in torch.linspace(0, 0.1, depth)]
+    torch.manual_seed(37)
+    with RandRecorder() as rr:
+        x, pos, mel_patches, h, w, plen = enc.prepare_tokens(mel, None, length)
+        blocks = []
+        for blk in enc.blocks:
+            x = blk(x, plen + 1)
+            blocks.append(x)
+        cls = enc.norm(x)[:, 0]
+    (cls * R).sum().backward()
+    keep = keep_from_draws(rr.draws, depth, rates)
+    # the same forward through AST.forward with the same draws replayed must give the same CLS (the block loop above IS forward())
+    torch.manual_seed(37)
+    with torch.no_grad():
+        cls2 = enc(mel, length=length)
+    assert torch.allclose(cls2, cls.detach(), atol=1e-6), float((cls2 - cls).abs().max())
+    arrs = dict(S=S, depth=depth, length=length.numpy(), patch_length=plen.numpy(), cls=cls.detach().numpy(), keep=keep.numpy(), rates=np.array(rates))
+    for i, b in enumerate(blocks):
+        arrs[f"block{i}"] = b.detach().numpy()[:, ::10, ::8]
+    arrs.update(grad_digest(enc.named_parameters()))
+    save(name, **arrs)
+
+
+def gen_base_step(name="base_2views_depth2"):
+    """One 2-view training step of an ATST("base")-shaped model at depth 2: the reference's MultiCropWrapper (byol.py:75-121) around
+    AST(embed_dim 768, 12 heads) -- what ATST.__init__ builds for arch == "base" (atst.py:11-17) with a shallower encoder -- its
+    ByolLoss(2), backward, BN running statistics and the EMA update (atst.py:29-34)."""
+    from audiossl.models.atst.byol import MultiCropWrapper, ByolLoss
+    depth, B = 2, 16
+    mk = lambda: AST(depth=depth, embed_dim=768, num_heads=12, patch_h=64, patch_w=4, qkv_bias=False,
+                     norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), drop_path_rate=0.1)
+    torch.manual_seed(123)
+    student = MultiCropWrapper(mk(), 768, predictor=True)
+    teacher = MultiCropWrapper(mk(), 768, predictor=False)
+    for p in teacher.parameters():
+        p.requires_grad = False
+    loss_fn = ByolLoss(2)
+    W = O.recipe_weights("base", depth=depth, seed=41)
+    student.load_state_dict({k[len("student."):]: v for k, v in W.items() if k.startswith("student.")})
+    teacher.load_state_dict({k[len("teacher."):]: v for k, v in W.items() if k.startswith("teacher.")})
+    student.train(); teacher.train()
+    widths = [1001, 1001]
+    mels = [O.recipe_mel(B, w, seed=43 + i) for i, w in enumerate(widths)]
+    lens = [torch.tensor([1001] * B), torch.tensor([1001 - 60 * (i % 4) for i in range(B)])]
+    rates = [x.item() for x in torch.linspace(0, 0.1, depth)]
+    torch.manual_seed(47)
+    with RandRecorder() as rr:
+        t_out = teacher(mels, lens)
+        n_t = len(rr.draws)
+        s_out = student(mels, lens)
+        loss, std_s, std_t = loss_fn(s_out, t_out)
+    loss.backward()
+    arrs = dict(B=B, depth=depth, widths=np.array(widths), lengths=np.stack([l.numpy() for l in lens]), loss=loss.item(), std_s=std_s.item(),
+                std_t=std_t.item(), teacher_out=t_out.detach().numpy()[:8], student_out=s_out.detach().numpy()[:8],
+                keep_t0=keep_from_draws(rr.draws[:n_t], depth, rates).numpy(), keep_s0=keep_from_draws(rr.draws[n_t:], depth, rates).numpy())
+    arrs.update(grad_digest(student.named_parameters()))
+    sd = {**{"student." + k: v for k, v in student.state_dict().items()}, **{"teacher." + k: v for k, v in teacher.state_dict().items()}}
+    for k in ("student.projector.1.running_mean", "student.projector.1.running_var", "student.predictor.1.running_var",
+              "teacher.projector.1.running_mean", "teacher.projector.1.running_var"):
+        arrs["bn/" + k] = sd[k][sample_idx(4096)].numpy()
+    with torch.no_grad():                                              # ATST.update_teacher (atst.py:29-34) on the un-stepped student
+        for net in ("encoder", "projector"):
+            for pq, pk in zip(getattr(student, net).parameters(), getattr(teacher, net).parameters()):
+                pk.data.mul_(0.99).add_((1 - 0.99) * pq.detach().data)
+    tsd = teacher.state_dict()
+    for k in ("encoder.pos_embed", "encoder.blocks.1.mlp.fc1.weight", "projector.0.weight"):
+        v = tsd[k].reshape(-1)
+        arrs["ema/teacher." + k] = v[sample_idx(v.numel())].numpy()
+    save(name, **arrs)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["blocks", "clip2", "clip2_nodrop", "clip6", "frame", "sched", "encgrad", "clip2_b16", "clip2_b64", "infer", "aug", "frame_infer", "frame_asym", "frame_cnn"]
+    which = sys.argv[1:] or ["blocks", "clip2", "clip2_nodrop", "clip6", "frame", "sched", "encgrad", "clip2_b16", "clip2_b64", "infer", "aug", "frame_infer", "frame_asym", "frame_cnn", "base_encgrad", "base_step"]
     if "aug" in which:
         gen_aug()
     if "frame_infer" in which:
@@ -433,3 +518,7 @@ if __name__ == "__main__":
         gen_frame_cnn()
     if "sched" in which:
         gen_sched()
+    if "base_encgrad" in which:
+        gen_base_encoder_grad()
+    if "base_step" in which:
+        gen_base_step()

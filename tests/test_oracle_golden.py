@@ -200,3 +200,50 @@ def test_frame_inference_api_vs_reference_golden():
     assert np.abs(frames.numpy()[:, ::5, ::4] - G["frames"]).max() < 5e-5
     short = O.frame_intermediate_layers(W, "teacher.encoder.", O.recipe_mel(2, 401, seed=65), torch.tensor([401, 401]), n=12)
     assert np.abs(short.numpy() - G["scene_short"]).max() < 2e-5
+
+
+def test_base_encoder_grad_vs_reference_golden(golden_dir):
+    """ATST-base geometry (d = 768, 12 heads; what AST_base builds, audio_transformer.py:371-374) at depth 3 pinned to the imported
+    reference: per-block activations, CLS and the gradient of sum(CLS * R), ragged lengths, recorded DropPath draws."""
+    G = load(golden_dir, "base_depth3_encoder_grad")
+    S, depth = int(G["S"]), int(G["depth"])
+    W = O.recipe_weights("base", depth=depth, seed=31)
+    leaves = [(k[len("student.encoder."):], v.requires_grad_(True)) for k, v in W.items() if k.startswith("student.encoder.")]
+    length = torch.from_numpy(G["length"])
+    assert np.array_equal(O.patch_length(length).numpy(), G["patch_length"])
+    assert np.array_equal(np.array(O.drop_path_rates(depth), np.float64), G["rates"])
+    R = torch.from_numpy(np.random.default_rng(35).standard_normal((S, 768)).astype(np.float32))
+    cls, blocks = O.encoder_forward(W, "student.encoder.", O.recipe_mel(S, 1001, seed=33), length, "base", depth,
+                                    keep=torch.from_numpy(G["keep"]), return_blocks=True)
+    (cls * R).sum().backward()
+    for i, b in enumerate(blocks):
+        assert rel(b.detach().numpy()[:, ::10, ::8], G[f"block{i}"]) < 1e-5, i
+    assert rel(cls.detach().numpy(), G["cls"]) < 1e-5
+    grad_check(G, leaves)
+
+
+def test_base_step_vs_reference_golden(golden_dir):
+    """2-view training step of an ATST("base")-shaped model at depth 2 (reference MultiCropWrapper + ByolLoss around AST(768, 12 heads))."""
+    G = load(golden_dir, "base_2views_depth2")
+    B, depth = int(G["B"]), int(G["depth"])
+    W = O.recipe_weights("base", depth=depth, seed=41)
+    leaves = student_leaves(W)
+    mels = [O.recipe_mel(B, int(w), seed=43 + i) for i, w in enumerate(G["widths"])]
+    lens = [torch.from_numpy(l) for l in G["lengths"]]
+    with torch.no_grad():
+        t = O.net_forward(W, "teacher.", mels, lens, "base", False, [torch.from_numpy(G["keep_t0"])], depth, 0.1)
+    s = O.net_forward(W, "student.", mels, lens, "base", True, [torch.from_numpy(G["keep_s0"])], depth, 0.1)
+    loss, std_s, std_t = O.byol_loss(s, t, 2)
+    loss.backward()
+    assert rel(t.numpy()[:8], G["teacher_out"]) < 1e-5 and rel(s.detach().numpy()[:8], G["student_out"]) < 1e-5
+    assert abs(loss.item() - float(G["loss"])) < 1e-5 * max(1.0, abs(float(G["loss"])))
+    assert abs(std_s.item() - float(G["std_s"])) < 1e-5 and abs(std_t.item() - float(G["std_t"])) < 1e-5
+    grad_check(G, [(n, p) for n, p in leaves])
+    for k in ("student.projector.1.running_mean", "student.projector.1.running_var", "teacher.projector.1.running_var"):
+        assert rel(W[k].detach()[sample_idx(4096)].numpy(), G["bn/" + k]) < 1e-4, k
+    for v in W.values():
+        v.requires_grad_(False) if v.dtype == torch.float32 else None
+    O.ema_update(W, 0.99)
+    for k in ("teacher.encoder.pos_embed", "teacher.encoder.blocks.1.mlp.fc1.weight", "teacher.projector.0.weight"):
+        v = W[k].reshape(-1)
+        assert rel(v[sample_idx(v.numel())].numpy(), G["ema/" + k]) < 1e-6, k

@@ -195,6 +195,73 @@ def test_base_arch_encoder_vs_oracle():
     assert num / den < 1.0e-2 and worst[1] < 2.4e-2             # measured 6.9e-3 / 1.6e-2 (x1.5)
 
 
+def test_base_encoder_gradient_vs_reference_golden():
+    """ATST-base geometry (d = 768, 12 heads: what AST_base builds, audio_transformer.py:371-374) pinned to the IMPORTED REFERENCE
+    (tests/golden/base_depth3_encoder_grad.npz): block activations, CLS and the gradient of sum(CLS * R) at depth 3,
+    ragged lengths, the reference's recorded DropPath draws.  Same bounds as the d = 384 golden test."""
+    G = load("base_depth3_encoder_grad")
+    S, depth = int(G["S"]), int(G["depth"])
+    eng = AtstEngine("base", depth=depth)
+    eng.load_weights(O.recipe_weights("base", depth=depth, seed=31))
+    length = torch.from_numpy(G["length"])
+    ep = eng._pass("student", S, 1001, True, 0)
+    valid = eng._valid(length, 1)
+    assert torch.equal(valid.cpu() - 1, torch.from_numpy(G["patch_length"]).int())           # integer: bit-exact
+    out = ep.forward(O.recipe_mel(S, 1001, seed=33).cuda(), valid, None, eng.drop_path_scales(S, torch.from_numpy(G["keep"])))
+    for i in range(depth):
+        b = ep.block_out(i).reshape(S, 256, 768)[:, :251].cpu().numpy()
+        assert rel(b[:, ::10, ::8], G[f"block{i}"]) < 1e-2, i
+    cls = out.float().reshape(S, 256, 768)[:, 0].cpu().numpy()
+    assert rel(cls, G["cls"]) < 1e-2
+    R = torch.from_numpy(np.random.default_rng(35).standard_normal((S, 768)).astype(np.float32)).cuda()
+    eng.g32.zero_(); ep.dout.zero_()
+    rows = (torch.arange(S, dtype=torch.int32, device="cuda") * 256).contiguous()
+    hip.call("atst_scatter_rows_bf16", hip.ptr(R), hip.ptr(rows), S, 768, hip.ptr(ep.dout), hip.stream())
+    ep.backward()
+    tab = {k: v for k, v in grad_table(eng, G, strip="encoder.").items() if k.startswith("encoder.")}
+    assert len(tab) == 6 + 11 * depth                                  # every encoder tensor except mask_embed
+    mean = sum(r * n for r, _, n in tab.values()) / sum(n for _, _, n in tab.values())
+    worst = max(tab.items(), key=lambda kv: kv[1][0])
+    print(f"\n[base encoder grad vs reference golden] weighted mean rel-L2 {mean:.3e}; worst {worst[0]} {worst[1][0]:.3e}")
+    assert mean < 1.0e-2 and worst[1][0] < 2.4e-2
+    assert max(abs(nerr) for _, nerr, _ in tab.values()) < 1e-2
+
+
+def test_base_step_vs_reference_golden():
+    """One 2-view training step of an ATST("base")-shaped model at depth 2 against the imported reference (MultiCropWrapper + ByolLoss
+    around AST(768, 12 heads), tests/golden/base_2views_depth2.npz): loss, head outputs, gradients, BN buffers, EMA."""
+    G = load("base_2views_depth2")
+    B, depth = int(G["B"]), int(G["depth"])
+    eng = AtstEngine("base", depth=depth, drop_path_rate=0.1)
+    eng.load_weights(O.recipe_weights("base", depth=depth, seed=41))
+    mels = [O.recipe_mel(B, int(w), seed=43 + i) for i, w in enumerate(G["widths"])]
+    lens = [torch.from_numpy(l) for l in G["lengths"]]
+    loss, std_s, std_t = eng.forward(mels, lens, None, [torch.from_numpy(G["keep_t0"])], [torch.from_numpy(G["keep_s0"])])
+    eng.backward()
+    s_out, t_out = eng.last_outputs
+    rs, rt = rel(s_out.cpu().numpy()[:8], G["student_out"]), rel(t_out.cpu().numpy()[:8], G["teacher_out"])
+    print(f"\n[base step] loss {loss.item():.6f} (ref {float(G['loss']):.6f}) std_s {std_s.item():.5f}/{float(G['std_s']):.5f} out rel {rs:.2e} {rt:.2e}")
+    assert abs(loss.item() - float(G["loss"])) < 5e-3
+    assert abs(std_s.item() - float(G["std_s"])) < 2e-3 and abs(std_t.item() - float(G["std_t"])) < 2e-3
+    assert rs < 2.5e-2 and rt < 2.5e-2
+    tab = grad_table(eng, G)
+    assert len(tab) == 6 + 11 * depth + 8                              # encoder (minus mask_embed, grad None) + two heads
+    assert tab["predictor.3.weight"][0] < 3e-2 and tab["predictor.1.weight"][0] < 3e-2
+    for k, (r, nerr, n) in tab.items():
+        if k in CANCELLING:
+            continue
+        assert abs(nerr) < 5e-2, (k, nerr)
+        assert r < 0.19, (k, r)                                        # ReLU-gate flips (see the module docstring); B = 16
+    for k in ("student.projector.1.running_mean", "student.projector.1.running_var", "teacher.projector.1.running_var"):
+        net, which, _, buf = k.split(".")
+        got = eng.bn_buffers[f"{net}.{which}"][buf].cpu()[sample_idx(4096)].numpy()
+        assert rel(got, G["bn/" + k]) < 2e-2, k
+    eng.ema_update(0.99)
+    for k in ("teacher.encoder.pos_embed", "teacher.encoder.blocks.1.mlp.fc1.weight", "teacher.projector.0.weight"):
+        v = eng.param_view("teacher", k[len("teacher."):]).reshape(-1).cpu()
+        assert rel(v[sample_idx(v.numel())].numpy(), G["ema/" + k]) < 1e-6, k
+
+
 @pytest.mark.parametrize("S", [5, 64])                  # 64 sequences: the packed layout (row stride = token count < tile rows)
 @pytest.mark.parametrize("width,NP", [(401, 128), (201, 64), (101, 32), (41, 32)])
 def test_short_clip_geometries_vs_oracle(width, NP, S):
