@@ -10,7 +10,7 @@
 
 extern "C" {
 
-int atst_version(void) { return 100; }
+int atst_version(void) { return ATST_ABI_VERSION; }
 int atst_tune_gemm_variant(int v) { if (v >= 400) atst_attn_set_variant(v - 400); else atst_gemm_nt_set_variant(v); return 0; }
 
 int atst_mel_frontend_f32(const float* wave, int n_clips, int n_samples, int wave_ld, int n_mels, int win_length, const float* window,

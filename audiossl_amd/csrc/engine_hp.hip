@@ -8,7 +8,7 @@
 // wiring mistake.  This mode removes the rounding and keeps everything else -- the Python engine (view grouping, heads, loss,
 // optimizer, EMA, ATST-Frame row gather), the token stage, DropPath / key-padding semantics, the parameter and gradient
 // layout, and the production GEMM / wgrad kernels and their fp32 epilogues -- so that gradients can be pinned to the reference
-// goldens at <= 2e-3 per tensor (tests/test_precise_gpu.py).  Tiny shapes only; it is 17x slower than the bf16 path (bench.py --precise, profiles/r04_a_bench_precise_clip2_b64.json).
+// goldens at <= 2e-3 per tensor (tests/test_precise_gpu.py).  Tiny shapes only; measured 18-20x slower than the bf16 path at the same batch (232 vs 4570 clips/s, 2 views x 64 clips: bench.py --precise, profiles/r04_g_bench_precise_clip2_b64.json).
 // Reference math: audiossl/modules/transformer.py:95-159, audiossl/models/atst/audio_transformer.py:153-221.
 #include "common.h"
 #include "kernels.h"

@@ -1625,16 +1625,24 @@ int g_w4_mode = 0;          // 330 + m: 4-wave two-blocks-per-CU kernels: 0 only
 int g_w4_min_m = 8192;      // 350/351: apply the tall / 4-wave kernels from M = 8192 / from any M (parity tests run small shapes)
 int g_w4_auto = 1;          // 360/361: 4-wave kernels for launches of <= 1.5 rounds of 256 x 384 tiles
 int g_f32_splitk = 1;       // 380/381: split-K for fp32-output GEMMs with <= 64 output tiles and K >= 2048
-// Split-K workspace: per stream (kernels of one stream run in order, so one buffer per stream is race-free), grown on demand, never shrunk.
+// Split-K workspace: per (device, stream) -- kernels of one stream run in order, so one buffer per stream is race-free; the null stream is the same
+// handle on every device, hence the device in the key (round-4 ADVICE).  Sized on first use for the largest head shape of the path
+// (24 splits x 2048 rows x 4096 columns fp32 = 768 MiB would be the ATST-Frame extreme; the clip heads need <= 16 MB), grown on demand (a
+// stream synchronise + hipFree: once, in warm-up), never shrunk, never freed: the ONE piece of device memory the library owns.
 struct SplitKWs { float* ws = nullptr; size_t cap = 0; };
+struct SplitKKey { int dev; hipStream_t st; bool operator==(const SplitKKey& o) const { return dev == o.dev && st == o.st; } };
+struct SplitKHash { size_t operator()(const SplitKKey& k) const { return std::hash<const void*>()((const void*)k.st) ^ ((size_t)k.dev * 0x9E3779B97F4A7C15ull); } };
 int splitk_workspace(hipStream_t st, size_t floats, float** ws) {
   static std::mutex mu;
-  static std::unordered_map<hipStream_t, SplitKWs> table;
+  static std::unordered_map<SplitKKey, SplitKWs, SplitKHash> table;
+  int dev = 0;
+  { hipError_t e = hipGetDevice(&dev); if (e != hipSuccess) return (int)e; }
   std::lock_guard<std::mutex> lk(mu);
-  SplitKWs& w = table[st];
+  SplitKWs& w = table[SplitKKey{dev, st}];
   if (floats > w.cap) {
     if (w.ws) { hipError_t e = hipStreamSynchronize(st); if (e != hipSuccess) return (int)e; (void)hipFree(w.ws); w.ws = nullptr; w.cap = 0; }
-    const size_t want = floats + floats / 4;
+    size_t want = floats + floats / 4;
+    if (want < (size_t)4 << 20) want = (size_t)4 << 20;           // 16 MB floor: covers every clip-head shape of the bench from the first call
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&w.ws), want * sizeof(float));
     if (e != hipSuccess) return (int)e;
     w.cap = want;

@@ -956,19 +956,24 @@ class AtstEngine:
         return {"student": int(v[0]), "teacher": int(v[1])}
 
     def fp8_state(self) -> Optional[dict]:
-        """Delayed-scaling state of the fp8 dgrad path (optimizer state: saved with the moments, see trainer.save_checkpoint)."""
-        if not (self.fp8 and getattr(self, "fp8_bwd_state", 0)):
+        """Delayed-scaling state of the fp8 path (optimizer state: saved with the moments, see trainer.save_checkpoint).  The forward activation
+        scales, their 16-step window and its cursor belong to EVERY fp8 engine (ATST-small fp8, or ATST_FP8_BWD=0, quantise their forward too: a
+        resumed run must quantise as the saved one did -- ADVICE r4); the g8_* keys of the e4m3 dgrad only exist when that path is on."""
+        if not self.fp8:
             return None
-        return {"g8_scale": self.g8_scale.cpu(), "g8_hist": self.g8_hist.cpu(), "hist_k": int(self._g8_hist_k), "state": int(self.fp8_bwd_state),
-                "f8a_scale": self.f8a_scale.cpu(), "f8a_hist": self.f8a_hist.cpu(), "f8a_hist_k": int(self._f8a_hist_k)}
+        st = {"f8a_scale": self.f8a_scale.cpu(), "f8a_hist": self.f8a_hist.cpu(), "f8a_hist_k": int(self._f8a_hist_k)}
+        if getattr(self, "fp8_bwd_state", 0):
+            st.update({"g8_scale": self.g8_scale.cpu(), "g8_hist": self.g8_hist.cpu(), "hist_k": int(self._g8_hist_k), "state": int(self.fp8_bwd_state)})
+        return st
 
     def load_fp8_state(self, st: Optional[dict]):
-        if not st or not (self.fp8 and getattr(self, "fp8_bwd_state", 0)):
+        if not st or not self.fp8:
             return
-        self.g8_scale.copy_(st["g8_scale"]); self.g8_hist.copy_(st["g8_hist"])
-        self._g8_hist_k, self.fp8_bwd_state = int(st["hist_k"]), int(st["state"])
         if "f8a_scale" in st:
             self.f8a_scale.copy_(st["f8a_scale"]); self.f8a_hist.copy_(st["f8a_hist"]); self._f8a_hist_k = int(st["f8a_hist_k"])
+        if "g8_scale" in st and getattr(self, "fp8_bwd_state", 0):
+            self.g8_scale.copy_(st["g8_scale"]); self.g8_hist.copy_(st["g8_hist"])
+            self._g8_hist_k, self.fp8_bwd_state = int(st["hist_k"]), int(st["state"])
 
     def _reduce_async(self, a: int, b: int):
         """Sum g32[a:b] over ranks on the communication stream, ordered after everything enqueued so far."""
@@ -986,20 +991,25 @@ class AtstEngine:
         if not parallel._collective():
             return
         bufs = [self.p32, self.t32] + [t for b in self.bn_buffers.values() for t in b.values()]
-        f8 = optimizer_state and self.fp8 and getattr(self, "fp8_bwd_state", 0)
+        f8a = bool(optimizer_state and self.fp8)                                          # forward scales: every fp8 engine
+        f8 = bool(f8a and getattr(self, "fp8_bwd_state", 0))                              # e4m3 dgrad state: only when that path is on
         if optimizer_state:
             bufs += [self.m32, self.v32]
+        if f8a:
+            bufs += [self.f8a_scale, self.f8a_hist]
         if f8:
-            bufs += [self.g8_scale, self.g8_hist, self.f8a_scale, self.f8a_hist]
+            bufs += [self.g8_scale, self.g8_hist]
         for t in bufs:
             dist.broadcast(t, 0)
         if optimizer_state:
-            step = torch.tensor([self.opt_step, self._g8_hist_k if f8 else 0, self.fp8_bwd_state if f8 else 0, self._f8a_hist_k if f8 else 0],
+            step = torch.tensor([self.opt_step, self._g8_hist_k if f8 else 0, self.fp8_bwd_state if f8 else 0, self._f8a_hist_k if f8a else 0],
                                 dtype=torch.int64, device=self.device)
             dist.broadcast(step, 0)
             self.opt_step = int(step[0].item())
+            if f8a:
+                self._f8a_hist_k = int(step[3].item())
             if f8:
-                self._g8_hist_k, self.fp8_bwd_state, self._f8a_hist_k = int(step[1].item()), int(step[2].item()), int(step[3].item())
+                self._g8_hist_k, self.fp8_bwd_state = int(step[1].item()), int(step[2].item())
         self.sync_shadows(force=True)
 
     def allreduce_grads(self):

@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libatst_hip.so")
 if os.environ.get("ATST_LIB_TAG"):          # experiment builds side by side (audiossl_amd/build.py): A/B runs inside one gpurun call
     LIB_PATH = os.path.join(_HERE, "lib", f"libatst_hip_{os.environ['ATST_LIB_TAG']}.so")
 ATST_MAX_DEPTH = 24
+ABI_VERSION = 110                                     # include/atst_hip.h ATST_ABI_VERSION these bindings were written for
 
 EPI_BF16, EPI_F32, EPI_BIAS_GELU, EPI_RESID, EPI_DGELU, EPI_PATCH, EPI_LNBWD = range(7)
 AMAX_SLOTS, AMAX_SLOT_STRIDE = 16, 64                 # include/atst_hip.h ATST_AMAX_*: a running-amax site is 16 slots, 256 B apart
@@ -142,6 +143,8 @@ def load(path: Optional[str] = None):
         except AttributeError as e:
             raise HipError(f"{p} does not export {name}") from e
         fn.restype, fn.argtypes = res, args
+    if lib.atst_version() != ABI_VERSION:                    # struct layouts / buffer contracts differ between versions: refuse, do not guess
+        raise HipError(f"{p} reports ABI version {lib.atst_version()}, these bindings are written for {ABI_VERSION} (include/atst_hip.h) -- rebuild")
     if path is None:
         _lib = lib
         for v in filter(None, os.environ.get("ATST_TUNE", "").split(",")):      # tuning hooks for A/B runs (include/atst_hip.h)

@@ -16,7 +16,12 @@ class FrameATSTLightningModule(ATSTLightningModule):
         self.hparams.update(self._frame_cfg)
 
     def _build_model(self, arch, kwargs):
-        return FrameATST(arch=arch, **self._frame_cfg)
+        # the reference hands **kwargs (= vars(args): spec_h = n_mels, patch_h, patch_w, ... train.py:15,17,50-51) down to FrameAST_small / _base,
+        # which pick the geometry out of them (atstframe/audio_transformer.py:283-291); the same keys are picked here
+        geo = {k: int(kwargs[k]) for k in ("patch_h", "patch_w", "spec_w") if kwargs.get(k) is not None}
+        if kwargs.get("spec_h") is not None and int(kwargs["spec_h"]) != geo.get("patch_h", 64):
+            raise NotImplementedError("one patch row: spec_h (= n_mels) must equal patch_h")
+        return FrameATST(arch=arch, **self._frame_cfg, **geo)
 
     def training_step(self, batch, batch_idx):
         self.schedule()

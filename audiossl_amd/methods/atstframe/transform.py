@@ -29,8 +29,8 @@ class FrameATSTBatchViews:
     """GPU stage: the collated crop [B,1,n] -> [view0, view1], each [B,1,64,T].  Mixup / RandomResizeCrop objects are
     per view like the reference's two Compose pipelines (transform.py:46-66): each Mixup keeps its own memory bank."""
 
-    def __init__(self, win_length=1024, aug_tea=True, aug_stu=True, mix_up=True, freq_wrap=True, device=None):
-        self.mel_feature = LogMelFrontend(win_length, device)
+    def __init__(self, win_length=1024, aug_tea=True, aug_stu=True, mix_up=True, freq_wrap=True, device=None, sr=16000, n_mels=64):
+        self.mel_feature = LogMelFrontend(win_length, device, sr=sr, n_mels=n_mels)             # ref: transform.py:15-16 (sr, n_mels)
         def pipeline(on):
             if not on:
                 return (None, None)
@@ -56,8 +56,13 @@ class FrameATSTTrainTransform:
     def __init__(self, sr=16000, win_length=1024, aug_tea=True, aug_stu=True, mix_up=True, freq_wrap=True, mask_ratio=0.75,
                  mask_nooverlap=False, min_mask_len=2, mask_len=5, mask_type="random", anchor_len=6., patch_h=64, patch_w=4,
                  n_mels=64, **kwargs):
-        if n_mels != 64 or patch_h != 64 or patch_w != 4:
-            raise NotImplementedError("the HIP front end / patch embed implement the shipped geometry: 64 mel bands, 64x4 patches")
+        # sr / n_mels / patch_h / patch_w as the reference threads them (transform.py:14-17, train.py:15,50-51: spec_h = n_mels).  The HIP front
+        # end is compiled for 64 or 128 bands and the engine for ONE patch row (patch_h = n_mels) of 4 or 8 frames -- BASELINE.json configs[4]
+        # is sr 32000, n_mels 128, patch 128 x 8.
+        if n_mels not in (64, 128) or patch_h != n_mels or patch_w not in (4, 8):
+            raise NotImplementedError(f"supported geometries: n_mels 64 / 128 with patch_h = n_mels (one patch row) and patch_w 4 / 8; got "
+                                      f"n_mels {n_mels}, patch {patch_h} x {patch_w}")
+        self.sr = sr
         self.anchor_len = anchor_len
         self.max_positive_len = self.anchor_len
         self.mask_ratio, self.mask_type = mask_ratio, mask_type
@@ -70,7 +75,7 @@ class FrameATSTTrainTransform:
 
     def batch_views(self, device=None) -> FrameATSTBatchViews:
         """The GPU stage configured like this transform (what Trainer(batch_hook=...) wants)."""
-        return FrameATSTBatchViews(self.win_length, self.aug_tea, self.aug_stu, self.mix_up, self.freq_wrap, device)
+        return FrameATSTBatchViews(self.win_length, self.aug_tea, self.aug_stu, self.mix_up, self.freq_wrap, device, sr=self.sr, n_mels=self.n_mels)
 
     def _mask(self, num_patches):
         # ref: transform.py:86-91
@@ -82,7 +87,8 @@ class FrameATSTTrainTransform:
 
     def __call__(self, input):
         anchor_len = self.anchor_len
-        n = int(anchor_len * 16000)
+        n = int(anchor_len * 16000)            # the reference counts anchor_len in units of 16000 SAMPLES whatever `sr` is (transform.py:76,81,93-98):
+                                               # 10 s at 32 kHz = anchor_len 20 -> 320000 samples -> 2001 frames; `sr` only enters the mel filterbank
         self._crop.size = n
         crop = self._crop(input)                                                     # ref: transform.py:76-78
         frames = n // 160 + 1

@@ -113,6 +113,71 @@ def launch_ranks(n: int) -> int:
     return 0
 
 
+def build_job(workload, arch, dtype, hires, B, world, rank, dev, total, precise=False, overlap=False):
+    """Engine + resident synthetic input + the step closure of one workload (the headline, or one of the `also` passes).
+    One step = mel front end of every view -> teacher fwd -> student fwd -> loss -> student bwd -> (all-reduce) -> fused HF-AdamW + EMA."""
+    from audiossl_amd.engine import AtstEngine
+    from audiossl_amd.frontend import LogMelFrontend
+    from audiossl_amd.utils.common import cosine_scheduler_step
+    frame = workload == "frame"
+    ncrops = 6 if workload == "clip6" else 2
+    sr, n_mels, patch = (32000, 128, (128, 8)) if hires else (16000, 64, (64, 4))
+    clip_len, buf_len = 10 * sr, 12 * sr
+    eng = AtstEngine(arch, frame=frame, ncrops=ncrops, fp8=dtype == "fp8", patch_h=patch[0], patch_w=patch[1], precise=precise)
+    eng.init_weights(seed=0)
+    eng.broadcast_parameters()                                       # DDP init: every rank takes rank 0's replica (no-op at world 1)
+    eng.overlap_teacher = overlap
+    fe = LogMelFrontend(1024 if not frame else 640, sr=sr, n_mels=n_mels)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    buf = torch.clamp(0.1 * torch.randn(B, buf_len, device=dev, generator=g), -1.0, 1.0)      # 12 s, resident in HBM
+    lr_tab = cosine_scheduler_step(5e-4 * world * B / 256, 1e-6, 39100, 1300)
+    wd_tab = cosine_scheduler_step(0.04, 0.4, 39100, 0)
+    ema_tab = cosine_scheduler_step(0.99, 1, 39100, 0)
+    cpu_gen = torch.Generator().manual_seed(99 + rank)
+    offs = torch.randint(0, buf_len - clip_len, (total, 6), generator=cpu_gen).tolist()
+    mask_sets = None
+    if frame:
+        import numpy as np
+        rs = np.random.RandomState(1234 + rank)
+        from audiossl_amd.methods.atstframe.random_mask import block_mask
+        # host-side masks, one draw per clip per step, as the DataLoader would deliver them (the transform draws them
+        # with numpy on the workers: methods/atstframe/transform.py:84-101); generated before the timed region
+        mask_sets = [torch.from_numpy(np.stack([block_mask(250, 0.65, 5, rng=rs) for _ in range(B)])) for _ in range(total)]
+
+    # every view group gets ONE [V * B, 1, n_mels, T] buffer: the front end reads the waveform slices in place (row stride) and
+    # writes each view into its rows, so the engine sees a ready concatenated group (no slice copies, no torch.cat)
+    n_glob = 1 if frame else 2
+    g_buf = torch.empty(n_glob * B, 1, n_mels, 1 + clip_len // 160, device=dev)
+    l_buf = torch.empty(4 * B, 1, n_mels, 1 + (clip_len // 10) // 160, device=dev) if ncrops == 6 else None
+    Tg, Tl = 1 + clip_len // 160, 1 + (clip_len // 10) // 160
+
+    def step(k):
+        o = offs[k]
+        masks = None
+        if frame:
+            mel = fe(buf[:, o[0]:o[0] + clip_len], out=g_buf)
+            mels, lens = [mel, mel], [torch.full((B,), Tg)] * 2
+            masks = [mask_sets[k], mask_sets[k]]              # ONE mask shared by both views (transform.py:99)
+        else:
+            mels = [fe(buf[:, o[v]:o[v] + clip_len], out=g_buf[v * B:(v + 1) * B]) for v in range(2)]
+            lens = [torch.full((B,), Tg)] * 2
+            if ncrops == 6:                                  # 4 local views of 1 s -> 101 frames -> 25 patches + CLS
+                mels += [fe(buf[:, o[2 + v]:o[2 + v] + clip_len // 10], out=l_buf[v * B:(v + 1) * B]) for v in range(4)]
+                lens += [torch.full((B,), Tl)] * 4
+        loss, _, _ = eng.forward(mels, lens, masks)
+        eng.backward()
+        eng.allreduce_grads()
+        eng.optimizer_step(float(lr_tab[k]), float(wd_tab[k]), float(ema_tab[k + 1]))
+        return loss
+
+    return eng, step, dict(frame=frame, ncrops=ncrops, patch=patch, khz="32kHz" if hires else "16kHz")
+
+
+WORKLOAD_NAMES = {"clip6": "ATST-small clip-level, 2 global (10 s) + 4 local (1 s) views", "clip2": "ATST-small clip-level, 2 views (10 s)",
+                  "frame": "ATST-Frame small, masked frame objective (10 s)"}
+DTYPE_NAMES = {"bf16": "bf16", "fp8": "fp8 (e4m3 forward + fc2/fc1/proj dgrad GEMMs) + bf16"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -133,6 +198,11 @@ def main():
                     help="BASELINE.json configs[4] input geometry: 10 s @ 32 kHz, 128 mel bands, one patch row of 128 x 8 (the reference's "
                          "sr / n_mels / patch_h / patch_w parameters) -> 2001 frames, 250 patches of 1024 values; use with --arch base --dtype fp8")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--also", dest="also", action="store_true", default=None,
+                    help="after the headline's timed region, short passes of the other BASELINE.json configurations (ATST-Frame, 2-view, ATST-base bf16 / fp8 / "
+                         "fp8 at 32 kHz) attached as `also` in the same JSON line; default: on for the default headline at one GPU")
+    ap.add_argument("--no-also", dest="also", action="store_false")
+    ap.add_argument("--also-steps", type=int, default=10)
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--profile-stride", type=int, default=17,
                     help="HIP events around one launch in n of each kernel kind, a hashed subset of the launch indices (1 = all: costs ~6 %% of the step; 7: ~0.6 %%; "
@@ -142,6 +212,9 @@ def main():
                     help="nccl = RCCL over xGMI (one rank per GPU); gloo = test transport, lets several ranks share one GPU")
     args = ap.parse_args()
 
+    if args.also is None:                                           # the driver's default command gets them; explicit workloads / A-B runs do not
+        args.also = (args.workload, args.arch, args.dtype, args.hires, args.batch, args.precise) == ("clip6", "small", "bf16", False, 256, False) \
+            and not args.no_cpu_baseline and not args.no_profile
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus))                           # parent: never touches the GPU, relays rank 0's line
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -167,67 +240,16 @@ def main():
     torch.manual_seed(4321 + rank)                                   # DropPath draws (device generator): reproducible runs
 
     from audiossl_amd import hip
-    from audiossl_amd.engine import AtstEngine
-    from audiossl_amd.frontend import LogMelFrontend
-    from audiossl_amd.utils.common import cosine_scheduler_step
     lib = hip.load()
 
-    B, frame = args.batch, args.workload == "frame"
-    ncrops = 6 if args.workload == "clip6" else 2
-    sr, n_mels, patch = (32000, 128, (128, 8)) if args.hires else (16000, 64, (64, 4))
-    clip_len, buf_len = 10 * sr, 12 * sr
+    B = args.batch
     if args.precise:
         if args.dtype != "bf16":
             ap.error("--precise is the fp32 parity mode; it excludes --dtype fp8")
         args.no_profile = True                                      # the parity-mode kernels are not instrumented
-    eng = AtstEngine(args.arch, frame=frame, ncrops=ncrops, fp8=args.dtype == "fp8", patch_h=patch[0], patch_w=patch[1], precise=args.precise)
-    eng.init_weights(seed=0)
-    eng.broadcast_parameters()                                       # DDP init: every rank takes rank 0's replica (no-op at world 1)
-    eng.overlap_teacher = args.overlap
-    fe = LogMelFrontend(1024 if not frame else 640, sr=sr, n_mels=n_mels)
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    buf = torch.clamp(0.1 * torch.randn(B, buf_len, device=dev, generator=g), -1.0, 1.0)      # 12 s, resident in HBM
     total = args.warmup + args.steps + 2
-    lr_tab = cosine_scheduler_step(5e-4 * world * B / 256, 1e-6, 39100, 1300)
-    wd_tab = cosine_scheduler_step(0.04, 0.4, 39100, 0)
-    ema_tab = cosine_scheduler_step(0.99, 1, 39100, 0)
-    cpu_gen = torch.Generator().manual_seed(99 + rank)
-    offs = torch.randint(0, buf_len - clip_len, (total, 6), generator=cpu_gen).tolist()
-    masks = None
-    if frame:
-        import numpy as np
-        rs = np.random.RandomState(1234 + rank)
-        from audiossl_amd.methods.atstframe.random_mask import block_mask
-        # host-side masks, one draw per clip per step, as the DataLoader would deliver them (the transform draws them
-        # with numpy on the workers: methods/atstframe/transform.py:84-101); generated before the timed region
-        mask_sets = [torch.from_numpy(np.stack([block_mask(250, 0.65, 5, rng=rs) for _ in range(B)])) for _ in range(total)]
-
-    # every view group gets ONE [V * B, 1, n_mels, T] buffer: the front end reads the waveform slices in place (row stride) and
-    # writes each view into its rows, so the engine sees a ready concatenated group (no slice copies, no torch.cat)
-    n_glob = 1 if frame else 2
-    g_buf = torch.empty(n_glob * B, 1, n_mels, 1 + clip_len // 160, device=dev)
-    l_buf = torch.empty(4 * B, 1, n_mels, 1 + (clip_len // 10) // 160, device=dev) if ncrops == 6 else None
-    Tg, Tl = 1 + clip_len // 160, 1 + (clip_len // 10) // 160
-
-    def step(k):
-        nonlocal masks
-        o = offs[k]
-        if frame:
-            mel = fe(buf[:, o[0]:o[0] + clip_len], out=g_buf)
-            mels, lens = [mel, mel], [torch.full((B,), Tg)] * 2
-        else:
-            mels = [fe(buf[:, o[v]:o[v] + clip_len], out=g_buf[v * B:(v + 1) * B]) for v in range(2)]
-            lens = [torch.full((B,), Tg)] * 2
-            if ncrops == 6:                                  # 4 local views of 1 s -> 101 frames -> 25 patches + CLS
-                mels += [fe(buf[:, o[2 + v]:o[2 + v] + clip_len // 10], out=l_buf[v * B:(v + 1) * B]) for v in range(4)]
-                lens += [torch.full((B,), Tl)] * 4
-        if frame:
-            masks = [mask_sets[k], mask_sets[k]]              # ONE mask shared by both views (transform.py:99)
-        loss, _, _ = eng.forward(mels, lens, masks)
-        eng.backward()
-        eng.allreduce_grads()
-        eng.optimizer_step(float(lr_tab[k]), float(wd_tab[k]), float(ema_tab[k + 1]))
-        return loss
+    eng, step, info = build_job(args.workload, args.arch, args.dtype, args.hires, B, world, rank, dev, total, args.precise, args.overlap)
+    frame, ncrops, patch = info["frame"], info["ncrops"], info["patch"]
 
     def sync():
         if dist.is_initialized():
@@ -277,6 +299,9 @@ def main():
                 if has_flops:
                     rec["tflops"] = round(work[i] / secs / 1e12, 2)
                     rec["flop_per_byte"] = round(work[i] / byts[i], 1)
+                if name == "stft_mel_db_kernel":                        # `achieved` stays its algorithmic HBM bytes / time, but HBM is not what bounds it
+                    rec["bound"] = "lds"
+                    rec["note"] = "LDS-bandwidth-bound (three in-place FFT passes through LDS, DESIGN.md section 3); its HBM traffic is ~0.03 ms per launch"
                 tab.append(rec)
         tab.sort(key=lambda r: -r["total_ms"])
         return tab
@@ -300,16 +325,18 @@ def main():
             eng.overlap_local_teacher = True
         if kernels:
             # the dominant class: largest share of kernel time when nothing overlaps (= kernels[0] when there is no second stream)
-            d = kernels[0] if not exclusive else next(r for r in kernels if r["kernel"] == max(exclusive.values(), key=lambda x: x["total_ms"])["kernel"])
+            # (live and exclusive tables are each a hashed subset of the launches: a class missing from the live one falls back to its largest)
+            d = kernels[0] if not exclusive else next((r for r in kernels if r["kernel"] == max(exclusive.values(), key=lambda x: x["total_ms"])["kernel"]), kernels[0])
             peak = PEAK_BF16_TFLOPS if d["bound"] == "mfma" else PEAK_HBM_GBS
             roof = {"bound": d["bound"], "kernel": d["kernel"], "achieved": d["achieved"], "peak": peak, "unit": d["unit"],
                     "frac": round(d["achieved"] / peak, 4), "traffic": None, "algorithmic_bytes_per_launch": d["bytes_per_launch"],
                     "avg_launch_us": d["avg_us"], "launches": d["launches"], "timed_one_launch_in": args.profile_stride,
+                    "timed_every_nth_launch": args.profile_stride,      # the key's name before round 4 (kept as an alias)
                     "share_of_timed_kernel_ms": round(d["total_ms"] / sum(r["total_ms"] for r in kernels), 3)}
             if "tflops" in d:
                 roof["tflops"], roof["flop_per_byte"] = d["tflops"], d["flop_per_byte"]
                 roof["mfma_frac"] = round(d["tflops"] / PEAK_BF16_TFLOPS, 4)       # the same kernel priced against the dense bf16 MFMA peak
-            if exclusive:
+            if exclusive and d["kernel"] in exclusive:
                 x = exclusive[d["kernel"]]
                 roof["concurrency"] = ("two HIP streams: the local-view groups run beside the teacher pass (forward) and beside the global-view group "
                                        "(backward); achieved / frac / avg_launch_us above are LIVE event times of the timed region and include the time a "
@@ -348,6 +375,60 @@ def main():
                                              "hbm_frac": round(n0["bytes_per_launch"] / (n0["avg_us"] * 1e-6) / 1e9 / PEAK_HBM_GBS, 4),
                                              "share_of_timed_kernel_ms": round(n0["total_ms"] / sum(r["total_ms"] for r in kernels), 3)}
 
+    # ---- the other configurations of BASELINE.json, short passes OUTSIDE the timed region: configs[2] (ATST-Frame), the
+    # 2-view recipe, and the single-GPU content of configs[4] (ATST-base, e4m3 GEMMs, 32 kHz / 128 mel / 128 x 8 patches).  New engines, freed
+    # afterwards; same process (no exec, no re-launch); headline fields unchanged.
+    also = []
+    if args.also and world == 1 and not args.precise:
+        headline = (args.workload, args.arch, args.dtype, args.hires)
+        del eng, step
+        torch.cuda.empty_cache()
+        for wl, arch, dtype, hires in (("frame", "small", "bf16", False), ("clip2", "small", "bf16", False), ("clip2", "base", "bf16", False),
+                                       ("clip2", "base", "fp8", False), ("clip2", "base", "fp8", True)):
+            if (wl, arch, dtype, hires) == headline:
+                continue
+            n_w, n_t = 3, args.also_steps
+            eng2, step2, info2 = build_job(wl, arch, dtype, hires, B, world, rank, dev, n_w + n_t + 2)
+            for k in range(n_w):
+                step2(k)
+            sync()
+            lib.atst_profile_enable(5)
+            t1 = time.perf_counter()
+            for k in range(n_w, n_w + n_t):
+                step2(k)
+            sync()
+            dt2 = time.perf_counter() - t1
+            lib.atst_profile_enable(0)
+            tab = kernel_table()
+            fpc2 = flops_per_clip(wl, d=768 if arch == "base" else 384, patch_k=info2["patch"][0] * info2["patch"][1])
+            v2 = B * n_t / dt2
+            rec = {"workload": WORKLOAD_NAMES[wl].replace("small", arch) + (", 10s@32kHz, 128 mel, 128 x 8 patches" if hires else ", 10s@16kHz"),
+                   "arch": arch, "dtype": DTYPE_NAMES[dtype], "clips_per_gpu": B, "steps": n_t, "warmup": n_w, "value": round(v2, 2), "unit": "clips/s",
+                   "ms_per_step": round(dt2 / n_t * 1e3, 3), "flops_per_clip_G": round(fpc2 / 1e9, 2),
+                   "mfma_roofline_frac_step": round(v2 * fpc2 / 1e12 / PEAK_BF16_TFLOPS, 4)}
+            if tab:
+                d2 = tab[0]
+                pk = PEAK_BF16_TFLOPS if d2["bound"] == "mfma" else PEAK_HBM_GBS
+                rec["dominant_kernel"] = {"kernel": d2["kernel"], "bound": d2["bound"], "achieved": d2["achieved"], "unit": d2["unit"], "peak": pk,
+                                          "frac": round(d2["achieved"] / pk, 4), "avg_launch_us": d2["avg_us"],
+                                          "share_of_timed_kernel_ms": round(d2["total_ms"] / sum(r["total_ms"] for r in tab), 3), "timed_one_launch_in": 5}
+                if "tflops" in d2:
+                    rec["dominant_kernel"]["mfma_frac"] = round(d2["tflops"] / PEAK_BF16_TFLOPS, 4)
+            also.append(rec)
+            del eng2, step2
+            torch.cuda.empty_cache()
+
+    # N ranks on N distinct devices, as RCCL sees them: every rank reports its device index and PCI bus id
+    rccl = None
+    if dist.is_initialized():
+        pr = torch.cuda.get_device_properties(local)
+        bus = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", -1) & 0xff, getattr(pr, "pci_device_id", 0))
+        mine = {"rank": rank, "local_rank": local, "device": local, "pci_bus_id": bus, "name": pr.name, "uuid": str(getattr(pr, "uuid", ""))}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        rccl = {"backend": dist.get_backend(), "world": dist.get_world_size(), "devices": gathered,
+                "distinct_devices": len({(g["pci_bus_id"], g["uuid"]) for g in gathered})}
+
     if rank == 0:
         clips = B * world * args.steps
         value = clips / dt
@@ -374,6 +455,10 @@ def main():
             tbs = step_hbm["traffic_bytes_per_step"] / (dt / args.steps) / 1e12
             step_hbm.update({"TB_per_s": round(tbs, 3), "frac_of_8TBs_peak": round(tbs / (PEAK_HBM_GBS / 1e3), 4)})
             out["step_hbm"] = step_hbm
+        if also:
+            out["also"] = also
+        if rccl:
+            out["rccl"] = rccl
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

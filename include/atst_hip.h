@@ -34,7 +34,13 @@ extern "C" {
 enum { ATST_EPI_BF16 = 0, ATST_EPI_F32 = 1, ATST_EPI_BIAS_GELU = 2, ATST_EPI_RESID = 3, ATST_EPI_DGELU = 4, ATST_EPI_PATCH = 5,
        ATST_EPI_LNBWD = 6 /* only through atst_gemm_nt_lnbwd_bf16 */ };
 
-int atst_version(void);
+/* ABI version of this header: bumped whenever a struct layout, a buffer contract or an argument meaning changes.  A caller built against another
+ * version must not proceed (audiossl_amd/hip.py checks it at load time).
+ *   100  rounds 1-3
+ *   110  round 4: atst_encoder_t grew f8_sat / f8_act_scale / f8_act_amax ; every amax argument (atst_quant_fp8_dyn_bf16, g8_amax, f8_act_amax) is an
+ *        ATST_AMAX_SITE_STRIDE-float SITE, not one float ; fb_weights of atst_mel_frontend_f32 is tap-major [fb_maxlen][n_mels]               */
+#define ATST_ABI_VERSION 110
+int atst_version(void);   /* = ATST_ABI_VERSION of the header the library was built from */
 /* Tuning hooks for A/B measurements (tools/gemm_bench.py, env ATST_TUNE=a,b,... read by audiossl_amd/hip.py); defaults are the
  * measured best.  These are PROCESS-GLOBAL test knobs (plain ints inside the library, read at launch time, no locking): set them from one
  * thread, before the launches they are meant for, and restore the default afterwards (the tests do).  Nothing in the product path calls this.
@@ -221,9 +227,9 @@ typedef struct {
    * 0 = NP.  n_tok + use_cls <= row_stride < NP packs the sequences (NP < 256 only): 1 s views are 26 tokens in tiles of 32, and the
    * GEMM / LayerNorm / weight-gradient kernels then run over S * row_stride rows.  The workspace is sized for NP either way.      */
   int row_stride;
-  /* fp8 forward: device counter (or NULL) that every activation-quantising kernel of the pass adds its number of CLIPPED elements to --
-   * the activation scales are constants (8 for LayerNorm / attention outputs, 4 behind GELU: |x| > 56 / 112 saturates at +-448); the
-   * caller clears and reads it (AtstEngine.fp8_saturation()).  A non-zero count means the fixed scales no longer fit the run.      */
+  /* fp8 forward: device counter (or NULL) that every activation-quantising kernel of the pass adds its number of CLIPPED elements to
+   * (values beyond +-448 / scale of their site; scales: f8_act_scale below, or the constants 8 / 8 / 8 / 4 when that is NULL); the
+   * caller clears and reads it (AtstEngine.fp8_saturation()).  A non-zero count means a site's scale lagged behind the run.          */
   uint32_t* f8_sat;
   /* fp8 forward, running (delayed) activation scales: f8_act_scale [depth][4] device floats, f8_act_amax [depth][4] amax SITES
    * (ATST_AMAX_SITE_STRIDE floats each); site k of block i = 0: LayerNorm-1 output (qkv GEMM),

@@ -34,7 +34,10 @@ def test_library_exports_every_declared_symbol(lib_path):
     missing = [s for s in header_symbols() if not hasattr(lib, s)]
     assert not missing, missing
     lib.atst_version.restype = ctypes.c_int
-    assert lib.atst_version() >= 100                       # host-only entry point: callable without a GPU
+    from audiossl_amd import hip
+    hdr = open(os.path.join(ROOT, "include", "atst_hip.h")).read()
+    ver = int(re.search(r"#define ATST_ABI_VERSION (\d+)", hdr).group(1))
+    assert lib.atst_version() == ver == hip.ABI_VERSION     # host-only entry point: callable without a GPU ; header, library and bindings agree
 
 
 def test_ctypes_binding_matches_header(lib_path):
@@ -82,3 +85,26 @@ def test_no_spill_reload_under_a_narrowed_exec_mask():
         pytest.skip("hipcc not available")
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_exec_reload.py")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_exec_reload_scanner_on_synthetic_isa():
+    """The scanner of tools/check_exec_reload.py itself: the hazard is found; a reload inside the inner body, a reload behind an
+    exec restore, behind an `s_*_saveexec_b64` (implicit exec write) or behind `s_endpgm` / the next kernel symbol is not."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_exec_reload", os.path.join(ROOT, "tools", "check_exec_reload.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    hazard = ["_Z1kv:", " s_and_b64 exec, exec, s[4:5]", " global_store_dword v0, v1, s[2:3]", ".LBB0_2:", " scratch_load_dword v7, off, off offset:16",
+              " s_or_b64 exec, exec, s[6:7]", " s_endpgm"]
+    assert len(mod.scan(hazard)) == 1 and mod.scan(hazard)[0][0] == "_Z1kv"
+    inner = ["_Z1kv:", " s_and_b64 exec, exec, s[4:5]", " scratch_load_dword v7, off, off offset:16", ".LBB0_2:", " s_or_b64 exec, exec, s[6:7]"]
+    assert mod.scan(inner) == []
+    restored = ["_Z1kv:", " s_and_b64 exec, exec, s[4:5]", ".LBB0_2:", " s_or_b64 exec, exec, s[6:7]", " scratch_load_dword v7, off, off offset:16"]
+    assert mod.scan(restored) == []
+    saveexec = ["_Z1kv:", " s_andn2_b64 exec, exec, s[4:5]", ".LBB0_2:", " s_or_saveexec_b64 s[8:9], s[10:11]", " scratch_load_dword v7, off, off"]
+    assert mod.scan(saveexec) == []
+    saveexec2 = ["_Z1kv:", " s_and_b64 exec, exec, s[4:5]", ".LBB0_2:", " s_and_saveexec_b64 s[8:9], vcc", " scratch_load_dword v7, off, off"]
+    assert mod.scan(saveexec2) == []
+    endpgm = ["_Z1kv:", " s_and_b64 exec, exec, s[4:5]", ".LBB0_2:", " s_endpgm", ".LBB0_3:", " scratch_load_dword v7, off, off"]
+    assert mod.scan(endpgm) == []
+    nextk = ["_Z1kv:", " s_and_b64 exec, exec, s[4:5]", ".LBB0_2:", "_Z2k2v:", ".LBB1_1:", " scratch_load_dword v7, off, off"]
+    assert mod.scan(nextk) == []

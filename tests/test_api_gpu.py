@@ -297,3 +297,28 @@ def test_downstream_harness_attribute_walk_through_aliased_imports(tmp_path):
         assert float((emb - emb2).abs().max()) == 0.0
     finally:
         audiossl_amd.compat.uninstall()
+
+
+def test_frame_transform_and_module_at_the_hires_geometry():
+    """The reference threads sr / n_mels / patch_h / patch_w through the Frame transform, the CLI and the module (atstframe/transform.py:14-17,
+    train.py:15,50-51).  BASELINE.json configs[4]'s geometry -- 32 kHz, 128 bands, 128 x 8 patches, 10 s = anchor_len 20 in the transform's
+    16000-sample units -> 2001 frames -> 250 tokens -- through FrameATSTTrainTransform (mel vs the oracle) and one FrameATSTLightningModule step."""
+    from audiossl_amd.methods.atstframe.transform import FrameATSTTrainTransform
+    t = FrameATSTTrainTransform(sr=32000, n_mels=128, patch_h=128, patch_w=8, win_length=1024, aug_tea=False, aug_stu=False, mask_type="block",
+                                mask_ratio=0.65, anchor_len=20, mask_len=5)
+    wave = O.recipe_wave(1, 320000, seed=77)
+    views, lengths, masks = t(wave.cuda())
+    assert [tuple(v.shape) for v in views] == [(1, 128, 2001)] * 2 and lengths == [2001, 2001] and masks[0].shape == (250,)
+    want = O.log_mel(wave, 1024, n_mels=128, sample_rate=32000)[0]
+    assert float((views[0].cpu() - want).abs().max()) < 2e-3
+    module = FrameATSTLightningModule(arch="small", max_steps=4, warmup_steps=1, spec_h=128, patch_h=128, patch_w=8, spec_w=2001)
+    assert module.model.engine.patch_h == 128 and module.model.engine.patch_w == 8
+    module.trainer = type("T", (), {"optimizers": module.configure_optimizers()})()
+    B = 2
+    mels = [O.recipe_mel(B, 2001, seed=3, n_mels=128).cuda()] * 2
+    rs = np.random.RandomState(0)
+    m = torch.from_numpy(np.stack([O.block_mask(250, 0.65, 5, rng=rs) for _ in range(B)]))
+    loss = module.training_step(((mels, [torch.full((B,), 2001)] * 2, [m, m]), None), 0)
+    loss.backward()
+    module.trainer.optimizers[0].step()
+    assert torch.isfinite(loss)

@@ -115,7 +115,14 @@ def test_frame_transform_batch_contract():
     u = FrameATSTTrainTransform(mask_type="uniform", mask_ratio=0.65, anchor_len=10, min_mask_len=2)
     assert u(wave)[2][0].shape == (250,)
     with pytest.raises(NotImplementedError):
-        FrameATSTTrainTransform(n_mels=128)
+        FrameATSTTrainTransform(n_mels=128)                                # patch_h must follow n_mels (one patch row: train.py:15 spec_h = n_mels)
+    with pytest.raises(NotImplementedError):
+        FrameATSTTrainTransform(n_mels=80, patch_h=80)
+    # the reference's sr / n_mels / patch_h / patch_w parameters (transform.py:14-17, train.py:15,50-51) at BASELINE.json configs[4]'s geometry:
+    # 32 kHz, 128 bands, 128 x 8 patches; anchor_len counts units of 16000 samples (transform.py:76), so 10 s at 32 kHz is anchor_len 20
+    hi = FrameATSTTrainTransform(sr=32000, n_mels=128, patch_h=128, patch_w=8, win_length=1024, mask_type="block", mask_ratio=0.65, anchor_len=20, mask_len=5)
+    crops, lengths, masks = hi(0.1 * torch.randn(1, 330000))
+    assert crops[0].shape == (1, 320000) and lengths == [2001, 2001] and masks[0].shape == (250,) and get_num_patches(128, 2001, 128, 8) == 250
     # collate: what training_step receives -- ((crops, lengths, masks), label), ref: atstframe/model.py:120
     dm = FrameATSTDataModule(batch_size_per_gpu=4, num_workers=0, subset=8, win_length=640, aug_tea=False, mask_ratio=0.65,
                              anchor_len=10, mix_up=False)

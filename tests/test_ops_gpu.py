@@ -798,3 +798,28 @@ def test_fp8_forward_saturation_counter_and_running_scales():
     eng.forward(mels, lens); eng.fp8_saturation(reset=True)
     eng.forward(mels, lens)
     assert eng.fp8_saturation() == {"student": 0, "teacher": 0}               # adapted: nothing clips any more
+
+
+def test_fp8_forward_only_state_is_saved_and_restored():
+    """the forward activation scales, their 16-step amax window and its cursor are live for EVERY fp8 engine, also when the e4m3
+    dgrad is off (ATST-small, or ATST_FP8_BWD=0) -- fp8_state() / load_fp8_state() must carry them, or a resumed run restarts from the
+    constants 8 / 8 / 8 / 4 with an empty window."""
+    from audiossl_amd.engine import AtstEngine
+    depth, B = 1, 2
+    W = O.recipe_weights("small", depth=depth, seed=7)
+    mels = [O.recipe_mel(B, 1001, seed=1).to(DEV), O.recipe_mel(B, 1001, seed=2).to(DEV)]
+    lens = [torch.full((B,), 1001)] * 2
+    eng = AtstEngine("small", depth=depth, drop_path_rate=0.0, fp8=True)
+    assert eng.fp8_bwd_state == 0                                              # d = 384: forward-only fp8
+    eng.load_weights(W)
+    for _ in range(3):
+        eng.forward(mels, lens)
+    st = eng.fp8_state()
+    assert st is not None and "f8a_scale" in st and "g8_scale" not in st and st["f8a_hist_k"] == 3
+    assert not torch.equal(st["f8a_scale"], torch.tensor([8.0, 8.0, 8.0, 4.0]).repeat(2, depth))
+    eng2 = AtstEngine("small", depth=depth, drop_path_rate=0.0, fp8=True)
+    eng2.load_weights(W)
+    eng2.load_fp8_state(st)
+    assert torch.equal(eng2.f8a_scale.cpu(), st["f8a_scale"]) and torch.equal(eng2.f8a_hist.cpu(), st["f8a_hist"]) and eng2._f8a_hist_k == 3
+    l1, l2 = eng.forward(mels, lens)[0], eng2.forward(mels, lens)[0]           # the resumed engine quantises as the saved one does
+    assert float(l1) == float(l2)
