@@ -1217,6 +1217,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_w4_kernel(GemmArgs p) {
   }
 }
 
+#include "gemm_p8.h"
+
 // ---- wgrad: dW[n,k] += sum_m dY[m,n] X[m,k] -------------------------------------------------------------------------
 constexpr int WM = 64;                          // contraction rows per stage
 constexpr int W_LD = 128 + 32;                  // 160 bf16 = 320 B row stride: 4 consecutive rows x 64 B (one ds_read_b64_tr_b16 half) on 4 distinct bank windows
@@ -1624,6 +1626,9 @@ int g_dgelu_row384 = 2;     // 306/307/308: dGELU GEMM on the 256x384 tile never
 int g_w4_mode = 0;          // 330 + m: 4-wave two-blocks-per-CU kernels: 0 only for small grids ; 2 = 256x192 (plain epilogues) + 128x384 (row-wise) everywhere ; 3 = 256x192 for the plain epilogues only
 int g_w4_min_m = 8192;      // 350/351: apply the tall / 4-wave kernels from M = 8192 / from any M (parity tests run small shapes)
 int g_w4_auto = 1;          // 360/361: 4-wave kernels for launches of <= 1.5 rounds of 256 x 384 tiles
+int g_p8_skew = 0;          // 1000 + c: start-up skew of every other first-round block of the phased kernel, c x 1024 cycles (experiment)
+int g_p8 = 1;               // 390/391/392: 256 x 256 phased kernel (gemm_p8.h) for N % 256 == 0, K % 128 == 0, M % 256 == 0, M >= 8192: off / bf16 operands (default) / also e4m3 operands
+                            // (392 measured SLOWER in the step: base fp8 2255 vs 2494 clips/s -- with 6 k-tiles at K = 768 the e4m3 form is all prologue and last-pair code, which also spills)
 int g_f32_splitk = 1;       // 380/381: split-K for fp32-output GEMMs with <= 64 output tiles and K >= 2048
 // Split-K workspace: per (device, stream) -- kernels of one stream run in order, so one buffer per stream is race-free; the null stream is the same
 // handle on every device, hence the device in the key (round-4 ADVICE).  Sized on first use for the largest head shape of the path
@@ -1711,10 +1716,31 @@ int launch_nt_w4_cfg(const GemmArgs& a, hipStream_t st) {
   hipLaunchKernelGGL((gemm_nt_w4_kernel<EPI, WM, LN>), dim3(nblk), dim3(256), LDS, st, a);
   return (int)hipGetLastError();
 }
+template <int EPI, bool F8 = false>
+int launch_nt_p8(const GemmArgs& a, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_p8_kernel<EPI, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, p8::RING);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  ProfScope ps(prof_kind<EPI>(), (F8 ? 4.0 : 2.0) * a.M * a.N * a.K, st, nt_bytes<EPI>(a));      // F8: K counts byte pairs here
+  GemmArgs b = a; b.skew = g_p8_skew;
+  hipLaunchKernelGGL((gemm_nt_p8_kernel<EPI, F8>), dim3((a.M / p8::BM) * (a.N / p8::BNP)), dim3(p8::THREADS), p8::RING, st, b);
+  return (int)hipGetLastError();
+}
+// shapes the phased kernel takes (a.K, a.lda, a.ldb in bf16 elements -- for e4m3 operands the launcher has already halved them)
+template <int EPI>
+bool p8_ok(const GemmArgs& a) {
+  constexpr bool epi_ok = EPI == EPI_BF16 || EPI == EPI_F32 || EPI == EPI_BIAS_GELU || EPI == EPI_RESID || EPI == EPI_DGELU;
+  return epi_ok && g_p8 && !a.ln_out && (a.fp8 || !a.q8) && a.N % p8::BNP == 0 && a.K % (2 * p8::BKP) == 0 && a.M % p8::BM == 0 &&
+         a.M >= (g_w4_min_m < 8192 ? 256 : 8192) && a.lda % 8 == 0 && a.ldb % 8 == 0;
+}
 template <int EPI>
 int launch_nt_row384(const GemmArgs& a, hipStream_t st) {
   if (a.fp8) {                                                    // e4m3 operands seen as byte pairs: K, lda, ldb are already halved
     if constexpr (EPI == EPI_BF16 || EPI == EPI_BIAS_GELU || EPI == EPI_RESID || EPI == EPI_F32 || EPI == EPI_DGELU) {
+      if (g_nt_variant < 0 && g_p8 >= 2 && p8_ok<EPI>(a)) return launch_nt_p8<EPI, true>(a, st);
       ProfScope ps(prof_kind<EPI>(), 4.0 * a.M * a.N * a.K, st, nt_bytes<EPI>(a));
       if constexpr (EPI == EPI_BF16) { if (g_bf16_tr) return launch_nt_row384_cfg<EPI, 4, false, true, true>(a, st); }
       return launch_nt_row384_cfg<EPI, 4, false, true>(a, st);
@@ -1763,6 +1789,9 @@ int launch_nt(const GemmArgs& a, hipStream_t st) {
       if constexpr (EPI == EPI_RESID) return launch_nt_row384<EPI>(a, st);
     }
     int v = g_nt_variant;
+    if constexpr (EPI != EPI_PATCH && EPI != EPI_LNBWD) {
+      if (v < 0 && !a.fp8 && p8_ok<EPI>(a)) return launch_nt_p8<EPI>(a, st);
+    }
     if constexpr (EPI == EPI_F32) {
       // A handful of output tiles with a long K (the head Linears: 1536 x 256 x 12288 = 24 tiles of 384 k-tiles, 103 us on 24 CUs): split K
       // over the idle CUs; partial tiles go to a library-owned workspace and splitk_reduce_kernel sums them in a fixed order.  The split
@@ -1794,7 +1823,9 @@ int launch_nt(const GemmArgs& a, hipStream_t st) {
 }  // namespace
 
 void atst_gemm_nt_set_variant(int v) {
-  if (v >= 380) g_f32_splitk = v - 380;
+  if (v >= 1000 && v < 2000) g_p8_skew = v - 1000;
+  else if (v >= 390) g_p8 = v - 390;
+  else if (v >= 380) g_f32_splitk = v - 380;
   else if (v >= 370) g_bf16_tr = v - 370;
   else if (v >= 360) g_w4_auto = v - 360;
   else if (v >= 350) g_w4_min_m = v == 351 ? 1 : 8192;

@@ -148,6 +148,46 @@ def test_gemm_nt_epilogues(M):
     assert relerr(t, want) < 2e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 768), (1024, 2304, 768), (8192, 768, 3072), (8192 + 256, 3072, 768), (768, 1536, 384)])
+def test_gemm_nt_p8_phased_kernel(M, N, K):
+    """The 256 x 256 phased kernel (csrc/gemm_p8.h; N % 256 == 0, K % 128 == 0, M % 256 == 0; hook 391 on / 390 off; hook 351 admits it below
+    8192 rows): every epilogue it carries against the fp32 formula, and against the kernels it replaces.  Asymmetric operands catch a
+    transposed fragment; K = 128 (two k-tiles) is all prologue + tail, K = 3072 runs 22 steady iterations."""
+    lib = hip.load()
+    A, B = bf(rnd(M, K, seed=1, scale=0.5)), bf(rnd(N, K, seed=2, scale=0.5))
+    bias = rnd(N, seed=3)
+    ref = A.float() @ B.float().t()
+    rps = 64
+    resid = rnd(M, N, seed=4)
+    scale = torch.tensor([1.0, 0.0, 1.25, 1.0, 1.25, 0.0, 1.0, 1.0, 1.0, 1.25], device=DEV).repeat(M // (10 * rps) + 1)[:M // rps].contiguous()
+    U = bf(rnd(M, N, seed=5))
+    res = {}
+    try:
+        lib.atst_tune_gemm_variant(351)
+        for hook in (390, 391):
+            lib.atst_tune_gemm_variant(hook)
+            f32, _ = gemm_nt(A, B, hip.EPI_F32, torch.float32, bias=bias)
+            b16, _ = gemm_nt(A, B, hip.EPI_BF16, torch.bfloat16, bias=bias)
+            b16nb, _ = gemm_nt(A, B, hip.EPI_BF16, torch.bfloat16)
+            u, a = gemm_nt(A, B, hip.EPI_BIAS_GELU, torch.bfloat16, bias=bias)
+            x, _ = gemm_nt(A, B, hip.EPI_RESID, torch.float32, bias=bias, resid=resid, row_scale=scale, rps=rps)
+            cs = torch.full((N,), 0.25, device=DEV)
+            d, _ = gemm_nt(A, B, hip.EPI_DGELU, torch.bfloat16, U=U, colsum=cs)
+            res[hook] = (f32, b16, b16nb, u, a, x, d, cs)
+    finally:
+        lib.atst_tune_gemm_variant(391); lib.atst_tune_gemm_variant(350)
+    f32, b16, b16nb, u, a, x, d, cs = res[391]
+    assert relerr(f32, ref + bias) < 2e-5
+    assert relerr(b16.float(), ref + bias) < 4e-3 and relerr(b16nb.float(), ref) < 4e-3
+    assert relerr(u.float(), ref + bias) < 4e-3 and relerr(a.float(), torch.nn.functional.gelu(ref + bias)) < 5e-3
+    assert relerr(x, resid + scale.repeat_interleave(rps)[:, None] * (ref + bias)) < 2e-5
+    uf = U.float().requires_grad_(True)
+    torch.nn.functional.gelu(uf).backward(ref)
+    assert relerr(d.float(), uf.grad) < 5e-3 and relerr(cs, uf.grad.sum(0) + 0.25) < 2e-3
+    for got, other in zip(res[391], res[390]):                            # the kernels it replaces: same sums up to the fp32 accumulation order
+        assert relerr(got.float(), other.float()) < 4e-3
+
+
 @pytest.mark.parametrize("M,N,K,split", [(1000, 256, 384, 0), (64, 128, 128, 0), (4099, 384, 256, 512), (777, 1152, 384, 0),
                                          (8192, 384, 384, 0), (16384 + 64, 1152, 384, 0), (8192 + 128, 384, 1536, 0)])   # last three: 192x384 LDS-DMA tile
 def test_gemm_tn(M, N, K, split):
@@ -823,3 +863,44 @@ def test_fp8_forward_only_state_is_saved_and_restored():
     assert torch.equal(eng2.f8a_scale.cpu(), st["f8a_scale"]) and torch.equal(eng2.f8a_hist.cpu(), st["f8a_hist"]) and eng2._f8a_hist_k == 3
     l1, l2 = eng.forward(mels, lens)[0], eng2.forward(mels, lens)[0]           # the resumed engine quantises as the saved one does
     assert float(l1) == float(l2)
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 768, 768), (1024, 2304, 768), (8192, 768, 3072), (8192 + 256, 3072, 768)])
+def test_gemm_fp8_phased_kernel(M, N, K):
+    """The e4m3 form of the 256 x 256 phased kernel (csrc/gemm_p8.h, F8 = true: one v_mfma_scale_f32_32x32x64_f8f6f4 per 64-byte k-step) through
+    atst_gemm_nt_fp8: every epilogue of the C ABI against an fp32 matmul of the SAME e4m3 values, and against the kernel it replaces (hook 390)."""
+    lib = hip.load()
+    g = torch.Generator().manual_seed(M + N)
+    A = (torch.randn(M, K, generator=g) * 1.5).to(DEV).bfloat16()
+    W = (torch.randn(N, K, generator=g) * 0.05).to(DEV).bfloat16()
+    A8 = torch.empty(M, K, dtype=torch.uint8, device=DEV); W8 = torch.empty(N, K, dtype=torch.uint8, device=DEV)
+    hip.call("atst_quant_fp8_bf16", hip.ptr(A), M * K, 8.0, hip.ptr(A8), hip.stream())
+    hip.call("atst_quant_fp8_bf16", hip.ptr(W), N * K, 64.0, hip.ptr(W8), hip.stream())
+    dq = torch.tensor([1.0 / 64.0], device=DEV)
+    ref = (A8.view(torch.float8_e4m3fn).double() @ W8.view(torch.float8_e4m3fn).double().t()).float() / (8.0 * 64.0)
+    bias = torch.randn(N, device=DEV)
+    rps = 64
+    resid = rnd(M, N, seed=4)
+    scale = torch.tensor([1.0, 0.0, 1.25, 1.0], device=DEV).repeat(M // (4 * rps) + 1)[:M // rps].contiguous()
+    res = {}
+    try:
+        lib.atst_tune_gemm_variant(351)
+        for hook in (390, 392):                                               # 392: the phased kernel also for e4m3 operands (not the default: slower in the step)
+            lib.atst_tune_gemm_variant(hook)
+            outs = []
+            for epi, dt in ((hip.EPI_F32, torch.float32), (hip.EPI_BF16, torch.bfloat16), (hip.EPI_BIAS_GELU, torch.bfloat16), (hip.EPI_RESID, torch.float32)):
+                out = torch.empty(M, N, device=DEV, dtype=dt)
+                c2 = torch.empty(M, N, device=DEV, dtype=torch.bfloat16) if epi == hip.EPI_BIAS_GELU else None
+                hip.call("atst_gemm_nt_fp8", hip.ptr(A8), hip.ptr(W8), M, N, K, K, K, epi, hip.ptr(out), N, hip.ptr(c2), hip.ptr(bias),
+                         hip.ptr(resid) if epi == hip.EPI_RESID else None, hip.ptr(scale) if epi == hip.EPI_RESID else None, rps, hip.ptr(dq), 1.0 / 8.0, hip.stream())
+                outs += [out] + ([c2] if c2 is not None else [])
+            res[hook] = outs
+    finally:
+        lib.atst_tune_gemm_variant(391); lib.atst_tune_gemm_variant(350)
+    f32, b16, u, a, x = res[392]
+    assert relerr(f32, ref + bias) < 5e-5
+    assert relerr(b16.float(), ref + bias) < 4e-3 and relerr(u.float(), ref + bias) < 4e-3
+    assert relerr(a.float(), torch.nn.functional.gelu(ref + bias)) < 5e-3
+    assert relerr(x, resid + scale.repeat_interleave(rps)[:, None] * (ref + bias)) < 5e-5
+    for got, other in zip(res[392], res[390]):
+        assert relerr(got.float(), other.float()) < 4e-3
