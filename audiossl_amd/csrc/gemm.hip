@@ -1627,8 +1627,9 @@ int g_w4_mode = 0;          // 330 + m: 4-wave two-blocks-per-CU kernels: 0 only
 int g_w4_min_m = 8192;      // 350/351: apply the tall / 4-wave kernels from M = 8192 / from any M (parity tests run small shapes)
 int g_w4_auto = 1;          // 360/361: 4-wave kernels for launches of <= 1.5 rounds of 256 x 384 tiles
 int g_p8_skew = 0;          // 1000 + c: start-up skew of every other first-round block of the phased kernel, c x 1024 cycles (experiment)
-int g_p8 = 1;               // 390/391/392: 256 x 256 phased kernel (gemm_p8.h) for N % 256 == 0, K % 128 == 0, M % 256 == 0, M >= 8192: off / bf16 operands (default) / also e4m3 operands
-                            // (392 measured SLOWER in the step: base fp8 2255 vs 2494 clips/s -- with 6 k-tiles at K = 768 the e4m3 form is all prologue and last-pair code, which also spills)
+int g_p8 = 2;               // 390/391/392: 256 x 256 phased kernel (gemm_p8.h) for N % 256 == 0, K % 128 == 0, M % 256 == 0, M >= 8192: off / bf16 operands only / also e4m3
+                            // operands (default; except fc1 + GELU, whose e4m3 epilogue -- u, a, the e4m3 copy of a, amax -- measured 640 vs 647 us on the 256 x 384 tile).
+                            // Same box, same call, base fp8 step: 2405-2407 (391) -> 2453-2476 clips/s (392), profiles/r05_p8_fp8_step_ab.txt
 int g_f32_splitk = 1;       // 380/381: split-K for fp32-output GEMMs with <= 64 output tiles and K >= 2048
 // Split-K workspace: per (device, stream) -- kernels of one stream run in order, so one buffer per stream is race-free; the null stream is the same
 // handle on every device, hence the device in the key (round-4 ADVICE).  Sized on first use for the largest head shape of the path
@@ -1740,7 +1741,7 @@ template <int EPI>
 int launch_nt_row384(const GemmArgs& a, hipStream_t st) {
   if (a.fp8) {                                                    // e4m3 operands seen as byte pairs: K, lda, ldb are already halved
     if constexpr (EPI == EPI_BF16 || EPI == EPI_BIAS_GELU || EPI == EPI_RESID || EPI == EPI_F32 || EPI == EPI_DGELU) {
-      if (g_nt_variant < 0 && g_p8 >= 2 && p8_ok<EPI>(a)) return launch_nt_p8<EPI, true>(a, st);
+      if (g_nt_variant < 0 && g_p8 >= 2 && EPI != EPI_BIAS_GELU && p8_ok<EPI>(a)) return launch_nt_p8<EPI, true>(a, st);
       ProfScope ps(prof_kind<EPI>(), 4.0 * a.M * a.N * a.K, st, nt_bytes<EPI>(a));
       if constexpr (EPI == EPI_BF16) { if (g_bf16_tr) return launch_nt_row384_cfg<EPI, 4, false, true, true>(a, st); }
       return launch_nt_row384_cfg<EPI, 4, false, true>(a, st);

@@ -86,6 +86,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(GemmArgs p) {
   const unsigned lds0 = lds_addr(smem_raw) + (2 * wid) * 1024;    // this wave's two pieces of a unit (LDS byte address)
   // unit slots of a k-tile buffer: 0 = A lower rows, 1 = A upper rows, 2 = B lower columns, 3 = B upper columns
   auto stage = [&](int kt, int unit) {                            // kt: k-tile, unit: 0..3
+    if constexpr (F8) kt = kt < nk ? kt : nk - 2 + (kt & 1);      // (see the loop: no separate last pair)
     const unsigned dst = lds0 + (kt & 1) * TILEB + unit * UNIT;
     const char* base = (unit < 2 ? baseA + (unit & 1) * a_half : baseB + (unit & 1) * b_half) + (size_t)kt * (BKP * 2);
 #pragma unroll
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(GemmArgs p) {
       if constexpr (q == 0) read_b(buf, 0);
       if constexpr (q == 1) read_b(buf, 1);
       if constexpr (q == 2) read_a(buf, 1);
-      if constexpr (q == 3) { if (FIRST || !last) read_a(buf ^ 1, 0); }
+      if constexpr (q == 3) { if (FIRST || !last) read_a(buf ^ 1, 0); }   // (F8, last k-tile: reads the other buffer's lower A rows, unused)
       if ((FIRST && q == 0) || !last) {
         if constexpr (q == 0) stage(t + 1, 1);
         if constexpr (q == 1) stage(t + 2, 0);
@@ -229,8 +230,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(GemmArgs p) {
     phase(t + 1, P8_B(L), P8_I(1), P8_I(1), P8_B(false), P8_I(0));          \
     phase(t + 1, P8_B(L), P8_I(2), P8_I(1), P8_B(false), P8_I(-1));         \
     phase(t + 1, P8_B(L), P8_I(3), P8_I(1), P8_B(false), P8_I(-1));
-  for (; t + 2 < nk; t += 2) { P8_PAIR(false) }
-  P8_PAIR(true)
+  if constexpr (F8) {
+    // e4m3: K = 768 is six k-tiles, a third of them in the last pair -- whose straight-line copy hipcc register-allocates badly (8-register operand
+    // tuples: freshly read fragments spilled).  Every pair runs the steady body instead; stage() clamps a target beyond the last k-tile to the last
+    // k-tile of the same parity, i.e. re-writes a slot with the bytes it already holds (harmless to concurrent readers; 7 units of extra L2 -> LDS
+    // traffic per tile), and the waits stay `vmcnt(10)`.
+    for (; t < nk; t += 2) { P8_PAIR(false) }
+    p8_wait_vm<0>();
+  } else {
+    for (; t + 2 < nk; t += 2) { P8_PAIR(false) }
+    P8_PAIR(true)
+  }
 #undef P8_PAIR
 #undef P8_I
 #undef P8_B
@@ -324,7 +334,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(GemmArgs p) {
   // flight per CU instead of one part's.  A CU's epilogue rate is bytes in flight / memory latency; with one part in flight it is ~22 GB/s, which
   // only equals a fair share of HBM when all 256 CUs run their epilogues at the same moment (profiles/r05_p8_ablate.txt).  The fragment registers of
   // the main loop are free here, so the deeper queue costs nothing.
-  constexpr int PF = EPI == EPI_DGELU ? 2 : 0;
+  constexpr int PF = (EPI == EPI_DGELU && !F8) ? 2 : 0;           // (the e4m3 instantiation has no registers for it: spills)
   EpiAux aux[PF + 1][SLOTS];
   auto fetch_part = [&](int part, EpiAux (&a)[SLOTS]) {
 #pragma unroll

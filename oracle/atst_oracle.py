@@ -62,20 +62,32 @@ ARCH = {  # ref: audio_transformer.py:367-374
 # HIP-vs-reference gradient differences: HIP vs this mode must agree to ~1e-3, this mode vs plain fp32 is the bf16 floor.
 # ----------------------------------------------------------------------------------------------------------------------
 _EMU = False
+_EMU_OFF: frozenset = frozenset()
+# Rounding sites of the encoder (names for emulate_bf16(off=...), tools/parity_report.py --by-site).  Forward values: "w" (bf16 weight shadows), "patches"
+# (patch-embed operand), "ln1" / "ln2" / "ln_final" (LayerNorm outputs = GEMM operands), "qkv" (qkv GEMM output), "P" (softmax probabilities), "attn_out"
+# (attention output = proj operand), "gelu_out" (a = fc2 operand), "u_saved" (the bf16 copy of the pre-activation GELU' is evaluated on).  Gradient operands:
+# "g_ln1" / "g_ln2" / "g_final" (d LayerNorm output), "g_qkv", "g_S" (d scores), "g_attn_out", "g_proj_out" / "g_fc2_out" (branch gradients = dY of the
+# proj / fc2 backward), "g_fc1_out" (du), "g_patch".
+ROUNDING_SITES = ("w", "patches", "ln1", "qkv", "P", "attn_out", "ln2", "gelu_out", "u_saved", "ln_final",
+                  "g_ln1", "g_qkv", "g_S", "g_attn_out", "g_proj_out", "g_ln2", "g_fc1_out", "g_fc2_out", "g_patch", "g_final")
 
 
 class emulate_bf16:
-    def __init__(self, on: bool = True):
-        self.on = on
+    """off: rounding sites (ROUNDING_SITES) left in fp32 -- attribution of the bf16 gradient error to the places that round."""
+
+    def __init__(self, on: bool = True, off=()):
+        self.on, self.off = on, frozenset(off)
+        assert self.off <= set(ROUNDING_SITES), self.off - set(ROUNDING_SITES)
 
     def __enter__(self):
-        global _EMU
-        self.prev, _EMU = _EMU, self.on
+        global _EMU, _EMU_OFF
+        self.prev, _EMU = (_EMU, _EMU_OFF), self.on
+        _EMU_OFF = self.off
         return self
 
     def __exit__(self, *a):
-        global _EMU
-        _EMU = self.prev
+        global _EMU, _EMU_OFF
+        _EMU, _EMU_OFF = self.prev
 
 
 _GATES: Dict[str, Tensor] = {}
@@ -127,7 +139,7 @@ class _RoundGrad(torch.autograd.Function):          # value untouched, gradient 
 class _GeluSavedBf16(torch.autograd.Function):      # a = gelu(u) on the fp32 accumulator; GELU' on the bf16 copy of u that is saved
     @staticmethod
     def forward(ctx, u):
-        ctx.save_for_backward(_bf(u))
+        ctx.save_for_backward(u if "u_saved" in _EMU_OFF else _bf(u))
         return F.gelu(u)
 
     @staticmethod
@@ -241,21 +253,21 @@ def _linear(x: Tensor, W: Weights, key: str, b: Optional[Tensor], act_scale: flo
     return y if b is None else y + b
 
 
-def _r(x):
-    return _RoundFwd.apply(x) if _EMU else x
+def _r(x, site=None):
+    return _RoundFwd.apply(x) if (_EMU and site not in _EMU_OFF) else x
 
 
-def _rg(x):
-    return _RoundGrad.apply(x) if (_EMU and x.requires_grad) else x
+def _rg(x, site=None):
+    return _RoundGrad.apply(x) if (_EMU and x.requires_grad and site not in _EMU_OFF) else x
 
 
-def _rb(x):
-    return _rg(_r(x))
+def _rb(x, site=None, gsite=None):
+    return _rg(_r(x, site), gsite)
 
 
 def _w(W: Weights, k: str) -> Tensor:
     """a GEMM weight operand: the bf16 shadow when emulating."""
-    return _r(W[k])
+    return _r(W[k], "w")
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -363,23 +375,23 @@ def block_forward(W: Weights, pre: str, x: Tensor, bias: Optional[Tensor], num_h
     streams differ); output scaled by 1/(1-drop_prob).  ref: transformer.py:95-150."""
     S, N, C = x.shape
     hd = C // num_heads
-    h = _rb(F.layer_norm(x, (C,), W[pre + "norm1.weight"], W[pre + "norm1.bias"], LN_EPS))
-    qkv = _rb(_linear(h, W, pre + "attn.qkv.weight", W.get(pre + "attn.qkv.bias")))
+    h = _rb(F.layer_norm(x, (C,), W[pre + "norm1.weight"], W[pre + "norm1.bias"], LN_EPS), "ln1", "g_ln1")
+    qkv = _rb(_linear(h, W, pre + "attn.qkv.weight", W.get(pre + "attn.qkv.bias")), "qkv", "g_qkv")
     qkv = qkv.reshape(S, N, 3, num_heads, hd).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0], qkv[1], qkv[2]
     att = torch.matmul(q, k.transpose(-2, -1)) * (hd ** -0.5)
     if bias is not None:
         att = att + bias
-    att = _r(_rg(att).softmax(dim=-1))
-    y = _rb(torch.matmul(att, v).transpose(1, 2).reshape(S, N, C))
-    y = _rg(_linear(y, W, pre + "attn.proj.weight", W[pre + "attn.proj.bias"]))
+    att = _r(_rg(att, "g_S").softmax(dim=-1), "P")
+    y = _rb(torch.matmul(att, v).transpose(1, 2).reshape(S, N, C), "attn_out", "g_attn_out")
+    y = _rg(_linear(y, W, pre + "attn.proj.weight", W[pre + "attn.proj.bias"]), "g_proj_out")
     if keep_attn is not None and drop_prob > 0.0:
         y = y / (1.0 - drop_prob) * keep_attn.to(y.dtype)[:, None, None]
     x = x + y
-    h = _rb(F.layer_norm(x, (C,), W[pre + "norm2.weight"], W[pre + "norm2.bias"], LN_EPS))
-    h = _rg(_linear(h, W, pre + "mlp.fc1.weight", W[pre + "mlp.fc1.bias"]))
-    h = _r(_GeluSavedBf16.apply(h)) if _EMU else F.gelu(h)      # exact erf GELU (nn.GELU default)
-    h = _rg(_linear(h, W, pre + "mlp.fc2.weight", W[pre + "mlp.fc2.bias"], FP8_ACT_SCALE_GELU))
+    h = _rb(F.layer_norm(x, (C,), W[pre + "norm2.weight"], W[pre + "norm2.bias"], LN_EPS), "ln2", "g_ln2")
+    h = _rg(_linear(h, W, pre + "mlp.fc1.weight", W[pre + "mlp.fc1.bias"]), "g_fc1_out")
+    h = _r(_GeluSavedBf16.apply(h), "gelu_out") if _EMU else F.gelu(h)      # exact erf GELU (nn.GELU default)
+    h = _rg(_linear(h, W, pre + "mlp.fc2.weight", W[pre + "mlp.fc2.bias"], FP8_ACT_SCALE_GELU), "g_fc2_out")
     if keep_mlp is not None and drop_prob > 0.0:
         h = h / (1.0 - drop_prob) * keep_mlp.to(h.dtype)[:, None, None]
     return x + h
@@ -392,8 +404,8 @@ def encoder_tokens(W: Weights, pre: str, mel: Tensor, length: Optional[Tensor], 
     # patch geometry from the shapes: one patch row of patch_h = spec_h bands (reference --patch_h with spec_h = n_mels) x patch_w frames
     ph = mel.shape[2]
     pw = W[pre + "patch_embed.patch_embed.weight"].shape[1] // ph
-    patches = _r(patchify(mel, ph, pw))
-    x = _rg(F.linear(patches, _w(W, pre + "patch_embed.patch_embed.weight"), W[pre + "patch_embed.patch_embed.bias"]))
+    patches = _r(patchify(mel, ph, pw), "patches")
+    x = _rg(F.linear(patches, _w(W, pre + "patch_embed.patch_embed.weight"), W[pre + "patch_embed.patch_embed.bias"]), "g_patch")
     S, T, C = x.shape
     plen = patch_length(length, mel.shape[2], ph, pw) if length is not None else None
     if mask_index is not None and mask_input:
@@ -429,10 +441,10 @@ def encoder_forward(W: Weights, pre: str, mel: Tensor, length: Tensor, arch: str
             outs.append(x)
     C = x.shape[-1]
     if use_cls:
-        y = _rb(F.layer_norm(x, (C,), W[pre + "norm.weight"], W[pre + "norm.bias"], LN_EPS))
+        y = _rb(F.layer_norm(x, (C,), W[pre + "norm.weight"], W[pre + "norm.bias"], LN_EPS), "ln_final", "g_final")
         out = y[:, 0]
     else:
-        y = _rb(F.layer_norm(x, (C,), W[pre + "norm_frame.weight"], W[pre + "norm_frame.bias"], LN_EPS))
+        y = _rb(F.layer_norm(x, (C,), W[pre + "norm_frame.weight"], W[pre + "norm_frame.bias"], LN_EPS), "ln_final", "g_final")
         lm = torch.arange(x.shape[1])[None, :] < plen[:, None]
         out = y[mask_index & lm]
     return (out, outs) if return_blocks else out
