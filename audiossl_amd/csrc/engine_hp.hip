@@ -8,7 +8,7 @@
 // wiring mistake.  This mode removes the rounding and keeps everything else -- the Python engine (view grouping, heads, loss,
 // optimizer, EMA, ATST-Frame row gather), the token stage, DropPath / key-padding semantics, the parameter and gradient
 // layout, and the production GEMM / wgrad kernels and their fp32 epilogues -- so that gradients can be pinned to the reference
-// goldens at <= 2e-3 per tensor (tests/test_precise_gpu.py).  Tiny shapes only; measured 18-20x slower than the bf16 path at the same batch (232 vs 4570 clips/s, 2 views x 64 clips: bench.py --precise, profiles/r04_g_bench_precise_clip2_b64.json).
+// goldens at <= 2e-3 per tensor (tests/test_precise_gpu.py).  Measured 6.9x slower than the bf16 path at the same batch (662 vs 4582 clips/s, 2 views x 64 clips: bench.py --precise, profiles/r05_k_bench_precise_clip2_b64.json; round 4: 232 clips/s = 18-20x, when its attention / LayerNorm-backward / GELU' twins re-read every row from global memory).
 // Reference math: audiossl/modules/transformer.py:95-159, audiossl/models/atst/audio_transformer.py:153-221.
 #include "common.h"
 #include "kernels.h"
@@ -53,28 +53,50 @@ __global__ __launch_bounds__(256) void ln_fwd_hp_kernel(const float* __restrict_
   for (int c = lane; c < C; c += 64) y[(size_t)row * C + c] = (xr[c] - mu) * rs * gamma[c] + beta[c];
   if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
-// dx = dres + LN'(dy) ; g = row_scale dx (fp32, the upstream Linear's gradient operand) ; dgamma, dbeta, dbias_up += column sums
+// dx = dres + LN'(dy) ; g = row_scale dx (fp32, the upstream Linear's gradient operand) ; dgamma, dbeta, dbias_up += column sums.
+// A wave walks LNB_ROWS consecutive rows and keeps the column sums of its lanes' columns in registers: one atomic per column per wave instead of three
+// per ELEMENT (round 5: this kernel was 10 % of the parity-mode step).
+constexpr int LNB_ROWS = 16, LNB_MAXC = 768 / 64;
 __global__ __launch_bounds__(256) void ln_bwd_hp_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
                                                         const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ dres,
                                                         float* __restrict__ dx, float* __restrict__ g, const float* __restrict__ row_scale, int rps,
                                                         float* dgamma, float* dbeta, float* dbias_up, int M, int C) {
-  const int lane = threadIdx.x & 63, row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (row >= M) return;
-  const size_t base = (size_t)row * C;
-  const float mu = mean[row], rs = rstd[row];
-  float s1 = 0.f, s2 = 0.f;
-  for (int c = lane; c < C; c += 64) {
-    const float xh = (x[base + c] - mu) * rs, d = dy[base + c], dg = d * gamma[c];
-    s1 += dg; s2 += dg * xh;
-    atomicAdd(dgamma + c, d * xh); atomicAdd(dbeta + c, d);
+  const int lane = threadIdx.x & 63, w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nc = C / 64;
+  float sg[LNB_MAXC], sb[LNB_MAXC], su[LNB_MAXC];
+#pragma unroll
+  for (int k = 0; k < LNB_MAXC; ++k) sg[k] = sb[k] = su[k] = 0.f;
+  for (int r = 0; r < LNB_ROWS; ++r) {
+    const int row = w * LNB_ROWS + r;
+    if (row >= M) break;
+    const size_t base = (size_t)row * C;
+    const float mu = mean[row], rs = rstd[row];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < LNB_MAXC; ++k) {
+      if (k >= nc) break;
+      const int c = lane + 64 * k;
+      const float xh = (x[base + c] - mu) * rs, d = dy[base + c], dg = d * gamma[c];
+      s1 += dg; s2 += dg * xh;
+      sg[k] += d * xh; sb[k] += d;
+    }
+    const float c1 = wave_sum(s1) / C, c2 = wave_sum(s2) / C;
+    const float sc = row_scale ? row_scale[row / rps] : 1.0f;
+#pragma unroll
+    for (int k = 0; k < LNB_MAXC; ++k) {
+      if (k >= nc) break;
+      const int c = lane + 64 * k;
+      const float xh = (x[base + c] - mu) * rs;
+      const float o = (dres ? dres[base + c] : 0.f) + rs * (dy[base + c] * gamma[c] - c1 - xh * c2);
+      dx[base + c] = o;
+      if (g) { const float gs = o * sc; g[base + c] = gs; su[k] += gs; }
+    }
   }
-  const float c1 = wave_sum(s1) / C, c2 = wave_sum(s2) / C;
-  const float sc = row_scale ? row_scale[row / rps] : 1.0f;
-  for (int c = lane; c < C; c += 64) {
-    const float xh = (x[base + c] - mu) * rs;
-    const float o = (dres ? dres[base + c] : 0.f) + rs * (dy[base + c] * gamma[c] - c1 - xh * c2);
-    dx[base + c] = o;
-    if (g) { const float gs = o * sc; g[base + c] = gs; if (dbias_up) atomicAdd(dbias_up + c, gs); }
+#pragma unroll
+  for (int k = 0; k < LNB_MAXC; ++k) {
+    if (k >= nc) break;
+    const int c = lane + 64 * k;
+    atomicAdd(dgamma + c, sg[k]); atomicAdd(dbeta + c, sb[k]);
+    if (g && dbias_up) atomicAdd(dbias_up + c, su[k]);
   }
 }
 
@@ -103,79 +125,119 @@ __global__ void dgelu_hp_kernel(const float* __restrict__ dA, const float* __res
 // ---- attention in plain fp32: one block per (sequence, head), one thread per query / per key ------------------------------
 // scores = q k^T / 8 over the `valid` keys (the reference adds -10000 to the others: their weight is exp(-10000 + ...) == 0 in
 // fp32), softmax, o = p v.  lse saved for the backward.  ref: audiossl/modules/transformer.py:95-126.
-__global__ void attn_hp_fwd_kernel(const float* __restrict__ qkv, const int* __restrict__ valid, float* __restrict__ o, float* __restrict__ lse,
-                                   int H, int NP) {
+// Round 5: the rows every thread walks (K, V ; in the backward also Q, dO) are staged in LDS once per block (2 x NP x 64 fp32 = 128 KB at NP = 256) and
+// read back as broadcast 16-B reads -- before, all 256 threads re-read every row from global memory and the two kernels were 66 % of the
+// parity-mode step (profiles/r05_precise_kernel_stats.csv).  Same arithmetic in the same order; the backward is one launch (dq, then dk / dv).
+DEVFN void hp_stage_rows(const float* __restrict__ src /* row 0 of the head's 64 columns */, size_t ld, int NP, float* __restrict__ dst) {
+  for (int idx = threadIdx.x; idx < NP * 16; idx += blockDim.x) {
+    const int row = idx >> 4, c4 = (idx & 15) * 4;
+    *reinterpret_cast<f32x4*>(dst + row * 64 + c4) = *reinterpret_cast<const f32x4*>(src + (size_t)row * ld + c4);
+  }
+}
+__global__ __launch_bounds__(256) void attn_hp_fwd_kernel(const float* __restrict__ qkv, const int* __restrict__ valid, float* __restrict__ o,
+                                                          float* __restrict__ lse, int H, int NP) {
+  extern __shared__ __attribute__((aligned(16))) float hp_sm[];
+  float* sK = hp_sm; float* sV = hp_sm + NP * 64;
   const int s = blockIdx.x / H, h = blockIdx.x % H, C = H * 64, i = threadIdx.x;
-  if (i >= NP) return;
   const int nv = valid[s];
   const float* base = qkv + (size_t)s * NP * 3 * C;
+  hp_stage_rows(base + C + h * 64, 3 * (size_t)C, NP, sK);
+  hp_stage_rows(base + 2 * C + h * 64, 3 * (size_t)C, NP, sV);
+  __syncthreads();
+  if (i >= NP) return;
   float q[64];
   for (int d = 0; d < 64; ++d) q[d] = base[(size_t)i * 3 * C + h * 64 + d];
   float m = -INFINITY;
   for (int j = 0; j < nv; ++j) {
-    const float* k = base + (size_t)j * 3 * C + C + h * 64;
+    const float* k = sK + j * 64;
     float sc = 0.f;
+#pragma unroll
     for (int d = 0; d < 64; ++d) sc += q[d] * k[d];
     m = fmaxf(m, sc * 0.125f);
   }
   float l = 0.f, acc[64];
   for (int d = 0; d < 64; ++d) acc[d] = 0.f;
   for (int j = 0; j < nv; ++j) {
-    const float* k = base + (size_t)j * 3 * C + C + h * 64;
-    const float* v = base + (size_t)j * 3 * C + 2 * C + h * 64;
+    const float* k = sK + j * 64;
+    const float* v = sV + j * 64;
     float sc = 0.f;
+#pragma unroll
     for (int d = 0; d < 64; ++d) sc += q[d] * k[d];
     const float p = expf(sc * 0.125f - m);
     l += p;
+#pragma unroll
     for (int d = 0; d < 64; ++d) acc[d] += p * v[d];
   }
   const float inv = 1.0f / l;
   for (int d = 0; d < 64; ++d) o[((size_t)s * NP + i) * C + h * 64 + d] = acc[d] * inv;
   lse[((size_t)s * H + h) * NP + i] = m + logf(l);
 }
-// phase 0 (thread = query i): dq_i ; phase 1 (thread = key j): dk_j, dv_j.  p_ij recomputed from q, k and the saved lse.
-__global__ void attn_hp_bwd_kernel(const float* __restrict__ qkv, const int* __restrict__ valid, const float* __restrict__ o,
-                                   const float* __restrict__ lse, const float* __restrict__ d_o, float* __restrict__ dqkv, int H, int NP, int phase) {
+// thread = query i: dq_i (K, V in LDS) ; then thread = key j: dk_j, dv_j (Q, dO in LDS ; D_i = rowsum(dO o) and lse_i from the first half).
+// p_ij recomputed from q, k and the saved lse.
+__global__ __launch_bounds__(256) void attn_hp_bwd_kernel(const float* __restrict__ qkv, const int* __restrict__ valid, const float* __restrict__ o,
+                                                          const float* __restrict__ lse, const float* __restrict__ d_o, float* __restrict__ dqkv, int H, int NP) {
+  extern __shared__ __attribute__((aligned(16))) float hp_sm[];
+  float* sA = hp_sm; float* sB = hp_sm + NP * 64; float* sD = sB + NP * 64; float* sL = sD + NP;
   const int s = blockIdx.x / H, h = blockIdx.x % H, C = H * 64, t = threadIdx.x;
-  if (t >= NP) return;
   const int nv = valid[s];
   const float* base = qkv + (size_t)s * NP * 3 * C;
-  auto Q = [&](int i) { return base + (size_t)i * 3 * C + h * 64; };
-  auto K = [&](int j) { return base + (size_t)j * 3 * C + C + h * 64; };
-  auto V = [&](int j) { return base + (size_t)j * 3 * C + 2 * C + h * 64; };
-  auto DO = [&](int i) { return d_o + ((size_t)s * NP + i) * C + h * 64; };
-  auto O = [&](int i) { return o + ((size_t)s * NP + i) * C + h * 64; };
-  float* out = dqkv + ((size_t)s * NP + t) * 3 * C + h * 64;
-  if (phase == 0) {
+  const float* dob = d_o + (size_t)s * NP * C + h * 64;
+  hp_stage_rows(base + C + h * 64, 3 * (size_t)C, NP, sA);          // K
+  hp_stage_rows(base + 2 * C + h * 64, 3 * (size_t)C, NP, sB);      // V
+  __syncthreads();
+  float* out = dqkv + ((size_t)s * NP + (t < NP ? t : 0)) * 3 * C + h * 64;
+  if (t < NP) {
     const int i = t;
     float q[64], g[64], acc[64];
     float D = 0.f;
-    for (int d = 0; d < 64; ++d) { q[d] = Q(i)[d]; g[d] = DO(i)[d]; D += g[d] * O(i)[d]; acc[d] = 0.f; }
+    const float* qi = base + (size_t)i * 3 * C + h * 64;
+    const float* oi = o + ((size_t)s * NP + i) * C + h * 64;
+    for (int d = 0; d < 64; ++d) { q[d] = qi[d]; g[d] = dob[(size_t)i * C + d]; D += g[d] * oi[d]; acc[d] = 0.f; }
     const float L = lse[((size_t)s * H + h) * NP + i];
     for (int j = 0; j < nv; ++j) {
+      const float* kj = sA + j * 64; const float* vj = sB + j * 64;
       float sc = 0.f, dp = 0.f;
-      for (int d = 0; d < 64; ++d) { sc += q[d] * K(j)[d]; dp += g[d] * V(j)[d]; }
+#pragma unroll
+      for (int d = 0; d < 64; ++d) { sc += q[d] * kj[d]; dp += g[d] * vj[d]; }
       const float ds = expf(sc * 0.125f - L) * (dp - D) * 0.125f;
-      for (int d = 0; d < 64; ++d) acc[d] += ds * K(j)[d];
+#pragma unroll
+      for (int d = 0; d < 64; ++d) acc[d] += ds * kj[d];
     }
     for (int d = 0; d < 64; ++d) out[d] = acc[d];
-  } else {
-    const int j = t;
-    float dk[64], dv[64];
-    for (int d = 0; d < 64; ++d) dk[d] = dv[d] = 0.f;
-    if (j < nv) {
-      float k[64], v[64];
-      for (int d = 0; d < 64; ++d) { k[d] = K(j)[d]; v[d] = V(j)[d]; }
-      for (int i = 0; i < NP; ++i) {                            // every query row attends (pad queries carry zero upstream gradient)
-        float sc = 0.f, dp = 0.f, D = 0.f;
-        for (int d = 0; d < 64; ++d) { sc += Q(i)[d] * k[d]; dp += DO(i)[d] * v[d]; D += DO(i)[d] * O(i)[d]; }
-        const float p = expf(sc * 0.125f - lse[((size_t)s * H + h) * NP + i]);
-        const float ds = p * (dp - D) * 0.125f;
-        for (int d = 0; d < 64; ++d) { dv[d] += p * DO(i)[d]; dk[d] += ds * Q(i)[d]; }
-      }
-    }
-    for (int d = 0; d < 64; ++d) { out[C + d] = dk[d]; out[2 * C + d] = dv[d]; }
+    sD[i] = D; sL[i] = L;
   }
+  float k[64], v[64];
+  const bool live = t < NP && t < nv;
+  if (live) { for (int d = 0; d < 64; ++d) { k[d] = sA[t * 64 + d]; v[d] = sB[t * 64 + d]; } }
+  __syncthreads();                                                  // every thread is done with K / V: the buffers take Q and dO
+  hp_stage_rows(base + h * 64, 3 * (size_t)C, NP, sA);              // Q
+  hp_stage_rows(dob, (size_t)C, NP, sB);                            // dO
+  __syncthreads();
+  if (t >= NP) return;
+  float dk[64], dv[64];
+  for (int d = 0; d < 64; ++d) dk[d] = dv[d] = 0.f;
+  if (live) {
+    for (int i = 0; i < NP; ++i) {                                  // every query row attends (pad queries carry zero upstream gradient)
+      const float* qi = sA + i * 64; const float* gi = sB + i * 64;
+      float sc = 0.f, dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < 64; ++d) { sc += qi[d] * k[d]; dp += gi[d] * v[d]; }
+      const float p = expf(sc * 0.125f - sL[i]);
+      const float ds = p * (dp - sD[i]) * 0.125f;
+#pragma unroll
+      for (int d = 0; d < 64; ++d) { dv[d] += p * gi[d]; dk[d] += ds * qi[d]; }
+    }
+  }
+  for (int d = 0; d < 64; ++d) { out[C + d] = dk[d]; out[2 * C + d] = dv[d]; }
+}
+static int hp_attn_lds_attr(int NP) {                               // dynamic LDS beyond 64 KB needs the attribute (once per kernel)
+  static bool done = false;
+  if (done) return ATST_OK;
+  hipError_t e = hipFuncSetAttribute((const void*)attn_hp_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 64 * 4);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_hp_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * 256 * 64 + 2 * 256) * 4);
+  if (e != hipSuccess) return (int)e;
+  done = true; (void)NP;
+  return ATST_OK;
 }
 
 // ---- token plumbing in fp32 ------------------------------------------------------------------------------------------------
@@ -285,7 +347,7 @@ struct Hp {
   }
   int ln_bwd(const float* dy, const float* x, const float* mean, const float* rstd, int64_t g_off, const float* dres, float* dx, float* g,
              const float* row_scale, float* dgamma, float* dbeta, float* dbias_up) {
-    hipLaunchKernelGGL(ln_bwd_hp_kernel, dim3((M + 3) / 4), dim3(256), 0, st, dy, x, mean, rstd, e->p32 + g_off, dres, dx, g, row_scale, e->NP,
+    hipLaunchKernelGGL(ln_bwd_hp_kernel, dim3((M + 4 * LNB_ROWS - 1) / (4 * LNB_ROWS)), dim3(256), 0, st, dy, x, mean, rstd, e->p32 + g_off, dres, dx, g, row_scale, e->NP,
                        dgamma, dbeta, dbias_up, M, C);
     LAUNCH_OK();
     return ATST_OK;
@@ -332,7 +394,8 @@ extern "C" int atst_encoder_hp_fwd(const atst_encoder_t* e, void* stream) {
     const float* s2 = e->dp_scale ? e->dp_scale + (size_t)(2 * i + 1) * S : nullptr;
     RUN(hp.ln_fwd(w.x[2 * i], lo.ln1_w, lo.ln1_b, l.h1, l.mean1, l.rstd1));
     RUN(hp.linear(l.h1, lo.qkv_w, 3 * C, C, EPI_F32, l.qkv, nullptr));
-    hipLaunchKernelGGL(attn_hp_fwd_kernel, dim3(S * e->H), dim3(256), 0, st, l.qkv, e->valid, l.o, l.lse, e->H, NP);
+    RUN(hp_attn_lds_attr(NP));
+    hipLaunchKernelGGL(attn_hp_fwd_kernel, dim3(S * e->H), dim3(256), 2 * NP * 64 * 4, st, l.qkv, e->valid, l.o, l.lse, e->H, NP);
     LAUNCH_OK();
     RUN(hp.linear(l.o, lo.proj_w, C, C, EPI_RESID, w.x[2 * i + 1], p + lo.proj_b, w.x[2 * i], s1, NP));
     RUN(hp.ln_fwd(w.x[2 * i + 1], lo.ln2_w, lo.ln2_b, l.h2, l.mean2, l.rstd2));
@@ -364,15 +427,15 @@ extern "C" int atst_encoder_hp_bwd(const atst_encoder_t* e, void* stream) {
     const LayerHp& l = w.L[i];
     // ---- MLP branch: x_out = x_mid + s2 (fc2(gelu(fc1(LN2(x_mid)))) + b2) ; w.g = s2 d(x_out)
     RUN(hp.linear_t(w.g, lo.fc2_w, C, 4 * C, w.dA));
-    hipLaunchKernelGGL(dgelu_hp_kernel, dim3((4 * C + 255) / 256, 16), dim3(256), 0, st, w.dA, l.u, M, 4 * C, w.du, G + lo.fc1_b);
+    hipLaunchKernelGGL(dgelu_hp_kernel, dim3((4 * C + 255) / 256, M >= 16384 ? 256 : 16), dim3(256), 0, st, w.dA, l.u, M, 4 * C, w.du, G + lo.fc1_b);
     LAUNCH_OK();
     RUN(hp.linear_t(w.du, lo.fc1_w, 4 * C, C, w.dh));
     RUN(hp.ln_bwd(w.dh, w.x[2 * i + 1], l.mean2, l.rstd2, lo.ln2_w, cur, oth, w.g2, dps(i, 0), G + lo.ln2_w, G + lo.ln2_b, G + lo.proj_b));
     { float* t = cur; cur = oth; oth = t; }
     // ---- attention branch: x_mid = x_in + s1 (proj(attn(LN1(x_in))) + bp) ; w.g2 = s1 d(x_mid)
     RUN(hp.linear_t(w.g2, lo.proj_w, C, C, w.d_o));
-    hipLaunchKernelGGL(attn_hp_bwd_kernel, dim3(S * e->H), dim3(256), 0, st, l.qkv, e->valid, l.o, l.lse, w.d_o, w.dqkv, e->H, NP, 0);
-    hipLaunchKernelGGL(attn_hp_bwd_kernel, dim3(S * e->H), dim3(256), 0, st, l.qkv, e->valid, l.o, l.lse, w.d_o, w.dqkv, e->H, NP, 1);
+    RUN(hp_attn_lds_attr(NP));
+    hipLaunchKernelGGL(attn_hp_bwd_kernel, dim3(S * e->H), dim3(256), (2 * NP * 64 + 2 * NP) * 4, st, l.qkv, e->valid, l.o, l.lse, w.d_o, w.dqkv, e->H, NP);
     LAUNCH_OK();
     RUN(hp.wgrad(w.du, l.h2, 4 * C, C, G + lo.fc1_w));
     RUN(hp.wgrad(w.g, l.a, C, 4 * C, G + lo.fc2_w));
