@@ -135,6 +135,43 @@ DEVFN float gelu_grad_bf16dst(float x) {
 #endif
 }
 
+// The same two functions on PAIRS (round 5): the polynomial chains, the squares and the final FMAs are v_pk_fma_f32 / v_pk_mul_f32 -- one VALU
+// instruction for two elements -- where hipcc left the scalar forms scalar (the epilogues' 8-element loops are not SLP-vectorised); |x|, max(x, 0),
+// the exponential and the sign transfer stay per element.  Per element the operations and their order are those of the scalar forms: bit-identical results
+// (tests/test_gelu_poly_cpu.py checks the scalar forms; tests/test_ops_gpu.py::test_gemm_nt_epilogues the kernels).
+#ifndef ATST_GELU_PACKED        // A/B builds: 0 = the scalar forms per element
+#define ATST_GELU_PACKED 1
+#endif
+DEVFN f32x2 gelu_bf16dst2(f32x2 x) {
+#if ATST_GELU_MODE != 2 || !ATST_GELU_PACKED
+  return f32x2{gelu_bf16dst(x[0]), gelu_bf16dst(x[1])};
+#else
+  const f32x2 t = {fabsf(x[0]), fabsf(x[1])};
+  f32x2 r = {-2.707532258e-04f, -2.707532258e-04f};
+  r = r * t + f32x2{5.308957305e-03f, 5.308957305e-03f}; r = r * t + f32x2{-4.637051746e-02f, -4.637051746e-02f};
+  r = r * t + f32x2{-4.668221772e-01f, -4.668221772e-01f}; r = r * t + f32x2{-1.147834420e+00f, -1.147834420e+00f};
+  r = r * t + f32x2{-1.000225544e+00f, -1.000225544e+00f};
+  const f32x2 q = {__builtin_amdgcn_exp2f(r[0]), __builtin_amdgcn_exp2f(r[1])};
+  const f32x2 relu = {fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)};
+  return relu - t * q;                                   // contracted to one packed FMA: fma(-t, q, relu), as in the scalar form
+#endif
+}
+DEVFN f32x2 gelu_grad_bf16dst2(f32x2 x) {
+#if ATST_GELU_MODE != 2 || !ATST_GELU_PACKED
+  return f32x2{gelu_grad_bf16dst(x[0]), gelu_grad_bf16dst(x[1])};
+#else
+  const f32x2 t = {fabsf(x[0]), fabsf(x[1])};
+  const f32x2 a = (x * x) * f32x2{-0.7213475204f, -0.7213475204f} + f32x2{-1.3257480647f, -1.3257480647f};
+  const f32x2 e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+  f32x2 r = {-1.765343361e-03f, -1.765343361e-03f};
+  r = r * t + f32x2{2.015891671e-02f, 2.015891671e-02f}; r = r * t + f32x2{-9.944655001e-02f, -9.944655001e-02f};
+  r = r * t + f32x2{2.931324542e-01f, 2.931324542e-01f}; r = r * t + f32x2{-6.126822829e-01f, -6.126822829e-01f};
+  r = r * t + f32x2{1.998164177e+00f, 1.998164177e+00f}; r = r * t + f32x2{-1.253274918e+00f, -1.253274918e+00f};
+  const f32x2 w = e * r + f32x2{0.5f, 0.5f};
+  return f32x2{0.5f + __builtin_copysignf(w[0], x[0]), 0.5f + __builtin_copysignf(w[1], x[1])};
+#endif
+}
+
 // fp8 forward saturation accounting: the activation scales of the e4m3 forward are constants (csrc/engine.hip ACT_SCALE); a value
 // beyond +-448 / scale is clipped.  Every quantising kernel counts the elements it clipped (n per lane, summed over the wave, one atomic
 // per wave that clipped anything) into the counter of its encoder pass (atst_encoder_t.f8_sat): a run whose activations outgrow the

@@ -106,7 +106,10 @@ DEVFN void epilogue8(const GemmArgs& p, int row, int col, f32x4 v0, f32x4 v1, co
     if (p.C) st_bf16(p.C, idx, v0, v1);                            // pre-activation u (saved for backward; skipped in inference)
     f32x4 g0, g1;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { g0[e] = gelu_bf16dst(v0[e]); g1[e] = gelu_bf16dst(v1[e]); }
+    for (int e = 0; e < 4; e += 2) {                                // pairs: packed FMAs (common.h gelu_bf16dst2)
+      const f32x2 a0 = gelu_bf16dst2(f32x2{v0[e], v0[e + 1]}), a1 = gelu_bf16dst2(f32x2{v1[e], v1[e + 1]});
+      g0[e] = a0[0]; g0[e + 1] = a0[1]; g1[e] = a1[0]; g1[e + 1] = a1[1];
+    }
     st_bf16_b(p.C2, idx, g0, g1, std::integral_constant<int, 5>{});    // activation a (bit 5: the next GEMM reads it whole)
     if (p.q8) {                                                    // fp8 forward: e4m3 copy of the SAME bf16 values for the fc2 GEMM
       const float s = x.s;                                         // running (delayed) activation scale, or the constant: the caller read it once
@@ -130,7 +133,10 @@ DEVFN void epilogue8(const GemmArgs& p, int row, int col, f32x4 v0, f32x4 v1, co
   } else if constexpr (EPI == EPI_DGELU) {
     const bf16x8 u = __builtin_bit_cast(bf16x8, x.a0);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { v0[e] *= gelu_grad_bf16dst(bf2f(u[e])); v1[e] *= gelu_grad_bf16dst(bf2f(u[4 + e])); }
+    for (int e = 0; e < 4; e += 2) {                                // pairs: packed FMAs (common.h gelu_grad_bf16dst2)
+      const f32x2 d0 = gelu_grad_bf16dst2(f32x2{bf2f(u[e]), bf2f(u[e + 1])}), d1 = gelu_grad_bf16dst2(f32x2{bf2f(u[4 + e]), bf2f(u[5 + e])});
+      v0[e] *= d0[0]; v0[e + 1] *= d0[1]; v1[e] *= d1[0]; v1[e + 1] *= d1[1];
+    }
     st_bf16(p.C, idx, v0, v1);
     w0 = v0; w1 = v1;
     if (p.q8) {                                                    // fp8 dgrad: e4m3 copy of the SAME bf16 values for the fc1 dgrad GEMM (scale in x.s)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round measurement pass on the GPU box: bench lines, rocprofv3 kernel stats of the default bench command, PMC traffic passes.
 # usage (inside gpurun): bash tools/round_measure.sh <tag>
-tag=${1:-r04}
+tag=${1:-r05}
 head=${2:-$(cat tools/.head 2>/dev/null || echo unknown)}      # the GPU box has no .git: pass HEAD as $2 (or write tools/.head before the call)
 out=gpurun_out/$tag
 mkdir -p $out
