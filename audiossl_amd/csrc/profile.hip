@@ -9,7 +9,26 @@ int g_stride = 1;                       // time one launch in g_stride of each k
 long long g_seen[PK_COUNT] = {};
 bool g_open = false;
 std::vector<Rec> g_recs;
+size_t g_head = 0;                      // records [0, g_head) have been retired into g_acc
 std::vector<hipEvent_t> g_pool;
+struct Acc { double ms = 0, work = 0, bytes = 0; long long n = 0; } g_acc[PK_COUNT];
+// Records are retired while the run goes on (round 5): a 100-step timed region used to keep ~8000 recorded events alive until the collect call, and a
+// process has a bounded number of interrupt-capable completion signals -- ATST-Frame (most launches per step) ran 2-5x slower with profiling on, on some
+// boxes and not on others, its host thread blocked inside hipLaunchKernel.  Only COMPLETED records are retired (hipEventQuery: never blocks).
+void retire(bool wait_all) {
+  while (g_head < g_recs.size()) {
+    const Rec& r = g_recs[g_head];
+    if (wait_all) { if (hipEventSynchronize(r.e1) != hipSuccess) return; }
+    else if (hipEventQuery(r.e1) != hipSuccess) return;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) return;
+    Acc& a = g_acc[r.kind];
+    a.ms += t; a.work += r.work; a.bytes += r.bytes; a.n += 1;
+    g_pool.push_back(r.e0); g_pool.push_back(r.e1);
+    ++g_head;
+  }
+  g_recs.clear(); g_head = 0;
+}
 hipEvent_t g_cur0; int g_kind; double g_work, g_bytes;
 const char* const NAMES[PK_COUNT] = {
   "gemm_nt_kernel<0:bf16>", "gemm_nt_kernel<1:f32>", "gemm_nt_kernel<2:bias_gelu>", "gemm_nt_kernel<3:resid>",
@@ -37,6 +56,7 @@ void prof_end(hipStream_t st) {
   hipEvent_t e1 = get_event();
   hipEventRecord(e1, st);
   g_recs.push_back(Rec{g_cur0, e1, g_kind, g_work, g_bytes});
+  if (g_recs.size() - g_head >= 256) retire(false);                // keep the number of live events bounded
 }
 
 // on: 0 = off, n >= 1 = time one launch in n of each kernel kind (1 = all), a fixed pseudo-random subset of the launch indices
@@ -49,16 +69,11 @@ extern "C" int atst_profile_kinds(void) { return PK_COUNT; }
 extern "C" const char* atst_profile_name(int kind) { return kind >= 0 && kind < PK_COUNT ? NAMES[kind] : ""; }
 // Synchronises on every recorded event, accumulates per-kind milliseconds / work / launch counts, clears the records.
 extern "C" int atst_profile_collect(double* ms, double* work, double* bytes, long long* launches) {
-  for (int k = 0; k < PK_COUNT; ++k) { ms[k] = 0; work[k] = 0; bytes[k] = 0; launches[k] = 0; }
-  for (const Rec& r : g_recs) {
-    hipError_t e = hipEventSynchronize(r.e1);
-    if (e != hipSuccess) return (int)e;
-    float t = 0.f;
-    e = hipEventElapsedTime(&t, r.e0, r.e1);
-    if (e != hipSuccess) return (int)e;
-    ms[r.kind] += t; work[r.kind] += r.work; bytes[r.kind] += r.bytes; launches[r.kind] += 1;
-    g_pool.push_back(r.e0); g_pool.push_back(r.e1);
+  retire(true);
+  if (g_head < g_recs.size()) return (int)hipErrorUnknown;
+  for (int k = 0; k < PK_COUNT; ++k) {
+    ms[k] = g_acc[k].ms; work[k] = g_acc[k].work; bytes[k] = g_acc[k].bytes; launches[k] = g_acc[k].n;
+    g_acc[k] = Acc{};
   }
-  g_recs.clear();
   return 0;
 }
