@@ -346,6 +346,25 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   *reinterpret_cast<f32x4*>(C + (size_t)row * ldc + col) = acc;
 }
 
+// ---- helpers of the phased main loops (gemm_nt_row384_kernel<.., PH>, gemm_p8.h) ----
+template <int N> DEVFN void p8_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+// LDS-DMA of 16 B per lane as inline assembly in the scalar-base form: address = SGPR pair + 32-bit lane offset.  Through the builtin hipcc turned the
+// (wave-uniform) k-tile advance into per-lane 64-bit pointers that it then spilled -- and every spill reload is a `s_waitcnt vmcnt(0)`, which drains
+// the five units the loop keeps in flight.  As with attention.hip's glds16_asm the compiler does not count these loads: the waits are the kernel's own.
+// a pointer the compiler cannot prove wave-uniform (tile origins come out of an integer division done on the VALU) made visibly so: the "s" constraint of
+// the asm below does not insert the v_readfirstlane itself -- it hands the assembler a VGPR pair
+DEVFN const char* sgpr_ptr(const void* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi_ = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<const char*>(((unsigned long long)hi_ << 32) | lo);
+}
+DEVFN void p8_glds16(unsigned voff, const void* sbase /* wave-uniform */, unsigned lds_dst /* wave-uniform LDS byte address */) {
+  unsigned keep;                                     // M0 is compiler-reserved and not preserved around a statement: saved, set, restored inside it
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
+
 // ---- 384-column tiles: 8 waves (2 x 4) ---------------------------------------------------------------------------------
 // Every N on the encoder path (384, 1152, 1536, 768...) is a multiple of 384.  MI = 32-row accumulator blocks per wave:
 //   MI = 2: 128 x 384 tile, wave 64 x 96, 2-stage ring of 32 KB, two blocks per CU (M < 8192)
@@ -583,9 +602,16 @@ DEVFN void lnb_flush(const GemmArgs& p, const LnbCols& cs, float* red, int tid) 
 #ifndef ATST_MI2_WPS           // waves per SIMD the 128-row instantiation is compiled for: 4 = two blocks per CU (128 registers), 2 = one (256, no spills)
 #define ATST_MI2_WPS 4
 #endif
-template <int EPI, int MI, bool LN = false, bool F8 = false, bool TR = false>
+// PH (round 5, MI = 4, bf16 operands): the PHASED main loop -- the structure of gemm_p8.h inside this kernel's tile, so that every epilogue below
+// (in particular the row-wise LayerNorm ones, which need the 384-column tile) is reused unchanged.  A 32-deep k-tile is four phases (ks, mh): 6 MFMAs
+// of the wave's row blocks 2 mh, 2 mh + 1 against its three column blocks at k-step ks; fragments in two register sets per operand (A by mh, B by ks:
+// 40 registers beside the 192 accumulators); the two wave rows run one barrier apart, so that each SIMD's two waves alternate between their MFMA
+// cluster and their fragment reads / LDS-DMA; k-tile t + 2 is staged during phases 1-3 of k-tile t (inline-asm LDS-DMA, scalar base + lane offset)
+// and the only vector-memory wait is a counted `vmcnt(5)` in the last phase of a k-tile.
+template <int EPI, int MI, bool LN = false, bool F8 = false, bool TR = false, bool PH = false>
 __global__ __launch_bounds__(512, (MI == 2 ? ATST_MI2_WPS : 2)) void gemm_nt_row384_kernel(GemmArgs p) {
   static_assert(!TR || (EPI == EPI_BF16 && !LN), "transposed accumulators: store-only bf16 epilogue");
+  static_assert(!PH || (MI == 4 && !F8 && !TR), "phased main loop: 256-row tile, bf16 operands");
   using namespace row384;
   using RG = row384::Geo<MI>;
   constexpr int BMR = RG::BMR, A_BYTES = RG::A_BYTES, STAGE = RG::STAGE, NSTG = RG::NSTG, ROWB = RG::ROWB;
@@ -639,6 +665,88 @@ __global__ __launch_bounds__(512, (MI == 2 ? ATST_MI2_WPS : 2)) void gemm_nt_row
     }
   }
 
+  if constexpr (PH) {
+    const int nk = p.K / BK;                                       // >= 2 (checked by the launcher)
+    const int wu = __builtin_amdgcn_readfirstlane(wid);
+    // LDS-DMA sources: scalar base (tile origin + k-tile) + 32-bit lane offsets; wave w stages pieces 2 w, 2 w + 1 of A and 3 w .. 3 w + 2 of B
+    unsigned voA[2], voB[3];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = (wu * 2 + j) * 16 + lrow;
+      int ra = m0 + row; ra = ra < p.M ? ra : p.M - 1;              // clamp: rows >= M are never stored
+      voA[j] = (unsigned)((ra - m0) * p.lda + (lchunk ^ swz_key(row)) * 8) * 2u;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int row = (wu * 3 + j) * 16 + lrow;
+      voB[j] = (unsigned)(row * p.ldb + (lchunk ^ swz_key(row)) * 8) * 2u;
+    }
+    const char* baseA = sgpr_ptr(p.A + (size_t)m0 * p.lda);
+    const char* baseB = sgpr_ptr(p.B + (size_t)n0 * p.ldb);
+    const unsigned ldsA = lds_addr(smem_raw) + wu * 2 * 1024, ldsB = lds_addr(smem_raw) + A_BYTES + wu * 3 * 1024;
+    auto stage_piece = [&](int kt, int slot, int j) {               // j: 0, 1 = A pieces ; 2 .. 4 = B pieces
+      const size_t kofs = (size_t)kt * (BK * 2);
+      if (j < 2) p8_glds16(voA[j < 2 ? j : 0], baseA + kofs, ldsA + slot * STAGE + j * 1024);
+      else p8_glds16(voB[j >= 2 ? j - 2 : 0], baseB + kofs, ldsB + slot * STAGE + (j - 2) * 1024);
+    };
+    // fragment addresses: (row base | c0) ^ (ks << 5), c0 = (hi ^ key) << 4 ; re-derived from a laundered copy at every read (see gemm_p8.h)
+    const int xk = swz_key(l31);
+    const int fA0 = (wm * 128 + l31) * ROWB + ((hi ^ xk) << 4), fB0 = A_BYTES + (wn * 96 + l31) * ROWB + ((hi ^ xk) << 4);
+    bf16x8 fa[2][2], fb[2][3];                                      // A: [mh][rb] ; B: [ks][ni]
+    auto read_a = [&](int slot, int ks, int mh) {
+      int b0 = fA0; asm volatile("" : "+v"(b0));
+      const char* s = lds + slot * STAGE + mh * 64 * ROWB;
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) fa[mh][rb] = *reinterpret_cast<const bf16x8*>(s + (b0 ^ (ks << 5)) + rb * 32 * ROWB);
+    };
+    auto read_b = [&](int slot, int ks) {
+      int b0 = fB0; asm volatile("" : "+v"(b0));
+      const char* s = lds + slot * STAGE;
+#pragma unroll
+      for (int ni = 0; ni < 3; ++ni) fb[ks][ni] = *reinterpret_cast<const bf16x8*>(s + (b0 ^ (ks << 5)) + ni * 32 * ROWB);
+    };
+    // prologue: k-tiles 0 and 1 ; wait for k-tile 0 ; the upper wave row runs one barrier behind the lower one
+#pragma unroll
+    for (int j = 0; j < 5; ++j) stage_piece(0, 0, j);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) stage_piece(1, 1, j);
+    p8_wait_vm<5>();
+    asm volatile("s_barrier" ::: "memory");
+    if ((wu >> 2) == 1) asm volatile("s_barrier" ::: "memory");
+    int slot = 0;                                                   // ring slot of k-tile t (t % 3), slot2 = slot of k-tile t + 2
+    for (int t = 0; t < nk; ++t) {
+      const int slot2 = slot == 0 ? 2 : slot - 1;
+      const bool more = t + 2 < nk;
+      auto phase = [&](auto kstag, auto mhtag) {
+        constexpr int ks = decltype(kstag)::value, mh = decltype(mhtag)::value, ph = 2 * ks + mh;
+        if constexpr (mh == 0) read_b(slot, ks);
+        read_a(slot, ks, mh);
+        if (more) {                                                 // k-tile t + 2 into the slot k-tile t - 1 was read from (last read two phases ago or more)
+          if constexpr (ph == 1) { stage_piece(t + 2, slot2, 0); stage_piece(t + 2, slot2, 2); }
+          if constexpr (ph == 2) { stage_piece(t + 2, slot2, 1); stage_piece(t + 2, slot2, 3); }
+          if constexpr (ph == 3) stage_piece(t + 2, slot2, 4);
+        }
+        if constexpr (ph == 3) { if (more) p8_wait_vm<5>(); else p8_wait_vm<0>(); }   // k-tile t + 1 has landed -- mine; read in the next phase
+        asm volatile("s_barrier" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+          for (int ni = 0; ni < 3; ++ni) acc[2 * mh + rb][ni] = mfma32(fa[mh][rb], fb[ks][ni], acc[2 * mh + rb][ni]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_barrier" ::: "memory");
+      };
+      phase(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+      phase(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+      phase(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+      phase(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+      slot = slot == 2 ? 0 : slot + 1;
+    }
+    if ((wu >> 2) == 0) asm volatile("s_barrier" ::: "memory");     // re-align the wave rows: every operand read is done, the ring is free
+  } else {
   const int nk = p.K / BK;
   const int xr = swz_key(l31);                                     // every fragment row is l31 plus a multiple of 32
   const int offA = (wm * 32 * MI + l31) * ROWB, offB = A_BYTES + (wn * 96 + l31) * ROWB;
@@ -729,6 +837,7 @@ __global__ __launch_bounds__(512, (MI == 2 ? ATST_MI2_WPS : 2)) void gemm_nt_row
   }
   asm volatile("s_barrier" ::: "memory");
 
+  }
   if constexpr (TR) {
     constexpr int TP = row384::TR_PITCH;
     char* stg = smem_raw + wid * (32 * TP);                       // this wave's strip: 32 rows x 96 bf16 (+ pad)
@@ -1632,6 +1741,7 @@ int g_dgelu_row384 = 2;     // 306/307/308: dGELU GEMM on the 256x384 tile never
 int g_w4_mode = 0;          // 330 + m: 4-wave two-blocks-per-CU kernels: 0 only for small grids ; 2 = 256x192 (plain epilogues) + 128x384 (row-wise) everywhere ; 3 = 256x192 for the plain epilogues only
 int g_w4_min_m = 8192;      // 350/351: apply the tall / 4-wave kernels from M = 8192 / from any M (parity tests run small shapes)
 int g_w4_auto = 1;          // 360/361: 4-wave kernels for launches of <= 1.5 rounds of 256 x 384 tiles
+int g_ph = 1;               // 396/397: phased main loop (template parameter PH) of the 256 x 384 tile: off / on
 int g_p8_skew = 0;          // 1000 + c: start-up skew of every other first-round block of the phased kernel, c x 1024 cycles (experiment)
 int g_p8 = 2;               // 390/391/392: 256 x 256 phased kernel (gemm_p8.h) for N % 256 == 0, K % 128 == 0, M % 256 == 0, M >= 8192: off / bf16 operands only / also e4m3
                             // operands (default; except fc1 + GELU, whose e4m3 epilogue -- u, a, the e4m3 copy of a, amax -- measured 640 vs 647 us on the 256 x 384 tile).
@@ -1694,18 +1804,18 @@ int launch_nt_cfg(const GemmArgs& a, hipStream_t st) {
   hipLaunchKernelGGL((gemm_nt_kernel<EPI, BMT, NSTG, WTM, KS>), dim3(nblk), dim3(G::THREADS), G::LDS, st, a);
   return (int)hipGetLastError();
 }
-template <int EPI, int MI, bool LN, bool F8 = false, bool TR = false>
+template <int EPI, int MI, bool LN, bool F8 = false, bool TR = false, bool PH = false>
 int launch_nt_row384_cfg(const GemmArgs& a, hipStream_t st) {
   using RG = row384::Geo<MI>;
   constexpr int LDS = TR ? RG::NSTG * RG::STAGE + row384::BNR * 4 : row384::lds_bytes<MI, EPI, LN>();
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_row384_kernel<EPI, MI, LN, F8, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_row384_kernel<EPI, MI, LN, F8, TR, PH>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
   const int nblk = ((a.M + RG::BMR - 1) / RG::BMR) * (a.N / row384::BNR);
-  hipLaunchKernelGGL((gemm_nt_row384_kernel<EPI, MI, LN, F8, TR>), dim3(nblk), dim3(row384::THREADS), LDS, st, a);
+  hipLaunchKernelGGL((gemm_nt_row384_kernel<EPI, MI, LN, F8, TR, PH>), dim3(nblk), dim3(row384::THREADS), LDS, st, a);
   return (int)hipGetLastError();
 }
 template <int EPI, int WM, bool LN>
@@ -1777,13 +1887,14 @@ int launch_nt_row384(const GemmArgs& a, hipStream_t st) {
   }
   // 256-row tiles: the operand ring of one block covers twice the output (6.7 vs 10.7 KB staged per 128x128 unit)
   const bool tall = a.M >= (g_w4_min_m < 8192 ? g_w4_min_m : 8192) && (g_row384_tall == 2 || (g_row384_tall == 1 && EPI == EPI_BF16 && (a.K >= 768 || a.N >= 768)));
+  const bool ph = g_ph && tall && a.K >= 2 * BK;                   // phased main loop of the 256-row tile
   if constexpr (EPI == EPI_RESID) {
-    if (a.ln_out) return tall ? launch_nt_row384_cfg<EPI, 4, true>(a, st) : launch_nt_row384_cfg<EPI, 2, true>(a, st);
+    if (a.ln_out) return tall ? (ph ? launch_nt_row384_cfg<EPI, 4, true, false, false, true>(a, st) : launch_nt_row384_cfg<EPI, 4, true>(a, st)) : launch_nt_row384_cfg<EPI, 2, true>(a, st);
   }
   if constexpr (EPI == EPI_BF16) {
     if (g_bf16_tr) return tall ? launch_nt_row384_cfg<EPI, 4, false, false, true>(a, st) : launch_nt_row384_cfg<EPI, 2, false, false, true>(a, st);
   }
-  return tall ? launch_nt_row384_cfg<EPI, 4, false>(a, st) : launch_nt_row384_cfg<EPI, 2, false>(a, st);
+  return tall ? (ph ? launch_nt_row384_cfg<EPI, 4, false, false, false, true>(a, st) : launch_nt_row384_cfg<EPI, 4, false>(a, st)) : launch_nt_row384_cfg<EPI, 2, false>(a, st);
 }
 template <int EPI>
 int launch_nt(const GemmArgs& a, hipStream_t st) {
@@ -1831,6 +1942,7 @@ int launch_nt(const GemmArgs& a, hipStream_t st) {
 
 void atst_gemm_nt_set_variant(int v) {
   if (v >= 1000 && v < 2000) g_p8_skew = v - 1000;
+  else if (v >= 396 && v <= 397) g_ph = v - 396;
   else if (v >= 390) g_p8 = v - 390;
   else if (v >= 380) g_f32_splitk = v - 380;
   else if (v >= 370) g_bf16_tr = v - 370;

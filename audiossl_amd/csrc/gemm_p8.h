@@ -32,16 +32,6 @@ static_assert(EPI_FLOATS * 4 <= RING, "the epilogue re-uses the operand ring");
 #ifndef ATST_P8_ABL            // experiment builds (tools/p8_ablate.sh): 1 = no epilogue at all ; 2 = staging + read-back but no global loads / stores
 #define ATST_P8_ABL 0
 #endif
-template <int N> DEVFN void p8_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
-// LDS-DMA of 16 B per lane as inline assembly in the scalar-base form: address = SGPR pair + 32-bit lane offset.  Through the builtin hipcc turned the
-// (wave-uniform) k-tile advance into per-lane 64-bit pointers that it then spilled -- and every spill reload is a `s_waitcnt vmcnt(0)`, which drains
-// the five units the loop keeps in flight.  As with attention.hip's glds16_asm the compiler does not count these loads: the waits are the kernel's own.
-DEVFN void p8_glds16(unsigned voff, const void* sbase /* wave-uniform */, unsigned lds_dst /* wave-uniform LDS byte address */) {
-  unsigned keep;                                     // M0 is compiler-reserved and not preserved around a statement: saved, set, restored inside it
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
-}
-
 // F8: the operands are OCP e4m3 bytes, passed as byte PAIRS (K, lda, ldb halved by the launcher, as for gemm_nt_row384_kernel<.., F8>): the ring, the
 // units, the swizzle and the LDS-DMA are byte-identical; a 128-byte row is two 64-byte k-steps of ONE v_mfma_scale_f32_32x32x64_f8f6f4 each (unit block
 // scales), so a phase is 4 MFMAs over K = 128 -- twice the FLOPs of a bf16 phase in the same matrix-pipe time.  p.dq / dq_mul / dq_div undo the
@@ -79,8 +69,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(GemmArgs p) {
     voA[j] = (unsigned)(((u >> 6) * 128 + (u & 63)) * p.lda + ch * 8) * 2u;
     voB[j] = (unsigned)(((u >> 5) * 64 + (u & 31)) * p.ldb + ch * 8) * 2u;
   }
-  const char* baseA = reinterpret_cast<const char*>(p.A + (size_t)m0 * p.lda);
-  const char* baseB = reinterpret_cast<const char*>(p.B + (size_t)n0 * p.ldb);
+  const char* baseA = sgpr_ptr(p.A + (size_t)m0 * p.lda);
+  const char* baseB = sgpr_ptr(p.B + (size_t)n0 * p.ldb);
   const size_t a_half = (size_t)64 * p.lda * 2, b_half = (size_t)32 * p.ldb * 2;
   char* lds = smem_raw;
   const unsigned lds0 = lds_addr(smem_raw) + (2 * wid) * 1024;    // this wave's two pieces of a unit (LDS byte address)

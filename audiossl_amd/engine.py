@@ -233,6 +233,15 @@ class EncoderPass:
         return self.ws.view(f(C.byref(self.e), i), (self.M, self.e.C), torch.float32)
 
 
+def _rows_buf(R: int, cols: int, dtype, dev) -> torch.Tensor:
+    """[R, cols] buffer whose ALLOCATION does not depend on the exact row count: ATST-Frame's head batches are the masked rows of the step (about
+    83 k at 256 clips, a different count every step), and torch's caching allocator answers GB-sized requests of ever-changing size with fresh
+    hipMalloc / hipFree calls (a device-wide synchronisation each) -- measured as 1.1 - 5x slower Frame steps on some boxes and not on others
+    (round 5).  The capacity is the row count rounded up to 4096 rows; the [:R] view is contiguous."""
+    cap = R if R <= 4096 else (R + 4095) // 4096 * 4096
+    return torch.empty(cap, cols, dtype=dtype, device=dev)[:R]
+
+
 class HeadPass:
     """Linear(no bias) -> BatchNorm1d(train, cross-rank statistics) -> ReLU -> Linear(no bias), forward and backward.
     ref: audiossl/models/atst/byol.py:6-22 ; SyncBatchNorm semantics from Trainer(sync_batchnorm=True), methods/atst/train.py:22."""
@@ -267,11 +276,11 @@ class HeadPass:
         # split-bf16 operands ([hi|lo|hi] x [hi|hi|lo] along K): the Linear in front of BatchNorm+ReLU is evaluated to
         # ~2^-16 so that bf16 noise does not flip ReLU gates (DESIGN.md "Precision")
         K = self.in_dim
-        x3 = torch.empty(R, 3 * K, dtype=torch.bfloat16, device=dev)
+        x3 = _rows_buf(R, 3 * K, torch.bfloat16, dev)
         hip.call("atst_split3_bf16", hip.ptr(x), R, K, 0, hip.ptr(x3), st)
         w3 = torch.empty(HEAD_HIDDEN, 3 * K, dtype=torch.bfloat16, device=dev)
         hip.call("atst_split3_bf16", hip.ptr(self._w("0.weight", f32=True)), HEAD_HIDDEN, K, 1, hip.ptr(w3), st)
-        h = torch.empty(R, HEAD_HIDDEN, device=dev)
+        h = _rows_buf(R, HEAD_HIDDEN, torch.float32, dev)
         _gemm(x3, w3, R, HEAD_HIDDEN, 3 * K, hip.EPI_F32, h)
         x16 = x3                                            # columns [0,K) = bf16(x): wgrad operand, ld = 3K
         mean, m2 = torch.empty(HEAD_HIDDEN, device=dev), torch.empty(HEAD_HIDDEN, device=dev)
@@ -295,12 +304,12 @@ class HeadPass:
         hip.call("atst_bn_finish_f32", hip.ptr(mean), hip.ptr(m2), 0.0 if on_dev else float(count), hip.ptr(cdev), BN_MOMENTUM, BN_EPS,
                  hip.ptr(bn["running_mean"]), hip.ptr(bn["running_var"]), hip.ptr(bn["num_batches_tracked"]), hip.ptr(rstd), HEAD_HIDDEN, st)
         # second Linear also in split-bf16: its output feeds the next head's BatchNorm+ReLU gates
-        y3 = torch.empty(R, 3 * HEAD_HIDDEN, dtype=torch.bfloat16, device=dev)
+        y3 = _rows_buf(R, 3 * HEAD_HIDDEN, torch.bfloat16, dev)
         hip.call("atst_bn_apply_relu_split3_bf16", hip.ptr(h), hip.ptr(mean), hip.ptr(rstd), hip.ptr(self._w("1.weight", f32=True)),
                  hip.ptr(self._w("1.bias", f32=True)), R, HEAD_HIDDEN, hip.ptr(y3), st)
         w3b = torch.empty(HEAD_OUT, 3 * HEAD_HIDDEN, dtype=torch.bfloat16, device=dev)
         hip.call("atst_split3_bf16", hip.ptr(self._w("3.weight", f32=True)), HEAD_OUT, HEAD_HIDDEN, 1, hip.ptr(w3b), st)
-        out = torch.empty(R, HEAD_OUT, device=dev)
+        out = _rows_buf(R, HEAD_OUT, torch.float32, dev)
         _gemm(y3, w3b, R, HEAD_OUT, 3 * HEAD_HIDDEN, hip.EPI_F32, out)
         y16 = y3                                            # columns [0, 4096) = bf16(y), ld = 3 * 4096
         if train:
@@ -316,7 +325,7 @@ class HeadPass:
         R, dev, st, K = x3.shape[0], x3.device, hip.stream(), self.in_dim
 
         def split_cols(x, rows, cols, b_layout):                       # fp32 [rows, cols] -> bf16 [rows, 3 cols]
-            out = torch.empty(rows, 3 * cols, dtype=torch.bfloat16, device=dev)
+            out = _rows_buf(rows, 3 * cols, torch.bfloat16, dev)
             hip.call("atst_split3_bf16", hip.ptr(x.contiguous()), rows, cols, b_layout, hip.ptr(out), st)
             return out
 
@@ -332,7 +341,7 @@ class HeadPass:
         w3 = self._w("3.weight", f32=True).view(HEAD_OUT, HEAD_HIDDEN)
         w0 = self._w("0.weight", f32=True).view(HEAD_HIDDEN, K)
         _wgrad(rows_dy(dout), rows_x(y3, HEAD_HIDDEN), 3 * R, HEAD_OUT, HEAD_HIDDEN, self._w("3.weight", grad=True))
-        dy = torch.empty(R, HEAD_HIDDEN, device=dev)
+        dy = _rows_buf(R, HEAD_HIDDEN, torch.float32, dev)
         _gemm(split_cols(dout, R, HEAD_OUT, 0), split_cols(w3.t(), HEAD_HIDDEN, HEAD_OUT, 1), R, HEAD_HIDDEN, 3 * HEAD_OUT, hip.EPI_F32, dy)
         gamma, beta = self._w("1.weight", f32=True), self._w("1.bias", f32=True)
         s1, s2 = torch.empty(HEAD_HIDDEN, device=dev), torch.empty(HEAD_HIDDEN, device=dev)
@@ -347,11 +356,11 @@ class HeadPass:
             s1, s2 = (s1 / count).contiguous(), (s2 / count).contiguous()
         else:
             inv = 1.0 / count
-        dh = torch.empty(R, HEAD_HIDDEN, device=dev)
+        dh = _rows_buf(R, HEAD_HIDDEN, torch.float32, dev)
         hip.call("atst_bn_bwd_dx_f32", hip.ptr(dy), hip.ptr(h), hip.ptr(mean), hip.ptr(rstd), hip.ptr(gamma), hip.ptr(beta),
                  hip.ptr(s1), hip.ptr(s2), inv, R, HEAD_HIDDEN, hip.ptr(dh), st)
         _wgrad(rows_dy(dh), rows_x(x3, K), 3 * R, HEAD_HIDDEN, K, self._w("0.weight", grad=True))
-        dx = torch.empty(R, K, device=dev)
+        dx = _rows_buf(R, K, torch.float32, dev)
         _gemm(split_cols(dh, R, HEAD_HIDDEN, 0), split_cols(w0.t(), K, HEAD_HIDDEN, 1), R, K, 3 * HEAD_HIDDEN, hip.EPI_F32, dx)
         self.saved = None
         return dx
@@ -362,10 +371,10 @@ class HeadPass:
             return self._backward_precise(dout)
         x16, h, mean, rstd, y16, count = self.saved
         R, dev, st = x16.shape[0], x16.device, hip.stream()
-        d16 = torch.empty(R, HEAD_OUT, dtype=torch.bfloat16, device=dev)
+        d16 = _rows_buf(R, HEAD_OUT, torch.bfloat16, dev)
         hip.call("atst_cast_bf16", hip.ptr(dout), R * HEAD_OUT, hip.ptr(d16), st)
         _wgrad(d16, y16, R, HEAD_OUT, HEAD_HIDDEN, self._w("3.weight", grad=True), ldx=3 * HEAD_HIDDEN)
-        dy = torch.empty(R, HEAD_HIDDEN, device=dev)
+        dy = _rows_buf(R, HEAD_HIDDEN, torch.float32, dev)
         _gemm(d16, self._w("3.weight", transposed=True), R, HEAD_HIDDEN, HEAD_OUT, hip.EPI_F32, dy)
         gamma, beta = self._w("1.weight", f32=True), self._w("1.bias", f32=True)
         s1, s2 = torch.empty(HEAD_HIDDEN, device=dev), torch.empty(HEAD_HIDDEN, device=dev)
@@ -380,11 +389,11 @@ class HeadPass:
             s1, s2 = (s1 / count).contiguous(), (s2 / count).contiguous()
         else:
             inv = 1.0 / count
-        dh16 = torch.empty(R, HEAD_HIDDEN, dtype=torch.bfloat16, device=dev)
+        dh16 = _rows_buf(R, HEAD_HIDDEN, torch.bfloat16, dev)
         hip.call("atst_bn_bwd_dx_bf16", hip.ptr(dy), hip.ptr(h), hip.ptr(mean), hip.ptr(rstd), hip.ptr(gamma), hip.ptr(beta),
                  hip.ptr(s1), hip.ptr(s2), inv, R, HEAD_HIDDEN, hip.ptr(dh16), st)
         _wgrad(dh16, x16, R, HEAD_HIDDEN, self.in_dim, self._w("0.weight", grad=True), ldx=3 * self.in_dim)
-        dx = torch.empty(R, self.in_dim, device=dev)
+        dx = _rows_buf(R, self.in_dim, torch.float32, dev)
         _gemm(dh16, self._w("0.weight", transposed=True), R, self.in_dim, HEAD_HIDDEN, hip.EPI_F32, dx)
         self.saved = None
         return dx
@@ -745,7 +754,7 @@ class AtstEngine:
             if ep.precise:                                  # fp32 rows: plain indexing (parity mode, speed is not the point)
                 f = out16.index_select(0, rows.long())
             else:
-                f = torch.empty(rows.numel(), self.cfg["embed_dim"], device=self.device)
+                f = _rows_buf(rows.numel(), self.cfg["embed_dim"], torch.float32, self.device)
                 hip.call("atst_gather_rows_bf16", hip.ptr(out16), hip.ptr(rows), rows.numel(), self.cfg["embed_dim"], hip.ptr(f), hip.stream())
             feats.append(f)
             groups.append((ep, rows))
@@ -805,7 +814,7 @@ class AtstEngine:
         if self.overlap_teacher:
             main.wait_stream(self._side)
         self._teacher_keep = (tf, t_out)
-        self._ds = torch.empty_like(s_out)
+        self._ds = _rows_buf(s_out.shape[0], s_out.shape[1], s_out.dtype, s_out.device)
         if asym:
             if s_out.shape[0] != t_out.shape[0]:
                 raise hip.HipError("asymmetric ATST-Frame loss: teacher view 0 and student view 1 must select the same rows "
