@@ -870,6 +870,7 @@ class AtstEngine:
         side_bwd = self.overlap_local_teacher and len(order) > 1 and not self.precise and not self.frame
         joined = not side_bwd
         keep_alive = []
+        side_events = {}
         for k, gi in enumerate(order):
             ep, rows = groups[gi]
             n = rows.numel()
@@ -882,7 +883,20 @@ class AtstEngine:
                 with torch.cuda.stream(self._side):
                     ep.dout.zero_()
                     hip.call("atst_scatter_rows_bf16", hip.ptr(src), hip.ptr(rows), n, self.cfg["embed_dim"], hip.ptr(ep.dout), hip.stream())
-                    ep.backward()
+                    if overlap and k == len(order) - 2:
+                        # the last side group walks the blocks in the SAME slices as the gradient buckets and leaves an event behind each: the
+                        # communication stream then waits for "the side chain has passed slice j", not for the whole side chain (round 5;
+                        # before, the first encoder bucket was handed over only after all 12 blocks of the side chain)
+                        cuts = self.bucket_cuts()
+                        for hi, lo in zip(cuts[:-1], cuts[1:]):
+                            if hi == lo:
+                                continue
+                            ep.backward_range(lo, hi)
+                            ev = torch.cuda.Event()
+                            ev.record(self._side)
+                            side_events[(hi, lo)] = ev
+                    else:
+                        ep.backward()
                 continue
             ep.dout.zero_()
             if ep.precise:
@@ -899,10 +913,11 @@ class AtstEngine:
                     ep.backward_range(lo, hi)
                     a = 0 if lo == 0 else L.entries[f"encoder.blocks.{lo}.norm1.weight"][0]
                     # LN1 backward of block lo adds the fc2 bias gradient of block lo-1 (below the cut: reduced later)
-                    if not joined:
-                        main.wait_stream(self._side)               # every group has passed this slice only once the side chain is done
+                    ev = side_events.get((hi, lo))
+                    if ev is None and not joined:
+                        main.wait_stream(self._side)               # no per-slice events: every group has passed this slice only once the side chain is done
                         joined = True
-                    self._reduce_async(a, top)
+                    self._reduce_async(a, top, ev)                 # (ev: the side chain's pass over this slice, awaited by the communication stream only)
                     top = a
             else:
                 ep.backward()
@@ -984,10 +999,13 @@ class AtstEngine:
             self.g8_scale.copy_(st["g8_scale"]); self.g8_hist.copy_(st["g8_hist"])
             self._g8_hist_k, self.fp8_bwd_state = int(st["hist_k"]), int(st["state"])
 
-    def _reduce_async(self, a: int, b: int):
-        """Sum g32[a:b] over ranks on the communication stream, ordered after everything enqueued so far."""
+    def _reduce_async(self, a: int, b: int, also=None):
+        """Sum g32[a:b] over ranks on the communication stream, ordered after everything enqueued so far on the current stream (and after
+        the event `also`, recorded on another stream that accumulates into the same slice)."""
         main = torch.cuda.current_stream()
         self._comm.wait_stream(main)
+        if also is not None:
+            self._comm.wait_event(also)
         with torch.cuda.stream(self._comm):
             parallel.allreduce_sum_(self.g32[a:b])
 
