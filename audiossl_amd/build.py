@@ -13,7 +13,7 @@ TAG = os.environ.get("ATST_LIB_TAG", "")
 LIB = os.path.join(LIBDIR, f"libatst_hip_{TAG}.so" if TAG else "libatst_hip.so")
 OBJDIR = os.path.join(LIBDIR, f"obj_{TAG}") if TAG else LIBDIR
 SOURCES = ["api.hip", "engine.hip", "engine_hp.hip", "gemm.hip", "layernorm.hip", "attention.hip", "tokens.hip", "head.hip", "optim.hip",
-           "frontend.hip", "profile.hip", "augment.hip"]
+           "frontend.hip", "profile.hip", "augment.hip", "gemm_tn8.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
 if os.environ.get("ATST_EXTRA_FLAGS"):      # experiment builds: e.g. ATST_EXTRA_FLAGS="-DATST_ABLATE_ATTN_STORE"
     FLAGS += os.environ["ATST_EXTRA_FLAGS"].split()

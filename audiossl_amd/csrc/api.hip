@@ -87,6 +87,11 @@ int atst_gemm_tn_bf16(const uint16_t* dY, const uint16_t* X, int M, int N, int K
   return atst_gemm_tn(a, ST(stream));
 }
 
+int atst_gemm_tn_fp8(const uint8_t* dY8, const uint8_t* X8, int M, int N, int K, int ldy, int ldx, float* dW, int ldw, const float* scale_y,
+                     const float* scale_x, void* stream) {
+  return atst_gemm_tn8(dY8, X8, M, N, K, ldy, ldx, dW, ldw, scale_y, scale_x, ST(stream));
+}
+
 int atst_gemm_tn_group_bf16(const atst_wgrad_t* items, int n, void* stream) {
   if (!items || n < 1 || n > ATST_WGRAD_GROUP_MAX) return ATST_EINVAL;
   WgradArgs a[ATST_WGRAD_GROUP_MAX] = {};

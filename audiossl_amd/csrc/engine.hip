@@ -11,6 +11,7 @@ namespace {
 struct LayerWs {
   bf16 *h1, *qkv, *o, *h2, *u, *a;
   float *mean1, *rstd1, *mean2, *rstd2, *lse;
+  uint8_t *o8, *h28, *a8;             // fp8 training: the e4m3 copies of the proj / fc1 / fc2 inputs are KEPT per layer (operands of the e4m3 weight gradients)
 };
 struct Ws {
   bf16* patches; float* table;
@@ -52,10 +53,12 @@ Ws carve(void* ws, int S, int NP, int C, int H, int depth, int train, int fp8, i
     l.h2 = c.take<bf16>(M * C); l.u = c.take<bf16>(M * 4 * C); l.a = c.take<bf16>(M * 4 * C);
     l.mean1 = c.take<float>(M); l.rstd1 = c.take<float>(M); l.mean2 = c.take<float>(M); l.rstd2 = c.take<float>(M);
     l.lse = c.take<float>((size_t)S * H * NP);
+    if (fp8 && train) { l.o8 = c.take<uint8_t>(M * C); l.h28 = c.take<uint8_t>(M * C); l.a8 = c.take<uint8_t>(M * 4 * C); }
   }
   for (int i = nl; i < depth; ++i) w.L[i] = w.L[0];
   w.hN = c.take<bf16>(M * C); w.meanN = c.take<float>(M); w.rstdN = c.take<float>(M);
   if (fp8) { w.q8a = c.take<uint8_t>(M * C); w.q8b = c.take<uint8_t>(M * 4 * C); }   // e4m3 operand copies: only the fp8 forward carves them
+  if (fp8 && !train) for (int i = 0; i < depth; ++i) { w.L[i].o8 = w.L[i].h28 = w.q8a; w.L[i].a8 = w.q8b; }   // inference: transient
   if (train) {
     w.dxA = c.take<float>(M * C); w.dxB = c.take<float>(M * C);
     w.g = c.take<bf16>(M * C); w.g2 = c.take<bf16>(M * C); w.dh = c.take<bf16>(M * C); w.du = c.take<bf16>(M * 4 * C);
@@ -203,13 +206,13 @@ extern "C" int atst_encoder_fwd(const atst_encoder_t* e, void* stream) {
       AttnArgs at{};
       at.qkv = l.qkv; at.valid = e->valid; at.o = l.o; at.lse = l.lse; at.S = S; at.H = e->H; at.NP = NP; at.stride = RS;
       RUN(atst_attn_fwd(at, st));
-      if (scp(1)) RUN(atst_quant_fp8_dyn(l.o, MC, scp(1), w.q8a, amp(1), st, sat));
-      else RUN(atst_quant_fp8(l.o, MC, ACT_SCALE, w.q8a, st, sat));
-      RUN(gemm8(w.q8a, q8 + lo.proj_w, M, C, C, EPI_RESID, w.x[2 * i + 1], st, dq + 1, ACT_SCALE, p + lo.proj_b, w.x[2 * i], s1, RS, nullptr, nullptr, 1.0f, nullptr, scp(1)));
-      RUN(atst_ln_fwd(w.x[2 * i + 1], p + lo.ln2_w, p + lo.ln2_b, l.h2, l.mean2, l.rstd2, M, C, st, w.q8a, ACT_SCALE, sat, scp(2), amp(2)));
-      RUN(gemm8(w.q8a, q8 + lo.fc1_w, M, 4 * C, C, EPI_BIAS_GELU, e->train ? l.u : nullptr, st, dq + 2, ACT_SCALE, p + lo.fc1_b, nullptr, nullptr, 1, l.a,
-                w.q8b, ACT_SCALE_GELU, sat, scp(2), scp(3), amp(3)));
-      RUN(gemm8(w.q8b, q8 + lo.fc2_w, M, C, 4 * C, EPI_RESID, w.x[2 * i + 2], st, dq + 3, ACT_SCALE_GELU, p + lo.fc2_b, w.x[2 * i + 1], s2, RS, nullptr, nullptr, 1.0f, nullptr, scp(3)));
+      if (scp(1)) RUN(atst_quant_fp8_dyn(l.o, MC, scp(1), l.o8, amp(1), st, sat));
+      else RUN(atst_quant_fp8(l.o, MC, ACT_SCALE, l.o8, st, sat));
+      RUN(gemm8(l.o8, q8 + lo.proj_w, M, C, C, EPI_RESID, w.x[2 * i + 1], st, dq + 1, ACT_SCALE, p + lo.proj_b, w.x[2 * i], s1, RS, nullptr, nullptr, 1.0f, nullptr, scp(1)));
+      RUN(atst_ln_fwd(w.x[2 * i + 1], p + lo.ln2_w, p + lo.ln2_b, l.h2, l.mean2, l.rstd2, M, C, st, l.h28, ACT_SCALE, sat, scp(2), amp(2)));
+      RUN(gemm8(l.h28, q8 + lo.fc1_w, M, 4 * C, C, EPI_BIAS_GELU, e->train ? l.u : nullptr, st, dq + 2, ACT_SCALE, p + lo.fc1_b, nullptr, nullptr, 1, l.a,
+                l.a8, ACT_SCALE_GELU, sat, scp(2), scp(3), amp(3)));
+      RUN(gemm8(l.a8, q8 + lo.fc2_w, M, C, 4 * C, EPI_RESID, w.x[2 * i + 2], st, dq + 3, ACT_SCALE_GELU, p + lo.fc2_b, w.x[2 * i + 1], s2, RS, nullptr, nullptr, 1.0f, nullptr, scp(3)));
     } else {
       if (i == 0 || !fuse_ln) RUN(atst_ln_fwd(w.x[2 * i], p + lo.ln1_w, p + lo.ln1_b, l.h1, l.mean1, l.rstd1, M, C, st));
       RUN(gemm(l.h1, q + lo.qkv_w, M, 3 * C, C, EPI_BF16, l.qkv, st));
@@ -286,6 +289,7 @@ static int encoder_bwd_range(const atst_encoder_t* e, int lo, int hi, bool head,
   // g8_amax[4 i + k]; fp8_bwd == 1 only records (first step: bf16 dgrad), == 2 also computes in fp8.
   const bool rec8 = e->fp8 && e->fp8_bwd >= 1 && e->g8_amax && !fuse_lnb;
   const bool use8 = rec8 && e->fp8_bwd >= 2 && e->p8t && e->g8_scale && e->w_dq;
+  const bool use8w = use8 && e->fp8_wgrad && e->f8_act_scale_bwd && M % 64 == 0;   // e4m3 weight gradients of fc1 / fc2 / proj (C = 768: N, K multiples of 256)
   auto gs8 = [&](int layer, int k) -> const float* { return use8 ? e->g8_scale + 4 * layer + k : nullptr; };
   auto ga8 = [&](int layer, int k) -> float* { return rec8 ? e->g8_amax + (size_t)(4 * layer + k) * AMAX_SITE_STRIDE : nullptr; };
   float* cur = w.dxA; float* oth = w.dxB;
@@ -334,7 +338,16 @@ static int encoder_bwd_range(const atst_encoder_t* e, int lo, int hi, bool head,
     at.qkv = l.qkv; at.valid = e->valid; at.o = l.o; at.lse = l.lse; at.d_o = w.d_o; at.dqkv = w.dqkv; at.dscratch = w.dscr;
     at.S = S; at.H = e->H; at.NP = NP; at.stride = RS;
     RUN(atst_attn_bwd(at, st));
-    {
+    if (use8w) {
+      // e4m3 weight gradients of fc1 / fc2 / proj (round 5): dY8 = the e4m3 gradient operands the dgrad GEMMs of this block have just used (scales
+      // g8_scale[4 i + k]), X8 = the e4m3 activation copies the forward kept (scales f8_act_scale_bwd[4 i + k]: what the forward quantised WITH, the
+      // caller's snapshot -- its running scales have moved on since).  The qkv gradient stays bf16: dqkv has no e4m3 copy.
+      const float* sxb = e->f8_act_scale_bwd + 4 * i;
+      RUN(atst_gemm_tn8(w.du8, l.h28, M, 4 * C, C, 4 * C, C, G + lo_.fc1_w, C, gs8(i, 1), sxb + 2, st));
+      RUN(atst_gemm_tn8(w.g8, l.a8, M, C, 4 * C, C, 4 * C, G + lo_.fc2_w, 4 * C, gs8(i, 0), sxb + 3, st));
+      RUN(atst_gemm_tn8(w.g28, l.o8, M, C, C, C, C, G + lo_.proj_w, C, gs8(i, 2), sxb + 1, st));
+      RUN(wgrad(w.dqkv, l.h1, M, 3 * C, C, G + lo_.qkv_w, st));
+    } else {
       WgradArgs wg[4] = {};
       auto set = [&](int k, const bf16* dY, const bf16* X, int N, int K, float* dW) {
         wg[k].dY = dY; wg[k].X = X; wg[k].M = M; wg[k].N = N; wg[k].K = K; wg[k].ldy = N; wg[k].ldx = K; wg[k].dW = dW; wg[k].ldw = K;

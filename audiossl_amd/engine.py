@@ -186,6 +186,10 @@ class EncoderPass:
                 e.f8_act_amax = eng.f8a_amax_sites[k].data_ptr()
             if net == "student" and train:
                 e.p8t, e.g8_scale, e.g8_amax = eng.p8t.data_ptr(), eng.g8_scale.data_ptr(), eng.g8_amax_sites.data_ptr()
+                # e4m3 weight gradients (fc1 / fc2 / proj): the backward needs the activation scales the forward of THIS step quantised with --
+                # f8a_scale itself is advanced by _fp8_after_forward() between the two
+                e.fp8_wgrad = 1 if eng.fp8_wgrad else 0
+                e.f8_act_scale_bwd = eng.f8a_scale_used.data_ptr()
         e.ws, e.ws_bytes = self.ws.buf.data_ptr(), nbytes
         self.e = e
         if self.precise:
@@ -211,6 +215,7 @@ class EncoderPass:
 
     def backward(self):
         self.e.fp8_bwd = int(getattr(self.eng, "fp8_bwd_state", 0)) if self.eng.fp8 else 0
+        self.e.fp8_wgrad = int(bool(getattr(self.eng, "fp8_wgrad", False))) if self.eng.fp8 else 0
         if self.precise:
             hip.check(hip.load().atst_encoder_hp_bwd(C.byref(self.e), hip.stream()), "atst_encoder_hp_bwd")
         else:
@@ -223,6 +228,7 @@ class EncoderPass:
     def backward_range(self, lo: int, hi: int):
         """blocks [lo, hi) descending (+ final LayerNorm when hi == depth, + token stage when lo == 0)."""
         self.e.fp8_bwd = int(getattr(self.eng, "fp8_bwd_state", 0)) if self.eng.fp8 else 0
+        self.e.fp8_wgrad = int(bool(getattr(self.eng, "fp8_wgrad", False))) if self.eng.fp8 else 0
         hip.check(hip.load().atst_encoder_bwd_range(C.byref(self.e), lo, hi, hip.stream()), "atst_encoder_bwd_range")
 
     def tokens(self):
@@ -500,6 +506,10 @@ class AtstEngine:
             self.g8_scale, self.g8_amax = torch.ones(4 * self.depth, device=dev), z(4 * self.depth)
             self.g8_amax_sites = z(4 * self.depth * hip.AMAX_SITE_STRIDE).view(4 * self.depth, hip.AMAX_SITE_STRIDE)
             self.fp8_bwd_state = 1 if (self.cfg["embed_dim"] == 768 and os.environ.get("ATST_FP8_BWD", "1") != "0") else 0
+            # e4m3 weight gradients of fc1 / fc2 / proj (round 5; with the e4m3 dgrad only: they share its gradient-operand copies).  f8a_scale_used:
+            # the student's forward activation scales as the forward of the current step used them (snapshot taken before they are advanced)
+            self.fp8_wgrad = bool(self.fp8_bwd_state) and os.environ.get("ATST_FP8_WGRAD", "1") != "0"
+            self.f8a_scale_used = self.f8a_scale[0].clone()
             self.fp8_margin = 2.0
             # amax HISTORY: the scale of a site is 448 / (margin * max amax over the last FP8_HISTORY steps), so one quiet step does not
             # shrink the headroom of the next (round-3 ADVICE: a single previous step with margin 2 saturates on any 2x spike); the
@@ -958,6 +968,7 @@ class AtstEngine:
         that saw nothing keep their scale.  MAX-reduced over the ranks (replicas quantise on one grid)."""
         if not self.fp8 or self.f8a_hist is None:
             return
+        self.f8a_scale_used.copy_(self.f8a_scale[0])                 # what this step's student forward quantised with (read by its backward)
         torch.amax(self.f8a_amax_sites, dim=-1, out=self.f8a_amax)
         self.f8a_amax_sites.zero_()
         if parallel._collective():

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libatst_hip.so")
 if os.environ.get("ATST_LIB_TAG"):          # experiment builds side by side (audiossl_amd/build.py): A/B runs inside one gpurun call
     LIB_PATH = os.path.join(_HERE, "lib", f"libatst_hip_{os.environ['ATST_LIB_TAG']}.so")
 ATST_MAX_DEPTH = 24
-ABI_VERSION = 110                                     # include/atst_hip.h ATST_ABI_VERSION these bindings were written for
+ABI_VERSION = 120                                     # include/atst_hip.h ATST_ABI_VERSION these bindings were written for
 
 EPI_BF16, EPI_F32, EPI_BIAS_GELU, EPI_RESID, EPI_DGELU, EPI_PATCH, EPI_LNBWD = range(7)
 AMAX_SLOTS, AMAX_SLOT_STRIDE = 16, 64                 # include/atst_hip.h ATST_AMAX_*: a running-amax site is 16 slots, 256 B apart
@@ -49,7 +49,8 @@ class Encoder(C.Structure):
                 ("ws", C.c_void_p), ("ws_bytes", C.c_size_t), ("tap", C.c_void_p), ("tap_first", C.c_int),
                 ("p8", C.c_void_p), ("w_dq", C.c_void_p), ("fp8", C.c_int), ("patch_h", C.c_int), ("patch_w", C.c_int),
                 ("p8t", C.c_void_p), ("g8_scale", C.c_void_p), ("g8_amax", C.c_void_p), ("fp8_bwd", C.c_int), ("row_stride", C.c_int),
-                ("f8_sat", C.c_void_p), ("f8_act_scale", C.c_void_p), ("f8_act_amax", C.c_void_p)]
+                ("f8_sat", C.c_void_p), ("f8_act_scale", C.c_void_p), ("f8_act_amax", C.c_void_p),
+                ("fp8_wgrad", C.c_int), ("f8_act_scale_bwd", C.c_void_p)]
 
 
 _SIGS = {
@@ -71,6 +72,7 @@ _SIGS = {
     "atst_quant_weights_fp8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "atst_gemm_tn_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                     C.c_int, C.c_void_p]),
+    "atst_gemm_tn_fp8": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "atst_gemm_tn_group_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "atst_layernorm_fwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p]),
     "atst_layernorm_fwd_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p]),

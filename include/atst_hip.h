@@ -38,8 +38,9 @@ enum { ATST_EPI_BF16 = 0, ATST_EPI_F32 = 1, ATST_EPI_BIAS_GELU = 2, ATST_EPI_RES
  * version must not proceed (audiossl_amd/hip.py checks it at load time).
  *   100  rounds 1-3
  *   110  round 4: atst_encoder_t grew f8_sat / f8_act_scale / f8_act_amax ; every amax argument (atst_quant_fp8_dyn_bf16, g8_amax, f8_act_amax) is an
- *        ATST_AMAX_SITE_STRIDE-float SITE, not one float ; fb_weights of atst_mel_frontend_f32 is tap-major [fb_maxlen][n_mels]               */
-#define ATST_ABI_VERSION 110
+ *        ATST_AMAX_SITE_STRIDE-float SITE, not one float ; fb_weights of atst_mel_frontend_f32 is tap-major [fb_maxlen][n_mels]
+ *   120  round 5: atst_encoder_t grew fp8_wgrad / f8_act_scale_bwd ; an fp8 training workspace also holds per-layer e4m3 activation copies ; atst_gemm_tn_fp8 */
+#define ATST_ABI_VERSION 120
 int atst_version(void);   /* = ATST_ABI_VERSION of the header the library was built from */
 /* Tuning hooks for A/B measurements (tools/gemm_bench.py, env ATST_TUNE=a,b,... read by audiossl_amd/hip.py); defaults are the
  * measured best.  These are PROCESS-GLOBAL test knobs (plain ints inside the library, read at launch time, no locking): set them from one
@@ -113,6 +114,10 @@ int atst_quant_weights_fp8(const float* p32, const int32_t* table, int n, uint8_
 /* dW[N,K] += dY[M,N]^T X[M,K]  (fp32 accumulate); autograd of the same nn.Linear calls.                              */
 int atst_gemm_tn_bf16(const uint16_t* dY, const uint16_t* X, int M, int N, int K, int ldy, int ldx, float* dW, int ldw,
                       int m_per_split, void* stream);
+/* The same on OCP e4m3 copies of both operands (m-major bytes, as the fp8 forward / dgrad write them), v_mfma_scale_f32_32x32x64_f8f6f4 on
+ * transposed LDS reads (ds_read_b64_tr_b8): dW[N,K] += dY8[M,N]^T X8[M,K] / (*scale_y * *scale_x).  N, K multiples of 256, M a multiple of 64.       */
+int atst_gemm_tn_fp8(const uint8_t* dY8, const uint8_t* X8, int M, int N, int K, int ldy, int ldx, float* dW, int ldw, const float* scale_y,
+                     const float* scale_x, void* stream);
 /* Up to 4 independent weight gradients in one launch (the four nn.Linear of a Block, modules/transformer.py:124-150):
  * each dW_i[N_i,K_i] += dY_i^T X_i.  Same result as n calls of atst_gemm_tn_bf16; fewer M-splits, fewer atomics.        */
 typedef struct { const uint16_t* dY; const uint16_t* X; float* dW; int M, N, K, ldy, ldx, ldw; } atst_wgrad_t;
@@ -223,7 +228,7 @@ typedef struct {
    * (g into fc2, du into fc1, g2 into proj, dqkv into qkv):
    * the operand is quantised with g8_scale (delayed scaling: derived from the previous step's amax by atst_fp8_update_scales) and this
    * step's max |x| is recorded in g8_amax.  fp8_bwd: 0 = bf16 backward, 1 = bf16 backward + amax recording (first step), 2 = fp8 dgrad.
-   * Weight gradients always use the bf16 operands.                                                                          */
+   * Weight gradients use the bf16 operands unless fp8_wgrad is set (below).                                                  */
   const uint8_t* p8t; const float* g8_scale; float* g8_amax; int fp8_bwd;
   /* rows between consecutive sequences in every [tokens, *] tensor of the pass (tokens, activations, gradients, atst_encoder_out):
    * 0 = NP.  n_tok + use_cls <= row_stride < NP packs the sequences (NP < 256 only): 1 s views are 26 tokens in tiles of 32, and the
@@ -239,6 +244,10 @@ typedef struct {
    * the producing kernels quantise with and the consuming GEMMs divide by; f8_act_amax (or NULL) receives max |x| of every site of this pass
    * (atomicMax) -- the caller turns it into the next step's scales (atst_fp8_update_scales; AtstEngine: 448 / (2 * max over 16 steps)).    */
   const float* f8_act_scale; float* f8_act_amax;
+  /* fp8 weight gradients (ABI 120): fp8_wgrad != 0 with fp8_bwd == 2 runs the fc1 / fc2 / proj weight gradients on the e4m3 gradient operands of
+   * the dgrad GEMMs and on the e4m3 activation copies the forward KEPT per layer (a training workspace with fp8 carves them).  f8_act_scale_bwd
+   * [depth][4]: the activation scales the forward of THIS step quantised with (a snapshot: f8_act_scale itself is advanced between forward and backward). */
+  int fp8_wgrad; const float* f8_act_scale_bwd;
 } atst_encoder_t;
 
 size_t atst_encoder_ws_bytes(int S, int NP, int C, int H, int depth, int train, int fp8 /* = atst_encoder_t.fp8: also carve the e4m3 operand copies */);

@@ -201,15 +201,17 @@ class emulate_fp8_dgrad:
     run on OCP e4m3 copies of their operands.  The gradient operand of site k (= the bf16 gradient arriving at that Linear's output) is
     quantised with a DELAYED scale -- 448 / (margin * amax of the same site in the previous step), csrc/optim.hip fp8_update_scales --
     and the transposed weight shadow with the per-tensor factor of the forward copy (448 / amax of the fp32 master, applied to the bf16
-    shadow: atst_quant_bf16_table_fp8).  The qkv dgrad and every weight gradient stay on bf16 operands.
+    shadow: atst_quant_bf16_table_fp8).  The qkv dgrad stays on bf16 operands; so does every weight gradient unless wgrad=True (round 5:
+    csrc/gemm_tn8.hip): then the fc2 / fc1 / proj weight gradients are products of the SAME e4m3 gradient operand and of the e4m3 activation
+    copy the forward used (x quantised with its forward activation scale).
       scales = None  -> record only (what the engine's first backward does): bf16 dgrad, self.amax[site] filled
       scales = {site: s} -> e4m3 dgrad at those sites with those scales; self.amax again holds this step's amax.
     `site` is the weight key ("student.encoder.blocks.0.mlp.fc2.weight").  next_scales() turns the recorded amax into the next step's
     scales exactly like the device kernel."""
     SITES = ("mlp.fc2.weight", "mlp.fc1.weight", "attn.proj.weight")
 
-    def __init__(self, scales=None, margin: float = 2.0):
-        self.scales, self.margin, self.amax = scales, margin, {}
+    def __init__(self, scales=None, margin: float = 2.0, wgrad: bool = False):
+        self.scales, self.margin, self.amax, self.wgrad = scales, margin, {}, wgrad
 
     def next_scales(self):
         return {k: 448.0 / (self.margin * v) for k, v in self.amax.items() if v > 0}
@@ -228,7 +230,7 @@ class _Fp8Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, w_master, act_scale, key):
         ctx.save_for_backward(x, w, w_master)
-        ctx.key = key
+        ctx.key, ctx.act_scale = key, act_scale
         ws = 448.0 / w_master.abs().max().clamp_min(1e-30)          # the e4m3 shadow is cut from the fp32 master
         return _q8(x, act_scale) @ _q8(w_master, ws).t()
 
@@ -241,7 +243,10 @@ class _Fp8Linear(torch.autograd.Function):
             st.amax[key] = max(st.amax.get(key, 0.0), float(g.abs().max()))      # g is the bf16 gradient operand (emulate_bf16 rounds it)
             if st.scales is not None and key in st.scales:
                 ws = 448.0 / w_master.abs().max().clamp_min(1e-30)
-                return _q8(g, st.scales[key]) @ _q8(w, ws), dw, None, None, None    # w = the bf16 shadow (its transposed copy is what gets quantised)
+                g8 = _q8(g, st.scales[key])
+                if st.wgrad:                                         # e4m3 weight gradient: the same gradient copy x the forward's activation copy
+                    dw = g8.reshape(-1, g.shape[-1]).t() @ _q8(x, ctx.act_scale).reshape(-1, x.shape[-1])
+                return g8 @ _q8(w, ws), dw, None, None, None         # w = the bf16 shadow (its transposed copy is what gets quantised)
         return g @ w, dw, None, None, None
 
 

@@ -649,7 +649,7 @@ def test_fp8_dgrad_step_base():
     eng.backward()
     g_fp8 = eng.g32.clone()
     assert torch.isfinite(g_fp8).all()
-    _, o_fp8 = oracle_grads(W, fwd, True, gates2, ctxs=(O.emulate_fp8(act_scales=act2), O.emulate_fp8_dgrad(inject)))
+    _, o_fp8 = oracle_grads(W, fwd, True, gates2, ctxs=(O.emulate_fp8(act_scales=act2), O.emulate_fp8_dgrad(inject, wgrad=eng.fp8_wgrad)))   # e4m3 weight gradients of fc1 / fc2 / proj emulated too
     # the same forward once more (activation scales put back to what step 2 used: bit-identical forward, same gates) with the dgrad on bf16
     # operands (recording mode): isolates what the e4m3 gradient operands change
     eng.f8a_scale.copy_(act2_dev); eng.fp8_bwd_state = 1
@@ -687,6 +687,24 @@ def test_fp8_dgrad_step_base():
     # predictor / projector weight gradients do not pass through any encoder dgrad GEMM: unchanged up to atomics order
     off, shape = eng.layout.entries["predictor.3.weight"]
     assert relerr(g_fp8[off:off + math.prod(shape)], g_bf[off:off + math.prod(shape)]) < 1e-5
+    # e4m3 WEIGHT gradients (csrc/gemm_tn8.hip, fc1 / fc2 / proj of every block) against the same step with bf16 weight gradients (e4m3 dgrad in both):
+    # the operands are 2^-4-relative copies, the sums run over M = 4096 rows -- a few per cent per tensor, and what the oracle's emulation predicts
+    assert eng.fp8_wgrad
+    eng.f8a_scale.copy_(act2_dev); eng.fp8_bwd_state = 2; eng.g8_scale.view(depth, 4).copy_(sc); eng.fp8_wgrad = False
+    eng.forward(mels, lens); eng.backward()
+    g_w16 = eng.g32.clone()
+    eng.fp8_wgrad = True
+    _, o_w16 = oracle_grads(W, fwd, True, gates2, ctxs=(O.emulate_fp8(act_scales=act2), O.emulate_fp8_dgrad(inject, wgrad=False)))
+    for i in range(depth):
+        for nm in ("mlp.fc1.weight", "mlp.fc2.weight", "attn.proj.weight"):
+            off, shape = eng.layout.entries[f"encoder.blocks.{i}.{nm}"]
+            n = math.prod(shape)
+            r_hip = relerr(g_fp8[off:off + n], g_w16[off:off + n])
+            r_or = relerr(o_fp8[f"encoder.blocks.{i}.{nm}"].reshape(-1), o_w16[f"encoder.blocks.{i}.{nm}"].reshape(-1))
+            print(f"  e4m3 vs bf16 weight gradient, block {i} {nm}: HIP {r_hip:.3e}  oracle {r_or:.3e}")
+            assert 1e-4 < r_hip < 6e-2 and abs(r_hip - r_or) < 0.6 * max(r_hip, r_or), (nm, r_hip, r_or)
+        off, shape = eng.layout.entries[f"encoder.blocks.{i}.attn.qkv.weight"]
+        assert relerr(g_fp8[off:off + math.prod(shape)], g_w16[off:off + math.prod(shape)]) < 1e-5      # the qkv weight gradient stays bf16
     eng.optimizer_step(1e-3, 0.04, 0.99)
     l1 = float(eng.forward(mels, lens)[0]); eng.backward()
     assert math.isfinite(l1) and torch.isfinite(eng.p32).all()
@@ -744,7 +762,7 @@ def test_configs4_base_fp8_hires_as_one_thing():
     gates = {f"student.{w}.": (eng.heads[f"student.{w}"].saved[4][:, :4096].float() > 0).cpu() for w in ("projector", "predictor")}
     eng.backward()
     g = eng.g32.clone()
-    lo, go = oracle_grads(W, fwd, True, gates, ctxs=(O.emulate_fp8(act_scales=act2), O.emulate_fp8_dgrad(inject)))
+    lo, go = oracle_grads(W, fwd, True, gates, ctxs=(O.emulate_fp8(act_scales=act2), O.emulate_fp8_dgrad(inject, wgrad=eng.fp8_wgrad)))
     num = den = 0.0
     worst = ("", 0.0)
     for name, (off, shape) in eng.layout.entries.items():
@@ -904,3 +922,24 @@ def test_gemm_fp8_phased_kernel(M, N, K):
     assert relerr(x, resid + scale.repeat_interleave(rps)[:, None] * (ref + bias)) < 5e-5
     for got, other in zip(res[392], res[390]):
         assert relerr(got.float(), other.float()) < 4e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (1024, 768, 768), (8192 + 64, 768, 3072), (4096, 3072, 768)])
+def test_gemm_tn_fp8_weight_gradient(M, N, K):
+    """e4m3 weight gradient (csrc/gemm_tn8.hip: transposed LDS reads ds_read_b64_tr_b8 + MX-scaled MFMA): dW += dY8^T X8 / (sy sx) against an fp64
+    matmul of the SAME e4m3 values (only the summation order differs), accumulation into a non-zero dW, asymmetric operands (a transposed or
+    permuted fragment would show), ragged last M-split."""
+    g = torch.Generator().manual_seed(M + N + K)
+    dY = (torch.randn(M, N, generator=g) * 0.02).to(DEV).bfloat16(); X = (torch.randn(M, K, generator=g) * 1.5).to(DEV).bfloat16()
+    X[:, 0] = 3.0; dY[0] = 0.05                                                     # structure along both axes
+    sy, sx = torch.tensor([2048.0], device=DEV), torch.tensor([8.0], device=DEV)
+    dY8 = torch.empty(M, N, dtype=torch.uint8, device=DEV); X8 = torch.empty(M, K, dtype=torch.uint8, device=DEV)
+    hip.call("atst_quant_fp8_bf16", hip.ptr(dY), M * N, 2048.0, hip.ptr(dY8), hip.stream())
+    hip.call("atst_quant_fp8_bf16", hip.ptr(X), M * K, 8.0, hip.ptr(X8), hip.stream())
+    dW = torch.full((N, K), 0.5, device=DEV)
+    hip.call("atst_gemm_tn_fp8", hip.ptr(dY8), hip.ptr(X8), M, N, K, N, K, hip.ptr(dW), K, hip.ptr(sy), hip.ptr(sx), hip.stream())
+    ref = (dY8.view(torch.float8_e4m3fn).double().t() @ X8.view(torch.float8_e4m3fn).double()) / (2048.0 * 8.0) + 0.5
+    assert relerr(dW, ref.float()) < 2e-5
+    # and close to the bf16 weight gradient of the unquantised operands (e4m3: 2^-4 relative per element, averaged over M)
+    ref16 = dY.float().t() @ X.float() + 0.5
+    assert relerr(dW, ref16) < 8e-2
