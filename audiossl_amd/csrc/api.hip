@@ -136,6 +136,15 @@ int atst_attention_bwd(const uint16_t* qkv, const int* valid, const uint16_t* o,
   return atst_attn_bwd(a, ST(stream));
 }
 
+int atst_attention_bwd_fp8(const uint16_t* qkv, const int* valid, const uint16_t* o, const float* lse, const uint16_t* d_o,
+                           uint8_t* dqkv8, const float* scale, float* amax_site, float* dscratch, int S, int H, int NP, void* stream) {
+  if (!dqkv8 || !scale || !amax_site) return ATST_EINVAL;
+  AttnArgs a{};
+  a.qkv = CBF(qkv); a.valid = valid; a.o = BF(const_cast<uint16_t*>(o)); a.lse = const_cast<float*>(lse);
+  a.d_o = CBF(d_o); a.dqkv8 = dqkv8; a.q8_scale = scale; a.q8_amax = amax_site; a.dscratch = dscratch; a.S = S; a.H = H; a.NP = NP;
+  return atst_attn_bwd(a, ST(stream));
+}
+
 int atst_patchify_bf16(const float* mel, int S, int width, int NP, int use_cls, uint16_t* out, void* stream) {
   return atst_patchify(mel, S, width, NP, use_cls, BF(out), ST(stream));
 }

@@ -124,6 +124,62 @@ DEVFN void store_tile64_staged(bf16* g00 /* global address of (row 0, column 0) 
   }
 }
 
+// e4m3 copy of a gradient tile (fp8 qkv dgrad / weight gradient, round 5): the SAME values the bf16 store would write -- rounded to bf16 first --
+// times the delayed scale, clamped to +-448.  One dword = the lane's 4-element group.
+DEVFN unsigned pack4_e4m3(float a, float b, float c, float d, float s8) {
+  auto q = [&](float x) { return __builtin_amdgcn_fmed3f(bf2f(f2bf(x)) * s8, -448.f, 448.f); };
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(q(a), q(b), 0, false);
+  return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(q(c), q(d), w, true);
+}
+DEVFN float amax16(const f32x16& v, float m) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(v[r]));
+  return m;
+}
+// 64-wide e4m3 row per lane pair: after two half-wave swaps per tile a lane holds 16 contiguous columns (t * 32 + 16 hi ..): 2 dwordx4 stores per row
+DEVFN void store_row64_e4m3(uint8_t* row, const f32x16& t0, const f32x16& t1, float mul, float s8, int hi) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const f32x16& v = t == 0 ? t0 : t1;
+    unsigned X[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) X[g] = pack4_e4m3(v[4 * g] * mul, v[4 * g + 1] * mul, v[4 * g + 2] * mul, v[4 * g + 3] * mul, s8);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      auto r = __builtin_amdgcn_permlane32_swap(X[k], X[k + 2], false, false);   // lower lanes: {D_k, E_k}, upper: {D_k+2, E_k+2}
+      X[k] = r[0]; X[k + 2] = r[1];
+    }
+    const u32x4 o = {X[0], X[2], X[1], X[3]};
+    *reinterpret_cast<u32x4*>(row + t * 32 + 16 * hi) = o;
+  }
+}
+// the e4m3 twin of store_tile64_staged: 32 rows x 64 B through 2 KB of the wave's LDS region (16-B chunks XOR-permuted by the row pair), then
+// 2 store instructions of 16 complete 64-B rows each
+DEVFN void store_tile64_staged_e4m3(uint8_t* g00, size_t ld /* bytes between rows */, const f32x16& t0, const f32x16& t1, float mul, float s8,
+                                    char* stage, int lane) {
+  const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const f32x16& v = t == 0 ? t0 : t1;
+    unsigned X[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) X[g] = pack4_e4m3(v[4 * g] * mul, v[4 * g + 1] * mul, v[4 * g + 2] * mul, v[4 * g + 3] * mul, s8);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      auto r = __builtin_amdgcn_permlane32_swap(X[k], X[k + 2], false, false);
+      X[k] = r[0]; X[k + 2] = r[1];
+    }
+    const u32x4 o = {X[0], X[2], X[1], X[3]};                      // columns t * 32 + 16 hi .. + 15 = chunk 2 t + hi of row l31
+    *reinterpret_cast<u32x4*>(stage + l31 * 64 + (((2 * t + hi) ^ ((l31 >> 1) & 3)) << 4)) = o;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = 16 * j + (lane >> 2), c = lane & 3;
+    const u32x4 o = *reinterpret_cast<const u32x4*>(stage + row * 64 + ((c ^ ((row >> 1) & 3)) << 4));
+    *reinterpret_cast<u32x4*>(g00 + (size_t)row * ld + c * 16) = o;
+  }
+}
+
 DEVFN void zero16(f32x16& a) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) a[r] = 0.f;
@@ -864,14 +920,23 @@ template <int N> DEVFN void bwd_wait_head(bf16x8 (&k)[4], bf16x8 (&v)[4], float&
                : "n"(N) : "memory");
 }
 #if ATST_ATTN_ABL & 8
-constexpr int BWD_ST_DKV = 0, BWD_ST_DQ = 0;         // experiment build without stores
+constexpr int BWD_ST_DKV = 0, BWD_ST_DQ = 0, BWD_ST_DQ8 = 0;         // experiment build without stores
 #else
 constexpr int BWD_ST_DKV = 8, BWD_ST_DQ = 4;         // store instructions of store_row64 x 2 / x 1 (16 B per lane each: cannot be fewer)
+constexpr int BWD_ST_DQ8 = 2;                        // ... of store_row64_e4m3 (MODE 2)
 #endif
 
+// MODE (fp8 qkv gradient path, round 5): 0 = bf16 dqkv ; 2 = ONLY the e4m3 copy p.dqkv8 = e4m3(bf16(dqkv) * *p.q8_scale) + max |bf16(dqkv)| posted
+// to p.q8_amax (delayed scaling): both consumers (qkv dgrad, qkv weight gradient) then read e4m3, and the kernel stores 1 byte per element
+// instead of 2 (6 store instructions per head instead of 12).  (A bf16 + amax variant -- the recording step -- spilled 112 B next to the
+// asm-loaded registers: the engine records that one step's amax with a pass over the bf16 dqkv instead.)
+template <int MODE>
 __global__ __launch_bounds__(512, 2) void attn_bwd256_kernel(AttnArgs p, const float* __restrict__ Dg) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int NP = 256;
+  constexpr int ST_DQ = MODE == 2 ? BWD_ST_DQ8 : BWD_ST_DQ;
+  float s8 = 1.0f, gmax = 0.f;
+  if constexpr (MODE == 2) s8 = *p.q8_scale;
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), hi = lane >> 5, l31 = lane & 31;
   const int H = p.H, C = H * HD;
   const size_t ld = 3 * (size_t)C;
@@ -963,7 +1028,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd256_kernel(AttnArgs p, const f
     // Q, dO images (LDS-DMA) and this wave's K / V fragments, lse, D of head h have landed; only the previous head's dQ stores are
     // younger (head 0: nothing is, so everything is waited for -- by a statement without register operands)
     if (h == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    bwd_wait_head<BWD_ST_DQ>(kfn, vfn, plse, pd);
+    bwd_wait_head<ST_DQ>(kfn, vfn, plse, pd);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) { kf[ks] = kfn[ks]; vf[ks] = vfn[ks]; }
     if (tid < NP) { sLse[tid] = -plse * LOG2E; sD[tid] = pd; }         // exponent offset of P = exp2(c1 s - lse log2 e)
@@ -1047,8 +1112,13 @@ __global__ __launch_bounds__(512, 2) void attn_bwd256_kernel(AttnArgs p, const f
 #if ATST_ATTN_ABL & 8
         asm volatile("" :: "v"(dk0), "v"(dk1), "v"(dv0), "v"(dv1));
 #else
+        if constexpr (MODE != 0) gmax = fmaxf(amax16(dk0, amax16(dk1, 0.f)) * scale, amax16(dv0, amax16(dv1, gmax)));
         bf16* dk00 = p.dqkv + ((size_t)s * NP + k0) * ld + C + h * HD;
-        if (p.row_stores) {                                        // tuning hook 406: the round-3 row-per-lane stores (A/B only)
+        if constexpr (MODE == 2) {
+          uint8_t* dk8 = p.dqkv8 + ((size_t)s * NP + k0) * ld + C + h * HD;
+          store_tile64_staged_e4m3(dk8, ld, dk0, dk1, scale, s8, reinterpret_cast<char*>(sQ) + wid * 4096, lane);
+          store_tile64_staged_e4m3(dk8 + C, ld, dv0, dv1, 1.0f, s8, reinterpret_cast<char*>(sDO) + wid * 4096, lane);
+        } else if (p.row_stores) {                                        // tuning hook 406: the round-3 row-per-lane stores (A/B only)
           store_row64(dk00 + (size_t)l31 * ld, dk0, dk1, scale, hi);
           store_row64(dk00 + (size_t)l31 * ld + C, dv0, dv1, 1.0f, hi);
         } else {
@@ -1096,11 +1166,15 @@ __global__ __launch_bounds__(512, 2) void attn_bwd256_kernel(AttnArgs p, const f
 #if ATST_ATTN_ABL & 8
       asm volatile("" :: "v"(dq0), "v"(dq1));
 #else
-      store_row64(dqrow, dq0, dq1, scale, hi);
+      if constexpr (MODE != 0) gmax = fmaxf(gmax, amax16(dq0, amax16(dq1, 0.f)) * scale);
+      if constexpr (MODE == 2) store_row64_e4m3(p.dqkv8 + ((size_t)s * NP + q0 + l31) * ld + h * HD, dq0, dq1, scale, s8, hi);
+      else store_row64(dqrow, dq0, dq1, scale, hi);
 #endif
     }
     // (the barrier at the top of the next head separates this head's last K / V reads from the next K / V DMA)
   }
+  // the site takes max |bf16(x)|: rounding is monotonic, so it is the rounded maximum
+  if constexpr (MODE != 0) amax_post(p.q8_amax, bf2f(f2bf(wave_max(gmax))), lane, blockIdx.x * 8 + wid);
 }
 
 template <int NP> int fwd_lds() { return Geo<NP>::G * 2 * Geo<NP>::LDS_MAT * 2; }
@@ -1183,13 +1257,17 @@ int atst_attn_fwd(const AttnArgs& a, hipStream_t st) {
   }
   return ATST_EINVAL;
 }
+// the e4m3 output of the backward exists in the merged NP = 256 kernel only (engine.hip asks before it plans a block's qkv gradient GEMMs)
+bool atst_attn_bwd_q8_ok(int NP) { return NP == 256 && g_bwd256; }
 int atst_attn_bwd(const AttnArgs& a, hipStream_t st) {
   if (a.S <= 0) return ATST_OK;
+  if (a.dqkv8 && !(atst_attn_bwd_q8_ok(a.NP) && a.dscratch)) return ATST_EINVAL;
   if (a.stride < 0 || a.stride > a.NP || (a.NP == 256 && a.stride != 0 && a.stride != 256)) return ATST_EINVAL;
   if (a.NP == 256 && g_bwd256 && a.dscratch) {
     static bool done = false;
     if (!done) {
-      hipError_t e = hipFuncSetAttribute((const void*)attn_bwd256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, B256_LDS);
+      hipError_t e = hipFuncSetAttribute((const void*)attn_bwd256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, B256_LDS);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, B256_LDS);
       if (e != hipSuccess) return (int)e;
       done = true;
     }
@@ -1197,7 +1275,10 @@ int atst_attn_bwd(const AttnArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(attn_rowdot_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, a.d_o, (const bf16*)a.o, a.dscratch, a.S, a.H, 256);
     ProfScope ps(PK_ATTN_BWD_DKV, 14.0 * a.S * a.H * 256.0 * 256.0 * HD, st, 16.0 * a.S * a.H * 256.0 * HD);
     AttnArgs a2 = a; a2.row_stores = g_bwd_row_stores;
-    hipLaunchKernelGGL(attn_bwd256_kernel, dim3(a.S), dim3(512), B256_LDS, st, a2, (const float*)a.dscratch);
+    if (a.dqkv8) {
+      if (!a.q8_scale || !a.q8_amax) return ATST_EINVAL;
+      hipLaunchKernelGGL(attn_bwd256_kernel<2>, dim3(a.S), dim3(512), B256_LDS, st, a2, (const float*)a.dscratch);
+    } else hipLaunchKernelGGL(attn_bwd256_kernel<0>, dim3(a.S), dim3(512), B256_LDS, st, a2, (const float*)a.dscratch);
     return (int)hipGetLastError();
   }
   if (a.NP == 32 && g_bwd32) {                                     // one wave per (sequence, head): both halves from one staging pass

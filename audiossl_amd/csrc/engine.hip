@@ -11,7 +11,7 @@ namespace {
 struct LayerWs {
   bf16 *h1, *qkv, *o, *h2, *u, *a;
   float *mean1, *rstd1, *mean2, *rstd2, *lse;
-  uint8_t *o8, *h28, *a8;             // fp8 training: the e4m3 copies of the proj / fc1 / fc2 inputs are KEPT per layer (operands of the e4m3 weight gradients)
+  uint8_t *h18, *o8, *h28, *a8;       // fp8 training: the e4m3 copies of the qkv / proj / fc1 / fc2 inputs are KEPT per layer (operands of the e4m3 weight gradients)
 };
 struct Ws {
   bf16* patches; float* table;
@@ -22,7 +22,7 @@ struct Ws {
   // backward scratch
   float *dxA, *dxB;
   bf16 *g, *g2, *dh, *du, *dqkv, *d_o, *dout;
-  uint8_t *g8, *g28, *du8;            // fp8 dgrad: e4m3 copies of g, g2, du
+  uint8_t *g8, *g28, *du8, *dqkv8;    // fp8 dgrad: e4m3 copies of g, g2, du ; dqkv8: what the NP = 256 attention backward writes INSTEAD of dqkv
   float* dscr;
   size_t bytes;
 };
@@ -53,18 +53,20 @@ Ws carve(void* ws, int S, int NP, int C, int H, int depth, int train, int fp8, i
     l.h2 = c.take<bf16>(M * C); l.u = c.take<bf16>(M * 4 * C); l.a = c.take<bf16>(M * 4 * C);
     l.mean1 = c.take<float>(M); l.rstd1 = c.take<float>(M); l.mean2 = c.take<float>(M); l.rstd2 = c.take<float>(M);
     l.lse = c.take<float>((size_t)S * H * NP);
-    if (fp8 && train) { l.o8 = c.take<uint8_t>(M * C); l.h28 = c.take<uint8_t>(M * C); l.a8 = c.take<uint8_t>(M * 4 * C); }
+    if (fp8 && train) { l.h18 = c.take<uint8_t>(M * C); l.o8 = c.take<uint8_t>(M * C); l.h28 = c.take<uint8_t>(M * C); l.a8 = c.take<uint8_t>(M * 4 * C); }
   }
   for (int i = nl; i < depth; ++i) w.L[i] = w.L[0];
   w.hN = c.take<bf16>(M * C); w.meanN = c.take<float>(M); w.rstdN = c.take<float>(M);
-  if (fp8) { w.q8a = c.take<uint8_t>(M * C); w.q8b = c.take<uint8_t>(M * 4 * C); }   // e4m3 operand copies: only the fp8 forward carves them
-  if (fp8 && !train) for (int i = 0; i < depth; ++i) { w.L[i].o8 = w.L[i].h28 = w.q8a; w.L[i].a8 = w.q8b; }   // inference: transient
+  if (fp8 && !train) {                                             // inference: one transient pair of e4m3 operand copies shared by all layers
+    w.q8a = c.take<uint8_t>(M * C); w.q8b = c.take<uint8_t>(M * 4 * C);
+    for (int i = 0; i < depth; ++i) { w.L[i].h18 = w.L[i].o8 = w.L[i].h28 = w.q8a; w.L[i].a8 = w.q8b; }
+  }
   if (train) {
     w.dxA = c.take<float>(M * C); w.dxB = c.take<float>(M * C);
     w.g = c.take<bf16>(M * C); w.g2 = c.take<bf16>(M * C); w.dh = c.take<bf16>(M * C); w.du = c.take<bf16>(M * 4 * C);
     w.dqkv = c.take<bf16>(M * 3 * C); w.d_o = c.take<bf16>(M * C); w.dout = c.take<bf16>(M * C);
     w.dscr = c.take<float>((size_t)S * H * NP);
-    if (fp8) { w.g8 = c.take<uint8_t>(M * C); w.g28 = c.take<uint8_t>(M * C); w.du8 = c.take<uint8_t>(M * 4 * C); }
+    if (fp8) { w.g8 = c.take<uint8_t>(M * C); w.g28 = c.take<uint8_t>(M * C); w.du8 = c.take<uint8_t>(M * 4 * C); w.dqkv8 = c.take<uint8_t>(M * 3 * C); }
   }
   w.bytes = (c.off + 255) & ~(size_t)255;
   return w;
@@ -201,8 +203,8 @@ extern "C" int atst_encoder_fwd(const atst_encoder_t* e, void* stream) {
       // of every site; without them the constants ACT_SCALE / ACT_SCALE_GELU.
       auto scp = [&](int k) -> const float* { return e->f8_act_scale ? e->f8_act_scale + 4 * i + k : nullptr; };
       auto amp = [&](int k) -> float* { return e->f8_act_amax ? e->f8_act_amax + (size_t)(4 * i + k) * AMAX_SITE_STRIDE : nullptr; };
-      RUN(atst_ln_fwd(w.x[2 * i], p + lo.ln1_w, p + lo.ln1_b, l.h1, l.mean1, l.rstd1, M, C, st, w.q8a, ACT_SCALE, sat, scp(0), amp(0)));
-      RUN(gemm8(w.q8a, q8 + lo.qkv_w, M, 3 * C, C, EPI_BF16, l.qkv, st, dq + 0, ACT_SCALE, nullptr, nullptr, nullptr, 1, nullptr, nullptr, 1.0f, nullptr, scp(0)));
+      RUN(atst_ln_fwd(w.x[2 * i], p + lo.ln1_w, p + lo.ln1_b, l.h1, l.mean1, l.rstd1, M, C, st, l.h18, ACT_SCALE, sat, scp(0), amp(0)));
+      RUN(gemm8(l.h18, q8 + lo.qkv_w, M, 3 * C, C, EPI_BF16, l.qkv, st, dq + 0, ACT_SCALE, nullptr, nullptr, nullptr, 1, nullptr, nullptr, 1.0f, nullptr, scp(0)));
       AttnArgs at{};
       at.qkv = l.qkv; at.valid = e->valid; at.o = l.o; at.lse = l.lse; at.S = S; at.H = e->H; at.NP = NP; at.stride = RS;
       RUN(atst_attn_fwd(at, st));
@@ -284,12 +286,18 @@ static int encoder_bwd_range(const atst_encoder_t* e, int lo, int hi, bool head,
   // (no dh round trip through HBM, no separate pass over x and the residual gradient)
   const bool fuse_lnb = C == 384;
   // fp8 dgrad (BASELINE.json configs[4]): the fc2 / fc1 / proj dgrad GEMMs of a block on e4m3 operands; qkv dgrad and weight gradients stay bf16.  Gradient
-  // operands use DELAYED scaling: site (block i, k) -- k = 0: g (into fc2), 1: du (into fc1), 2: g2 (into proj); 3 (dqkv) unused -- is
+  // operands use DELAYED scaling: site (block i, k) -- k = 0: g (into fc2), 1: du (into fc1), 2: g2 (into proj), 3: dqkv (into qkv: fp8_wgrad >= 2) -- is
   // quantised with g8_scale[4 i + k], the scale derived from the amax seen in the previous step, and records this step's amax in
   // g8_amax[4 i + k]; fp8_bwd == 1 only records (first step: bf16 dgrad), == 2 also computes in fp8.
   const bool rec8 = e->fp8 && e->fp8_bwd >= 1 && e->g8_amax && !fuse_lnb;
   const bool use8 = rec8 && e->fp8_bwd >= 2 && e->p8t && e->g8_scale && e->w_dq;
   const bool use8w = use8 && e->fp8_wgrad && e->f8_act_scale_bwd && M % 64 == 0;   // e4m3 weight gradients of fc1 / fc2 / proj (C = 768: N, K multiples of 256)
+  // fp8_wgrad == 2: the qkv Linear too -- the NP = 256 attention backward then writes dqkv as e4m3 ONLY (site 3) and both the qkv weight gradient
+  // and the qkv dgrad read that copy.  fp8_wgrad == 3 (or 2 while the dgrad itself is still recording): bf16 qkv gradient, site 3's amax taken by
+  // a pass over the bf16 dqkv -- the step that gives the site its first scale.
+  const bool q8ok = atst_attn_bwd_q8_ok(NP) && w.dscr && w.dqkv8;
+  const bool use8q = use8w && e->fp8_wgrad == 2 && q8ok;
+  const bool rec8q = rec8 && !use8q && e->fp8_wgrad >= 2 && q8ok && e->g8_scale;
   auto gs8 = [&](int layer, int k) -> const float* { return use8 ? e->g8_scale + 4 * layer + k : nullptr; };
   auto ga8 = [&](int layer, int k) -> float* { return rec8 ? e->g8_amax + (size_t)(4 * layer + k) * AMAX_SITE_STRIDE : nullptr; };
   float* cur = w.dxA; float* oth = w.dxB;
@@ -337,16 +345,19 @@ static int encoder_bwd_range(const atst_encoder_t* e, int lo, int hi, bool head,
     AttnArgs at{};
     at.qkv = l.qkv; at.valid = e->valid; at.o = l.o; at.lse = l.lse; at.d_o = w.d_o; at.dqkv = w.dqkv; at.dscratch = w.dscr;
     at.S = S; at.H = e->H; at.NP = NP; at.stride = RS;
+    if (use8q) { at.dqkv = nullptr; at.dqkv8 = w.dqkv8; at.q8_scale = gs8(i, 3); at.q8_amax = ga8(i, 3); }
     RUN(atst_attn_bwd(at, st));
+    if (rec8q) RUN(atst_quant_fp8_dyn(w.dqkv, (size_t)M * 3 * C, e->g8_scale + 4 * i + 3, nullptr, ga8(i, 3), st, nullptr));   // amax only
     if (use8w) {
       // e4m3 weight gradients of fc1 / fc2 / proj (round 5): dY8 = the e4m3 gradient operands the dgrad GEMMs of this block have just used (scales
       // g8_scale[4 i + k]), X8 = the e4m3 activation copies the forward kept (scales f8_act_scale_bwd[4 i + k]: what the forward quantised WITH, the
-      // caller's snapshot -- its running scales have moved on since).  The qkv gradient stays bf16: dqkv has no e4m3 copy.
+      // caller's snapshot -- its running scales have moved on since).  The qkv gradient: e4m3 as well when the attention backward wrote dqkv8.
       const float* sxb = e->f8_act_scale_bwd + 4 * i;
       RUN(atst_gemm_tn8(w.du8, l.h28, M, 4 * C, C, 4 * C, C, G + lo_.fc1_w, C, gs8(i, 1), sxb + 2, st));
       RUN(atst_gemm_tn8(w.g8, l.a8, M, C, 4 * C, C, 4 * C, G + lo_.fc2_w, 4 * C, gs8(i, 0), sxb + 3, st));
       RUN(atst_gemm_tn8(w.g28, l.o8, M, C, C, C, C, G + lo_.proj_w, C, gs8(i, 2), sxb + 1, st));
-      RUN(wgrad(w.dqkv, l.h1, M, 3 * C, C, G + lo_.qkv_w, st));
+      if (use8q) RUN(atst_gemm_tn8(w.dqkv8, l.h18, M, 3 * C, C, 3 * C, C, G + lo_.qkv_w, C, gs8(i, 3), sxb + 0, st));
+      else RUN(wgrad(w.dqkv, l.h1, M, 3 * C, C, G + lo_.qkv_w, st));
     } else {
       WgradArgs wg[4] = {};
       auto set = [&](int k, const bf16* dY, const bf16* X, int N, int K, float* dW) {
@@ -363,9 +374,10 @@ static int encoder_bwd_range(const atst_encoder_t* e, int lo, int hi, bool head,
                      i > 0 ? dps(i - 1, 1) : nullptr, RS, G + lo_.ln1_w, G + lo_.ln1_b, i > 0 ? G + o.layer[i - 1].fc2_b : nullptr, st));
       float* t = cur; cur = oth; oth = t;
     } else {
-      // the qkv dgrad stays bf16: its operand dqkv comes out of the attention backward, and a quantisation pass of its own (906 MB,
-      // 255 us at M = 131072) costs more than the e4m3 GEMM saves (355 -> 188 us); measured 125.4 vs 124.x ms per step
-      RUN(gemm(w.dqkv, qt + lo_.qkv_w, M, C, 3 * C, EPI_BF16, w.dh, st));
+      // the qkv dgrad: e4m3 when the attention backward wrote the e4m3 dqkv itself (a quantisation PASS over a bf16 dqkv -- 906 MB, 255 us at
+      // M = 131072 -- costs more than the e4m3 GEMM saves: measured 125.4 vs 124.x ms per step in round 4)
+      if (use8q) RUN(gemm8_bwd(w.dqkv8, e->p8t + lo_.qkv_w, M, C, 3 * C, EPI_BF16, w.dh, st, e->w_dq + 4 * i + 0, gs8(i, 3)));
+      else RUN(gemm(w.dqkv, qt + lo_.qkv_w, M, C, 3 * C, EPI_BF16, w.dh, st));
       LnBwdArgs a{};
       if (i > 0) { a.g8 = use8 ? w.g8 : nullptr; a.g8_scale = gs8(i - 1, 0); a.g_amax = ga8(i - 1, 0); }
       a.dy = w.dh; a.x = w.x[2 * i]; a.mean = l.mean1; a.rstd = l.rstd1; a.gamma = p + lo_.ln1_w; a.dres = cur;

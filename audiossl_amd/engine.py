@@ -188,7 +188,7 @@ class EncoderPass:
                 e.p8t, e.g8_scale, e.g8_amax = eng.p8t.data_ptr(), eng.g8_scale.data_ptr(), eng.g8_amax_sites.data_ptr()
                 # e4m3 weight gradients (fc1 / fc2 / proj): the backward needs the activation scales the forward of THIS step quantised with --
                 # f8a_scale itself is advanced by _fp8_after_forward() between the two
-                e.fp8_wgrad = 1 if eng.fp8_wgrad else 0
+                e.fp8_wgrad = eng.fp8_wgrad_mode()
                 e.f8_act_scale_bwd = eng.f8a_scale_used.data_ptr()
         e.ws, e.ws_bytes = self.ws.buf.data_ptr(), nbytes
         self.e = e
@@ -215,7 +215,7 @@ class EncoderPass:
 
     def backward(self):
         self.e.fp8_bwd = int(getattr(self.eng, "fp8_bwd_state", 0)) if self.eng.fp8 else 0
-        self.e.fp8_wgrad = int(bool(getattr(self.eng, "fp8_wgrad", False))) if self.eng.fp8 else 0
+        self.e.fp8_wgrad = self.eng.fp8_wgrad_mode()
         if self.precise:
             hip.check(hip.load().atst_encoder_hp_bwd(C.byref(self.e), hip.stream()), "atst_encoder_hp_bwd")
         else:
@@ -228,7 +228,7 @@ class EncoderPass:
     def backward_range(self, lo: int, hi: int):
         """blocks [lo, hi) descending (+ final LayerNorm when hi == depth, + token stage when lo == 0)."""
         self.e.fp8_bwd = int(getattr(self.eng, "fp8_bwd_state", 0)) if self.eng.fp8 else 0
-        self.e.fp8_wgrad = int(bool(getattr(self.eng, "fp8_wgrad", False))) if self.eng.fp8 else 0
+        self.e.fp8_wgrad = self.eng.fp8_wgrad_mode()
         hip.check(hip.load().atst_encoder_bwd_range(C.byref(self.e), lo, hi, hip.stream()), "atst_encoder_bwd_range")
 
     def tokens(self):
@@ -509,6 +509,9 @@ class AtstEngine:
             # e4m3 weight gradients of fc1 / fc2 / proj (round 5; with the e4m3 dgrad only: they share its gradient-operand copies).  f8a_scale_used:
             # the student's forward activation scales as the forward of the current step used them (snapshot taken before they are advanced)
             self.fp8_wgrad = bool(self.fp8_bwd_state) and os.environ.get("ATST_FP8_WGRAD", "1") != "0"
+            # ... and the qkv Linear: the NP = 256 attention backward writes dqkv as e4m3 only, the qkv dgrad and weight gradient read that copy
+            # (gradient site 3).  fp8_qkv_state: 0 off, 1 recording site 3 (first step, or the first step after a checkpoint without it), 2 on.
+            self.fp8_qkv_state = 1 if (self.fp8_wgrad and os.environ.get("ATST_FP8_QKV", "1") != "0") else 0
             self.f8a_scale_used = self.f8a_scale[0].clone()
             self.fp8_margin = 2.0
             # amax HISTORY: the scale of a site is 448 / (margin * max amax over the last FP8_HISTORY steps), so one quiet step does not
@@ -947,6 +950,12 @@ class AtstEngine:
             cuts.insert(-1, 1)
         return cuts
 
+    def fp8_wgrad_mode(self) -> int:
+        """atst_encoder_t.fp8_wgrad: 0 = bf16 weight gradients, 1 = e4m3 fc1 / fc2 / proj, 2 = + the e4m3 qkv gradient path, 3 = 1 + record site 3."""
+        if not (self.fp8 and getattr(self, "fp8_wgrad", False)):
+            return 0
+        return {0: 1, 1: 3, 2: 2}[int(getattr(self, "fp8_qkv_state", 0))]
+
     def _fp8_after_backward(self):
         """Delayed scaling: this step's amax of every gradient operand becomes the next step's quantisation scale (448 / (margin amax));
         the first backward only records (bf16 dgrad), every later one runs the dgrad GEMMs on e4m3 operands."""
@@ -961,6 +970,8 @@ class AtstEngine:
             hip.call("atst_fp8_update_scales", hip.ptr(win), hip.ptr(self.g8_scale), win.numel(), float(self.fp8_margin), hip.stream())
             self.g8_amax.zero_()
             self.fp8_bwd_state = 2
+            if getattr(self, "fp8_qkv_state", 0) == 1:
+                self.fp8_qkv_state = 2
 
     def _fp8_after_forward(self):
         """Delayed scaling of the e4m3 forward: the amax every activation site recorded in this step's passes (student groups share
@@ -998,7 +1009,8 @@ class AtstEngine:
             return None
         st = {"f8a_scale": self.f8a_scale.cpu(), "f8a_hist": self.f8a_hist.cpu(), "f8a_hist_k": int(self._f8a_hist_k)}
         if getattr(self, "fp8_bwd_state", 0):
-            st.update({"g8_scale": self.g8_scale.cpu(), "g8_hist": self.g8_hist.cpu(), "hist_k": int(self._g8_hist_k), "state": int(self.fp8_bwd_state)})
+            st.update({"g8_scale": self.g8_scale.cpu(), "g8_hist": self.g8_hist.cpu(), "hist_k": int(self._g8_hist_k), "state": int(self.fp8_bwd_state),
+                       "qkv_state": int(getattr(self, "fp8_qkv_state", 0))})
         return st
 
     def load_fp8_state(self, st: Optional[dict]):
@@ -1009,6 +1021,8 @@ class AtstEngine:
         if "g8_scale" in st and getattr(self, "fp8_bwd_state", 0):
             self.g8_scale.copy_(st["g8_scale"]); self.g8_hist.copy_(st["g8_hist"])
             self._g8_hist_k, self.fp8_bwd_state = int(st["hist_k"]), int(st["state"])
+            if getattr(self, "fp8_qkv_state", 0):                        # a checkpoint from before the qkv path has no site-3 scale: record one step first
+                self.fp8_qkv_state = 2 if int(st.get("qkv_state", 0)) == 2 else 1
 
     def _reduce_async(self, a: int, b: int, also=None):
         """Sum g32[a:b] over ranks on the communication stream, ordered after everything enqueued so far on the current stream (and after
@@ -1040,14 +1054,16 @@ class AtstEngine:
         for t in bufs:
             dist.broadcast(t, 0)
         if optimizer_state:
-            step = torch.tensor([self.opt_step, self._g8_hist_k if f8 else 0, self.fp8_bwd_state if f8 else 0, self._f8a_hist_k if f8a else 0],
-                                dtype=torch.int64, device=self.device)
+            step = torch.tensor([self.opt_step, self._g8_hist_k if f8 else 0, self.fp8_bwd_state if f8 else 0, self._f8a_hist_k if f8a else 0,
+                                 getattr(self, "fp8_qkv_state", 0) if f8 else 0], dtype=torch.int64, device=self.device)
             dist.broadcast(step, 0)
             self.opt_step = int(step[0].item())
             if f8a:
                 self._f8a_hist_k = int(step[3].item())
             if f8:
                 self._g8_hist_k, self.fp8_bwd_state = int(step[1].item()), int(step[2].item())
+                if getattr(self, "fp8_qkv_state", 0):
+                    self.fp8_qkv_state = 2 if int(step[4].item()) == 2 else 1
         self.sync_shadows(force=True)
 
     def allreduce_grads(self):

@@ -39,7 +39,8 @@ enum { ATST_EPI_BF16 = 0, ATST_EPI_F32 = 1, ATST_EPI_BIAS_GELU = 2, ATST_EPI_RES
  *   100  rounds 1-3
  *   110  round 4: atst_encoder_t grew f8_sat / f8_act_scale / f8_act_amax ; every amax argument (atst_quant_fp8_dyn_bf16, g8_amax, f8_act_amax) is an
  *        ATST_AMAX_SITE_STRIDE-float SITE, not one float ; fb_weights of atst_mel_frontend_f32 is tap-major [fb_maxlen][n_mels]
- *   120  round 5: atst_encoder_t grew fp8_wgrad / f8_act_scale_bwd ; an fp8 training workspace also holds per-layer e4m3 activation copies ; atst_gemm_tn_fp8 */
+ *   120  round 5: atst_encoder_t grew fp8_wgrad / f8_act_scale_bwd ; an fp8 training workspace also holds per-layer e4m3 activation copies
+ *        and an e4m3 dqkv ; atst_gemm_tn_fp8, atst_attention_bwd_fp8 */
 #define ATST_ABI_VERSION 120
 int atst_version(void);   /* = ATST_ABI_VERSION of the header the library was built from */
 /* Tuning hooks for A/B measurements (tools/gemm_bench.py, env ATST_TUNE=a,b,... read by audiossl_amd/hip.py); defaults are the
@@ -136,6 +137,11 @@ int atst_attention_fwd(const uint16_t* qkv, const int* valid, uint16_t* o, float
 /* dscratch: optional fp32 [S,H,NP] scratch (rowsum(dO*O)); when given and NP == 256 the merged per-sequence kernel runs */
 int atst_attention_bwd(const uint16_t* qkv, const int* valid, const uint16_t* o, const float* lse, const uint16_t* d_o,
                        uint16_t* dqkv, float* dscratch, int S, int H, int NP, void* stream);
+/* the same backward (NP == 256 only, dscratch required) writing dqkv as OCP e4m3 ONLY: dqkv8 [S*NP, 3*C] = e4m3(bf16(dqkv) * *scale), clamped to +-448;
+ * max |bf16(dqkv)| is posted into the amax SITE (ATST_AMAX_SITE_STRIDE floats, atomicMax).  The operand of the e4m3 qkv dgrad / weight gradient of
+ * the fp8 training step (atst_encoder_t.fp8_wgrad == 2); ATST_EINVAL for any other NP.                                                       */
+int atst_attention_bwd_fp8(const uint16_t* qkv, const int* valid, const uint16_t* o, const float* lse, const uint16_t* d_o,
+                           uint8_t* dqkv8, const float* scale, float* amax_site, float* dscratch, int S, int H, int NP, void* stream);
 /* PatchEmbed_v2 gather: audiossl/models/atst/audio_transformer.py:56-75 (bit-exact index map, bf16 values)          */
 int atst_patchify_bf16(const float* mel, int S, int width, int NP, int use_cls, uint16_t* out, void* stream);
 int atst_gather_rows_bf16(const uint16_t* src, const int* rows, int R, int C, float* dst, void* stream);
@@ -246,7 +252,10 @@ typedef struct {
   const float* f8_act_scale; float* f8_act_amax;
   /* fp8 weight gradients (ABI 120): fp8_wgrad != 0 with fp8_bwd == 2 runs the fc1 / fc2 / proj weight gradients on the e4m3 gradient operands of
    * the dgrad GEMMs and on the e4m3 activation copies the forward KEPT per layer (a training workspace with fp8 carves them).  f8_act_scale_bwd
-   * [depth][4]: the activation scales the forward of THIS step quantised with (a snapshot: f8_act_scale itself is advanced between forward and backward). */
+   * [depth][4]: the activation scales the forward of THIS step quantised with (a snapshot: f8_act_scale itself is advanced between forward and backward).
+   * fp8_wgrad == 2 (NP = 256 passes): the qkv Linear as well -- the attention backward writes dqkv as e4m3 ONLY (gradient site 3), the qkv weight
+   * gradient and the qkv dgrad read that copy: all 12 GEMMs of a block on e4m3 operands.  fp8_wgrad == 3: as 1, and site 3's amax is recorded (the
+   * step that gives the site its first scale; fp8_wgrad == 2 while fp8_bwd == 1 does the same).                                              */
   int fp8_wgrad; const float* f8_act_scale_bwd;
 } atst_encoder_t;
 

@@ -201,17 +201,19 @@ class emulate_fp8_dgrad:
     run on OCP e4m3 copies of their operands.  The gradient operand of site k (= the bf16 gradient arriving at that Linear's output) is
     quantised with a DELAYED scale -- 448 / (margin * amax of the same site in the previous step), csrc/optim.hip fp8_update_scales --
     and the transposed weight shadow with the per-tensor factor of the forward copy (448 / amax of the fp32 master, applied to the bf16
-    shadow: atst_quant_bf16_table_fp8).  The qkv dgrad stays on bf16 operands; so does every weight gradient unless wgrad=True (round 5:
-    csrc/gemm_tn8.hip): then the fc2 / fc1 / proj weight gradients are products of the SAME e4m3 gradient operand and of the e4m3 activation
-    copy the forward used (x quantised with its forward activation scale).
+    shadow: atst_quant_bf16_table_fp8).  Every weight gradient stays on bf16 operands unless wgrad=True (round 5: csrc/gemm_tn8.hip): then the
+    weight gradients of the e4m3 sites are products of the SAME e4m3 gradient operand and of the e4m3 activation copy the forward used (x
+    quantised with its forward activation scale).  The qkv Linear stays on bf16 operands unless qkv=True (round 5: the NP = 256 attention
+    backward then writes dqkv as e4m3 only, csrc/attention.hip attn_bwd256_kernel<2>): it becomes a fourth site with the same rules.
       scales = None  -> record only (what the engine's first backward does): bf16 dgrad, self.amax[site] filled
       scales = {site: s} -> e4m3 dgrad at those sites with those scales; self.amax again holds this step's amax.
     `site` is the weight key ("student.encoder.blocks.0.mlp.fc2.weight").  next_scales() turns the recorded amax into the next step's
     scales exactly like the device kernel."""
     SITES = ("mlp.fc2.weight", "mlp.fc1.weight", "attn.proj.weight")
 
-    def __init__(self, scales=None, margin: float = 2.0, wgrad: bool = False):
+    def __init__(self, scales=None, margin: float = 2.0, wgrad: bool = False, qkv: bool = False):
         self.scales, self.margin, self.amax, self.wgrad = scales, margin, {}, wgrad
+        self.sites = self.SITES + (("attn.qkv.weight",) if qkv else ())
 
     def next_scales(self):
         return {k: 448.0 / (self.margin * v) for k, v in self.amax.items() if v > 0}
@@ -239,7 +241,7 @@ class _Fp8Linear(torch.autograd.Function):
         x, w, w_master = ctx.saved_tensors                           # weight gradient: as if the bf16 operands had been used
         dw = g.reshape(-1, g.shape[-1]).t() @ x.reshape(-1, x.shape[-1])
         st, key = _FP8_BWD, ctx.key
-        if st is not None and key.endswith(emulate_fp8_dgrad.SITES):
+        if st is not None and key.endswith(st.sites):
             st.amax[key] = max(st.amax.get(key, 0.0), float(g.abs().max()))      # g is the bf16 gradient operand (emulate_bf16 rounds it)
             if st.scales is not None and key in st.scales:
                 ws = 448.0 / w_master.abs().max().clamp_min(1e-30)

@@ -353,6 +353,24 @@ def test_attention(NP, valid):
         # keys beyond `valid` receive exactly zero gradient
         inval = (rowvalid == 0).reshape(-1)
         assert float(got[inval][:, 1:].abs().max()) == 0.0 if inval.any() else True
+    if NP == 256:
+        # the e4m3-only output of the merged kernel (fp8 qkv gradient path): the SAME bf16 values times the scale, as e4m3 codes -- bit for bit -- and
+        # their max |.| in the amax site; any other NP is refused
+        amax_true = float(dqkv.float().abs().max())
+        scale = torch.tensor([448.0 / (1.5 * amax_true)], device=DEV)              # margin 1.5: nothing clips ; a second scale that does clip
+        for sc in (scale, scale * 4.0):
+            d8 = torch.full((S * NP, 3 * C), 0x7F, dtype=torch.uint8, device=DEV)
+            site = torch.zeros(hip.AMAX_SITE_STRIDE, device=DEV)
+            hip.call("atst_attention_bwd_fp8", hip.ptr(qkv), hip.ptr(vt), hip.ptr(o), hip.ptr(lse), hip.ptr(d_o), hip.ptr(d8), hip.ptr(sc), hip.ptr(site),
+                     hip.ptr(scratch), S, H, NP, hip.stream())
+            want8 = (dqkv.float() * sc).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+            # -0 and +0 are distinct codes: compare the decoded values, and the codes wherever the value is not zero
+            assert torch.equal(d8.view(torch.float8_e4m3fn).float(), want8.view(torch.float8_e4m3fn).float())
+            assert float(site.max()) == amax_true
+    else:
+        rc = hip.load().atst_attention_bwd_fp8(hip.ptr(qkv), hip.ptr(vt), hip.ptr(o), hip.ptr(lse), hip.ptr(d_o), hip.ptr(qkv), hip.ptr(lse), hip.ptr(lse),
+                                               hip.ptr(scratch), S, H, NP, hip.stream())
+        assert rc != 0
     if NP == 32:                                                        # fused one-wave-per-pair backward (default, hook 409) against the two-kernel path (408)
         try:
             hip.load().atst_tune_gemm_variant(408)
@@ -604,12 +622,12 @@ def _act_scales(eng):
 
 
 def test_fp8_dgrad_step_base():
-    """BASELINE.json configs[4]: ATST-base with e4m3 forward AND fc2 / fc1 / proj dgrad GEMMs (qkv dgrad and weight gradients on bf16
-    operands).  Delayed scaling: the first backward records the amax of every gradient operand and runs in bf16, every later one
+    """BASELINE.json configs[4]: ATST-base with e4m3 forward AND e4m3 dgrad / weight-gradient GEMMs of all four Linears of a block (round 5: the
+    qkv pair reads the e4m3 dqkv the NP = 256 attention backward writes).  Delayed scaling: the first backward records the amax of every gradient operand and runs in bf16, every later one
     quantises with the previous step's scale.  Checked against the ORACLE's emulation of the same scheme (oracle.emulate_fp8_dgrad:
     e4m3 rounding of the bf16 gradient operand with the delayed scale, e4m3 copy of the bf16 weight shadow), with the HIP run's ReLU
     gates injected as in tests/test_step_gpu.py:
-      1. recording step: HIP's next-step scales = 448 / (2 amax) agree with the oracle's at all 3 x depth sites;
+      1. recording step: HIP's next-step scales = 448 / (2 amax) agree with the oracle's at all 4 x depth sites;
       2. fp8-dgrad step: per-tensor gradients HIP vs oracle (the oracle quantises on HIP's grid: the recorded scales are injected);
       3. the fp8-dgrad gradients stay within the e4m3 staircase of the bf16-dgrad gradients of the same engine state."""
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -623,7 +641,7 @@ def test_fp8_dgrad_step_base():
     lens = [torch.full((B,), 1001)] * 2
     eng = AtstEngine("base", depth=depth, drop_path_rate=0.0, fp8=True)
     eng.load_weights(W)
-    assert eng.fp8_bwd_state == 1
+    assert eng.fp8_bwd_state == 1 and eng.fp8_qkv_state == 1 and eng.fp8_wgrad_mode() == 3
     eng.forward(mels, lens)
     gates = {f"student.{w}.": (eng.heads[f"student.{w}"].saved[4][:, :4096].float() > 0).cpu() for w in ("projector", "predictor")}
     eng.backward()                                                # step 1: bf16 dgrad, amax recorded
@@ -631,11 +649,12 @@ def test_fp8_dgrad_step_base():
     sc = eng.g8_scale.view(depth, 4).clone()
     act2, act2_dev = _act_scales(eng), eng.f8a_scale.clone()      # forward activation scales of step 2 (running amax of step 1)
     assert all(v > 1.0 for v in act2.values()) and any(abs(v - 8.0) > 1e-3 for v in act2.values())
-    assert eng.fp8_bwd_state == 2 and float(sc[:, :3].min()) > 1.0 and float(eng.g8_amax.abs().max()) == 0.0   # sites g, du, g2 (qkv dgrad stays bf16)
+    assert eng.fp8_bwd_state == 2 and float(sc.min()) > 1.0 and float(eng.g8_amax.abs().max()) == 0.0   # sites g, du, g2, dqkv
+    assert eng.fp8_qkv_state == 2 and eng.fp8_wgrad_mode() == 2
     fwd = lambda Wl: O.atst_forward(Wl, mels_c, lens, "base", 2, depth=depth, drop_path_rate=0.0)
-    rec = O.emulate_fp8_dgrad(None)
+    rec = O.emulate_fp8_dgrad(None, qkv=True)
     _, o_first = oracle_grads(W, fwd, True, gates, ctxs=(O.emulate_fp8(), rec))
-    site = {0: "mlp.fc2.weight", 1: "mlp.fc1.weight", 2: "attn.proj.weight"}
+    site = {0: "mlp.fc2.weight", 1: "mlp.fc1.weight", 2: "attn.proj.weight", 3: "attn.qkv.weight"}
     nxt, inject = rec.next_scales(), {}
     for i in range(depth):
         for k, nm in site.items():
@@ -649,13 +668,13 @@ def test_fp8_dgrad_step_base():
     eng.backward()
     g_fp8 = eng.g32.clone()
     assert torch.isfinite(g_fp8).all()
-    _, o_fp8 = oracle_grads(W, fwd, True, gates2, ctxs=(O.emulate_fp8(act_scales=act2), O.emulate_fp8_dgrad(inject, wgrad=eng.fp8_wgrad)))   # e4m3 weight gradients of fc1 / fc2 / proj emulated too
+    _, o_fp8 = oracle_grads(W, fwd, True, gates2, ctxs=(O.emulate_fp8(act_scales=act2), O.emulate_fp8_dgrad(inject, wgrad=eng.fp8_wgrad, qkv=True)))   # e4m3 weight gradients emulated too
     # the same forward once more (activation scales put back to what step 2 used: bit-identical forward, same gates) with the dgrad on bf16
     # operands (recording mode): isolates what the e4m3 gradient operands change
     eng.f8a_scale.copy_(act2_dev); eng.fp8_bwd_state = 1
     eng.forward(mels, lens); eng.backward()
     g_bf = eng.g32.clone()
-    _, o_bf = oracle_grads(W, fwd, True, gates2, ctxs=(O.emulate_fp8(act_scales=act2), O.emulate_fp8_dgrad(None)))
+    _, o_bf = oracle_grads(W, fwd, True, gates2, ctxs=(O.emulate_fp8(act_scales=act2), O.emulate_fp8_dgrad(None, qkv=True)))
 
     def table(get_a, get_b):
         worst, num, den = ("", 0.0), 0.0, 0.0
@@ -687,16 +706,29 @@ def test_fp8_dgrad_step_base():
     # predictor / projector weight gradients do not pass through any encoder dgrad GEMM: unchanged up to atomics order
     off, shape = eng.layout.entries["predictor.3.weight"]
     assert relerr(g_fp8[off:off + math.prod(shape)], g_bf[off:off + math.prod(shape)]) < 1e-5
-    # e4m3 WEIGHT gradients (csrc/gemm_tn8.hip, fc1 / fc2 / proj of every block) against the same step with bf16 weight gradients (e4m3 dgrad in both):
-    # the operands are 2^-4-relative copies, the sums run over M = 4096 rows -- a few per cent per tensor, and what the oracle's emulation predicts
+    # e4m3 WEIGHT gradients (csrc/gemm_tn8.hip, all four Linears of every block) + the e4m3 qkv dgrad against the same step with bf16 weight gradients and
+    # a bf16 qkv gradient path (e4m3 fc2 / fc1 / proj dgrad in both): the operands are 2^-4-relative copies, the sums run over M = 4096 rows -- a few per
+    # cent per tensor, and what the oracle's emulation predicts
     assert eng.fp8_wgrad
+    inject3 = {k: v for k, v in inject.items() if not k.endswith("attn.qkv.weight")}
     eng.f8a_scale.copy_(act2_dev); eng.fp8_bwd_state = 2; eng.g8_scale.view(depth, 4).copy_(sc); eng.fp8_wgrad = False
+    assert eng.fp8_wgrad_mode() == 0
     eng.forward(mels, lens); eng.backward()
     g_w16 = eng.g32.clone()
     eng.fp8_wgrad = True
-    _, o_w16 = oracle_grads(W, fwd, True, gates2, ctxs=(O.emulate_fp8(act_scales=act2), O.emulate_fp8_dgrad(inject, wgrad=False)))
+    _, o_w16 = oracle_grads(W, fwd, True, gates2, ctxs=(O.emulate_fp8(act_scales=act2), O.emulate_fp8_dgrad(inject3, wgrad=False)))
+    # ... and the intermediate mode (ATST_FP8_QKV=0: e4m3 fc1 / fc2 / proj weight gradients, bf16 qkv pair) against ITS emulation
+    eng.f8a_scale.copy_(act2_dev); eng.fp8_bwd_state = 2; eng.g8_scale.view(depth, 4).copy_(sc); eng.fp8_qkv_state = 0
+    assert eng.fp8_wgrad_mode() == 1
+    eng.forward(mels, lens); eng.backward()
+    g_q16 = eng.g32.clone()
+    eng.fp8_qkv_state = 2
+    _, o_q16 = oracle_grads(W, fwd, True, gates2, ctxs=(O.emulate_fp8(act_scales=act2), O.emulate_fp8_dgrad(inject3, wgrad=True)))
+    m4, w4 = table(hip_of(g_q16), or_of(o_q16))
+    print(f"[fp8 base depth {depth}] HIP vs oracle, e4m3 dgrad + weight gradients without the qkv pair: mean {m4:.3e} worst {w4[0]} {w4[1]:.3e}")
+    assert m4 < 9e-2 and w4[1] < 0.2
     for i in range(depth):
-        for nm in ("mlp.fc1.weight", "mlp.fc2.weight", "attn.proj.weight"):
+        for nm in ("mlp.fc1.weight", "mlp.fc2.weight", "attn.proj.weight", "attn.qkv.weight"):
             off, shape = eng.layout.entries[f"encoder.blocks.{i}.{nm}"]
             n = math.prod(shape)
             r_hip = relerr(g_fp8[off:off + n], g_w16[off:off + n])
@@ -704,7 +736,7 @@ def test_fp8_dgrad_step_base():
             print(f"  e4m3 vs bf16 weight gradient, block {i} {nm}: HIP {r_hip:.3e}  oracle {r_or:.3e}")
             assert 1e-4 < r_hip < 6e-2 and abs(r_hip - r_or) < 0.6 * max(r_hip, r_or), (nm, r_hip, r_or)
         off, shape = eng.layout.entries[f"encoder.blocks.{i}.attn.qkv.weight"]
-        assert relerr(g_fp8[off:off + math.prod(shape)], g_w16[off:off + math.prod(shape)]) < 1e-5      # the qkv weight gradient stays bf16
+        assert relerr(g_q16[off:off + math.prod(shape)], g_w16[off:off + math.prod(shape)]) < 1e-5   # mode 1: the bf16 qkv weight gradient of the same dqkv (the weight-gradient mode does not touch the data gradients)
     eng.optimizer_step(1e-3, 0.04, 0.99)
     l1 = float(eng.forward(mels, lens)[0]); eng.backward()
     assert math.isfinite(l1) and torch.isfinite(eng.p32).all()
@@ -754,15 +786,15 @@ def test_configs4_base_fp8_hires_as_one_thing():
     e_cls = relerr(cls, cls_o)
     eng.backward()                                                         # recording step (bf16 dgrad)
     sc = eng.g8_scale.view(depth, 4).clone()
-    site = {0: "mlp.fc2.weight", 1: "mlp.fc1.weight", 2: "attn.proj.weight"}
+    site = {0: "mlp.fc2.weight", 1: "mlp.fc1.weight", 2: "attn.proj.weight", 3: "attn.qkv.weight"}
     inject = {f"student.encoder.blocks.{i}.{nm}": float(sc[i, k]) for i in range(depth) for k, nm in site.items()}
-    assert eng.fp8_bwd_state == 2 and min(inject.values()) > 1.0
+    assert eng.fp8_bwd_state == 2 and min(inject.values()) > 1.0 and eng.fp8_wgrad_mode() == 2      # all 12 GEMMs of a block on e4m3 operands
     act2 = _act_scales(eng)                                                # the running forward scales step 2 quantises with
     loss2 = float(eng.forward(mels, lens)[0])                              # e4m3 dgrad step, same weights and inputs
     gates = {f"student.{w}.": (eng.heads[f"student.{w}"].saved[4][:, :4096].float() > 0).cpu() for w in ("projector", "predictor")}
     eng.backward()
     g = eng.g32.clone()
-    lo, go = oracle_grads(W, fwd, True, gates, ctxs=(O.emulate_fp8(act_scales=act2), O.emulate_fp8_dgrad(inject, wgrad=eng.fp8_wgrad)))
+    lo, go = oracle_grads(W, fwd, True, gates, ctxs=(O.emulate_fp8(act_scales=act2), O.emulate_fp8_dgrad(inject, wgrad=eng.fp8_wgrad, qkv=True)))
     num = den = 0.0
     worst = ("", 0.0)
     for name, (off, shape) in eng.layout.entries.items():

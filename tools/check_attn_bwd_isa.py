@@ -24,10 +24,21 @@ def regs(tok):
     return out
 
 
+def successors(body, labels, i):
+    l = body[i]
+    m = re.match(r"s_c?branch\w*\s+(\.\w+)", l)
+    if l.startswith("s_branch"):
+        return [labels[m.group(1)]]
+    if l.startswith("s_cbranch"):
+        return [labels[m.group(1)], i + 1]
+    return [i + 1]
+
+
 def audit(asm, kernel, min_stores):
     start = next(i for i, l in enumerate(asm) if re.match(r"^" + kernel + r".*:", l))
     end = next(i for i in range(start, len(asm)) if asm[i].strip().startswith("s_endpgm"))
     body = [l.strip() for l in asm[start:end]]
+    labels = {m.group(1): i for i, l in enumerate(body) for m in [re.match(r"(\.\w+):", l)] if m}
     bad, in_asm, loads = [], False, []
     for i, l in enumerate(body):
         if l.startswith(";;#ASMSTART"):
@@ -38,25 +49,29 @@ def audit(asm, kernel, min_stores):
             loads.append((i, regs(l.split(",")[0])))
     dest = set().union(*[r for _, r in loads])
     last = max(i for i, _ in loads)
-    hdr = next(i for i, l in enumerate(body) if "Loop Header" in l)
-    waits = [i for i, l in enumerate(body) if re.match(r"s_waitcnt vmcnt\(\d+\)$", l) and i > hdr]
-    tied = next(i for i in waits if body[i] != "s_waitcnt vmcnt(0)")
-    for i in list(range(last + 1, len(body))) + list(range(hdr, tied)):      # program order inside the loop: loads ... back edge ... tied wait
-        l = body[i]
-        if not l or l[0] in ";." or l.startswith("s_"):
+    tied = next(i for i, l in enumerate(body) if re.match(r"s_waitcnt vmcnt\(\d+\)$", l) and l != "s_waitcnt vmcnt(0)")
+    # every instruction that can execute between the last load and the tied wait (CFG walk, stopping at the wait; the statically possible but
+    # never taken exit path behind the loads is walked too: conservative)
+    seen, todo, load_at = set(), [last + 1], {i for i, _ in loads}
+    while todo:
+        i = todo.pop()
+        if i in seen or i == tied or i >= len(body) or i in load_at:      # (the loads again: the rotated iteration's path around the wait, h = -1 only)
             continue
-        if regs(l) & dest:
+        seen.add(i)
+        l = body[i]
+        if l and l[0] not in ";." and not l.startswith("s_") and regs(l) & dest:
             bad.append((i, l))
+        todo.extend(successors(body, labels, i))
     if any(l.startswith("scratch_") for l in body):
         bad.append((-1, "scratch access"))
-    zero_waits = [i for i in waits if body[i] == "s_waitcnt vmcnt(0)"]
+    zero_waits = [i for i, l in enumerate(body) if l == "s_waitcnt vmcnt(0)"]
     if len(zero_waits) > 1:
-        bad.append((zero_waits[1], "more than one vmcnt(0) inside the head loop"))
-    stores = [i for i, l in enumerate(body) if l.startswith("global_store")]       # block placement may put loop blocks ahead of the header label
+        bad.append((zero_waits[1], "more than one bare vmcnt(0) in the kernel (the head-0 one is the only one written)"))
+    stores = [i for i, l in enumerate(body) if l.startswith("global_store")]
     if len(stores) < min_stores:
         bad.append((-1, f"{len(stores)} store instructions, the waits assume >= {min_stores}"))
-    print(f"{kernel}: {len(body)} lines, {len(loads)} asm register loads into v{min(dest)}..v{max(dest)}, tied wait '{body[tied]}' at line {tied}, "
-          f"{len(stores)} store instructions, {'OK' if not bad else 'VIOLATIONS'}")
+    print(f"{kernel}: {len(body)} lines, {len(loads)} asm register loads into v{min(dest)}..v{max(dest)}, tied wait '{body[tied]}' at line "
+          f"{tied}, {len(seen)} instructions between the loads and the wait, {len(stores)} store instructions, {'OK' if not bad else 'VIOLATIONS'}")
     for i, l in bad:
         print("  VIOLATION", i, l)
     return not bad
@@ -65,7 +80,8 @@ def audit(asm, kernel, min_stores):
 def main():
     asm = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-S", "--cuda-device-only",
                           "-o", "-", SRC], capture_output=True, text=True).stdout.split("\n")
-    ok = audit(asm, "_ZN12_GLOBAL__N_118attn_bwd256_kernel", 12)
+    # MODE 0: bf16 dqkv (8 dK / dV + 4 dQ store instructions per head) ; MODE 2: e4m3 only (4 + 2)
+    ok = all([audit(asm, "_ZN12_GLOBAL__N_118attn_bwd256_kernelILi%dEEE" % mode, n) for mode, n in ((0, 12), (2, 6))])
     sys.exit(0 if ok else 1)
 
 
