@@ -203,7 +203,11 @@ extern "C" int atst_encoder_fwd(const atst_encoder_t* e, void* stream) {
       // of every site; without them the constants ACT_SCALE / ACT_SCALE_GELU.
       auto scp = [&](int k) -> const float* { return e->f8_act_scale ? e->f8_act_scale + 4 * i + k : nullptr; };
       auto amp = [&](int k) -> float* { return e->f8_act_amax ? e->f8_act_amax + (size_t)(4 * i + k) * AMAX_SITE_STRIDE : nullptr; };
-      RUN(atst_ln_fwd(w.x[2 * i], p + lo.ln1_w, p + lo.ln1_b, l.h1, l.mean1, l.rstd1, M, C, st, l.h18, ACT_SCALE, sat, scp(0), amp(0)));
+      // bf16 copies nobody will read are not written (fp8_lean; an inference pass never reads them): every GEMM of this forward takes the e4m3
+      // copy, and the backward's only readers are the bf16 weight gradients -- lean >= 1: fc1 / fc2 take h28 / a8, lean >= 2: qkv takes h18
+      const int lean = e->train ? e->fp8_lean : 2;
+      bf16* const h1o = lean >= 2 ? nullptr : l.h1; bf16* const h2o = lean >= 1 ? nullptr : l.h2; bf16* const ao = lean >= 1 ? nullptr : l.a;
+      RUN(atst_ln_fwd(w.x[2 * i], p + lo.ln1_w, p + lo.ln1_b, h1o, l.mean1, l.rstd1, M, C, st, l.h18, ACT_SCALE, sat, scp(0), amp(0)));
       RUN(gemm8(l.h18, q8 + lo.qkv_w, M, 3 * C, C, EPI_BF16, l.qkv, st, dq + 0, ACT_SCALE, nullptr, nullptr, nullptr, 1, nullptr, nullptr, 1.0f, nullptr, scp(0)));
       AttnArgs at{};
       at.qkv = l.qkv; at.valid = e->valid; at.o = l.o; at.lse = l.lse; at.S = S; at.H = e->H; at.NP = NP; at.stride = RS;
@@ -211,8 +215,8 @@ extern "C" int atst_encoder_fwd(const atst_encoder_t* e, void* stream) {
       if (scp(1)) RUN(atst_quant_fp8_dyn(l.o, MC, scp(1), l.o8, amp(1), st, sat));
       else RUN(atst_quant_fp8(l.o, MC, ACT_SCALE, l.o8, st, sat));
       RUN(gemm8(l.o8, q8 + lo.proj_w, M, C, C, EPI_RESID, w.x[2 * i + 1], st, dq + 1, ACT_SCALE, p + lo.proj_b, w.x[2 * i], s1, RS, nullptr, nullptr, 1.0f, nullptr, scp(1)));
-      RUN(atst_ln_fwd(w.x[2 * i + 1], p + lo.ln2_w, p + lo.ln2_b, l.h2, l.mean2, l.rstd2, M, C, st, l.h28, ACT_SCALE, sat, scp(2), amp(2)));
-      RUN(gemm8(l.h28, q8 + lo.fc1_w, M, 4 * C, C, EPI_BIAS_GELU, e->train ? l.u : nullptr, st, dq + 2, ACT_SCALE, p + lo.fc1_b, nullptr, nullptr, 1, l.a,
+      RUN(atst_ln_fwd(w.x[2 * i + 1], p + lo.ln2_w, p + lo.ln2_b, h2o, l.mean2, l.rstd2, M, C, st, l.h28, ACT_SCALE, sat, scp(2), amp(2)));
+      RUN(gemm8(l.h28, q8 + lo.fc1_w, M, 4 * C, C, EPI_BIAS_GELU, e->train ? l.u : nullptr, st, dq + 2, ACT_SCALE, p + lo.fc1_b, nullptr, nullptr, 1, ao,
                 l.a8, ACT_SCALE_GELU, sat, scp(2), scp(3), amp(3)));
       RUN(gemm8(l.a8, q8 + lo.fc2_w, M, C, 4 * C, EPI_RESID, w.x[2 * i + 2], st, dq + 3, ACT_SCALE_GELU, p + lo.fc2_b, w.x[2 * i + 1], s2, RS, nullptr, nullptr, 1.0f, nullptr, scp(3)));
     } else {
@@ -298,13 +302,17 @@ static int encoder_bwd_range(const atst_encoder_t* e, int lo, int hi, bool head,
   const bool q8ok = atst_attn_bwd_q8_ok(NP) && w.dscr && w.dqkv8;
   const bool use8q = use8w && e->fp8_wgrad == 2 && q8ok;
   const bool rec8q = rec8 && !use8q && e->fp8_wgrad >= 2 && q8ok && e->g8_scale;
+  // a lean forward (fp8_lean) did not write the bf16 activations the bf16 weight gradients would read: the backward must be the e4m3 one it announced
+  if (e->fp8 && ((e->fp8_lean >= 1 && !use8w) || (e->fp8_lean >= 2 && !use8q))) return ATST_EINVAL;
+  // ... and with e4m3 dgrads + weight gradients the bf16 copies of g, g2 and du have no reader either (backward-internal: no contract with the forward)
+  const bool skip16 = use8w;
   auto gs8 = [&](int layer, int k) -> const float* { return use8 ? e->g8_scale + 4 * layer + k : nullptr; };
   auto ga8 = [&](int layer, int k) -> float* { return rec8 ? e->g8_amax + (size_t)(4 * layer + k) * AMAX_SITE_STRIDE : nullptr; };
   float* cur = w.dxA; float* oth = w.dxB;
   if (head) {
     LnBwdArgs a{};
     a.dy = w.dout; a.x = w.x[2 * D]; a.mean = w.meanN; a.rstd = w.rstdN; a.gamma = p + o.norm_w; a.dres = nullptr;
-    a.dx = cur; a.g = w.g; a.row_scale = dps(D - 1, 1); a.rows_per_seq = RS;
+    a.dx = cur; a.g = skip16 ? nullptr : w.g; a.row_scale = dps(D - 1, 1); a.rows_per_seq = RS;
     a.dgamma = G + o.norm_w; a.dbeta = G + o.norm_b; a.dbias_up = G + o.layer[D - 1].fc2_b; a.M = M; a.C = C;
     a.g8 = use8 ? w.g8 : nullptr; a.g8_scale = gs8(D - 1, 0); a.g_amax = ga8(D - 1, 0);
     RUN(atst_ln_bwd(a, st));
@@ -316,7 +324,7 @@ static int encoder_bwd_range(const atst_encoder_t* e, int lo, int hi, bool head,
     // The block's four weight gradients are independent of everything downstream: they are launched together after the
     // attention backward (atst_gemm_tn_group), which is why the two residual-branch gradients live in separate buffers.
     if (use8) {
-      RUN(gemm8_bwd(w.g8, e->p8t + lo_.fc2_w, M, 4 * C, C, EPI_DGELU, w.du, st, e->w_dq + 4 * i + 3, gs8(i, 0), l.u, G + lo_.fc1_b,
+      RUN(gemm8_bwd(w.g8, e->p8t + lo_.fc2_w, M, 4 * C, C, EPI_DGELU, skip16 ? nullptr : w.du, st, e->w_dq + 4 * i + 3, gs8(i, 0), l.u, G + lo_.fc1_b,
                     w.du8, gs8(i, 1), ga8(i, 1)));
     } else {
       GemmArgs a{};
@@ -334,7 +342,7 @@ static int encoder_bwd_range(const atst_encoder_t* e, int lo, int hi, bool head,
       LnBwdArgs a{};
       a.g8 = use8 ? w.g28 : nullptr; a.g8_scale = gs8(i, 2); a.g_amax = ga8(i, 2);
       a.dy = w.dh; a.x = w.x[2 * i + 1]; a.mean = l.mean2; a.rstd = l.rstd2; a.gamma = p + lo_.ln2_w; a.dres = cur;
-      a.dx = oth; a.g = w.g2; a.row_scale = dps(i, 0); a.rows_per_seq = RS;
+      a.dx = oth; a.g = skip16 ? nullptr : w.g2; a.row_scale = dps(i, 0); a.rows_per_seq = RS;
       a.dgamma = G + lo_.ln2_w; a.dbeta = G + lo_.ln2_b; a.dbias_up = G + lo_.proj_b; a.M = M; a.C = C;
       RUN(atst_ln_bwd(a, st));
       float* t = cur; cur = oth; oth = t;
@@ -381,7 +389,7 @@ static int encoder_bwd_range(const atst_encoder_t* e, int lo, int hi, bool head,
       LnBwdArgs a{};
       if (i > 0) { a.g8 = use8 ? w.g8 : nullptr; a.g8_scale = gs8(i - 1, 0); a.g_amax = ga8(i - 1, 0); }
       a.dy = w.dh; a.x = w.x[2 * i]; a.mean = l.mean1; a.rstd = l.rstd1; a.gamma = p + lo_.ln1_w; a.dres = cur;
-      a.dx = oth; a.g = i > 0 ? w.g : nullptr; a.row_scale = i > 0 ? dps(i - 1, 1) : nullptr; a.rows_per_seq = RS;
+      a.dx = oth; a.g = (i > 0 && !skip16) ? w.g : nullptr; a.row_scale = i > 0 ? dps(i - 1, 1) : nullptr; a.rows_per_seq = RS;
       a.dgamma = G + lo_.ln1_w; a.dbeta = G + lo_.ln1_b; a.dbias_up = i > 0 ? G + o.layer[i - 1].fc2_b : nullptr;
       a.M = M; a.C = C;
       RUN(atst_ln_bwd(a, st));

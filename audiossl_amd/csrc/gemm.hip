@@ -110,7 +110,7 @@ DEVFN void epilogue8(const GemmArgs& p, int row, int col, f32x4 v0, f32x4 v1, co
       const f32x2 a0 = gelu_bf16dst2(f32x2{v0[e], v0[e + 1]}), a1 = gelu_bf16dst2(f32x2{v1[e], v1[e + 1]});
       g0[e] = a0[0]; g0[e + 1] = a0[1]; g1[e] = a1[0]; g1[e + 1] = a1[1];
     }
-    st_bf16_b(p.C2, idx, g0, g1, std::integral_constant<int, 5>{});    // activation a (bit 5: the next GEMM reads it whole)
+    if (p.C2) st_bf16_b(p.C2, idx, g0, g1, std::integral_constant<int, 5>{});    // activation a (bit 5: the next GEMM reads it whole); not written when every reader takes the e4m3 copy
     if (p.q8) {                                                    // fp8 forward: e4m3 copy of the SAME bf16 values for the fc2 GEMM
       const float s = x.s;                                         // running (delayed) activation scale, or the constant: the caller read it once
       auto c = [&](float a_) { return __builtin_amdgcn_fmed3f(bf2f(f2bf(a_)) * s, -448.f, 448.f); };
@@ -137,7 +137,7 @@ DEVFN void epilogue8(const GemmArgs& p, int row, int col, f32x4 v0, f32x4 v1, co
       const f32x2 d0 = gelu_grad_bf16dst2(f32x2{bf2f(u[e]), bf2f(u[e + 1])}), d1 = gelu_grad_bf16dst2(f32x2{bf2f(u[4 + e]), bf2f(u[5 + e])});
       v0[e] *= d0[0]; v0[e + 1] *= d0[1]; v1[e] *= d1[0]; v1[e + 1] *= d1[1];
     }
-    st_bf16(p.C, idx, v0, v1);
+    if (p.C) st_bf16(p.C, idx, v0, v1);                             // du (bf16): not written when every reader takes the e4m3 copy (fp8 dgrad + e4m3 weight gradients)
     w0 = v0; w1 = v1;
     if (p.q8) {                                                    // fp8 dgrad: e4m3 copy of the SAME bf16 values for the fc1 dgrad GEMM (scale in x.s)
       auto c = [&](float a_) { return __builtin_amdgcn_fmed3f(bf2f(f2bf(a_)) * x.s, -448.f, 448.f); };
@@ -1781,9 +1781,9 @@ double nt_bytes(const GemmArgs& a) {
   double b = 2.0 * a.K * ((double)a.M + a.N);
   if (EPI == EPI_BF16) b += 2.0 * mn;
   if (EPI == EPI_F32) b += 4.0 * mn;
-  if (EPI == EPI_BIAS_GELU) b += 2.0 * mn + (a.C ? 2.0 * mn : 0.0);            // a always, u only when it is saved (training)
+  if (EPI == EPI_BIAS_GELU) b += (a.C2 ? 2.0 * mn : 0.0) + (a.C ? 2.0 * mn : 0.0) + (a.q8 ? mn : 0.0);   // a (bf16 and / or e4m3), u only when it is saved (training)
   if (EPI == EPI_RESID) b += 8.0 * mn + (a.ln_out ? 2.0 * mn : 0.0);
-  if (EPI == EPI_DGELU) b += 4.0 * mn;
+  if (EPI == EPI_DGELU) b += 2.0 * mn + (a.C ? 2.0 * mn : 0.0) + (a.q8 ? mn : 0.0);      // u in ; du out (bf16 and / or e4m3)
   if (EPI == EPI_PATCH) b += 4.0 * mn;
   if (EPI == EPI_LNBWD) b += 8.0 * mn + (a.resid ? 4.0 * mn : 0.0) + (a.lnb_g ? 2.0 * mn : 0.0);   // x in, dx out, dres in, g out
   return b;
@@ -1961,6 +1961,8 @@ void atst_gemm_nt_set_variant(int v) {
 
 int atst_gemm_nt(const GemmArgs& a0, hipStream_t st) {
   GemmArgs a = a0;
+  // outputs that may be left out: the bf16 activation of fc1 + GELU and the bf16 du of the dGELU dgrad, when an e4m3 copy is written instead
+  if ((a.epi == EPI_BIAS_GELU && !a.C2 && !a.q8) || (a.epi == EPI_DGELU && !a.C && !a.q8) || (a.epi != EPI_BIAS_GELU && a.epi != EPI_DGELU && !a.C)) return ATST_EINVAL;
   if (a.fp8) {                                                    // e4m3: K a multiple of 64 bytes, row-384 tile only, no fused LayerNorm
     if (a.M <= 0 || a.N % 384 || a.K % 64 || a.lda % 16 || a.ldb % 16 || a.ln_out) return ATST_EINVAL;
     a.K /= 2; a.lda /= 2; a.ldb /= 2;

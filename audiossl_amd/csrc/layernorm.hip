@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         hvec ob; float r[W];
 #pragma unroll
         for (int e = 0; e < W; ++e) { ob[e] = f2bf(o[e]); r[e] = bf2f(ob[e]); }
-        *reinterpret_cast<hvec*>(yr + MP::col(i, lane)) = ob;
+        if (y) *reinterpret_cast<hvec*>(yr + MP::col(i, lane)) = ob;   // (fp8: not written when every reader takes the e4m3 copy)
         if (y8) {
           st_fp8<W>(y8 + (size_t)row * C + MP::col(i, lane), r, s8);   // fp8 forward: e4m3 copy of the SAME bf16 values (the next GEMM's A operand)
           float cm = 0.f;
@@ -182,7 +182,8 @@ int ln_grid(int M) { int b = (M + 3) / 4; return b < 2048 ? b : 2048; }
 int atst_ln_fwd(const float* x, const float* gamma, const float* beta, bf16* y, float* mean, float* rstd, int M, int C, hipStream_t st,
                 uint8_t* y8, float s8, unsigned* sat, const float* s8p, float* amax8) {
   if (M <= 0) return ATST_OK;
-  ProfScope ps(PK_LN_FWD, (double)M * C * (y8 ? 7.0 : 6.0), st);      // read fp32, write bf16 (+ e4m3)
+  if (!y && !y8) return ATST_EINVAL;
+  ProfScope ps(PK_LN_FWD, (double)M * C * (4.0 + (y ? 2.0 : 0.0) + (y8 ? 1.0 : 0.0)), st);      // read fp32, write bf16 and / or e4m3
   if (C == 384) hipLaunchKernelGGL(ln_fwd_kernel<6>, dim3(ln_grid(M)), dim3(256), 0, st, x, gamma, beta, y, mean, rstd, M, y8, s8, sat, s8p, amax8);
   else if (C == 768) hipLaunchKernelGGL(ln_fwd_kernel<12>, dim3(ln_grid(M)), dim3(256), 0, st, x, gamma, beta, y, mean, rstd, M, y8, s8, sat, s8p, amax8);
   else return ATST_EINVAL;
@@ -201,7 +202,7 @@ int atst_ln_fwd_f32(const float* x, const float* gamma, const float* beta, float
 int atst_ln_bwd(const LnBwdArgs& a, hipStream_t st) {
   if (a.M <= 0) return ATST_OK;
   int grid = (a.M + 63) / 64; if (grid > 1024) grid = 1024; if (grid < 1) grid = 1;
-  ProfScope ps(PK_LN_BWD, (double)a.M * a.C * (2.0 + 4.0 + (a.dres ? 4.0 : 0.0) + 4.0 + (a.g ? 2.0 : 0.0)), st);
+  ProfScope ps(PK_LN_BWD, (double)a.M * a.C * (2.0 + 4.0 + (a.dres ? 4.0 : 0.0) + 4.0 + (a.g ? 2.0 : 0.0) + (a.g8 ? 1.0 : 0.0)), st);
   if (a.C == 384) hipLaunchKernelGGL(ln_bwd_kernel<6>, dim3(grid), dim3(256), 0, st, a);
   else if (a.C == 768) hipLaunchKernelGGL(ln_bwd_kernel<12>, dim3(grid), dim3(256), 0, st, a);
   else return ATST_EINVAL;

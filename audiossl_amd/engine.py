@@ -207,13 +207,28 @@ class EncoderPass:
         e = self.e
         e.mel, e.valid = hip.ptr(mel), hip.ptr(valid)
         e.rowflag, e.dp_scale = hip.ptr(rowflag), hip.ptr(dp_scale)
+        e.fp8_lean = self._lean_mode()                      # bf16 activation copies the announced backward will not read are not written
         if self.precise:
             hip.check(hip.load().atst_encoder_hp_fwd(C.byref(e), hip.stream()), "atst_encoder_hp_fwd")
         else:
             hip.check(hip.load().atst_encoder_fwd(C.byref(e), hip.stream()), "atst_encoder_fwd")
         return self.out
 
+    def _lean_mode(self) -> int:
+        """atst_encoder_t.fp8_lean of a training pass: 1 when its backward will run the e4m3 fc1 / fc2 / proj weight gradients, 2 when the qkv one too."""
+        eng, e = self.eng, self.e
+        if not (eng.fp8 and e.train and getattr(eng, "fp8_lean", False)) or getattr(eng, "fp8_bwd_state", 0) != 2 or self.M % 64:
+            return 0
+        mode = eng.fp8_wgrad_mode()
+        return 0 if mode == 0 else (2 if (mode == 2 and e.NP == 256) else 1)
+
+    def _check_lean(self):
+        if self.e.fp8_lean and self.e.fp8_lean > self._lean_mode():
+            raise RuntimeError("fp8: the forward of this pass left out bf16 activation copies (fp8_lean) that the backward now asked for would read -- "
+                               "fp8_bwd_state / fp8_wgrad / fp8_qkv_state must not change between a forward and its backward")
+
     def backward(self):
+        self._check_lean()
         self.e.fp8_bwd = int(getattr(self.eng, "fp8_bwd_state", 0)) if self.eng.fp8 else 0
         self.e.fp8_wgrad = self.eng.fp8_wgrad_mode()
         if self.precise:
@@ -223,10 +238,14 @@ class EncoderPass:
 
     def backward_part(self, part: int, split: int):
         """part 0: final LayerNorm + blocks [split, depth) ; part 1: blocks [0, split) + token stage."""
+        self._check_lean()
+        self.e.fp8_bwd = int(getattr(self.eng, "fp8_bwd_state", 0)) if self.eng.fp8 else 0
+        self.e.fp8_wgrad = self.eng.fp8_wgrad_mode()
         hip.check(hip.load().atst_encoder_bwd_part(C.byref(self.e), part, split, hip.stream()), "atst_encoder_bwd_part")
 
     def backward_range(self, lo: int, hi: int):
         """blocks [lo, hi) descending (+ final LayerNorm when hi == depth, + token stage when lo == 0)."""
+        self._check_lean()
         self.e.fp8_bwd = int(getattr(self.eng, "fp8_bwd_state", 0)) if self.eng.fp8 else 0
         self.e.fp8_wgrad = self.eng.fp8_wgrad_mode()
         hip.check(hip.load().atst_encoder_bwd_range(C.byref(self.e), lo, hi, hip.stream()), "atst_encoder_bwd_range")
@@ -512,6 +531,8 @@ class AtstEngine:
             # ... and the qkv Linear: the NP = 256 attention backward writes dqkv as e4m3 only, the qkv dgrad and weight gradient read that copy
             # (gradient site 3).  fp8_qkv_state: 0 off, 1 recording site 3 (first step, or the first step after a checkpoint without it), 2 on.
             self.fp8_qkv_state = 1 if (self.fp8_wgrad and os.environ.get("ATST_FP8_QKV", "1") != "0") else 0
+            # bf16 activation copies whose only readers would be bf16 weight gradients are not written once those run on the e4m3 copies
+            self.fp8_lean = self.fp8_wgrad and os.environ.get("ATST_FP8_LEAN", "1") != "0"
             self.f8a_scale_used = self.f8a_scale[0].clone()
             self.fp8_margin = 2.0
             # amax HISTORY: the scale of a site is 448 / (margin * max amax over the last FP8_HISTORY steps), so one quiet step does not

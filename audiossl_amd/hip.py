@@ -50,7 +50,7 @@ class Encoder(C.Structure):
                 ("p8", C.c_void_p), ("w_dq", C.c_void_p), ("fp8", C.c_int), ("patch_h", C.c_int), ("patch_w", C.c_int),
                 ("p8t", C.c_void_p), ("g8_scale", C.c_void_p), ("g8_amax", C.c_void_p), ("fp8_bwd", C.c_int), ("row_stride", C.c_int),
                 ("f8_sat", C.c_void_p), ("f8_act_scale", C.c_void_p), ("f8_act_amax", C.c_void_p),
-                ("fp8_wgrad", C.c_int), ("f8_act_scale_bwd", C.c_void_p)]
+                ("fp8_wgrad", C.c_int), ("f8_act_scale_bwd", C.c_void_p), ("fp8_lean", C.c_int)]
 
 
 _SIGS = {

@@ -40,7 +40,7 @@ enum { ATST_EPI_BF16 = 0, ATST_EPI_F32 = 1, ATST_EPI_BIAS_GELU = 2, ATST_EPI_RES
  *   110  round 4: atst_encoder_t grew f8_sat / f8_act_scale / f8_act_amax ; every amax argument (atst_quant_fp8_dyn_bf16, g8_amax, f8_act_amax) is an
  *        ATST_AMAX_SITE_STRIDE-float SITE, not one float ; fb_weights of atst_mel_frontend_f32 is tap-major [fb_maxlen][n_mels]
  *   120  round 5: atst_encoder_t grew fp8_wgrad / f8_act_scale_bwd ; an fp8 training workspace also holds per-layer e4m3 activation copies
- *        and an e4m3 dqkv ; atst_gemm_tn_fp8, atst_attention_bwd_fp8 */
+ *        and an e4m3 dqkv ; fp8_lean ; atst_gemm_tn_fp8, atst_attention_bwd_fp8 */
 #define ATST_ABI_VERSION 120
 int atst_version(void);   /* = ATST_ABI_VERSION of the header the library was built from */
 /* Tuning hooks for A/B measurements (tools/gemm_bench.py, env ATST_TUNE=a,b,... read by audiossl_amd/hip.py); defaults are the
@@ -257,6 +257,11 @@ typedef struct {
    * gradient and the qkv dgrad read that copy: all 12 GEMMs of a block on e4m3 operands.  fp8_wgrad == 3: as 1, and site 3's amax is recorded (the
    * step that gives the site its first scale; fp8_wgrad == 2 while fp8_bwd == 1 does the same).                                              */
   int fp8_wgrad; const float* f8_act_scale_bwd;
+  /* fp8 training forward, bf16 copies without a reader: with e4m3 weight gradients the backward reads the e4m3 activation copies, so the forward need
+   * not write the bf16 ones.  fp8_lean >= 1: LayerNorm-2 output and GELU output are written as e4m3 only (fc1 / fc2 weight gradients must be e4m3:
+   * the backward of this pass needs fp8_bwd == 2, fp8_wgrad != 0, M % 64 == 0); >= 2: LayerNorm-1 output too (the qkv weight gradient must be e4m3:
+   * fp8_wgrad == 2, NP == 256).  A backward that cannot honour it returns ATST_EINVAL.  Inference passes (train == 0) never write those copies.       */
+  int fp8_lean;
 } atst_encoder_t;
 
 size_t atst_encoder_ws_bytes(int S, int NP, int C, int H, int depth, int train, int fp8 /* = atst_encoder_t.fp8: also carve the e4m3 operand copies */);
