@@ -136,6 +136,15 @@ int atst_attention_bwd(const uint16_t* qkv, const int* valid, const uint16_t* o,
   return atst_attn_bwd(a, ST(stream));
 }
 
+int atst_attention_fwd_fp8(const uint16_t* qkv, const int* valid, uint16_t* o, uint8_t* o8, const float* scale, float* amax_site, uint32_t* sat,
+                           float* lse, int S, int H, int NP, void* stream) {
+  if (!o8 || !scale) return ATST_EINVAL;
+  AttnArgs a{};
+  a.qkv = CBF(qkv); a.valid = valid; a.o = BF(o); a.lse = lse; a.S = S; a.H = H; a.NP = NP;
+  a.o8 = o8; a.o8_scale = scale; a.o8_amax = amax_site; a.o8_sat = sat;
+  return atst_attn_fwd(a, ST(stream));
+}
+
 int atst_attention_bwd_fp8(const uint16_t* qkv, const int* valid, const uint16_t* o, const float* lse, const uint16_t* d_o,
                            uint8_t* dqkv8, const float* scale, float* amax_site, float* dscratch, int S, int H, int NP, void* stream) {
   if (!dqkv8 || !scale || !amax_site) return ATST_EINVAL;

@@ -400,9 +400,16 @@ DEVFN void glds16_asm(const void* gsrc, unsigned lds_dst /* wave-uniform LDS byt
 }
 DEVFN void gload16_asm(bf16x8& dst, const void* src) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(src) : "memory"); }
 DEVFN void gload4_asm(float& dst, const void* src) { asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(src) : "memory"); }
+// MODE (fp8 forward, round 5): 0 = bf16 output ; 1 = bf16 + the e4m3 copy p.o8 = e4m3(bf16(o) * scale) the proj GEMM reads (training: the backward
+// needs the bf16 one) ; 2 = e4m3 only (inference / teacher passes).  With p.o8: max |bf16(o)| goes to the amax site p.o8_amax and the clipped
+// elements to the counter p.o8_sat, exactly what the separate quantisation pass (atst_quant_fp8_dyn) did over the stored bf16 values.  (MODE 1 keeps
+// 44 B of loop invariants -- the next head's LDS-DMA source offsets -- in scratch; they are reloaded right behind the head's own vmcnt(0) + barrier.)
+template <int MODE>
 __global__ __launch_bounds__(512, 2) void attn_fwd256v2_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   typedef const void __attribute__((address_space(1))) * gptr_t;
+  float s8 = 1.0f, rmax = 0.f;
+  if constexpr (MODE != 0) s8 = p.o8_scale ? *p.o8_scale : p.o8_scale_k;
   typedef void __attribute__((address_space(3))) * lptr_t;
   constexpr int NP = 256;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hi = lane >> 5, l31 = lane & 31;
@@ -515,8 +522,22 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256v2_kernel(AttnArgs p) {
 #ifdef ATST_ABLATE_ATTN_STORE
     if (rs == 12345.678f)                                           // experiment builds: no output stores
 #endif
-    store_row64(orow, o0, o1, inv, hi);                            // (full-line stores through an LDS transposition buffer, as in the backward: 60 B of scratch at 256 registers -- the score strip is the register file)
-    if (hi == 0) p.lse[((size_t)s * H + h) * NP + q0 + l31] = mx * 0.125f + __logf(rs);
+    if constexpr (MODE != 2) store_row64(orow, o0, o1, inv, hi);   // (full-line stores through an LDS transposition buffer, as in the backward: 60 B of scratch at 256 registers -- the score strip is the register file)
+    if constexpr (MODE != 0) {
+      store_row64_e4m3(p.o8 + ((size_t)s * NP + q0 + l31) * C + h * HD, o0, o1, inv, s8, hi);
+      const float cm = bf2f(f2bf(amax16(o0, amax16(o1, 0.f)) * inv));      // rounding is monotonic: the largest |bf16(x)| of this lane's 32 values
+      rmax = fmaxf(rmax, cm);
+      if (cm * s8 > 448.f && p.o8_sat) {                          // rare: something of this row piece was clipped -- count exactly, post at once (no counter kept live)
+        unsigned n = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) n += (fabsf(bf2f(f2bf(o0[r] * inv)) * s8) > 448.f ? 1u : 0u) + (fabsf(bf2f(f2bf(o1[r] * inv)) * s8) > 448.f ? 1u : 0u);
+        if (n) atomicAdd(p.o8_sat, n);
+      }
+    }
+    if (p.lse && hi == 0) p.lse[((size_t)s * H + h) * NP + q0 + l31] = mx * 0.125f + __logf(rs);
+  }
+  if constexpr (MODE != 0) {
+    if (p.o8_amax) amax_post(p.o8_amax, wave_max(rmax), lane, blockIdx.x * 8 + wid);
   }
 }
 
@@ -1222,20 +1243,28 @@ int g_bwd256 = 1;          // merged per-sequence backward kernel for NP = 256 (
 int g_fwd256 = 2;          // NP = 256 forward: 2 = two-pass softmax + LDS-DMA head loop, 1 = online-softmax head loop, 0 = per-(sequence, head) kernel (tuning hooks 404 / 401 / 400)
 int g_bwd32 = 1;           // 408 / 409: NP = 32 backward as two kernels (A/B) / one fused kernel (default)
 int g_bwd_row_stores = 0;  // 406 / 407: NP = 256 backward dK / dV stores row-per-lane (A/B) / LDS-transposed full lines (default)
-void atst_attn_set_variant(int v) { if (v == 8 || v == 9) g_bwd32 = v == 9; else if (v == 6 || v == 7) g_bwd_row_stores = v == 6; else if (v == 4) g_fwd256 = 2; else if (v >= 2) g_bwd256 = v - 2; else g_fwd256 = v; }
+int g_fwd_q8 = 1;          // 410 / 411: fp8 forward, e4m3 copy of the attention output by a separate pass (A/B) / by the NP = 256 forward kernel itself (default)
+void atst_attn_set_variant(int v) { if (v == 10 || v == 11) g_fwd_q8 = v == 11; else if (v == 8 || v == 9) g_bwd32 = v == 9; else if (v == 6 || v == 7) g_bwd_row_stores = v == 6; else if (v == 4) g_fwd256 = 2; else if (v >= 2) g_bwd256 = v - 2; else g_fwd256 = v; }
 
+// the e4m3 output of the forward exists in the two-pass NP = 256 kernel only (engine.hip asks; otherwise it quantises the bf16 output in a pass)
+bool atst_attn_fwd_q8_ok(int NP, int H) { return NP == 256 && g_fwd_q8 && g_fwd256 == 2 && (size_t)NP * 3 * H * HD * 2 < (1u << 30); }
 int atst_attn_fwd(const AttnArgs& a, hipStream_t st) {
   if (a.S <= 0) return ATST_OK;
+  if (a.o8 ? !atst_attn_fwd_q8_ok(a.NP, a.H) : !a.o) return ATST_EINVAL;
   if (a.stride < 0 || a.stride > a.NP || (a.NP == 256 && a.stride != 0 && a.stride != 256)) return ATST_EINVAL;   // packed sequences: NP < 256 kernels only
   if (a.NP == 256 && g_fwd256 == 2 && (size_t)a.NP * 3 * a.H * HD * 2 < (1u << 30)) {
     static bool done2 = false;
     if (!done2) {
-      hipError_t e = hipFuncSetAttribute((const void*)attn_fwd256v2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * F2_BUF);
+      hipError_t e = hipFuncSetAttribute((const void*)attn_fwd256v2_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * F2_BUF);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_fwd256v2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * F2_BUF);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_fwd256v2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * F2_BUF);
       if (e != hipSuccess) return (int)e;
       done2 = true;
     }
-    ProfScope ps(PK_ATTN_FWD, 4.0 * a.S * a.H * 256.0 * 256.0 * HD, st, 8.0 * a.S * a.H * 256.0 * HD);
-    hipLaunchKernelGGL(attn_fwd256v2_kernel, dim3(a.S), dim3(512), 2 * F2_BUF, st, a);
+    ProfScope ps(PK_ATTN_FWD, 4.0 * a.S * a.H * 256.0 * 256.0 * HD, st, (6.0 + (a.o ? 2.0 : 0.0) + (a.o8 ? 1.0 : 0.0)) * a.S * a.H * 256.0 * HD);
+    if (a.o8 && !a.o) hipLaunchKernelGGL(attn_fwd256v2_kernel<2>, dim3(a.S), dim3(512), 2 * F2_BUF, st, a);
+    else if (a.o8) hipLaunchKernelGGL(attn_fwd256v2_kernel<1>, dim3(a.S), dim3(512), 2 * F2_BUF, st, a);
+    else hipLaunchKernelGGL(attn_fwd256v2_kernel<0>, dim3(a.S), dim3(512), 2 * F2_BUF, st, a);
     return (int)hipGetLastError();
   }
   if (a.NP == 256 && g_fwd256) {

@@ -211,9 +211,18 @@ extern "C" int atst_encoder_fwd(const atst_encoder_t* e, void* stream) {
       RUN(gemm8(l.h18, q8 + lo.qkv_w, M, 3 * C, C, EPI_BF16, l.qkv, st, dq + 0, ACT_SCALE, nullptr, nullptr, nullptr, 1, nullptr, nullptr, 1.0f, nullptr, scp(0)));
       AttnArgs at{};
       at.qkv = l.qkv; at.valid = e->valid; at.o = l.o; at.lse = l.lse; at.S = S; at.H = e->H; at.NP = NP; at.stride = RS;
+      // the e4m3 copy of the attention output (the proj GEMM's operand) comes out of the NP = 256 forward kernel itself -- next to the bf16 output the
+      // backward reads, or instead of it in an inference pass; the other geometries quantise the bf16 output in a pass of their own
+      const bool o8fused = atst_attn_fwd_q8_ok(NP, e->H);
+      if (o8fused) {
+        at.o8 = l.o8; at.o8_scale = scp(1); at.o8_scale_k = ACT_SCALE; at.o8_amax = scp(1) ? amp(1) : nullptr; at.o8_sat = sat;
+        if (!e->train) at.o = nullptr;
+      }
       RUN(atst_attn_fwd(at, st));
-      if (scp(1)) RUN(atst_quant_fp8_dyn(l.o, MC, scp(1), l.o8, amp(1), st, sat));
-      else RUN(atst_quant_fp8(l.o, MC, ACT_SCALE, l.o8, st, sat));
+      if (!o8fused) {
+        if (scp(1)) RUN(atst_quant_fp8_dyn(l.o, MC, scp(1), l.o8, amp(1), st, sat));
+        else RUN(atst_quant_fp8(l.o, MC, ACT_SCALE, l.o8, st, sat));
+      }
       RUN(gemm8(l.o8, q8 + lo.proj_w, M, C, C, EPI_RESID, w.x[2 * i + 1], st, dq + 1, ACT_SCALE, p + lo.proj_b, w.x[2 * i], s1, RS, nullptr, nullptr, 1.0f, nullptr, scp(1)));
       RUN(atst_ln_fwd(w.x[2 * i + 1], p + lo.ln2_w, p + lo.ln2_b, h2o, l.mean2, l.rstd2, M, C, st, l.h28, ACT_SCALE, sat, scp(2), amp(2)));
       RUN(gemm8(l.h28, q8 + lo.fc1_w, M, 4 * C, C, EPI_BIAS_GELU, e->train ? l.u : nullptr, st, dq + 2, ACT_SCALE, p + lo.fc1_b, nullptr, nullptr, 1, ao,

@@ -84,6 +84,8 @@ struct AttnArgs {
   float* dscratch;                   // bwd scratch [S, H, NP] fp32 (rowsum(dO*O)); null -> two-kernel backward
   int S, H, NP;
   int row_stores;                    // tuning hook (NP = 256 backward): 1 = row-per-lane dK / dV stores instead of the LDS-transposed full-line ones
+  uint8_t* o8; const float* o8_scale; float o8_scale_k; float* o8_amax; unsigned* o8_sat;   // NP = 256 forward (fp8): o8 -> e4m3(bf16(o) * scale) [S*NP, C] next to
+                                     // o (or instead of it: o == null) ; scale = *o8_scale, or the constant o8_scale_k ; optional amax site / clipped-element counter
   uint8_t* dqkv8; const float* q8_scale; float* q8_amax;   // NP = 256 backward (fp8 qkv gradient path): dqkv8 -> e4m3(bf16(dqkv) * *q8_scale) [S*NP, 3*C]
                                      // written INSTEAD of dqkv, max |bf16(dqkv)| posted to the amax site q8_amax (all three needed)
   int stride;                        // rows between consecutive sequences in qkv / o / d_o / dqkv (0 = NP).  stride < NP: sequences are PACKED --
@@ -92,6 +94,7 @@ struct AttnArgs {
 };
 int atst_attn_fwd(const AttnArgs& a, hipStream_t st);
 bool atst_attn_bwd_q8_ok(int NP);
+bool atst_attn_fwd_q8_ok(int NP, int H);
 int atst_attn_bwd(const AttnArgs& a, hipStream_t st);
 void atst_attn_set_variant(int v);
 

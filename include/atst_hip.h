@@ -40,7 +40,7 @@ enum { ATST_EPI_BF16 = 0, ATST_EPI_F32 = 1, ATST_EPI_BIAS_GELU = 2, ATST_EPI_RES
  *   110  round 4: atst_encoder_t grew f8_sat / f8_act_scale / f8_act_amax ; every amax argument (atst_quant_fp8_dyn_bf16, g8_amax, f8_act_amax) is an
  *        ATST_AMAX_SITE_STRIDE-float SITE, not one float ; fb_weights of atst_mel_frontend_f32 is tap-major [fb_maxlen][n_mels]
  *   120  round 5: atst_encoder_t grew fp8_wgrad / f8_act_scale_bwd ; an fp8 training workspace also holds per-layer e4m3 activation copies
- *        and an e4m3 dqkv ; fp8_lean ; atst_gemm_tn_fp8, atst_attention_bwd_fp8 */
+ *        and an e4m3 dqkv ; fp8_lean ; atst_gemm_tn_fp8, atst_attention_fwd_fp8, atst_attention_bwd_fp8 */
 #define ATST_ABI_VERSION 120
 int atst_version(void);   /* = ATST_ABI_VERSION of the header the library was built from */
 /* Tuning hooks for A/B measurements (tools/gemm_bench.py, env ATST_TUNE=a,b,... read by audiossl_amd/hip.py); defaults are the
@@ -61,6 +61,7 @@ int atst_version(void);   /* = ATST_ABI_VERSION of the header the library was bu
  *   390/391/392 256 x 256 phased GEMM kernel (csrc/gemm_p8.h) for N % 256 == 0, K % 128 == 0, M % 256 == 0: off / bf16 operands (default) / also e4m3 operands
  *   1000+c start-up skew of every other first-round block of that kernel, c x 1024 cycles (experiment: no effect)
  *   408/409 NP=32 attention backward: dK,dV kernel + dQ kernel / one fused kernel, one wave per (sequence, head) (default)
+ *   410/411 fp8 forward, e4m3 copy of the attention output: a quantisation pass over the bf16 output / written by the NP=256 forward kernel (default)
  * The measured-and-rejected GEMM variants of round 2 (64-deep ring stages, ping-pong main loop, register epilogue, start-up
  * skew, phase tracers) are not part of this library: tools/experiments/gemm_r02_variants.hip (ATST_GEMM_VARIANTS=1 build).          */
 int atst_tune_gemm_variant(int v);
@@ -134,6 +135,11 @@ int atst_layernorm_bwd(const uint16_t* dy, const float* x, const float* mean, co
                        float* dgamma, float* dbeta, float* dbias_up, int M, int C, void* stream);
 /* Attention.forward + get_attention_mask: audiossl/modules/transformer.py:107-121,152-159                            */
 int atst_attention_fwd(const uint16_t* qkv, const int* valid, uint16_t* o, float* lse, int S, int H, int NP, void* stream);
+/* the same forward (NP == 256 only) that also writes the OCP e4m3 copy o8 [S*NP, C] = e4m3(bf16(o) * *scale), clamped to +-448 -- the operand of the
+ * e4m3 proj GEMM -- next to o, or INSTEAD of it (o == NULL: inference passes).  amax_site (or NULL): max |bf16(o)| (ATST_AMAX_SITE_STRIDE floats,
+ * atomicMax) ; sat (or NULL): number of clipped elements added.  ATST_EINVAL for any other NP.                                                */
+int atst_attention_fwd_fp8(const uint16_t* qkv, const int* valid, uint16_t* o, uint8_t* o8, const float* scale, float* amax_site, uint32_t* sat,
+                           float* lse, int S, int H, int NP, void* stream);
 /* dscratch: optional fp32 [S,H,NP] scratch (rowsum(dO*O)); when given and NP == 256 the merged per-sequence kernel runs */
 int atst_attention_bwd(const uint16_t* qkv, const int* valid, const uint16_t* o, const float* lse, const uint16_t* d_o,
                        uint16_t* dqkv, float* dscratch, int S, int H, int NP, void* stream);

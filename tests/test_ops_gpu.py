@@ -354,6 +354,21 @@ def test_attention(NP, valid):
         inval = (rowvalid == 0).reshape(-1)
         assert float(got[inval][:, 1:].abs().max()) == 0.0 if inval.any() else True
     if NP == 256:
+        # fp8 forward: the e4m3 copy of the output written by the kernel itself, next to the bf16 output (training) or instead of it (inference):
+        # the codes of the SAME bf16 values, their max |.| in the amax site, the clipped elements counted
+        o_amax = float(o.float().abs().max())
+        for sc, clips in ((torch.tensor([448.0 / (1.5 * o_amax)], device=DEV), False), (torch.tensor([448.0 / (0.25 * o_amax)], device=DEV), True)):
+            want8 = (o.float() * sc).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+            n_clip = int(((o.float() * sc).abs() > 448.0).sum())
+            assert (n_clip > 0) == clips
+            for with_o in (True, False):
+                o2 = torch.full_like(o, float("nan")) if with_o else None
+                o8 = torch.full((S * NP, C), 0x7F, dtype=torch.uint8, device=DEV)
+                site, sat, lse2 = torch.zeros(hip.AMAX_SITE_STRIDE, device=DEV), torch.zeros(1, dtype=torch.int32, device=DEV), torch.empty_like(lse)
+                hip.call("atst_attention_fwd_fp8", hip.ptr(qkv), hip.ptr(vt), hip.ptr(o2), hip.ptr(o8), hip.ptr(sc), hip.ptr(site), hip.ptr(sat), hip.ptr(lse2),
+                         S, H, NP, hip.stream())
+                assert torch.equal(o8.view(torch.float8_e4m3fn).float(), want8.float()) and torch.equal(lse2, lse)
+                assert (o2 is None or torch.equal(o2, o)) and float(site.max()) == o_amax and int(sat) == n_clip
         # the e4m3-only output of the merged kernel (fp8 qkv gradient path): the SAME bf16 values times the scale, as e4m3 codes -- bit for bit -- and
         # their max |.| in the amax site; any other NP is refused
         amax_true = float(dqkv.float().abs().max())
