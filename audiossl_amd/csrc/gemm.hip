@@ -56,6 +56,9 @@ template <int BIT, class T> DEVFN T ld_pol(const T* src) { if constexpr ((ATST_N
 // Block barrier for LDS hand-offs inside the epilogues.  __syncthreads() also drains vmcnt (workgroup-scope fence): every part
 // would then wait for the acknowledgement of the global stores it has just issued and for the LDS-DMA refills in flight.
 DEVFN void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#ifndef ATST_EPI_ABL              // experiment builds (tools/epi_ablate.sh): 1 = no GELU / dGELU arithmetic, 2 = no e4m3 copy, 4 = no u store / load
+#define ATST_EPI_ABL 0
+#endif
 template <int EPI, bool SCALE = true>
 DEVFN void epi_fetch8(const GemmArgs& p, int row, int col, EpiAux& x) {
   const size_t idx = (size_t)row * p.ldc + col;
@@ -64,7 +67,11 @@ DEVFN void epi_fetch8(const GemmArgs& p, int row, int col, EpiAux& x) {
     x.a1 = ld_pol<3>(reinterpret_cast<const f32x4*>(p.resid + idx + 4));
     if constexpr (SCALE) x.s = p.row_scale ? p.row_scale[row / p.rows_per_seq] : 1.0f;   // else: the caller supplies it
   } else if constexpr (EPI == EPI_DGELU) {
+#if ATST_EPI_ABL & 4
+    x.a0 = f32x4{1.f, 1.f, 1.f, 1.f};
+#else
     x.a0 = ld_pol<3>(reinterpret_cast<const f32x4*>(p.U + idx));       // 8 bf16 pre-activations
+#endif
   } else if constexpr (EPI == EPI_PATCH) {
     const int tok = row % p.rows_per_seq;
     x.a0 = *reinterpret_cast<const f32x4*>(p.table + (size_t)tok * p.N + col);
@@ -103,14 +110,23 @@ DEVFN void epilogue8(const GemmArgs& p, int row, int col, f32x4 v0, f32x4 v1, co
     st_f32(p.C, idx, v0 + b0, v1 + b1);
   } else if constexpr (EPI == EPI_BIAS_GELU) {
     v0 += b0; v1 += b1;
+#if !(ATST_EPI_ABL & 4)
     if (p.C) st_bf16(p.C, idx, v0, v1);                            // pre-activation u (saved for backward; skipped in inference)
+#endif
     f32x4 g0, g1;
+#if ATST_EPI_ABL & 1
+    g0 = v0; g1 = v1;
+#else
 #pragma unroll
     for (int e = 0; e < 4; e += 2) {                                // pairs: packed FMAs (common.h gelu_bf16dst2)
       const f32x2 a0 = gelu_bf16dst2(f32x2{v0[e], v0[e + 1]}), a1 = gelu_bf16dst2(f32x2{v1[e], v1[e + 1]});
       g0[e] = a0[0]; g0[e + 1] = a0[1]; g1[e] = a1[0]; g1[e + 1] = a1[1];
     }
+#endif
     if (p.C2) st_bf16_b(p.C2, idx, g0, g1, std::integral_constant<int, 5>{});    // activation a (bit 5: the next GEMM reads it whole); not written when every reader takes the e4m3 copy
+#if ATST_EPI_ABL & 2
+    if (p.q8) { w0 = g0; w1 = g1; asm volatile("" :: "v"(g0), "v"(g1)); } else
+#endif
     if (p.q8) {                                                    // fp8 forward: e4m3 copy of the SAME bf16 values for the fc2 GEMM
       const float s = x.s;                                         // running (delayed) activation scale, or the constant: the caller read it once
       auto c = [&](float a_) { return __builtin_amdgcn_fmed3f(bf2f(f2bf(a_)) * s, -448.f, 448.f); };
@@ -132,13 +148,18 @@ DEVFN void epilogue8(const GemmArgs& p, int row, int col, f32x4 v0, f32x4 v1, co
     st_f32(p.C, idx, x.a0 + x.s * (v0 + b0), x.a1 + x.s * (v1 + b1));
   } else if constexpr (EPI == EPI_DGELU) {
     const bf16x8 u = __builtin_bit_cast(bf16x8, x.a0);
+#if !(ATST_EPI_ABL & 1)
 #pragma unroll
-    for (int e = 0; e < 4; e += 2) {                                // pairs: packed FMAs (common.h gelu_grad_bf16dst2)
+#endif
+    for (int e = 0; e < ((ATST_EPI_ABL & 1) ? 0 : 4); e += 2) {     // pairs: packed FMAs (common.h gelu_grad_bf16dst2)
       const f32x2 d0 = gelu_grad_bf16dst2(f32x2{bf2f(u[e]), bf2f(u[e + 1])}), d1 = gelu_grad_bf16dst2(f32x2{bf2f(u[4 + e]), bf2f(u[5 + e])});
       v0[e] *= d0[0]; v0[e + 1] *= d0[1]; v1[e] *= d1[0]; v1[e + 1] *= d1[1];
     }
     if (p.C) st_bf16(p.C, idx, v0, v1);                             // du (bf16): not written when every reader takes the e4m3 copy (fp8 dgrad + e4m3 weight gradients)
     w0 = v0; w1 = v1;
+#if ATST_EPI_ABL & 2
+    if (p.q8) { asm volatile("" :: "v"(v0), "v"(v1)); } else
+#endif
     if (p.q8) {                                                    // fp8 dgrad: e4m3 copy of the SAME bf16 values for the fc1 dgrad GEMM (scale in x.s)
       auto c = [&](float a_) { return __builtin_amdgcn_fmed3f(bf2f(f2bf(a_)) * x.s, -448.f, 448.f); };
       int lo = __builtin_amdgcn_cvt_pk_fp8_f32(c(v0[0]), c(v0[1]), 0, false); lo = __builtin_amdgcn_cvt_pk_fp8_f32(c(v0[2]), c(v0[3]), lo, true);
@@ -1836,14 +1857,15 @@ int launch_nt_w4_cfg(const GemmArgs& a, hipStream_t st) {
 template <int EPI, bool F8 = false>
 int launch_nt_p8(const GemmArgs& a, hipStream_t st) {
   static bool attr_done = false;
+  constexpr int lds = p8::RING;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_p8_kernel<EPI, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, p8::RING);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_p8_kernel<EPI, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
   ProfScope ps(prof_kind<EPI>(), (F8 ? 4.0 : 2.0) * a.M * a.N * a.K, st, nt_bytes<EPI>(a));      // F8: K counts byte pairs here
   GemmArgs b = a; b.skew = g_p8_skew;
-  hipLaunchKernelGGL((gemm_nt_p8_kernel<EPI, F8>), dim3((a.M / p8::BM) * (a.N / p8::BNP)), dim3(p8::THREADS), p8::RING, st, b);
+  hipLaunchKernelGGL((gemm_nt_p8_kernel<EPI, F8>), dim3((a.M / p8::BM) * (a.N / p8::BNP)), dim3(p8::THREADS), lds, st, b);
   return (int)hipGetLastError();
 }
 // shapes the phased kernel takes (a.K, a.lda, a.ldb in bf16 elements -- for e4m3 operands the launcher has already halved them)

@@ -27,6 +27,14 @@ constexpr int PL1 = 144, CLD2 = 288;            // epilogue staging: two planes 
 constexpr int RP = 32, SLOTS = RP * (BNP / 8) / THREADS;          // 32 staged rows per part, 2 slots of 8 columns per thread
 constexpr int EPI_FLOATS = RP * CLD2 + CLD2 + BM + BNP;           // staging | bias (two planes) | per-row scale | column sums
 static_assert(EPI_FLOATS * 4 <= RING, "the epilogue re-uses the operand ring");
+// dGELU on e4m3 operands: the saved pre-activations u of the tile arrive by LDS-DMA, 16 KB per 32-row part, three buffers in the ring behind the
+// staging area; part p + 2 is requested when part p starts.  (Measured alternatives, same A/B: parts 0 / 1 requested when the block starts, into
+// buffers behind the ring: -33 us instead of -44 ; the whole tile requested the moment the main loop is done, 80 KB in flight: -4 us.  What the u
+// read costs is its bytes next to everybody's operand fetches, not an exposed round trip: tools/epi_ablate.sh.)
+constexpr int U_BUF = RP * BNP * 2, U_OFF2 = 40960;
+static_assert(EPI_FLOATS * 4 <= U_OFF2 && U_OFF2 + 3 * U_BUF <= RING, "u buffers");
+template <int EPI, bool F8> constexpr bool udma() { return EPI == EPI_DGELU && F8; }
+constexpr int u_buf_off(int part) { return U_OFF2 + (part % 3) * U_BUF; }
 }
 
 #ifndef ATST_P8_ABL            // experiment builds (tools/p8_ablate.sh): 1 = no epilogue at all ; 2 = staging + read-back but no global loads / stores
@@ -53,6 +61,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(GemmArgs p) {
   const int id = xcd_remap(blockIdx.x, ntm * ntn);
   const int m0 = (id / ntn) * BM, n0 = (id % ntn) * BNP;
   const int nk = p.K / BKP;                                       // even, >= 2 (checked by the launcher)
+#ifndef ATST_P8_UDMA
+#define ATST_P8_UDMA 1
+#endif
+  constexpr bool UDMA_ON = ATST_P8_UDMA && !(ATST_EPI_ABL & 4) && !(ATST_P8_ABL & 3);
+  auto tile_row_of0 = [&](int part, int rl) { return (rl >> 4) * 128 + (part >> 1) * 32 + (part & 1) * 16 + (rl & 15); };
+  auto u_dma = [&](int part, int lane) {                          // (dGELU, e4m3 operands) part `part` of u -> its LDS buffer: 2 x 1 KB per wave
+    const void* ubase = sgpr_ptr(p.U + (size_t)m0 * p.ldc + n0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int kb = wid + 8 * j, rl = kb * 2 + (lane >> 5);
+      p8_glds16((unsigned)(tile_row_of0(part, rl) * p.ldc + (lane & 31) * 8) * 2u, ubase, lds_addr(smem_raw) + u_buf_off(part) + kb * 1024);
+    }
+  };
   if (p.skew > 0 && blockIdx.x < 256 && ((blockIdx.x >> 3) & 1)) {   // experiment (hook 1000 + c): every other block of the first round starts c x 1024 cycles late
     const long long t0 = __builtin_readcyclecounter();
     while (__builtin_readcyclecounter() - t0 < (long long)p.skew * 1024) __builtin_amdgcn_s_sleep(8);
@@ -324,7 +345,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(GemmArgs p) {
   // flight per CU instead of one part's.  A CU's epilogue rate is bytes in flight / memory latency; with one part in flight it is ~22 GB/s, which
   // only equals a fair share of HBM when all 256 CUs run their epilogues at the same moment (profiles/r05_p8_ablate.txt).  The fragment registers of
   // the main loop are free here, so the deeper queue costs nothing.
-  constexpr int PF = (EPI == EPI_DGELU && !F8) ? 2 : 0;           // (the e4m3 instantiation has no registers for it: spills)
+  // dGELU, e4m3 operands: u arrives by LDS-DMA (UDMA, see p8::udma): no register holds a load in flight, so this instantiation -- which had no
+  // registers for a prefetch -- is two parts ahead like the bf16 one (638 -> 594 us at M = 131072, same box).  A wave's 1-KB instructions are exactly
+  // the pieces its own threads read back (slot idx = 16-B piece idx), so its own counted vmcnt is the only synchronisation.  (The bf16 instantiation
+  // keeps its register prefetch: 770 vs 786 us with the DMA form.)
+  constexpr bool UDMA = udma<EPI, F8>() && UDMA_ON;
+  if constexpr (UDMA) { u_dma(0, lane); u_dma(1, lane); }
+  constexpr int PF = (EPI == EPI_DGELU && !F8 && !UDMA) ? 2 : 0;  // register prefetch (the e4m3 instantiation has no registers for it: spills)
   EpiAux aux[PF + 1][SLOTS];
   auto fetch_part = [&](int part, EpiAux (&a)[SLOTS]) {
 #pragma unroll
@@ -340,6 +367,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(GemmArgs p) {
 #pragma unroll
   for (int part = 0; part < 8; ++part) {
     const int mb = part >> 1, h = part & 1;
+    if constexpr (UDMA) { if (part + 2 < 8) u_dma(part + 2, lane); }
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
@@ -347,15 +375,23 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(GemmArgs p) {
         const int lrow = wr * 16 + (r8 & 3) + 8 * (r8 >> 2) + 4 * hi, ccol = wc * 64 + nb * 32 + l31;
         sC[lrow * CLD2 + ((ccol >> 3) << 2) + (ccol & 3) + ((ccol & 4) ? PL1 : 0)] = F8 ? acc[mb][nb][h * 8 + r8] * dqv : acc[mb][nb][h * 8 + r8];
       }
-    if (part + PF < 8) fetch_part(part + PF, aux[(part + PF) % (PF + 1)]);
+    if constexpr (!UDMA) { if (part + PF < 8) fetch_part(part + PF, aux[(part + PF) % (PF + 1)]); }
     if (part == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the bias table (LDS-DMA) has landed -- mine; the barrier makes it everyone's
     lds_barrier();
+    if constexpr (UDMA) {
+      // u of this part has landed (part 0: the vmcnt(0) above).  Behind its 2 DMA instructions this wave has issued the DMAs of the parts requested since
+      // (2 each) and the stores of the parts processed since -- SLOTS per part (du or its e4m3 copy; both: more stores, the wait is only stricter):
+      // part 1: 2 * 2 + 2 ; parts 2..5: 2 * 2 + 2 * 2 ; part 6: 2 + 4 ; part 7: 4
+      static_assert(SLOTS == 2, "the counts below");
+      if (part == 1 || part == 6) p8_wait_vm<6>(); else if (part == 7) p8_wait_vm<4>(); else if (part >= 2) p8_wait_vm<8>();
+    }
 #pragma unroll
     for (int i = 0; i < SLOTS; ++i) {
       const int idx = tid + THREADS * i, rl = idx >> 5, c8 = (idx & 31) * 8;
       const int trow = tile_row_of(part, rl), row = m0 + trow;
       f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = w0;
       EpiAux& ax = aux[part % (PF + 1)][i];
+      if constexpr (UDMA) ax.a0 = *reinterpret_cast<const f32x4*>(smem_raw + u_buf_off(part) + idx * 16);
       if constexpr (EPI == EPI_DGELU || EPI == EPI_BIAS_GELU) ax.s = q8s;
 #if ATST_P8_ABL & 2
       { f32x4 z0 = *reinterpret_cast<const f32x4*>(sC + rl * CLD2 + (c8 >> 1)), z1 = *reinterpret_cast<const f32x4*>(sC + rl * CLD2 + PL1 + (c8 >> 1));
