@@ -9,7 +9,8 @@
 // (byte position -> m) map is the same on both sides, which is all the contraction needs.
 //
 // Structure: 256 (n) x 256 (k) output tile, 8 waves 2 x 4, wave tile 128 x 64 (8 accumulators); a stage is 64 rows of m = ONE MFMA k-step: 16 KB of dY8 +
-// 16 KB of X8, four stages in a 128-KB ring filled by LDS-DMA (inline asm, scalar base + lane offset) three stages ahead, counted vmcnt(12).  The
+// 16 KB of X8, four stages in a 128-KB ring filled by LDS-DMA (inline asm, scalar base + lane offset) three stages ahead behind counted vmcnt waits;
+// the two wave rows run half a stage apart (one reads fragments while the other is in its MFMAs: see the main loop).  The
 // 16-B chunks of a 256-B image row are XOR-permuted by 2 (m & 7) (on the DMA's source side and in the read address): the 32 lanes a transposing
 // read serves together then fall on 32 distinct 8-byte bank pairs.
 // Reference math: the weight gradient of nn.Linear (audiossl/modules/transformer.py:87-90,109,119) on the e4m3 copies of its two operands.
@@ -108,14 +109,23 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(Wgrad8Args p) {
 #pragma unroll
   for (int s = 0; s < NSTG8 - 1; ++s)
     if (s < nst) stage(s);
-  for (int s = 0; s < nst; ++s) {
-    // my pieces of stage s have landed (the younger stages stay in flight); barrier: everyone's have, and everyone is done reading stage s - 1,
-    // whose buffer the next issue overwrites
-    const int younger = nst - 1 - s < NSTG8 - 2 ? nst - 1 - s : NSTG8 - 2;
-    if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  // my 4 LDS-DMA instructions of stage t have landed; the `y` younger stages issued so far stay in flight
+  auto wait_stage = [&](int y) {
+    if (y >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (y == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_barrier" ::: "memory");
+  };
+  auto issued = [&](int upto) { return upto < nst - 1 ? upto : nst - 1; };   // the last stage requested once stage `upto` has had its turn
+  // The two wave rows (waves 0-3 / 4-7: one wave of each on every SIMD) run HALF A STAGE apart -- row 1 passes one extra barrier first -- so that a
+  // SIMD's matrix pipe works on one row's 8 MFMAs (512 cycles) while the other row reads its 24 transposed fragments (the eight waves' reads of a
+  // stage are 96 KB = 768 LDS cycles: in step with the MFMAs they were a serial 40 % of the stage).  Two barriers per stage: B1 in front of the
+  // reads, B2 in front of the MFMAs; row 0's B1(s) is row 1's B2(s - 1).  A row has waited for ITS pieces of the stage the other row reads next
+  // before the barrier that releases those reads: row 0 for stage s before B1(s), row 1 for stage s + 1 before B2(s) (and for stage 0 before the
+  // extra barrier).  A buffer is refilled (stage s + 3 into the buffer of s - 1) behind B1(s), when both rows' reads of s - 1 are complete.
+  if (wn == 1) { wait_stage(issued(NSTG8 - 2)); asm volatile("s_barrier" ::: "memory"); }
+  for (int s = 0; s < nst; ++s) {
+    if (wn == 0) wait_stage(issued(s + NSTG8 - 2) - s);
+    asm volatile("s_barrier" ::: "memory");                        // B1
     if (s + NSTG8 - 1 < nst) stage(s + NSTG8 - 1);
     const unsigned so = (s & (NSTG8 - 1)) * STG;
     v8i_ b8[2], a8[4];
@@ -124,6 +134,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(Wgrad8Args p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) a8[i] = frag8(fa[i] + so);
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a8[0]), "+v"(a8[1]), "+v"(a8[2]), "+v"(a8[3]), "+v"(b8[0]), "+v"(b8[1]));
+    if (wn == 1 && s + 1 < nst) wait_stage(issued(s + NSTG8 - 1) - (s + 1));
+    asm volatile("s_barrier" ::: "memory");                        // B2
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -131,6 +143,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(Wgrad8Args p) {
       for (int j = 0; j < 2; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[i], b8[j], acc[i][j], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
   }
+  if (wn == 0) asm volatile("s_barrier" ::: "memory");            // row 1's last B2
   // epilogue: fp32 atomics, consecutive lanes on consecutive k (C layout: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
   const float dq = 1.0f / ((p.sy ? *p.sy : 1.0f) * (p.sx ? *p.sx : 1.0f));
   const int hi = lane >> 5, l31 = lane & 31;
