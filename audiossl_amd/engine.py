@@ -424,8 +424,16 @@ class HeadPass:
         return dx
 
 
+_HEAD_PAD = os.environ.get("ATST_HEAD_PAD", "1") != "0"
+
+
 def _gemm(A, B, M, N, K, epi, out):
-    hip.call("atst_gemm_nt_bf16", hip.ptr(A), hip.ptr(B), M, N, K, K, K, epi, hip.ptr(out), N, None, None, None, None, 1,
+    """out[M, N] = A[M, K] B[N, K]^T on the head path.  A and out are _rows_buf() views: above 4096 rows their allocations hold the row count rounded up
+    to 4096, so the GEMM may run over the next multiple of 256 rows -- the geometry the 256 x 256 phased kernel takes (ATST-Frame's ~83 k masked rows are
+    never such a multiple).  The extra output rows are computed from whatever the operand's padding rows hold and land in the output's padding rows; every
+    consumer (BatchNorm sums, the next kernels) works on [:M]."""
+    Mp = -(-M // 256) * 256 if (_HEAD_PAD and M > 4096) else M
+    hip.call("atst_gemm_nt_bf16", hip.ptr(A), hip.ptr(B), Mp, N, K, K, K, epi, hip.ptr(out), N, None, None, None, None, 1,
              None, None, None, None, None, hip.stream())
 
 
