@@ -328,15 +328,23 @@ class HeadPass:
         # rstd + running statistics + num_batches_tracked in one launch (nn.BatchNorm1d(train), models/atst/byol.py:13-16)
         hip.call("atst_bn_finish_f32", hip.ptr(mean), hip.ptr(m2), 0.0 if on_dev else float(count), hip.ptr(cdev), BN_MOMENTUM, BN_EPS,
                  hip.ptr(bn["running_mean"]), hip.ptr(bn["running_var"]), hip.ptr(bn["num_batches_tracked"]), hip.ptr(rstd), HEAD_HIDDEN, st)
-        # second Linear also in split-bf16: its output feeds the next head's BatchNorm+ReLU gates
-        y3 = _rows_buf(R, 3 * HEAD_HIDDEN, torch.bfloat16, dev)
-        hip.call("atst_bn_apply_relu_split3_bf16", hip.ptr(h), hip.ptr(mean), hip.ptr(rstd), hip.ptr(self._w("1.weight", f32=True)),
-                 hip.ptr(self._w("1.bias", f32=True)), R, HEAD_HIDDEN, hip.ptr(y3), st)
-        w3b = torch.empty(HEAD_OUT, 3 * HEAD_HIDDEN, dtype=torch.bfloat16, device=dev)
-        hip.call("atst_split3_bf16", hip.ptr(self._w("3.weight", f32=True)), HEAD_OUT, HEAD_HIDDEN, 1, hip.ptr(w3b), st)
         out = _rows_buf(R, HEAD_OUT, torch.float32, dev)
-        _gemm(y3, w3b, R, HEAD_OUT, 3 * HEAD_HIDDEN, hip.EPI_F32, out)
-        y16 = y3                                            # columns [0, 4096) = bf16(y), ld = 3 * 4096
+        if eng.precise or _HEAD_SPLIT2 == "all" or (_HEAD_SPLIT2 == "gated" and self.net == "student" and self.which == "projector"):
+            # second Linear in split-bf16 where its output feeds ANOTHER head's BatchNorm+ReLU gates: the student projector (the predictor follows)
+            y3 = _rows_buf(R, 3 * HEAD_HIDDEN, torch.bfloat16, dev)
+            hip.call("atst_bn_apply_relu_split3_bf16", hip.ptr(h), hip.ptr(mean), hip.ptr(rstd), hip.ptr(self._w("1.weight", f32=True)),
+                     hip.ptr(self._w("1.bias", f32=True)), R, HEAD_HIDDEN, hip.ptr(y3), st)
+            w3b = torch.empty(HEAD_OUT, 3 * HEAD_HIDDEN, dtype=torch.bfloat16, device=dev)
+            hip.call("atst_split3_bf16", hip.ptr(self._w("3.weight", f32=True)), HEAD_OUT, HEAD_HIDDEN, 1, hip.ptr(w3b), st)
+            _gemm(y3, w3b, R, HEAD_OUT, 3 * HEAD_HIDDEN, hip.EPI_F32, out)
+            y16 = y3                                        # columns [0, 4096) = bf16(y), ld = 3 * 4096
+        else:
+            # ... and on plain bf16 operands where it feeds the loss only (teacher projector, student predictor): a third of the activation bytes
+            # and of the second GEMM's contraction (ATST-Frame: ~83 k rows x 4096)
+            y16 = _rows_buf(R, HEAD_HIDDEN, torch.bfloat16, dev)
+            hip.call("atst_bn_apply_relu_bf16", hip.ptr(h), hip.ptr(mean), hip.ptr(rstd), hip.ptr(self._w("1.weight", f32=True)),
+                     hip.ptr(self._w("1.bias", f32=True)), R, HEAD_HIDDEN, hip.ptr(y16), st)
+            _gemm(y16, self._w("3.weight"), R, HEAD_OUT, HEAD_HIDDEN, hip.EPI_F32, out)
         if train:
             self.saved = (x16, h, mean, rstd, y16, count)
         return out
@@ -398,7 +406,7 @@ class HeadPass:
         R, dev, st = x16.shape[0], x16.device, hip.stream()
         d16 = _rows_buf(R, HEAD_OUT, torch.bfloat16, dev)
         hip.call("atst_cast_bf16", hip.ptr(dout), R * HEAD_OUT, hip.ptr(d16), st)
-        _wgrad(d16, y16, R, HEAD_OUT, HEAD_HIDDEN, self._w("3.weight", grad=True), ldx=3 * HEAD_HIDDEN)
+        _wgrad(d16, y16, R, HEAD_OUT, HEAD_HIDDEN, self._w("3.weight", grad=True), ldx=y16.shape[1])       # [hi | lo | hi] or plain bf16(y)
         dy = _rows_buf(R, HEAD_HIDDEN, torch.float32, dev)
         _gemm(d16, self._w("3.weight", transposed=True), R, HEAD_HIDDEN, HEAD_OUT, hip.EPI_F32, dy)
         gamma, beta = self._w("1.weight", f32=True), self._w("1.bias", f32=True)
@@ -425,6 +433,7 @@ class HeadPass:
 
 
 _HEAD_PAD = os.environ.get("ATST_HEAD_PAD", "1") != "0"
+_HEAD_SPLIT2 = os.environ.get("ATST_HEAD_SPLIT2", "gated")      # second head Linear in split-bf16: "gated" (only in front of another head), "all" (rounds 1-4)
 
 
 def _gemm(A, B, M, N, K, epi, out):
