@@ -1764,7 +1764,8 @@ int g_w4_min_m = 8192;      // 350/351: apply the tall / 4-wave kernels from M =
 int g_w4_auto = 1;          // 360/361: 4-wave kernels for launches of <= 1.5 rounds of 256 x 384 tiles
 int g_ph = 1;               // 396/397: phased main loop (template parameter PH) of the 256 x 384 tile: off / on
 int g_p8_skew = 0;          // 1000 + c: start-up skew of every other first-round block of the phased kernel, c x 1024 cycles (experiment)
-int g_p8 = 2;               // 390/391/392: 256 x 256 phased kernel (gemm_p8.h) for N % 256 == 0, K % 128 == 0, M % 256 == 0, M >= 8192: off / bf16 operands only / also e4m3
+int g_p8 = 3;               // 390/391/392/393: 256 x 256 phased kernel (gemm_p8.h) for N % 256 == 0, K % 128 == 0, M % 256 == 0, M >= 8192: off / bf16 operands only / also e4m3
+                            // except fc1 + GELU / every e4m3 GEMM (default since the lean outputs: fc1 + GELU 606 -> 592 us, base fp8 +0.8 ... 1.8 %)
                             // operands (default; except fc1 + GELU, whose e4m3 epilogue -- u, a, the e4m3 copy of a, amax -- measured 640 vs 647 us on the 256 x 384 tile).
                             // Same box, same call, base fp8 step: 2405-2407 (391) -> 2453-2476 clips/s (392), profiles/r05_p8_fp8_step_ab.txt
 int g_f32_splitk = 1;       // 380/381: split-K for fp32-output GEMMs with <= 64 output tiles and K >= 2048
@@ -1879,7 +1880,7 @@ template <int EPI>
 int launch_nt_row384(const GemmArgs& a, hipStream_t st) {
   if (a.fp8) {                                                    // e4m3 operands seen as byte pairs: K, lda, ldb are already halved
     if constexpr (EPI == EPI_BF16 || EPI == EPI_BIAS_GELU || EPI == EPI_RESID || EPI == EPI_F32 || EPI == EPI_DGELU) {
-      if (g_nt_variant < 0 && g_p8 >= 2 && EPI != EPI_BIAS_GELU && p8_ok<EPI>(a)) return launch_nt_p8<EPI, true>(a, st);
+      if (g_nt_variant < 0 && g_p8 >= 2 && (EPI != EPI_BIAS_GELU || g_p8 >= 3) && p8_ok<EPI>(a)) return launch_nt_p8<EPI, true>(a, st);
       ProfScope ps(prof_kind<EPI>(), 4.0 * a.M * a.N * a.K, st, nt_bytes<EPI>(a));
       if constexpr (EPI == EPI_BF16) { if (g_bf16_tr) return launch_nt_row384_cfg<EPI, 4, false, true, true>(a, st); }
       return launch_nt_row384_cfg<EPI, 4, false, true>(a, st);

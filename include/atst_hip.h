@@ -58,7 +58,8 @@ int atst_version(void);   /* = ATST_ABI_VERSION of the header the library was bu
  *   130/131 grouped wgrad: round-3 block order / (problem, split) groups packed onto XCDs (default)
  *   406/407 NP=256 attention backward dK / dV stores: row-per-lane / LDS-transposed full lines (default)
  *   370/371 store-only bf16 GEMM epilogue: fp32 staging (default) / transposed accumulators + wave-private bf16 staging      380/381 split-K of fp32-output GEMMs with <= 64 tiles off/on
- *   390/391/392 256 x 256 phased GEMM kernel (csrc/gemm_p8.h) for N % 256 == 0, K % 128 == 0, M % 256 == 0: off / bf16 operands (default) / also e4m3 operands
+ *   390/391/392/393 256 x 256 phased GEMM kernel (csrc/gemm_p8.h) for N % 256 == 0, K % 128 == 0, M % 256 == 0: off / bf16 operands only / also e4m3
+ *               operands except fc1 + GELU / every e4m3 GEMM (default)
  *   1000+c start-up skew of every other first-round block of that kernel, c x 1024 cycles (experiment: no effect)
  *   408/409 NP=32 attention backward: dK,dV kernel + dQ kernel / one fused kernel, one wave per (sequence, head) (default)
  *   410/411 fp8 forward, e4m3 copy of the attention output: a quantisation pass over the bf16 output / written by the NP=256 forward kernel (default)

@@ -175,7 +175,7 @@ def test_gemm_nt_p8_phased_kernel(M, N, K):
             d, _ = gemm_nt(A, B, hip.EPI_DGELU, torch.bfloat16, U=U, colsum=cs)
             res[hook] = (f32, b16, b16nb, u, a, x, d, cs)
     finally:
-        lib.atst_tune_gemm_variant(392); lib.atst_tune_gemm_variant(350)
+        lib.atst_tune_gemm_variant(393); lib.atst_tune_gemm_variant(350)
     f32, b16, b16nb, u, a, x, d, cs = res[391]
     assert relerr(f32, ref + bias) < 2e-5
     assert relerr(b16.float(), ref + bias) < 4e-3 and relerr(b16nb.float(), ref) < 4e-3
@@ -950,7 +950,7 @@ def test_gemm_fp8_phased_kernel(M, N, K):
     res = {}
     try:
         lib.atst_tune_gemm_variant(351)
-        for hook in (390, 392):                                               # 392 (default): the phased kernel also for e4m3 operands
+        for hook in (390, 393):                                               # 393 (default): the phased kernel for every e4m3 GEMM (392: all but fc1 + GELU)
             lib.atst_tune_gemm_variant(hook)
             outs = []
             for epi, dt in ((hip.EPI_F32, torch.float32), (hip.EPI_BF16, torch.bfloat16), (hip.EPI_BIAS_GELU, torch.bfloat16), (hip.EPI_RESID, torch.float32)):
@@ -961,13 +961,13 @@ def test_gemm_fp8_phased_kernel(M, N, K):
                 outs += [out] + ([c2] if c2 is not None else [])
             res[hook] = outs
     finally:
-        lib.atst_tune_gemm_variant(392); lib.atst_tune_gemm_variant(350)
-    f32, b16, u, a, x = res[392]
+        lib.atst_tune_gemm_variant(393); lib.atst_tune_gemm_variant(350)
+    f32, b16, u, a, x = res[393]
     assert relerr(f32, ref + bias) < 5e-5
     assert relerr(b16.float(), ref + bias) < 4e-3 and relerr(u.float(), ref + bias) < 4e-3
     assert relerr(a.float(), torch.nn.functional.gelu(ref + bias)) < 5e-3
     assert relerr(x, resid + scale.repeat_interleave(rps)[:, None] * (ref + bias)) < 5e-5
-    for got, other in zip(res[392], res[390]):
+    for got, other in zip(res[393], res[390]):
         assert relerr(got.float(), other.float()) < 4e-3
 
 

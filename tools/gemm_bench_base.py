@@ -12,7 +12,7 @@ dev = "cuda"
 M = int(os.environ.get("M", 131072))
 D = int(os.environ.get("D", 768))
 VARS = [[int(x) for x in v.split(",") if x] for v in os.environ.get("VARIANTS", "390;391").split(";")]
-RESET = [-1, 106, 111, 301, 304, 308, 330, 350, 361, 370, 381, 392]          # the shipped defaults of every hook family
+RESET = [-1, 106, 111, 301, 304, 308, 330, 350, 361, 370, 381, 393]          # the shipped defaults of every hook family
 
 
 def set_variant(vs):
