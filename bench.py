@@ -175,7 +175,7 @@ def build_job(workload, arch, dtype, hires, B, world, rank, dev, total, precise=
 
 WORKLOAD_NAMES = {"clip6": "ATST-small clip-level, 2 global (10 s) + 4 local (1 s) views", "clip2": "ATST-small clip-level, 2 views (10 s)",
                   "frame": "ATST-Frame small, masked frame objective (10 s)"}
-DTYPE_NAMES = {"bf16": "bf16", "fp8": "fp8 (e4m3 forward + fc2/fc1/proj dgrad + fc1/fc2/proj weight-gradient GEMMs) + bf16"}
+DTYPE_NAMES = {"bf16": "bf16", "fp8": "fp8 (e4m3 operands in all 12 GEMMs of a block: forward, dgrads, weight gradients; delayed scaling) + bf16"}
 
 
 def main():
@@ -188,9 +188,9 @@ def main():
     ap.add_argument("--arch", default="small", choices=["small", "base"],
                     help="small = the headline model (BASELINE configs[1..3]); base (d = 768, 12 heads) is an extra data point")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"],
-                    help="fp8: the four Linear layers of every block run their forward AND (d = 768) their fc2 / fc1 / proj dgrad and weight-gradient "
-                         "GEMMs on OCP e4m3 operands (MX-scaled MFMA, delayed scaling for the gradient operands); the qkv dgrad / weight gradient and "
-                         "the saved activations stay bf16 (BASELINE.json configs[4]: use with --arch base)")
+                    help="fp8: the four Linear layers of every block run their forward AND (d = 768) their dgrad and weight-gradient GEMMs on OCP e4m3 operands "
+                         "(MX-scaled MFMA, delayed scaling; the attention backward writes dqkv as e4m3); saved activations the attention needs stay bf16 "
+                         "(BASELINE.json configs[4]: use with --arch base)")
     ap.add_argument("--precise", action="store_true",
                     help="parity mode (AtstEngine(precise=True)): fp32 activations / gradients, every Linear as a split-bf16 MFMA GEMM (~2^-16); "
                          "the mode that meets north_star's 1e-3 gradient tolerance -- reported next to the bf16 number, never as the headline")
