@@ -11,7 +11,7 @@
 extern "C" {
 
 int atst_version(void) { return ATST_ABI_VERSION; }
-int atst_tune_gemm_variant(int v) { if (v >= 400) atst_attn_set_variant(v - 400); else atst_gemm_nt_set_variant(v); return 0; }
+int atst_tune_gemm_variant(int v) { if (v >= 1400 && v < 1500) g_tn8_splits = v - 1400; else if (v >= 400 && v < 1000) atst_attn_set_variant(v - 400); else atst_gemm_nt_set_variant(v); return 0; }
 
 int atst_mel_frontend_f32(const float* wave, int n_clips, int n_samples, int wave_ld, int n_mels, int win_length, const float* window,
                           const float* fb_weights, const int* fb_start, const int* fb_len, int fb_maxlen,
@@ -101,6 +101,14 @@ int atst_gemm_tn_group_bf16(const atst_wgrad_t* items, int n, void* stream) {
     a[i].ldy = items[i].ldy; a[i].ldx = items[i].ldx; a[i].ldw = items[i].ldw; a[i].m_per_split = 0;
   }
   return atst_gemm_tn_group(a, n, ST(stream));
+}
+
+int atst_gemm_tn_group_fp8(const atst_wgrad8_t* items, int n, int M, void* stream) {
+  if (!items || n < 1 || n > 4) return ATST_EINVAL;
+  Wgrad8Item a[4] = {};
+  for (int i = 0; i < n; ++i)
+    a[i] = Wgrad8Item{items[i].dY8, items[i].X8, items[i].N, items[i].K, items[i].ldy, items[i].ldx, items[i].dW, items[i].ldw, items[i].scale_y, items[i].scale_x};
+  return atst_gemm_tn8_group(a, n, M, ST(stream));
 }
 
 int atst_layernorm_fwd(const float* x, const float* gamma, const float* beta, uint16_t* y, float* mean, float* rstd,

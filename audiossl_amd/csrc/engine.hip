@@ -370,11 +370,14 @@ static int encoder_bwd_range(const atst_encoder_t* e, int lo, int hi, bool head,
       // g8_scale[4 i + k]), X8 = the e4m3 activation copies the forward kept (scales f8_act_scale_bwd[4 i + k]: what the forward quantised WITH, the
       // caller's snapshot -- its running scales have moved on since).  The qkv gradient: e4m3 as well when the attention backward wrote dqkv8.
       const float* sxb = e->f8_act_scale_bwd + 4 * i;
-      RUN(atst_gemm_tn8(w.du8, l.h28, M, 4 * C, C, 4 * C, C, G + lo_.fc1_w, C, gs8(i, 1), sxb + 2, st));
-      RUN(atst_gemm_tn8(w.g8, l.a8, M, C, 4 * C, C, 4 * C, G + lo_.fc2_w, 4 * C, gs8(i, 0), sxb + 3, st));
-      RUN(atst_gemm_tn8(w.g28, l.o8, M, C, C, C, C, G + lo_.proj_w, C, gs8(i, 2), sxb + 1, st));
-      if (use8q) RUN(atst_gemm_tn8(w.dqkv8, l.h18, M, 3 * C, C, 3 * C, C, G + lo_.qkv_w, C, gs8(i, 3), sxb + 0, st));
-      else RUN(wgrad(w.dqkv, l.h1, M, 3 * C, C, G + lo_.qkv_w, st));
+      // one launch for the block's e4m3 weight gradients: they share M, and together they need a fraction of the M-splits (= fp32 atomics) each needs alone
+      const Wgrad8Item items[4] = {
+        {w.du8, l.h28, 4 * C, C, 4 * C, C, G + lo_.fc1_w, C, gs8(i, 1), sxb + 2},
+        {w.g8, l.a8, C, 4 * C, C, 4 * C, G + lo_.fc2_w, 4 * C, gs8(i, 0), sxb + 3},
+        {w.g28, l.o8, C, C, C, C, G + lo_.proj_w, C, gs8(i, 2), sxb + 1},
+        {w.dqkv8, l.h18, 3 * C, C, 3 * C, C, G + lo_.qkv_w, C, gs8(i, 3), sxb + 0}};
+      RUN(atst_gemm_tn8_group(items, use8q ? 4 : 3, M, st));
+      if (!use8q) RUN(wgrad(w.dqkv, l.h1, M, 3 * C, C, G + lo_.qkv_w, st));
     } else {
       WgradArgs wg[4] = {};
       auto set = [&](int k, const bf16* dY, const bf16* X, int N, int K, float* dW) {

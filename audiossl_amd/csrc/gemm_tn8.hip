@@ -18,6 +18,10 @@
 #include "kernels.h"
 #include "profile.h"
 
+#ifndef ATST_TN8_ABL              // experiment builds (tools/tn8_ablate.sh): 1 = no fragment reads, 2 = no LDS-DMA, 4 = no MFMAs, 8 = no atomics
+#define ATST_TN8_ABL 0
+#endif
+int g_tn8_splits = 0;         // tuning hook 1400 + s: M-splits of the grouped e4m3 weight gradient (0 = automatic)
 namespace {
 typedef int v2i_ __attribute__((ext_vector_type(2)));
 typedef int v8i_ __attribute__((ext_vector_type(8)));
@@ -50,14 +54,19 @@ DEVFN v8i_ frag8(unsigned addr) {
   return v8i_{a[0], a[1], b[0], b[1], c[0], c[1], d[0], d[1]};
 }
 
-__global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(Wgrad8Args p) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+// one (tile, M-split) of one problem.  `p` may be an element of a kernel-argument ARRAY picked by a block-uniform index: every field is made visibly
+// uniform first (read through a lane-typed select of the element address they come back as VECTOR loads next to each use: gemm.hip tn_tall_body)
+DEVFN void tn8_body(const Wgrad8Args& pa, int tile, int split, char* smem_raw) {
+  Wgrad8Args p;
+  p.dY = reinterpret_cast<const uint8_t*>(sgpr_ptr8(pa.dY)); p.X = reinterpret_cast<const uint8_t*>(sgpr_ptr8(pa.X));
+  p.dW = reinterpret_cast<float*>(const_cast<char*>(sgpr_ptr8(pa.dW)));
+  p.sy = reinterpret_cast<const float*>(sgpr_ptr8(pa.sy)); p.sx = reinterpret_cast<const float*>(sgpr_ptr8(pa.sx));
+  p.M = __builtin_amdgcn_readfirstlane(pa.M); p.N = __builtin_amdgcn_readfirstlane(pa.N); p.K = __builtin_amdgcn_readfirstlane(pa.K);
+  p.ldy = __builtin_amdgcn_readfirstlane(pa.ldy); p.ldx = __builtin_amdgcn_readfirstlane(pa.ldx); p.ldw = __builtin_amdgcn_readfirstlane(pa.ldw);
+  p.m_per_split = __builtin_amdgcn_readfirstlane(pa.m_per_split);
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wid >> 2, wk = wid & 3;
-  const int ntk = p.K / TK8, ntn = p.N / TN8, tiles = ntn * ntk;
-  // all tiles of one M-split run on one XCD (they stream the same dY8 / X8 rows)
-  const int id = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile = id % tiles, split = id / tiles;
+  const int ntk = p.K / TK8;
   const int n0 = (tile / ntk) * TN8, k0 = (tile % ntk) * TK8;
   const int m_begin = split * p.m_per_split;
   int m_end = m_begin + p.m_per_split; if (m_end > p.M) m_end = p.M;
@@ -80,7 +89,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(Wgrad8Args p) {
   auto stage = [&](int s) {
     const unsigned dst = lds0 + (s & (NSTG8 - 1)) * STG;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < ((ATST_TN8_ABL & 2) ? 0 : 2); ++j) {
       glds16_s8(vo[0][j], by + (size_t)s * sty, dst + j * 1024);
       glds16_s8(vo[1][j], bx + (size_t)s * stx, dst + IMG + j * 1024);
     }
@@ -129,19 +138,30 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(Wgrad8Args p) {
     if (s + NSTG8 - 1 < nst) stage(s + NSTG8 - 1);
     const unsigned so = (s & (NSTG8 - 1)) * STG;
     v8i_ b8[2], a8[4];
+#if ATST_TN8_ABL & 1
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b8[j] = v8i_{(int)so, 1, 2, 3, 4, 5, 6, 7};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a8[i] = v8i_{(int)so, 1, 2, 3, 4, 5, 6, 7};
+#else
 #pragma unroll
     for (int j = 0; j < 2; ++j) b8[j] = frag8(fb[j] + so);
 #pragma unroll
     for (int i = 0; i < 4; ++i) a8[i] = frag8(fa[i] + so);
+#endif
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a8[0]), "+v"(a8[1]), "+v"(a8[2]), "+v"(a8[3]), "+v"(b8[0]), "+v"(b8[1]));
     if (wn == 1 && s + 1 < nst) wait_stage(issued(s + NSTG8 - 1) - (s + 1));
     asm volatile("s_barrier" ::: "memory");                        // B2
     __builtin_amdgcn_sched_barrier(0);
+#if ATST_TN8_ABL & 4
+    asm volatile("" :: "v"(a8[0]), "v"(a8[1]), "v"(a8[2]), "v"(a8[3]), "v"(b8[0]), "v"(b8[1]));
+#else
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[i], b8[j], acc[i][j], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+#endif
   }
   if (wn == 0) asm volatile("s_barrier" ::: "memory");            // row 1's last B2
   // epilogue: fp32 atomics, consecutive lanes on consecutive k (C layout: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
@@ -154,10 +174,36 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(Wgrad8Args p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + wn * 128 + i * 32 + crow32(r, hi), k = k0 + wk * 64 + j * 32 + l31;
-        atomicAdd(p.dW + (size_t)n * p.ldw + k, acc[i][j][r] * dq);
+        if (!(ATST_TN8_ABL & 8)) atomicAdd(p.dW + (size_t)n * p.ldw + k, acc[i][j][r] * dq); else asm volatile("" :: "v"(acc[i][j][r] * dq));
       }
 }
+
+__global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(Wgrad8Args p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int tiles = (p.N / TN8) * (p.K / TK8);
+  const int id = xcd_remap(blockIdx.x, gridDim.x);                // all tiles of one M-split run on one XCD (they stream the same dY8 / X8 rows)
+  tn8_body(p, id % tiles, id / tiles, smem_raw);
+}
+
+// The e4m3 weight gradients of ONE transformer block in one launch (the four Linears share M and the M-split): what a launch pays besides its MFMAs is
+// the fp32 atomics that combine the M-splits -- splits x 4 N K bytes per problem, and a problem launched alone needs ~512 / tiles splits to fill two rounds
+// of the chip: 132 MB of atomics for EVERY problem, 59-88 us each (tools/tn8_ablate.sh: 21 % of fc1's launch, 59 % of proj's).  Together the four
+// problems are 108 tiles: 7 splits fill three rounds, and the atomics of all four are 198 MB instead of 528.
+struct Wgrad8Group { Wgrad8Args it[4]; int first_tile[5]; int n; };
+__global__ __launch_bounds__(512, 2) void gemm_tn8_group_kernel(Wgrad8Group g) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int ntiles = g.first_tile[g.n];
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int t = id % ntiles, split = id / ntiles;                 // split-major: the tiles of one M-split (all problems) are neighbours on an XCD
+  int pi = 0;
+#pragma unroll
+  for (int q = 1; q < 4; ++q) if (q < g.n && t >= g.first_tile[q]) pi = q;
+  pi = __builtin_amdgcn_readfirstlane(pi);
+  tn8_body(g.it[pi], t - g.first_tile[pi], split, smem_raw);
+}
 }  // namespace
+
+static int tn8_splits(int tiles) { const int s = (192 + tiles - 1) / tiles; return s < 1 ? 1 : s; }   // one round, >= 3/4 of the 256 CUs
 
 // dW[N, K] (fp32, ldw) += (1 / (*scale_y * *scale_x)) dY8[M, N]^T X8[M, K]; N, K multiples of 256, M a multiple of 64, ldy / ldx multiples of 16.
 int atst_gemm_tn8(const uint8_t* dY8, const uint8_t* X8, int M, int N, int K, int ldy, int ldx, float* dW, int ldw, const float* scale_y,
@@ -165,7 +211,7 @@ int atst_gemm_tn8(const uint8_t* dY8, const uint8_t* X8, int M, int N, int K, in
   if (!dY8 || !X8 || !dW || M <= 0 || M % RM8 || N % TN8 || K % TK8 || ldy % 16 || ldx % 16) return ATST_EINVAL;
   Wgrad8Args a{dY8, X8, M, N, K, ldy, ldx, dW, ldw, scale_y, scale_x, 0};
   const int tiles = (N / TN8) * (K / TK8);
-  int splits = 512 / tiles; if (splits < 1) splits = 1;             // two rounds of one block per CU
+  int splits = tn8_splits(tiles);                                   // (two rounds -- 512 / tiles -- paid 132 MB of atomics per launch: tools/tn8_ablate.sh)
   int mps = (M + splits - 1) / splits;
   mps = ((mps + RM8 - 1) / RM8) * RM8;
   if (mps < 4 * RM8) mps = 4 * RM8;
@@ -179,5 +225,40 @@ int atst_gemm_tn8(const uint8_t* dY8, const uint8_t* X8, int M, int N, int K, in
   }
   ProfScope ps(PK_GEMM_TN, 2.0 * M * N * K, st, (double)M * ((double)N + K) + 4.0 * N * K);
   hipLaunchKernelGGL(gemm_tn8_kernel, dim3(tiles * splits), dim3(512), NSTG8 * STG, st, a);
+  return (int)hipGetLastError();
+}
+
+// dW_i += dY8_i^T X8_i / (scale_y_i scale_x_i) for up to four problems that share M (one transformer block); every N_i, K_i a multiple of 256.
+int atst_gemm_tn8_group(const Wgrad8Item* items, int n, int M, hipStream_t st) {
+  if (n < 1 || n > 4 || M <= 0 || M % RM8) return ATST_EINVAL;
+  Wgrad8Group g{}; g.n = n;
+  double flops = 0.0, bytes = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const Wgrad8Item& it = items[i];
+    if (!it.dY8 || !it.X8 || !it.dW || it.N % TN8 || it.K % TK8 || it.ldy % 16 || it.ldx % 16) return ATST_EINVAL;
+    g.it[i] = Wgrad8Args{it.dY8, it.X8, M, it.N, it.K, it.ldy, it.ldx, it.dW, it.ldw, it.scale_y, it.scale_x, 0};
+    g.first_tile[i + 1] = g.first_tile[i] + (it.N / TN8) * (it.K / TK8);
+    flops += 2.0 * M * it.N * it.K; bytes += (double)M * ((double)it.N + it.K) + 4.0 * it.N * it.K;
+  }
+  // M-splits: ONE round of blocks, the smallest count that occupies >= 3/4 of the chip.  Measured on the four problems of an ATST-base block (108 tiles,
+  // M = 131072; us per launch): 1 split 872, **2 splits 499**, 3: 658, 5: 621, 6: 547, 7 (three full rounds): 495-520, 14: 555-580 -- every split adds
+  // 28 MB of fp32 atomics, and a second, partly filled round costs more than the idle sixth of the chip
+  const int tiles = g.first_tile[n];
+  int best = tn8_splits(tiles);
+  int splits;
+  splits = g_tn8_splits > 0 ? g_tn8_splits : best;
+  int mps = (M + splits - 1) / splits;
+  mps = ((mps + RM8 - 1) / RM8) * RM8;
+  if (mps < 4 * RM8) mps = 4 * RM8;
+  splits = (M + mps - 1) / mps;
+  for (int i = 0; i < n; ++i) g.it[i].m_per_split = mps;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_tn8_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NSTG8 * STG);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  ProfScope ps(PK_GEMM_TN, flops, st, bytes);
+  hipLaunchKernelGGL(gemm_tn8_group_kernel, dim3(tiles * splits), dim3(512), NSTG8 * STG, st, g);
   return (int)hipGetLastError();
 }

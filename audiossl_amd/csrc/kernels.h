@@ -51,6 +51,9 @@ int atst_gemm_tn(const WgradArgs& a, hipStream_t st);
 // e4m3 weight gradient (gemm_tn8.hip): dW += dY8^T X8 / (*scale_y * *scale_x); N, K % 256 == 0, M % 64 == 0
 int atst_gemm_tn8(const uint8_t* dY8, const uint8_t* X8, int M, int N, int K, int ldy, int ldx, float* dW, int ldw, const float* scale_y,
                   const float* scale_x, hipStream_t st);
+struct Wgrad8Item { const uint8_t* dY8; const uint8_t* X8; int N, K, ldy, ldx; float* dW; int ldw; const float* scale_y; const float* scale_x; };
+int atst_gemm_tn8_group(const Wgrad8Item* items, int n, int M, hipStream_t st);   // up to four problems sharing M in one launch (one transformer block)
+extern int g_tn8_splits;
 #define ATST_WGRAD_GROUP_MAX 4
 int atst_gemm_tn_group(const WgradArgs* items, int n, hipStream_t st);   // independent weight gradients sharing one launch
 

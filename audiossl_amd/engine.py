@@ -442,6 +442,11 @@ def _gemm(A, B, M, N, K, epi, out):
     never such a multiple).  The extra output rows are computed from whatever the operand's padding rows hold and land in the output's padding rows; every
     consumer (BatchNorm sums, the next kernels) works on [:M]."""
     Mp = -(-M // 256) * 256 if (_HEAD_PAD and M > 4096) else M
+    if Mp != M:                                              # the padding rows must exist in both allocations (host-side check, no device work)
+        for t in (A, out):
+            room = t.untyped_storage().nbytes() - t.storage_offset() * t.element_size()
+            if room < Mp * t.stride(0) * t.element_size():
+                Mp = M
     hip.call("atst_gemm_nt_bf16", hip.ptr(A), hip.ptr(B), Mp, N, K, K, K, epi, hip.ptr(out), N, None, None, None, None, 1,
              None, None, None, None, None, hip.stream())
 

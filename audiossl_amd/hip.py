@@ -27,6 +27,12 @@ class HipError(RuntimeError):
     pass
 
 
+class Wgrad8(C.Structure):
+    """atst_wgrad8_t (include/atst_hip.h)"""
+    _fields_ = [("dY8", C.c_void_p), ("X8", C.c_void_p), ("dW", C.c_void_p), ("N", C.c_int), ("K", C.c_int), ("ldy", C.c_int), ("ldx", C.c_int),
+                ("ldw", C.c_int), ("scale_y", C.c_void_p), ("scale_x", C.c_void_p)]
+
+
 class Wgrad(C.Structure):
     """atst_wgrad_t (include/atst_hip.h)."""
     _fields_ = [("dY", C.c_void_p), ("X", C.c_void_p), ("dW", C.c_void_p)] + [(n, C.c_int) for n in ("M", "N", "K", "ldy", "ldx", "ldw")]
@@ -74,6 +80,7 @@ _SIGS = {
                                     C.c_int, C.c_void_p]),
     "atst_gemm_tn_fp8": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "atst_gemm_tn_group_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "atst_gemm_tn_group_fp8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "atst_layernorm_fwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p]),
     "atst_layernorm_fwd_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p]),
     "atst_layernorm_bwd": (C.c_int, [C.c_void_p] * 9 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_void_p]),

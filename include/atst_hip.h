@@ -40,7 +40,7 @@ enum { ATST_EPI_BF16 = 0, ATST_EPI_F32 = 1, ATST_EPI_BIAS_GELU = 2, ATST_EPI_RES
  *   110  round 4: atst_encoder_t grew f8_sat / f8_act_scale / f8_act_amax ; every amax argument (atst_quant_fp8_dyn_bf16, g8_amax, f8_act_amax) is an
  *        ATST_AMAX_SITE_STRIDE-float SITE, not one float ; fb_weights of atst_mel_frontend_f32 is tap-major [fb_maxlen][n_mels]
  *   120  round 5: atst_encoder_t grew fp8_wgrad / f8_act_scale_bwd ; an fp8 training workspace also holds per-layer e4m3 activation copies
- *        and an e4m3 dqkv ; fp8_lean ; atst_gemm_tn_fp8, atst_attention_fwd_fp8, atst_attention_bwd_fp8 */
+ *        and an e4m3 dqkv ; fp8_lean ; atst_gemm_tn_fp8, atst_gemm_tn_group_fp8, atst_attention_fwd_fp8, atst_attention_bwd_fp8 */
 #define ATST_ABI_VERSION 120
 int atst_version(void);   /* = ATST_ABI_VERSION of the header the library was built from */
 /* Tuning hooks for A/B measurements (tools/gemm_bench.py, env ATST_TUNE=a,b,... read by audiossl_amd/hip.py); defaults are the
@@ -60,7 +60,8 @@ int atst_version(void);   /* = ATST_ABI_VERSION of the header the library was bu
  *   370/371 store-only bf16 GEMM epilogue: fp32 staging (default) / transposed accumulators + wave-private bf16 staging      380/381 split-K of fp32-output GEMMs with <= 64 tiles off/on
  *   390/391/392/393 256 x 256 phased GEMM kernel (csrc/gemm_p8.h) for N % 256 == 0, K % 128 == 0, M % 256 == 0: off / bf16 operands only / also e4m3
  *               operands except fc1 + GELU / every e4m3 GEMM (default)
- *   1000+c start-up skew of every other first-round block of that kernel, c x 1024 cycles (experiment: no effect)
+ *   1000+c start-up skew of every other first-round block of that kernel, c x 1024 cycles (experiment: no effect; c < 400)
+ *   1400+s M-splits of the grouped e4m3 weight gradient (0 = automatic: one round of blocks on >= 3/4 of the CUs)
  *   408/409 NP=32 attention backward: dK,dV kernel + dQ kernel / one fused kernel, one wave per (sequence, head) (default)
  *   410/411 fp8 forward, e4m3 copy of the attention output: a quantisation pass over the bf16 output / written by the NP=256 forward kernel (default)
  * The measured-and-rejected GEMM variants of round 2 (64-deep ring stages, ping-pong main loop, register epilogue, start-up
@@ -125,6 +126,10 @@ int atst_gemm_tn_fp8(const uint8_t* dY8, const uint8_t* X8, int M, int N, int K,
  * each dW_i[N_i,K_i] += dY_i^T X_i.  Same result as n calls of atst_gemm_tn_bf16; fewer M-splits, fewer atomics.        */
 typedef struct { const uint16_t* dY; const uint16_t* X; float* dW; int M, N, K, ldy, ldx, ldw; } atst_wgrad_t;
 int atst_gemm_tn_group_bf16(const atst_wgrad_t* items, int n, void* stream);
+/* ... and of their e4m3 form: up to 4 problems that share M (the four Linears of one Block) in one launch.  What a launch pays besides its MFMAs is
+ * the fp32 atomics that combine the M-splits; alone every problem needs ~200 / tiles splits to occupy the chip, together the four need 2.       */
+typedef struct { const uint8_t* dY8; const uint8_t* X8; float* dW; int N, K, ldy, ldx, ldw; const float* scale_y; const float* scale_x; } atst_wgrad8_t;
+int atst_gemm_tn_group_fp8(const atst_wgrad8_t* items, int n, int M, void* stream);
 /* nn.LayerNorm(eps=1e-6): audiossl/modules/transformer.py:128,132 ; audio_transformer.py:113                         */
 int atst_layernorm_fwd(const float* x, const float* gamma, const float* beta, uint16_t* y, float* mean, float* rstd,
                        int M, int C, void* stream);

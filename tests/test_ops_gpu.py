@@ -10,6 +10,7 @@ import sys
 
 import numpy as np
 import pytest
+import ctypes as C_
 import torch
 
 pytestmark = pytest.mark.gpu
@@ -990,3 +991,34 @@ def test_gemm_tn_fp8_weight_gradient(M, N, K):
     # and close to the bf16 weight gradient of the unquantised operands (e4m3: 2^-4 relative per element, averaged over M)
     ref16 = dY.float().t() @ X.float() + 0.5
     assert relerr(dW, ref16) < 8e-2
+
+
+@pytest.mark.parametrize("M", [4096, 8192 + 192])
+def test_gemm_tn_group_fp8_matches_single_launches(M):
+    """The four e4m3 weight gradients of an ATST-base block in ONE launch (atst_gemm_tn_group_fp8: shared M, shared M-splits, a fraction of the fp32
+    atomics) against the same four problems launched one by one, and against the fp64 product of the e4m3 values; 3- and 4-problem groups, own scales."""
+    C = 768
+    shapes = [(4 * C, C), (C, 4 * C), (C, C), (3 * C, C)]                          # fc1, fc2, proj, qkv: (N, K)
+    g = torch.Generator().manual_seed(M)
+    ops = []
+    for i, (N, K) in enumerate(shapes):
+        dY = (torch.randn(M, N, generator=g) * 0.02).to(DEV).bfloat16(); X = (torch.randn(M, K, generator=g) * 1.5).to(DEV).bfloat16()
+        X[:, 0] = 3.0; dY[0] = 0.05
+        sy, sx = torch.tensor([1024.0 * (i + 1)], device=DEV), torch.tensor([8.0 / (i + 1)], device=DEV)
+        dY8 = torch.empty(M, N, dtype=torch.uint8, device=DEV); X8 = torch.empty(M, K, dtype=torch.uint8, device=DEV)
+        hip.call("atst_quant_fp8_bf16", hip.ptr(dY), M * N, float(sy), hip.ptr(dY8), hip.stream())
+        hip.call("atst_quant_fp8_bf16", hip.ptr(X), M * K, float(sx), hip.ptr(X8), hip.stream())
+        ops.append((dY8, X8, N, K, sy, sx))
+    for n in (3, 4):
+        one = [torch.full((N, K), 0.25, device=DEV) for _, _, N, K, _, _ in ops[:n]]
+        grp = [torch.full((N, K), 0.25, device=DEV) for _, _, N, K, _, _ in ops[:n]]
+        items = (hip.Wgrad8 * n)()
+        for i, (dY8, X8, N, K, sy, sx) in enumerate(ops[:n]):
+            hip.call("atst_gemm_tn_fp8", hip.ptr(dY8), hip.ptr(X8), M, N, K, N, K, hip.ptr(one[i]), K, hip.ptr(sy), hip.ptr(sx), hip.stream())
+            items[i].dY8, items[i].X8, items[i].dW = dY8.data_ptr(), X8.data_ptr(), grp[i].data_ptr()
+            items[i].N, items[i].K, items[i].ldy, items[i].ldx, items[i].ldw = N, K, N, K, K
+            items[i].scale_y, items[i].scale_x = sy.data_ptr(), sx.data_ptr()
+        hip.call("atst_gemm_tn_group_fp8", C_.byref(items), n, M, hip.stream())
+        for i, (dY8, X8, N, K, sy, sx) in enumerate(ops[:n]):
+            ref = (dY8.view(torch.float8_e4m3fn).double().t() @ X8.view(torch.float8_e4m3fn).double()) / (float(sy) * float(sx)) + 0.25
+            assert relerr(grp[i], ref.float()) < 2e-5 and relerr(grp[i], one[i]) < 2e-5, (n, i)
