@@ -11,7 +11,8 @@
 extern "C" {
 
 int atst_version(void) { return ATST_ABI_VERSION; }
-int atst_tune_gemm_variant(int v) { if (v >= 1400 && v < 1500) g_tn8_splits = v - 1400; else if (v >= 400 && v < 1000) atst_attn_set_variant(v - 400); else atst_gemm_nt_set_variant(v); return 0; }
+extern int g_tn_group_splits;
+int atst_tune_gemm_variant(int v) { if (v >= 1500 && v < 1600) g_tn_group_splits = v - 1500; else if (v >= 1400 && v < 1500) g_tn8_splits = v - 1400; else if (v >= 400 && v < 1000) atst_attn_set_variant(v - 400); else atst_gemm_nt_set_variant(v); return 0; }
 
 int atst_mel_frontend_f32(const float* wave, int n_clips, int n_samples, int wave_ld, int n_mels, int win_length, const float* window,
                           const float* fb_weights, const int* fb_start, const int* fb_len, int fb_maxlen,

@@ -1963,6 +1963,7 @@ int launch_nt(const GemmArgs& a, hipStream_t st) {
 
 }  // namespace
 
+int g_tn_group_splits = 0;   // tuning hook 1500 + s: M-splits of the grouped bf16 weight gradient (0 = cost model)
 void atst_gemm_nt_set_variant(int v) {
   if (v >= 1000 && v < 2000) g_p8_skew = v - 1000;
   else if (v >= 396 && v <= 397) g_ph = v - 396;
@@ -2090,6 +2091,7 @@ int atst_gemm_tn_group(const WgradArgs* items, int n, hipStream_t st) {
       const double cost = (double)((tiles * sp + 255) / 256) / sp * t_m + sp * t_atom;
       if (cost < best) { best = cost; splits = sp; }
     }
+    if (g_tn_group_splits > 0) splits = g_tn_group_splits;            // tuning hook 1500 + s
   }
   int max_splits = 1, min_splits = 1 << 30;
   for (int i = 0; i < n; ++i) {
