@@ -19,7 +19,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--mode", default="clip", choices=["clip", "frame", "frame_ragged"])
+    ap.add_argument("--mode", default="clip", choices=["clip", "frame", "frame_ragged", "base_fp8"])
     ap.add_argument("--out", required=True)
     ap.add_argument("--overlap", type=int, default=1)
     ap.add_argument("--batch", type=int, default=4, help="clips per rank")
@@ -35,9 +35,13 @@ def main():
     from audiossl_amd.engine import AtstEngine
     from oracle import atst_oracle as O                       # seeded input recipes only (test infrastructure)
 
-    frame = args.mode != "clip"
-    depth, Bt = 4, args.batch * args.ranks                    # total clips
-    eng = AtstEngine("small", frame=frame, depth=depth, ncrops=2 if frame else 3, drop_path_rate=0.1)
+    frame = args.mode in ("frame", "frame_ragged")
+    fp8 = args.mode == "base_fp8"                             # BASELINE.json configs[4] under DDP: ATST-base, every GEMM of a block on e4m3 operands
+    depth, Bt = (2 if fp8 else 4), args.batch * args.ranks    # total clips
+    if fp8:
+        eng = AtstEngine("base", depth=depth, ncrops=2, drop_path_rate=0.1, fp8=True)
+    else:
+        eng = AtstEngine("small", frame=frame, depth=depth, ncrops=2 if frame else 3, drop_path_rate=0.1)
     eng.overlap_comm = bool(args.overlap)
     eng.grad_buckets = 2
     eng.init_weights(seed=100 + rank)                          # rank-dependent on purpose
@@ -58,16 +62,16 @@ def main():
             lens = [torch.cat([lens[0][:per]] * args.ranks)] * 2
         masks = [torch.from_numpy(m)] * 2
     else:
-        widths = [1001, 1001, 101]
+        widths = [1001, 1001] if fp8 else [1001, 1001, 101]
         mels = [O.recipe_mel(Bt, w, seed=11 + i) for i, w in enumerate(widths)]
-        lens = [torch.full((Bt,), 1001), torch.tensor([1001, 900, 640, 1001, 801, 1001, 500, 1001] * Bt)[:Bt], torch.full((Bt,), 101)]
+        lens = [torch.full((Bt,), 1001), torch.tensor([1001, 900, 640, 1001, 801, 1001, 500, 1001] * Bt)[:Bt], torch.full((Bt,), 101)][:len(widths)]
         masks = None
     g = torch.Generator().manual_seed(3)
     # DropPath keep masks for the whole batch, per width group: [depth, 2, n_views_in_group * Bt]
     def keep_full(nv):
         rates = torch.linspace(0, 0.1, depth).view(-1, 1, 1)
         return torch.floor((1 - rates) + torch.rand(depth, 2, nv * Bt, generator=g))
-    if frame:
+    if frame or fp8:
         keep_t, keep_s = [keep_full(2)], [keep_full(2)]
     else:
         keep_t, keep_s = [keep_full(2)], [keep_full(2), keep_full(1)]
@@ -80,8 +84,14 @@ def main():
     lens_r = [l[lo:hi] for l in lens]
     masks_r = None if masks is None else [mk[lo:hi] for mk in masks]
     kt = [shard_keep(keep_t[0], 2)]
-    ks = [shard_keep(keep_s[0], 2)] + ([shard_keep(keep_s[1], 1)] if not frame else [])
+    ks = [shard_keep(keep_s[0], 2)] + ([shard_keep(keep_s[1], 1)] if not (frame or fp8) else [])
 
+    if fp8:                                                    # step 1 records the delayed scales (amax MAX-reduced over the ranks), step 2 -- reported -- runs in e4m3
+        eng.forward(mels_r, lens_r, masks_r, keep_teacher=kt, keep_student=ks)
+        eng.backward()
+        eng.allreduce_grads()
+        eng.optimizer_step(1e-3, 0.04, 0.99)
+        assert eng.fp8_bwd_state == 2 and eng.fp8_wgrad_mode() == 2
     loss, std_s, std_t = eng.forward(mels_r, lens_r, masks_r, keep_teacher=kt, keep_student=ks)
     eng.backward()
     eng.allreduce_grads()
@@ -105,7 +115,8 @@ def main():
         bn = {f"bn/{k}/{b}": t.detach().float().cpu().numpy() for k, d in eng.bn_buffers.items() for b, t in d.items()}
         np.savez(args.out, loss=lossv.cpu().numpy(), std_s=float(std_s), std_t=float(std_t), grads=grads.cpu().numpy(),
                  params=eng.p32.cpu().numpy(), teacher=eng.t32.cpu().numpy(), same=same.cpu().numpy(), world=world,
-                 backend=(dist.get_backend() if world > 1 else "none"), **bn)
+                 backend=(dist.get_backend() if world > 1 else "none"),
+                 g8_scale=(eng.g8_scale.cpu().numpy() if fp8 else np.zeros(1)), f8a_scale=(eng.f8a_scale.cpu().numpy() if fp8 else np.zeros(1)), **bn)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
