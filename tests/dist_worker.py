@@ -87,10 +87,11 @@ def main():
     ks = [shard_keep(keep_s[0], 2)] + ([shard_keep(keep_s[1], 1)] if not (frame or fp8) else [])
 
     if fp8:                                                    # step 1 records the delayed scales (amax MAX-reduced over the ranks), step 2 -- reported -- runs in e4m3
+        # (no optimizer step in between: the two steps then see the same weights, and sharded vs concatenated differ by summation order only)
         eng.forward(mels_r, lens_r, masks_r, keep_teacher=kt, keep_student=ks)
         eng.backward()
         eng.allreduce_grads()
-        eng.optimizer_step(1e-3, 0.04, 0.99)
+        eng.g32.zero_(); eng._grads_summed = False
         assert eng.fp8_bwd_state == 2 and eng.fp8_wgrad_mode() == 2
     loss, std_s, std_t = eng.forward(mels_r, lens_r, masks_r, keep_teacher=kt, keep_student=ks)
     eng.backward()

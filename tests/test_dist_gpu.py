@@ -118,13 +118,14 @@ def test_two_ranks_equal_one_rank_base_fp8(tmp_path):
     two = _worker(tmp_path, "two_fp8", 2, "base_fp8", 1, batch=8)
     assert int(two["world"]) == 2 and float(two["same"][0]) == 1.0          # ranks hold identical parameters after the step
     import numpy as np
+    g = _rel(two["grads"], one["grads"])
+    sg = float(np.max(np.abs(two["g8_scale"] * 2.0 / one["g8_scale"] - 1.0))); sa = float(np.max(np.abs(two["f8a_scale"] / one["f8a_scale"] - 1.0)))
+    print(f"\n[2 ranks vs 1, base fp8] loss {float(two['loss'][0]):.6f} vs {float(one['loss'][0]):.6f}; flat gradient rel {g:.2e}; scales: gradient sites {sg:.1e}, forward sites {sa:.1e}")
     # same quantisation grids: a rank's activation gradients are world x the single process's (its loss is the mean over ITS clips; DDP averages the
     # parameter gradients afterwards), so its gradient scales are 1 / world of them -- scale x value, i.e. the e4m3 code, is the same; forward scales equal
-    assert np.allclose(two["g8_scale"] * 2.0, one["g8_scale"], rtol=3e-2) and np.allclose(two["f8a_scale"], one["f8a_scale"], rtol=3e-2)   # an amax is ONE element: measured <= 1.1 % apart after the first optimizer step
-    g = _rel(two["grads"], one["grads"])
-    print(f"\n[2 ranks vs 1, base fp8] loss {float(two['loss'][0]):.6f} vs {float(one['loss'][0]):.6f}; flat gradient rel {g:.2e}")
+    assert sg < 1e-2 and sa < 1e-2
     assert abs(float(two["loss"][0]) - float(one["loss"][0])) < 2e-3
-    assert g < 3e-2, g
+    assert g < 4e-2, g                                                     # measured 2.1e-2 (loss 3e-6 apart, forward scales identical, gradient scales 1.5e-3 apart)
     assert _rel(two["teacher"], one["teacher"]) < 1e-4
 
 
