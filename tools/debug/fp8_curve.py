@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Loss curves of N optimizer steps on the same data and initial weights: bf16 | e4m3 forward only | e4m3 forward + dgrad (GPU box).
+"""Loss curves of N optimizer steps on the same data and initial weights: bf16 | e4m3 forward only | all 12 GEMMs of a block on e4m3 operands (GPU box;
+env N, DEPTH, B: e.g. DEPTH=12 N=48 B=32 for the full-depth ATST-base curve of profiles/r05_fp8_curve_depth12.txt).
 Prints per-step losses and the parameter distance to the bf16 run; tests/test_ops_gpu.py::test_fp8_multi_step_loss_curve_tracks_bf16 pins it."""
 import math, os, sys
 import torch
@@ -7,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from audiossl_amd.engine import AtstEngine
 from oracle import atst_oracle as O
-N, depth, B = int(os.environ.get("N", 24)), 2, 16
+N, depth, B = int(os.environ.get("N", 24)), int(os.environ.get("DEPTH", 2)), int(os.environ.get("B", 16))
 W = O.recipe_weights("base", depth=depth, seed=7)
 
 
@@ -47,6 +48,6 @@ print("bf16  " + " ".join(f"{v:7.4f}" for v in ref))
 for kind in ("fp8_fwd", "fp8"):
     l, p, sat = run(kind)
     d = [abs(a - b) for a, b in zip(l, ref)]
-    print(f"{kind:5s} " + " ".join(f"{v:7.4f}" for v in l))
+    print(f"{kind:7s}" + " ".join(f"{v:7.4f}" for v in l))
     print(f"      max |loss - bf16| {max(d):.4f}  mean {sum(d) / N:.4f}  last-4 mean loss {sum(l[-4:]) / 4:.4f} (bf16 {sum(ref[-4:]) / 4:.4f})  "
           f"|p - p_bf16| / |p_bf16 - p_0| {float((p - p_ref).norm() / (p_ref - P0).norm()):.3f}  sat {sat}")
