@@ -931,6 +931,53 @@ def test_fp8_forward_only_state_is_saved_and_restored():
     assert float(l1) == float(l2)
 
 
+def test_fp8_base_state_machine_checkpoint_and_lean_contract():
+    """Host-side contracts of the all-e4m3 base step (round 5):
+      * the delayed-scaling state incl. the qkv site (fp8_qkv_state) survives fp8_state() / load_fp8_state(), and the resumed engine takes the same step;
+      * a checkpoint written BEFORE the qkv path existed (no "qkv_state" key, site-3 scale never observed) makes the engine record one step first --
+        bf16 qkv pair, wgrad mode 3 -- instead of quantising dqkv with the placeholder scale 1;
+      * a forward that left out bf16 activation copies (fp8_lean) refuses a backward whose mode changed in between (it would read copies never written)."""
+    from audiossl_amd.engine import AtstEngine
+    depth, B = 1, 2
+    W = O.recipe_weights("base", depth=depth, seed=7)
+    mels = [O.recipe_mel(B, 1001, seed=1).to(DEV), O.recipe_mel(B, 1001, seed=2).to(DEV)]
+    lens = [torch.full((B,), 1001)] * 2
+    eng = AtstEngine("base", depth=depth, drop_path_rate=0.0, fp8=True)
+    eng.load_weights(W)
+    for _ in range(2):
+        eng.forward(mels, lens); eng.backward()
+    assert eng.fp8_bwd_state == 2 and eng.fp8_qkv_state == 2 and eng.fp8_wgrad_mode() == 2
+    st = eng.fp8_state()
+    assert st["state"] == 2 and st["qkv_state"] == 2 and float(st["g8_scale"].view(depth, 4)[:, 3].min()) > 1.0
+    eng2 = AtstEngine("base", depth=depth, drop_path_rate=0.0, fp8=True)
+    eng2.load_weights(W); eng2.load_fp8_state(st)
+    assert eng2.fp8_bwd_state == 2 and eng2.fp8_qkv_state == 2
+    la = float(eng.forward(mels, lens)[0]); eng.backward(); ga = eng.g32.clone()
+    lb = float(eng2.forward(mels, lens)[0]); eng2.backward()
+    assert la == lb and relerr(eng2.g32, ga) < 1e-5                             # same scales, same codes: only the order of the fp32 atomics differs
+    assert eng2._student_groups[0][0].e.fp8_lean == 2
+    # an old checkpoint: no qkv_state, site 3 never observed
+    old = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items() if k != "qkv_state"}
+    old["g8_scale"].view(depth, 4)[:, 3] = 1.0; old["g8_hist"].view(-1, depth, 4)[:, :, 3] = 0.0
+    eng3 = AtstEngine("base", depth=depth, drop_path_rate=0.0, fp8=True)
+    eng3.load_weights(W); eng3.load_fp8_state(old)
+    assert eng3.fp8_bwd_state == 2 and eng3.fp8_qkv_state == 1 and eng3.fp8_wgrad_mode() == 3
+    eng3.forward(mels, lens)
+    assert eng3._student_groups[0][0].e.fp8_lean == 1                           # fc1 / fc2 / proj weight gradients in e4m3, the qkv pair still bf16
+    eng3.backward()
+    assert eng3.fp8_qkv_state == 2 and float(eng3.g8_scale.view(depth, 4)[:, 3].min()) > 1.0 and torch.isfinite(eng3.g32).all()
+    ratio = float(eng3.g8_scale.view(depth, 4)[0, 3]) / float(st["g8_scale"].view(depth, 4)[0, 3])
+    assert 0.5 < ratio < 2.0, ratio                                            # one observation vs the other engine's window of two (measured 1.21)
+    # the lean contract
+    eng3.forward(mels, lens)
+    eng3.fp8_wgrad = False                                                        # would need the bf16 h2 / a this forward did not write
+    with pytest.raises(RuntimeError, match="fp8_lean"):
+        eng3.backward()
+    eng3.fp8_wgrad = True                                                         # (the refused backward had already consumed the heads' saved state: a fresh step)
+    eng3.forward(mels, lens); eng3.backward()
+    assert torch.isfinite(eng3.g32).all()
+
+
 @pytest.mark.parametrize("M,N,K", [(512, 768, 768), (1024, 2304, 768), (8192, 768, 3072), (8192 + 256, 3072, 768)])
 def test_gemm_fp8_phased_kernel(M, N, K):
     """The e4m3 form of the 256 x 256 phased kernel (csrc/gemm_p8.h, F8 = true: one v_mfma_scale_f32_32x32x64_f8f6f4 per 64-byte k-step) through
