@@ -894,6 +894,8 @@ class AtstEngine:
     def backward(self, grad_scale=1.0, zero_grad: bool = True):
         """Autograd of forward() wrt every student parameter, accumulated into the flat gradient buffer.
         grad_scale may be a python float or a 0-dim device tensor (the upstream d(loss))."""
+        for ep, _ in (self._student_groups or ()):                # fail before anything is consumed (heads' saved state, gradient buffer)
+            ep._check_lean()
         if zero_grad:
             self.g32.zero_()
         self._grads_summed = False
