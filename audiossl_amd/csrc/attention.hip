@@ -890,21 +890,25 @@ DEVFN bf16x8 b256_frag_tr(const bf16* X, int r0, int c0, int lane) {
   return u.v;
 }
 
-__global__ void attn_rowdot_kernel(const bf16* __restrict__ d_o, const bf16* __restrict__ o, float* __restrict__ D,
-                                   int S, int H, int NP) {
-  // one wave per token row: D[s,h,q] = sum_d dO[s,q,h,d] * O[s,q,h,d]
-  const int lane = threadIdx.x & 63;
-  const long row = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (row >= (long)S * NP) return;
-  const int C = H * HD;
-  const int s = (int)(row / NP), q = (int)(row % NP);
-  for (int c = lane; c < C / 8; c += 64) {                          // 8 elements per lane-chunk; a head = 8 chunks
-    const bf16x8 a = ld_frag(d_o + row * C + c * 8), b = ld_frag(o + row * C + c * 8);
+__global__ __launch_bounds__(256) void attn_rowdot_kernel(const bf16* __restrict__ d_o, const bf16* __restrict__ o, float* __restrict__ D,
+                                                          int S, int H, int NP) {
+  // D[s,h,q] = sum_d dO[s,q,h,d] * O[s,q,h,d].  One thread per 16-B chunk (8 elements) of the [rows, C] tensors, flat over rows: every lane of every
+  // wave loads (the round-1 form gave a wave one row -- 48 of 64 lanes at C = 384); a head is 8 consecutive chunks = 8 consecutive lanes (C / 8 and the
+  // wave size are multiples of 8, so a group never straddles a wave or a row)
+  const int cpr = H * (HD / 8);                                    // chunks per row
+  const size_t total = (size_t)S * NP * cpr;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ((total + 7) & ~(size_t)7); i += (size_t)gridDim.x * blockDim.x) {
     float d = 0.f;
+    if (i < total) {
+      const bf16x8 a = ld_frag(d_o + i * 8), b = ld_frag(o + i * 8);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) d += bf2f(a[e]) * bf2f(b[e]);
+      for (int e = 0; e < 8; ++e) d += bf2f(a[e]) * bf2f(b[e]);
+    }
     d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
-    if ((lane & 7) == 0) D[((size_t)s * H + (c >> 3)) * NP + q] = d;
+    if ((threadIdx.x & 7) == 0 && i < total) {
+      const size_t row = i / cpr; const int h = (int)(i % cpr) >> 3;
+      D[((size_t)(row / NP) * H + h) * NP + row % NP] = d;
+    }
   }
 }
 
@@ -1301,7 +1305,11 @@ int atst_attn_bwd(const AttnArgs& a, hipStream_t st) {
       done = true;
     }
     const long rows = (long)a.S * 256;
-    hipLaunchKernelGGL(attn_rowdot_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, a.d_o, (const bf16*)a.o, a.dscratch, a.S, a.H, 256);
+    {
+      const size_t chunks = (size_t)rows * a.H * (HD / 8);
+      size_t nb = (chunks + 255) / 256; if (nb > 65536) nb = 65536;
+      hipLaunchKernelGGL(attn_rowdot_kernel, dim3((unsigned)nb), dim3(256), 0, st, a.d_o, (const bf16*)a.o, a.dscratch, a.S, a.H, 256);
+    }
     ProfScope ps(PK_ATTN_BWD_DKV, 14.0 * a.S * a.H * 256.0 * 256.0 * HD, st, 16.0 * a.S * a.H * 256.0 * HD);
     AttnArgs a2 = a; a2.row_stores = g_bwd_row_stores;
     if (a.dqkv8) {
