@@ -1354,6 +1354,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_w4_kernel(GemmArgs p) {
 }
 
 #include "gemm_p8.h"
+#include "gemm_tt.h"
 
 // ---- wgrad: dW[n,k] += sum_m dY[m,n] X[m,k] -------------------------------------------------------------------------
 constexpr int WM = 64;                          // contraction rows per stage
@@ -1768,6 +1769,7 @@ int g_p8 = 3;               // 390/391/392/393: 256 x 256 phased kernel (gemm_p8
                             // except fc1 + GELU / every e4m3 GEMM (default since the lean outputs: fc1 + GELU 606 -> 592 us, base fp8 +0.8 ... 1.8 %)
                             // operands (default; except fc1 + GELU, whose e4m3 epilogue -- u, a, the e4m3 copy of a, amax -- measured 640 vs 647 us on the 256 x 384 tile).
                             // Same box, same call, base fp8 step: 2405-2407 (391) -> 2453-2476 clips/s (392), profiles/r05_p8_fp8_step_ab.txt
+int g_tt = 0;               // 2000 + v: two-team persistent kernel (gemm_tt.h): 0 off / 1 plain bf16 + fc1-GELU launches it takes
 int g_f32_splitk = 1;       // 380/381: split-K for fp32-output GEMMs with <= 64 output tiles and K >= 2048
 // Split-K workspace: per (device, stream) -- kernels of one stream run in order, so one buffer per stream is race-free; the null stream is the same
 // handle on every device, hence the device in the key (round-4 ADVICE).  Sized on first use for the largest head shape of the path
@@ -1876,6 +1878,40 @@ bool p8_ok(const GemmArgs& a) {
   return epi_ok && g_p8 && !a.ln_out && (a.fp8 || !a.q8) && a.N % p8::BNP == 0 && a.K % (2 * p8::BKP) == 0 && a.M % p8::BM == 0 &&
          a.M >= (g_w4_min_m < 8192 ? 256 : 8192) && a.lda % 8 == 0 && a.ldb % 8 == 0;
 }
+// two-team persistent kernel (gemm_tt.h): one block per CU, the epilogue of a tile under the main loop of the next
+template <int EPI>
+bool tt_ok(const GemmArgs& a) {
+  constexpr bool epi_ok = EPI == EPI_BF16 || EPI == EPI_BIAS_GELU;
+  return epi_ok && !a.fp8 && !a.q8 && !a.ln_out && a.M % tt::BM == 0 && a.N % tt::BNT == 0 && a.K % tt::BKT == 0 && a.K >= tt::BKT * tt::EP_STAGES &&
+         a.M >= (g_w4_min_m < 8192 ? 256 : 8192) && a.lda % 8 == 0 && a.ldb % 8 == 0 && (EPI != EPI_BIAS_GELU || a.C2);
+}
+int tt_num_cus() {
+  static int cus[16] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+  if (!cus[dev]) { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256; cus[dev] = n; }
+  return cus[dev];
+}
+template <int EPI, bool SU>
+int launch_nt_tt_cfg(const GemmArgs& a, hipStream_t st) {
+  static bool attr_done[16] = {false};
+  int dev = 0; (void)hipGetDevice(&dev); dev = dev < 0 || dev >= 16 ? 0 : dev;
+  if (!attr_done[dev]) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_tt_kernel<EPI, SU>, hipFuncAttributeMaxDynamicSharedMemorySize, tt::LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr_done[dev] = true;
+  }
+  const int T = (a.M / tt::BM) * (a.N / tt::BNT);
+  ProfScope ps(prof_kind<EPI>(), 2.0 * a.M * a.N * a.K, st, nt_bytes<EPI>(a));
+  hipLaunchKernelGGL((gemm_nt_tt_kernel<EPI, SU>), dim3(tt_num_cus()), dim3(tt::THREADS), tt::LDS_BYTES, st, a, T);
+  return (int)hipGetLastError();
+}
+template <int EPI>
+int launch_nt_tt(const GemmArgs& a, hipStream_t st) {
+  if constexpr (EPI == EPI_BIAS_GELU) { if (!a.C) return launch_nt_tt_cfg<EPI, false>(a, st); }
+  if constexpr (EPI == EPI_BF16 || EPI == EPI_BIAS_GELU) return launch_nt_tt_cfg<EPI, true>(a, st);
+  return ATST_EINVAL;
+}
 template <int EPI>
 int launch_nt_row384(const GemmArgs& a, hipStream_t st) {
   if (a.fp8) {                                                    // e4m3 operands seen as byte pairs: K, lda, ldb are already halved
@@ -1930,6 +1966,9 @@ int launch_nt(const GemmArgs& a, hipStream_t st) {
       if constexpr (EPI == EPI_RESID) return launch_nt_row384<EPI>(a, st);
     }
     int v = g_nt_variant;
+    if constexpr (EPI == EPI_BF16 || EPI == EPI_BIAS_GELU) {
+      if (v < 0 && g_tt && tt_ok<EPI>(a)) return launch_nt_tt<EPI>(a, st);
+    }
     if constexpr (EPI != EPI_PATCH && EPI != EPI_LNBWD) {
       if (v < 0 && !a.fp8 && p8_ok<EPI>(a)) return launch_nt_p8<EPI>(a, st);
     }
@@ -1965,7 +2004,8 @@ int launch_nt(const GemmArgs& a, hipStream_t st) {
 
 int g_tn_group_splits = 0;   // tuning hook 1500 + s: M-splits of the grouped bf16 weight gradient (0 = cost model)
 void atst_gemm_nt_set_variant(int v) {
-  if (v >= 1000 && v < 2000) g_p8_skew = v - 1000;
+  if (v >= 2000 && v < 2100) g_tt = v - 2000;
+  else if (v >= 1000 && v < 2000) g_p8_skew = v - 1000;
   else if (v >= 396 && v <= 397) g_ph = v - 396;
   else if (v >= 390) g_p8 = v - 390;
   else if (v >= 380) g_f32_splitk = v - 380;

@@ -47,7 +47,7 @@ def gemm_nt(A, B, epi, out_dtype, **kw):
     N = B.shape[0]
     Cout = torch.empty(M, N, dtype=out_dtype, device=DEV)
     C2 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV) if epi == hip.EPI_BIAS_GELU else None
-    hip.call("atst_gemm_nt_bf16", hip.ptr(A), hip.ptr(B), M, N, K, K, K, epi, hip.ptr(Cout), N, hip.ptr(C2),
+    hip.call("atst_gemm_nt_bf16", hip.ptr(A), hip.ptr(B), M, N, K, K, K, epi, None if kw.get("no_primary") else hip.ptr(Cout), N, hip.ptr(C2),
              hip.ptr(kw.get("bias")), hip.ptr(kw.get("resid")), hip.ptr(kw.get("row_scale")), kw.get("rps", 1),
              hip.ptr(kw.get("U")), hip.ptr(kw.get("table")), hip.ptr(kw.get("rowflag")), hip.ptr(kw.get("alt")), hip.ptr(kw.get("colsum")),
              hip.stream())
@@ -187,6 +187,38 @@ def test_gemm_nt_p8_phased_kernel(M, N, K):
     assert relerr(d.float(), uf.grad) < 5e-3 and relerr(cs, uf.grad.sum(0) + 0.25) < 2e-3
     for got, other in zip(res[391], res[390]):                            # the kernels it replaces: same sums up to the fp32 accumulation order
         assert relerr(got.float(), other.float()) < 4e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(768, 128, 384), (8192, 1152, 384), (16384, 1536, 384), (2048, 384, 1536), (256, 256, 416), (65536 + 256, 128, 384),
+                                   (4096, 768, 768)])
+def test_gemm_nt_two_team_kernel(M, N, K):
+    """The persistent two-team kernel (csrc/gemm_tt.h; hook 2001 on / 2000 off; hook 351 admits it below 8192 rows): the epilogue of tile i is stored by
+    one team of four waves while the other team multiplies tile i + 1.  Tile counts of 3 (253 of 256 blocks idle), 24, 96, 257 (one block with two
+    rounds, the others one), 288, 768 (three rounds per block: both teams in both roles) ; K = 384 (12 stages: every stage carries an epilogue slice),
+    416 (one idle stage), 768, 1536.  Against the fp32 formulas and against the kernels it replaces."""
+    lib = hip.load()
+    A, B = bf(rnd(M, K, seed=1, scale=0.5)), bf(rnd(N, K, seed=2, scale=0.5))
+    bias = rnd(N, seed=3)
+    ref = A.float() @ B.float().t()
+    res = {}
+    try:
+        lib.atst_tune_gemm_variant(351)
+        for hook in (2000, 2001):
+            lib.atst_tune_gemm_variant(hook)
+            b16, _ = gemm_nt(A, B, hip.EPI_BF16, torch.bfloat16, bias=bias)
+            b16nb, _ = gemm_nt(A, B, hip.EPI_BF16, torch.bfloat16)
+            u, a = gemm_nt(A, B, hip.EPI_BIAS_GELU, torch.bfloat16, bias=bias)
+            _, a2 = gemm_nt(A, B, hip.EPI_BIAS_GELU, torch.bfloat16, bias=bias, no_primary=True)      # teacher / inference: u is not saved
+            res[hook] = (b16, b16nb, u, a, a2)
+    finally:
+        lib.atst_tune_gemm_variant(2000); lib.atst_tune_gemm_variant(350)
+    b16, b16nb, u, a, a2 = res[2001]
+    assert relerr(b16.float(), ref + bias) < 4e-3 and relerr(b16nb.float(), ref) < 4e-3
+    assert relerr(u.float(), ref + bias) < 4e-3 and relerr(a.float(), torch.nn.functional.gelu(ref + bias)) < 5e-3
+    assert torch.equal(a, a2)
+    for got, other in zip(res[2001], res[2000]):                          # the kernels it replaces: same sums up to the fp32 accumulation order
+        assert relerr(got.float(), other.float()) < 4e-3
+    assert float((b16.float() - res[2000][0].float()).abs().max()) <= 0.07 * float(ref.abs().max())      # no misplaced row / column anywhere
 
 
 @pytest.mark.parametrize("M,N,K,split", [(1000, 256, 384, 0), (64, 128, 128, 0), (4099, 384, 256, 512), (777, 1152, 384, 0),
