@@ -1882,7 +1882,7 @@ bool p8_ok(const GemmArgs& a) {
 template <int EPI>
 bool tt_ok(const GemmArgs& a) {
   constexpr bool epi_ok = EPI == EPI_BF16 || EPI == EPI_BIAS_GELU;
-  return epi_ok && !a.fp8 && !a.q8 && !a.ln_out && a.M % tt::BM == 0 && a.N % tt::BNT == 0 && a.K % tt::BKT == 0 && a.K >= tt::BKT * tt::EP_STAGES &&
+  return epi_ok && !a.fp8 && !a.q8 && !a.ln_out && a.M % tt::BM == 0 && a.N % tt::BNT == 0 && a.K % tt::BKT == 0 && a.K >= tt::BKT * tt::MIN_STAGES &&
          a.M >= (g_w4_min_m < 8192 ? 256 : 8192) && a.lda % 8 == 0 && a.ldb % 8 == 0 && (EPI != EPI_BIAS_GELU || a.C2);
 }
 int tt_num_cus() {

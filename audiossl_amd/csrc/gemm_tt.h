@@ -11,71 +11,51 @@
 //   * the block walks its tiles in ROUNDS.  In round r team (r & 1) multiplies tile r (role ML) while the other team stores tile r - 1
 //     (role EP) from the accumulators it filled in round r - 1; then the roles swap.  The SIMD's issue arbiter interleaves the two
 //     instruction streams; nothing is interleaved by hand;
-//   * ONE operand stream for both teams: a round is K / 32 STAGES (A 256 x 32 + B 128 x 32 bf16 = 24 KB, rows of 64 B, chunk c of row r at
-//     c ^ ((r >> 2) & 3) as in gemm_nt_row384_kernel), a ring of 5 stages (120 KB) filled by LDS-DMA four stages ahead -- across tile
-//     boundaries, so no tile starts on a cold ring.  Every wave of both teams issues 3 of a stage's 24 one-KiB pieces per iteration,
-//     whatever its role: the vector-memory queue of every wave has the same static shape, and the only operand wait is a counted
-//     `s_waitcnt vmcnt(N)` (vmcnt retires loads AND stores in issue order) -- N = 6 for a wave that stores nothing, 6 + the stores and
-//     epilogue loads it has issued since, known at compile time per stage, for the EP role;
+//   * ONE operand stream for both teams, issued by the ML team: a round is K / 64 STAGES (A 256 x 64 + B 128 x 64 bf16 = 48 KB; rows of
+//     128 B = whole cache lines -- with 64-B rows the same bytes streamed at 28 B/clk/CU, with whole lines at 44, profiles/r06_tt_v1_*;
+//     chunk c of row r at c ^ ((r >> 1) & 7) as in gemm_p8.h), a ring of 3 stages (144 KB) filled by LDS-DMA two stages ahead -- across
+//     tile boundaries, so no tile starts on a cold ring.  The stream's waits are `vmcnt(0)` of the ML role (whose queue holds nothing but
+//     its 12 pieces per stage); the EP role's stores are never in front of a piece anyone waits for (vmcnt retires in issue order and a
+//     store's acknowledgement takes several stage times);
 //   * one `s_barrier` per stage for all eight waves: it publishes stage s + 1, frees the slot of stage s - 1, and keeps the EP team's
 //     slices in step with the ML team's stages.  The ML wave is software-pipelined over k-steps (fragments of the next k-step are read
 //     while the 8 MFMAs of this one execute; two register sets of 6 fragments);
-//   * EP role: wave-private staging (32 rows x 64 columns fp32 per wave, no block barrier in the epilogue): accumulator block row mb is
-//     written to LDS in stage 2 mb, read back as 16-B pieces of full 128-B output lines and stored in stages 2 mb + 1 and 2 mb + 2; the
-//     last store leaves in stage 8 of at least 12, so a wave that turns ML again has no store in its wait window.
-// LDS: 120 KB ring + 4 x 8.5 KB staging (the teams alternate in the EP role and share it) = 154 KB, one block per CU.
-// Shapes: M % 256 == 0, N % 128 == 0, K % 32 == 0, K >= 384.  Reference math: nn.Linear / GELU of audiossl/modules/transformer.py:70-92,
+//   * TRANSPOSED accumulators (the weight fragment is the MFMA's A operand): a lane owns ONE output row and four consecutive columns per
+//     register quad, so bias / GELU run on the registers, four values are packed to bf16 and staged with one ds_write_b64 (v1 staged fp32
+//     with 128 ds_write_b32 per tile and wave: 20 cycles each next to the other team's fragment reads) into a wave-private 4-KB buffer
+//     (32 rows x 128 B, 16-B chunks XOR-permuted by the row), read back as 16-B pieces of whole 128-B output lines.  No block barrier in
+//     the epilogue.  Block row q of the tile is staged in stage q + 1, read back while block row q + 1 is converted, stored in stage q + 2.
+// LDS: 144 KB ring + 4 x 4 KB staging (the teams alternate in the EP role and share it) = 160 KB, one block per CU.
+// Shapes: M % 256 == 0, N % 128 == 0, K % 64 == 0, K >= 384.  Reference math: nn.Linear / GELU of audiossl/modules/transformer.py:70-92,
 // 109,119 and their input gradients.
-#ifndef ATST_TT_ABL            // experiment builds (tools/tt_ablate.sh): 1 = the EP role does nothing but keep step ; 4 = no fragment reads / MFMAs ; 8 = whole-line stream sources
+#ifndef ATST_TT_ABL            // experiment builds (tools/tt_ablate.sh): 1 = the EP role does nothing but keep step ; 4 = no fragment reads / MFMAs
 #define ATST_TT_ABL 0
 #endif
 #ifndef ATST_TT_PRIO           // s_setprio: 0 none ; 1 the ML role runs at priority 2 ; 2 the EP role runs at priority 2
 #define ATST_TT_PRIO 1
 #endif
-#ifndef ATST_TT_ISS            // who issues the operand stream: 0 = every wave 3 pieces per stage ; 1 = the four waves of the ML team 6 each, the other team none
-#define ATST_TT_ISS 1
-#endif
 namespace tt {
-constexpr int BM = 256, BNT = 128, BKT = 32, ROWB = 64, A_BYTES = BM * ROWB, B_BYTES = BNT * ROWB, STAGE = A_BYTES + B_BYTES, NS = 5, RING = NS * STAGE;
-constexpr int SP = 68, STG_WAVE = 32 * SP * 4, LDS_BYTES = RING + 4 * STG_WAVE;     // staging rows of 64 floats + 4 (16-B aligned)
-constexpr int THREADS = 512, EP_STAGES = 12;
-constexpr int ISS = ATST_TT_ISS, NPW = ISS ? 6 : 3;                 // pieces per issuing wave per stage
+constexpr int BM = 256, BNT = 128, BKT = 64, ROWB = 128, A_BYTES = BM * ROWB, B_BYTES = BNT * ROWB, STAGE = A_BYTES + B_BYTES, NS = 3, RING = NS * STAGE;
+constexpr int STG_WAVE = 32 * 128, LDS_BYTES = RING + 4 * STG_WAVE;
+constexpr int THREADS = 512, MIN_STAGES = 6;
+constexpr int NPW = 12;                                             // pieces per ML wave per stage: 8 of A (8 rows each), 4 of B
 static_assert(LDS_BYTES <= 163840, "one block per CU");
-// vector-memory operations the EP role issues in stage s besides LDS-DMA pieces: P = register loads (in front of its pieces), S = stores (behind them)
-template <int EPI, bool SU> constexpr int ep_stores(int s) { return (ATST_TT_ABL & 1) ? 0 : (s >= 1 && s <= 8) ? ((EPI == EPI_BIAS_GELU && SU ? 2 : 1) * 2) : 0; }   // SU: fc1 + GELU also saves u
-template <int EPI> constexpr int ep_loads(int s) { return s == 0 ? 2 : 0; }          // bias: two 16-B loads per lane
-// Operations that may stay outstanding at the head of EP stage s, i.e. everything this wave has issued behind the pieces of stage s + 1 (which it
-// issued three stages earlier).  -1: the wave has no piece of that stage in flight -- no wait.
-//   ISS 0 (every wave issues): stores of s - 3, then [loads, 3 pieces, stores] of s - 2 and s - 1; stages < 0 are the previous round (ML / idle role).
-//   ISS 1 (ML team issues): the wave was ML in the previous round, so only stages 1 .. 3 of this round are its own: behind them the pieces of the
-//   previous round's later stages (6 each) and whatever the EP role has issued so far.  Its stores are never IN FRONT of a piece it waits for:
-//   vmcnt retires in order, and a store's acknowledgement takes several stage times -- with ISS 0 every operand wait of the EP role sat behind one.
-template <int EPI, bool SU> constexpr int ep_vmcnt(int s) {
-  if (ISS) {
-    if (s >= 3) return -1;
-    int n = 6 * (2 - s);
-    for (int i = 0; i < s; ++i) n += ep_loads<EPI>(i) + ep_stores<EPI, SU>(i);
-    return n;
-  }
-  int n = 6;
-  for (int d = 1; d <= 3; ++d) n += (s - d >= 0 ? ep_stores<EPI, SU>(s - d) : 0);
-  for (int d = 1; d <= 2; ++d) n += (s - d >= 0 ? ep_loads<EPI>(s - d) : 0);
-  return n;
 }
-}
+typedef unsigned int tt_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int tt_u32x4 __attribute__((ext_vector_type(4)));
 
-template <int N> DEVFN void tt_wait_tied(f32x4& a, f32x4& b) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory"); }
-DEVFN void tt_gload16x2(const void* src, f32x4& a, f32x4& b) {
-  asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16" : "=&v"(a), "=&v"(b) : "v"(src) : "memory");
+DEVFN void tt_gload16(const void* src, f32x4& a) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(a) : "v"(src) : "memory"); }
+DEVFN void tt_wait_all(f32x4 (&b)[2][4]) {
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[0][3]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[1][2]), "+v"(b[1][3]) :: "memory");
 }
-
 #ifdef ATST_TT_TRACE
-// s_memtime stamps of one block (tools/tt_trace.py): scalar stores (they do not touch vmcnt); [wave][round][stage][4] 64-bit, rounds TR0 .. TR0 + 3
+// s_memtime stamps of one block (tools/tt_trace.py): scalar stores (they do not touch vmcnt); [wave][round][stage][4] 64-bit, rounds 2 .. 5
 DEVFN void tt_stamp(unsigned long long* base, unsigned off_bytes) {
   unsigned long long t;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)\n\ts_store_dwordx2 %0, %1, %2" : "=&s"(t) : "s"(base), "s"(off_bytes) : "memory");
 }
 #endif
+
 template <int EPI, bool SU>
 __global__ __launch_bounds__(512, 2) void gemm_nt_tt_kernel(GemmArgs p, int T) {
   using namespace tt;
@@ -87,22 +67,29 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_tt_kernel(GemmArgs p, int T) {
   const int ntn = p.N / BNT;
   const int nt = rb < T ? (T - rb + G - 1) / G : 0;                 // tiles of this block: ids rb, rb + G, ...
   if (nt == 0) return;
-  const int nk = p.K / BKT;                                         // stages per tile, >= EP_STAGES (launcher)
+  const int nk = p.K / BKT;                                         // stages per tile, >= MIN_STAGES (launcher)
 #ifdef ATST_TT_TRACE
-  int tr_r = -1, tr_s = 0;                                          // round / stage of the stamps (set by the round loop / advanced by other_stream, ml_stage)
+  int tr_r = -1, tr_s = 0;
   auto stamp = [&](int k) {
     if (blockIdx.x == ATST_TT_TRACE - 1 && tr_r >= 2 && tr_r < 6 && tr_s < 48)
       tt_stamp(reinterpret_cast<unsigned long long*>(p.colsum), (unsigned)(((((wid * 4 + (tr_r - 2)) * 48 + tr_s) * 4) + k) * 8));
   };
+#define TT_NEXT_STAGE() ++tr_s
 #else
   auto stamp = [&](int) {};
+#define TT_NEXT_STAGE()
 #endif
 
-  // ---- operand stream (LDS-DMA): a stage is 16 A pieces (16 rows each) + 8 B pieces of 1 KiB; lane (lrow, chunk) of a piece fetches 16 B.
-  //   ISS 0: wave w issues A pieces w, w + 8 and B piece w.   ISS 1: wave tw of the ML team issues A pieces 4 tw .. 4 tw + 3 and B pieces 2 tw, 2 tw + 1.
-  const int lrow = lane >> 2, lch = (lane & 3) ^ ((lrow >> 2) & 3);
-  const unsigned voA = (unsigned)((lrow * p.lda + lch * 8) * 2), voB = (unsigned)((lrow * p.ldb + lch * 8) * 2);
-  const size_t pa = (size_t)16 * p.lda * 2, pb = (size_t)16 * p.ldb * 2;   // bytes between pieces
+  // ---- operand stream (LDS-DMA), issued by the ML team.  A stage = 32 A pieces + 16 B pieces of 1 KiB = 8 rows x 128 B; lane (r8, c) of a piece fetches
+  // chunk c ^ key(row) of its row, key = (row >> 1) & 7 = 4 (piece & 1) | (r8 >> 1).  Wave tw issues A pieces 8 tw .. 8 tw + 7 and B pieces 4 tw .. 4 tw + 3.
+  const int r8 = lane >> 3, c8l = lane & 7;
+  unsigned voA[2], voB[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par) {
+    const int ch = c8l ^ (4 * par + (r8 >> 1));
+    voA[par] = (unsigned)((r8 * p.lda + ch * 8) * 2); voB[par] = (unsigned)((r8 * p.ldb + ch * 8) * 2);
+  }
+  const size_t pa = (size_t)8 * p.lda * 2, pb = (size_t)8 * p.ldb * 2;     // bytes between pieces
   const unsigned lds0 = lds_addr(smem_raw);
   int cur_j = 0, cur_s = 0;
   const char* curA; const char* curB;
@@ -112,17 +99,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_tt_kernel(GemmArgs p, int T) {
     curA = sgpr_ptr(reinterpret_cast<const char*>(p.A) + (size_t)m0 * p.lda * 2);
     curB = sgpr_ptr(reinterpret_cast<const char*>(p.B) + (size_t)n0 * p.ldb * 2);
   };
-  auto dma_piece = [&](int i, int slot) {                             // i-th piece of this wave (0 .. NPW - 1) of the stage the cursor points at
-    const bool is_b = ISS ? i >= 4 : i == 2;
-    const int idx = ISS ? (is_b ? 2 * tw + (i - 4) : 4 * tw + i) : (is_b ? wid : wid + 8 * i);
+  auto dma_piece = [&](int i, int slot) {                             // i-th piece of this wave (0 .. 11) of the stage the cursor points at
+    const bool is_b = i >= 8;
+    const int idx = is_b ? 4 * tw + (i - 8) : 8 * tw + i;
     const unsigned dst = lds0 + slot * STAGE + (is_b ? A_BYTES : 0) + idx * 1024;
-#if ATST_TT_ABL & 8                                                   // whole-line sources (8 rows x 128 B per piece; stages 2 k / 2 k + 1 = upper / lower rows of k-tile k): same bytes, garbage results
-    const size_t odd = cur_s & 1;
-    const unsigned vfA = (unsigned)(((lane >> 3) * p.lda + (lane & 7) * 8) * 2), vfB = (unsigned)(((lane >> 3) * p.ldb + (lane & 7) * 8) * 2);
-    if (is_b) p8_glds16(vfB, curB + (idx + 8 * odd) * (pb / 2) - odd * 64, dst); else p8_glds16(vfA, curA + (idx + 16 * odd) * (pa / 2) - odd * 64, dst);
-    return;
-#endif
-    if (is_b) p8_glds16(voB, curB + idx * pb, dst); else p8_glds16(voA, curA + idx * pa, dst);
+    if (is_b) p8_glds16(voB[i & 1], curB + idx * pb, dst); else p8_glds16(voA[i & 1], curA + idx * pa, dst);     // (piece parity = i & 1: 8 tw and 4 tw are even)
   };
   auto dma_advance = [&]() {                                          // the stream continues into the block's next tile; past the last one it re-reads it (never consumed)
     curA += ROWB; curB += ROWB;
@@ -130,10 +111,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_tt_kernel(GemmArgs p, int T) {
   };
   int slot_c = 0;                                                     // ring slot of the stage being multiplied
   auto slot_next = [&]() { return slot_c == NS - 1 ? 0 : slot_c + 1; };
-  auto slot_issue = [&]() { return slot_c == 0 ? NS - 1 : slot_c - 1; };   // stage s + 4 goes where stage s - 1 was
+  auto slot_issue = [&]() { return slot_c == 0 ? NS - 1 : slot_c - 1; };   // stage s + 2 goes where stage s - 1 was
 
-  // ---- ML role: fragments (row l31 of a 32-row block, chunk (2 ks + hi) ^ key) and MFMAs
-  const int keyf = (l31 >> 2) & 3;
+  // ---- ML role: fragments (row l31 of a 32-row block, chunk (2 ks + hi) ^ key, key = (l31 >> 1) & 7) and MFMAs with the WEIGHT fragment as the A operand:
+  // acc[mb][nb] is the TRANSPOSE of the 32 x 32 output block -- lane l holds output row l31 (of block row mb), register r column 8 (r >> 2) + 4 hi + (r & 3).
+  const int keyf = (l31 >> 1) & 7;
   const int fA0 = (wr * 128 + l31) * ROWB + ((hi ^ keyf) << 4), fB0 = A_BYTES + (wc * 64 + l31) * ROWB + ((hi ^ keyf) << 4);
   f32x16 acc[4][2];
   auto rd = [&](int slot, int ks, bf16x8 (&fa)[4], bf16x8 (&fb)[2]) {
@@ -155,136 +137,149 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_tt_kernel(GemmArgs p, int T) {
     for (int nb = 0; nb < 2; ++nb) {
       if constexpr (FIRST) {
         const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        acc[mb][nb] = mfma32(fa[mb], fb[nb], z);
+        acc[mb][nb] = mfma32(fb[nb], fa[mb], z);
       } else {
-        acc[mb][nb] = mfma32(fa[mb], fb[nb], acc[mb][nb]);
+        acc[mb][nb] = mfma32(fb[nb], fa[mb], acc[mb][nb]);
       }
     }
   };
-  auto head = [&](auto ntag) {
-    constexpr int N = decltype(ntag)::value;
+  auto head = [&](bool wait) {
     stamp(0);
-    if constexpr (N >= 0) p8_wait_vm<(N >= 0 ? N : 0)>();
+    if (wait) p8_wait_vm<0>();
     stamp(1);
     asm volatile("s_barrier" ::: "memory");
     stamp(2);
   };
-#define TT_I(x) std::integral_constant<int, x>{}
 #define TT_B(x) std::integral_constant<bool, x>{}
 #define TT_FENCE() __builtin_amdgcn_sched_barrier(0)
 
   bf16x8 xa[4], xb[2], ya[4], yb[2];
-  // One stage of the ML role: [head] fragments of k-step 1 | 8 MFMAs of k-step 0 | fragments of the next stage's k-step 0 | 8 MFMAs of k-step 1, the wave's
-  // pieces of stage s + 4 between the MFMA pairs (a piece issued behind an MFMA pair blocks the wave while the matrix pipe is busy anyway).
-  auto ml_stage = [&](auto first, bool more) {
-    head(TT_I(2 * NPW));
+  // One stage (k-tile of 64) of the ML role: [head] then four k-steps of 8 MFMAs; the fragments of k-step ks + 1 (k-step 0 of the next stage after the third) are
+  // requested in front of the MFMAs of k-step ks; the wave's 12 pieces of stage s + 2 go between the MFMA pairs (three per k-step): a piece issued behind an
+  // MFMA pair blocks the wave while the matrix pipe is busy anyway.
+  auto ml_stage = [&](auto first, bool wait, bool more) {
+    head(wait);
     const int si = slot_issue();
     auto pc = [&](int i) { TT_FENCE(); dma_piece(i, si); TT_FENCE(); };
     rd(slot_c, 1, ya, yb);
     TT_FENCE();
-    mm2(first, 0, xa, xb); if (ISS) pc(0);
-    mm2(first, 1, xa, xb); pc(ISS ? 1 : 0);
-    mm2(first, 2, xa, xb); if (ISS) pc(2);
-    mm2(first, 3, xa, xb); if (!ISS) pc(1);
+    mm2(first, 0, xa, xb); pc(0); mm2(first, 1, xa, xb); pc(1); mm2(first, 2, xa, xb); pc(2); mm2(first, 3, xa, xb);
+    TT_FENCE();
+    rd(slot_c, 2, xa, xb);
+    TT_FENCE();
+    mm2(TT_B(false), 0, ya, yb); pc(3); mm2(TT_B(false), 1, ya, yb); pc(4); mm2(TT_B(false), 2, ya, yb); pc(5); mm2(TT_B(false), 3, ya, yb);
+    TT_FENCE();
+    rd(slot_c, 3, ya, yb);
+    TT_FENCE();
+    mm2(TT_B(false), 0, xa, xb); pc(6); mm2(TT_B(false), 1, xa, xb); pc(7); mm2(TT_B(false), 2, xa, xb); pc(8); mm2(TT_B(false), 3, xa, xb);
     TT_FENCE();
     if (more) rd(slot_next(), 0, xa, xb);                            // (stage s + 1 is visible since this stage's barrier)
     TT_FENCE();
-    mm2(TT_B(false), 0, ya, yb); if (ISS) pc(3);
-    mm2(TT_B(false), 1, ya, yb); pc(ISS ? 4 : 2);
-    mm2(TT_B(false), 2, ya, yb); if (ISS) pc(5);
-    mm2(TT_B(false), 3, ya, yb);
+    mm2(TT_B(false), 0, ya, yb); pc(9); mm2(TT_B(false), 1, ya, yb); pc(10); mm2(TT_B(false), 2, ya, yb); pc(11); mm2(TT_B(false), 3, ya, yb);
     TT_FENCE();
     dma_advance();
     slot_c = slot_next();
     stamp(3);
-#ifdef ATST_TT_TRACE
-    ++tr_s;
-#endif
+    TT_NEXT_STAGE();
   };
-  auto other_stream = [&]() {                                         // what a wave that is NOT multiplying does for the stream in one stage
-    if constexpr (!ISS) { const int si = slot_issue(); dma_piece(0, si); dma_piece(1, si); dma_piece(2, si); }
-    dma_advance();
-    slot_c = slot_next();
-  };
-  auto idle_stage = [&]() {
-    if constexpr (ISS) head(TT_I(-1)); else head(TT_I(6));
-    other_stream();
-    stamp(3);
-#ifdef ATST_TT_TRACE
-    ++tr_s;
-#endif
-  };
+  auto other_stream = [&]() { dma_advance(); slot_c = slot_next(); };      // a wave that is not multiplying only keeps its cursor in step
+  auto idle_stage = [&]() { head(false); other_stream(); stamp(3); TT_NEXT_STAGE(); };
 
   // ---- EP role
-  float* stg = reinterpret_cast<float*>(smem_raw + RING + tw * STG_WAVE);
+  char* stg = smem_raw + RING + tw * STG_WAVE;
+  const int wb0 = l31 * 128 + hi * 8 + ((l31 & 7) << 4);              // staging write: chunk ch of row l31 at (this ^ (ch << 4))
+  const int rb0 = r8 * 128 + ((c8l ^ r8) << 4);                      // staging read-back: row 8 j + r8, chunk c8l
+  const unsigned vst = (unsigned)((r8 * p.ldc + c8l * 8) * 2);         // byte offset of this lane's 16-B piece inside an 8-row group of the output
   int ep_m0 = 0, ep_n0 = 0;
-  f32x4 bia0, bia1;
-  auto ep_stage = [&](auto stag, auto fintag) {
-    constexpr int S = decltype(stag)::value;
-    constexpr bool FIN = decltype(fintag)::value;                   // the block's last round: nothing is multiplied any more -- no stream, no barrier
-    if constexpr (!FIN) head(TT_I((ep_vmcnt<EPI, SU>(S))));
-    if constexpr (S == 0) {                                          // bias of this lane's 8 columns (a valid dummy address when the GEMM has none)
-      const int col = ep_n0 + wc * 64 + (lane & 7) * 8;
-      const float* src = p.bias ? p.bias + col : reinterpret_cast<const float*>(p.B) + (lane & 7) * 8;
-      tt_gload16x2(src, bia0, bia1);
-    }
-    if constexpr (!FIN) other_stream();
-    if constexpr (S == 1) {                                          // behind the bias loads: (ISS 0) 3 pieces of stage 0, 3 of stage 1
-      if constexpr (FIN || ISS) tt_wait_tied<0>(bia0, bia1); else tt_wait_tied<6>(bia0, bia1);
-      if (!p.bias) { bia0 = f32x4{0.f, 0.f, 0.f, 0.f}; bia1 = bia0; }
-    }
-#if ATST_TT_ABL & 1
-    return;
-#endif
-    if constexpr (S >= 1 && S <= 8) {                                // read back + store: block row q, local rows 8 j + (lane >> 3), 8 columns per lane
-      constexpr int q = (S - 1) / 2, jb = ((S - 1) & 1) * 2;
+  f32x4 bb[2][4];                                                     // bias of this lane's columns: [nb][g] = columns nb * 32 + 8 g + 4 hi .. + 3 of the wave's 64
+  // Block row q of the tile as an ITEM: values -> bf16 -> staging (C) ... read back (R) ... whole-line stores (S).  PASS 0: acc + bias (plain output /
+  // pre-activation u) ; PASS 1: GELU of it.  The three steps of an item sit in different places of the instruction stream (v2a: with C, R, S of one item
+  // back to back a slice took 2.1-2.5 k cycles -- three exposed round trips through an LDS / vector-memory system the other team keeps saturated):
+  // an item is read back while the next one is computed, and stored a stage after it was staged.
+  auto ep_C = [&](auto qtag, auto passtag) __attribute__((always_inline)) {
+    constexpr int q = decltype(qtag)::value, PASS = decltype(passtag)::value;
 #pragma unroll
-      for (int j = jb; j < jb + 2; ++j) {
-        const int rl = j * 8 + (lane >> 3), c8 = (lane & 7) * 8;
-        f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + rl * SP + c8) + bia0;
-        f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + rl * SP + c8 + 4) + bia1;
-        const size_t idx = (size_t)(ep_m0 + wr * 128 + q * 32 + rl) * p.ldc + ep_n0 + wc * 64 + c8;
-        if constexpr (EPI == EPI_BF16) {
-          const float t[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-          st_pol<6>(pack8(t), reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.C) + idx));
-        } else if constexpr (EPI == EPI_BIAS_GELU) {
-          const float t[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-          if constexpr (SU) st_pol<0>(pack8(t), reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.C) + idx));        // pre-activation u (training)
-          float g[8];
+    for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-          for (int e = 0; e < 8; e += 2) { const f32x2 a = gelu_bf16dst2(f32x2{t[e], t[e + 1]}); g[e] = a[0]; g[e + 1] = a[1]; }
-          st_pol<5>(pack8(g), reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.C2) + idx));
+      for (int g = 0; g < 4; ++g) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[q][nb][4 * g + e] + bb[nb][g][e];
+        if constexpr (PASS == 1) {
+          const f32x2 a0 = gelu_bf16dst2(f32x2{v[0], v[1]}), a1 = gelu_bf16dst2(f32x2{v[2], v[3]});
+          v[0] = a0[0]; v[1] = a0[1]; v[2] = a1[0]; v[3] = a1[1];
         }
+        *reinterpret_cast<tt_u32x2*>(stg + (wb0 ^ ((nb * 4 + g) << 4))) = __builtin_bit_cast(tt_u32x2, pack_bf16x4(v));
       }
-    }
-    if constexpr (S % 2 == 0 && S <= 6) {                            // stage the next block row (LDS operations of a wave execute in order: behind the reads above)
-      constexpr int q = S / 2;
+  };
+  auto ep_R = [&](tt_u32x4 (&w)[4]) __attribute__((always_inline)) {   // (LDS operations of a wave execute in order: the reads see the item staged before them, the next item's writes follow them)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = *reinterpret_cast<const tt_u32x4*>(stg + rb0 + j * 1024);
+  };
+  auto ep_S = [&](int q, const tt_u32x4 (&w)[4], void* out) __attribute__((always_inline)) {
+    char* obase = reinterpret_cast<char*>(out) + ((size_t)(ep_m0 + wr * 128 + q * 32) * p.ldc + ep_n0 + wc * 64) * 2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) __builtin_nontemporal_store(w[j], reinterpret_cast<tt_u32x4*>(obase + (size_t)j * 8 * p.ldc * 2 + vst));
+  };
+  tt_u32x4 wq[4];                                                     // an item between its read-back and its stores
+  constexpr std::integral_constant<int, 0> P0{}; constexpr std::integral_constant<int, 1> P1{};
+  auto ep_stage = [&](auto stag, bool fin) __attribute__((always_inline)) {   // fin: the block's last round -- nothing is multiplied any more: no barrier
+    constexpr int S = decltype(stag)::value;
+    if (!fin) head(S == 0);                                          // S == 0: this wave multiplied in the previous round and its pieces of stage 1 are still in flight
+    if constexpr (S == 0) {
+      const float* src = p.bias ? p.bias + ep_n0 + wc * 64 + 4 * hi : reinterpret_cast<const float*>(p.B) + 4 * hi;     // (a valid dummy address when the GEMM has no bias)
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) stg[crow32(r, hi) * SP + nb * 32 + l31] = acc[q][nb][r];
+        for (int g = 0; g < 4; ++g) tt_gload16(src + nb * 32 + 8 * g, bb[nb][g]);
     }
-  };
-  auto ep_round = [&](auto fintag) {
-#ifdef ATST_TT_TRACE
-    static_for<EP_STAGES>([&](auto s) { ep_stage(s, fintag); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp(3); ++tr_s; });
-#else
-    static_for<EP_STAGES>([&](auto s) { ep_stage(s, fintag); });
+    if (!fin) other_stream();
+    if constexpr (S == 1) {
+      tt_wait_all(bb);
+      if (!p.bias) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) bb[nb][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+#if !(ATST_TT_ABL & 1)
+    constexpr std::integral_constant<int, (S >= 1 && S <= 4) ? S - 1 : 0> qc{};      // the block row staged in this stage
+    if constexpr (EPI == EPI_BIAS_GELU && SU) {
+      // items u0 a0 u1 a1 ... : stage S stages u(q), a(q) of q = S - 1, reads back a(q - 1), u(q), stores a(q - 1), u(q); stage 5: a(3)
+      if constexpr (S >= 2 && S <= 5) ep_R(wq);                      // a(q - 1)
+      if constexpr (S >= 1 && S <= 4) ep_C(qc, P0);
+      if constexpr (S >= 2 && S <= 5) ep_S(S - 2, wq, p.C2);
+      if constexpr (S >= 1 && S <= 4) { ep_R(wq); ep_C(qc, P1); ep_S(S - 1, wq, p.C); }
+    } else {
+      constexpr bool gelu = EPI == EPI_BIAS_GELU;
+      if constexpr (S >= 2 && S <= 5) ep_R(wq);
+      if constexpr (S >= 1 && S <= 4) { if constexpr (gelu) ep_C(qc, P1); else ep_C(qc, P0); }
+      if constexpr (S >= 2 && S <= 5) ep_S(S - 2, wq, gelu ? p.C2 : p.C);
+    }
 #endif
-    if constexpr (!decltype(fintag)::value) { for (int s = EP_STAGES; s < nk; ++s) idle_stage(); }
+#ifdef ATST_TT_TRACE
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+    stamp(3);
+    TT_NEXT_STAGE();
+  };
+  auto ep_round = [&](bool fin) __attribute__((always_inline)) {
+    static_for<6>([&](auto s) __attribute__((always_inline)) { ep_stage(s, fin); });
+    if (!fin) { for (int s = 6; s < nk; ++s) idle_stage(); }
   };
 
-  // ---- prologue: stages 0 .. 3 of the stream (ISS 1: issued by team 0, which multiplies first); stage 0 visible
+  // ---- prologue: stages 0 and 1 of the stream, issued by team 0 (which multiplies first); stage 0 visible
   set_tile(0);
 #pragma unroll
   for (int st = 0; st < NS - 1; ++st) {
-    if (!ISS || team == 0) {
+    if (team == 0) {
 #pragma unroll
       for (int i = 0; i < NPW; ++i) dma_piece(i, st);
     }
     dma_advance();
   }
-  p8_wait_vm<3 * NPW>();
+  p8_wait_vm<NPW>();
   asm volatile("s_barrier" ::: "memory");
 
   for (int r = 0; r <= nt; ++r) {
@@ -295,15 +290,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_tt_kernel(GemmArgs p, int T) {
       if (r < nt) {                                                  // ML: tile r
         if (ATST_TT_PRIO == 1) __builtin_amdgcn_s_setprio(2);
         rd(slot_c, 0, xa, xb);
-        ml_stage(TT_B(true), true);
-        for (int s = 1; s < nk; ++s) ml_stage(TT_B(false), s + 1 < nk);
+        ml_stage(TT_B(true), r == 0, true);                          // (stage 1 of a later round was issued -- and is waited for -- by the other team)
+        for (int s = 1; s < nk; ++s) ml_stage(TT_B(false), true, s + 1 < nk);
         if (ATST_TT_PRIO == 1) __builtin_amdgcn_s_setprio(0);
       }                                                              // (r == nt: this team has nothing left -- the other one stores the last tile alone)
     } else {
       if (r >= 1) {                                                  // EP: tile r - 1
         tile_mn(r - 1, ep_m0, ep_n0);
         if (ATST_TT_PRIO == 2) __builtin_amdgcn_s_setprio(2);
-        if (r < nt) ep_round(TT_B(false)); else ep_round(TT_B(true));
+        ep_round(r == nt);
         if (ATST_TT_PRIO == 2) __builtin_amdgcn_s_setprio(0);
       } else {
         for (int s = 0; s < nk; ++s) idle_stage();                   // round 0: nothing to store yet
@@ -313,7 +308,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_tt_kernel(GemmArgs p, int T) {
 #ifdef ATST_TT_TRACE
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb" ::: "memory");
 #endif
-#undef TT_I
 #undef TT_B
 #undef TT_FENCE
+#undef TT_NEXT_STAGE
 }

@@ -189,13 +189,13 @@ def test_gemm_nt_p8_phased_kernel(M, N, K):
         assert relerr(got.float(), other.float()) < 4e-3
 
 
-@pytest.mark.parametrize("M,N,K", [(768, 128, 384), (8192, 1152, 384), (16384, 1536, 384), (2048, 384, 1536), (256, 256, 416), (65536 + 256, 128, 384),
+@pytest.mark.parametrize("M,N,K", [(768, 128, 384), (8192, 1152, 384), (16384, 1536, 384), (2048, 384, 1536), (256, 256, 448), (65536 + 256, 128, 384),
                                    (4096, 768, 768)])
 def test_gemm_nt_two_team_kernel(M, N, K):
     """The persistent two-team kernel (csrc/gemm_tt.h; hook 2001 on / 2000 off; hook 351 admits it below 8192 rows): the epilogue of tile i is stored by
     one team of four waves while the other team multiplies tile i + 1.  Tile counts of 3 (253 of 256 blocks idle), 24, 96, 257 (one block with two
-    rounds, the others one), 288, 768 (three rounds per block: both teams in both roles) ; K = 384 (12 stages: every stage carries an epilogue slice),
-    416 (one idle stage), 768, 1536.  Against the fp32 formulas and against the kernels it replaces."""
+    rounds, the others one), 288, 768 (three rounds per block: both teams in both roles) ; K = 384 (6 stages of 64),
+    448 (seven stages of 64), 768, 1536.  Against the fp32 formulas and against the kernels it replaces."""
     lib = hip.load()
     A, B = bf(rnd(M, K, seed=1, scale=0.5)), bf(rnd(N, K, seed=2, scale=0.5))
     bias = rnd(N, seed=3)

@@ -21,7 +21,7 @@ for _ in range(3):
              hip.ptr(dbg.view(torch.float32)), hip.stream())
 torch.cuda.synchronize()
 t = dbg.cpu().view(8, 4, 48, 4).numpy().astype(np.int64)
-nk = min(K // 32, 48)
+nk = min(K // 64, 48)
 t0 = t[t > 0].min()
 print(f"N={N} K={K} epi={epi} nk={nk}: cycles; rounds 2..5; role of team 0 = ML in even rounds")
 for r in range(4):
