@@ -1207,12 +1207,12 @@ template <int NP> int dkv_lds() { return Geo<NP>::G * (2 * Geo<NP>::LDS_MAT * 2 
 
 template <int NP>
 int launch_fwd(const AttnArgs& a, hipStream_t st) {
-  static bool done = false;
+  static OncePerDevice done; int done_dev;
   const int lds = fwd_lds<NP>();
-  if (!done) {
+  if (done.need(done_dev)) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
-    done = true;
+    done.done(done_dev);
   }
   const int nblk = (a.S * a.H + Geo<NP>::G - 1) / Geo<NP>::G;
   ProfScope ps(PK_ATTN_FWD, 4.0 * a.S * a.H * (double)NP * NP * HD, st, 8.0 * a.S * a.H * (double)NP * HD);     // QK^T + PV on the padded geometry
@@ -1221,14 +1221,14 @@ int launch_fwd(const AttnArgs& a, hipStream_t st) {
 }
 template <int NP>
 int launch_bwd(const AttnArgs& a, hipStream_t st) {
-  static bool done = false;
+  static OncePerDevice done; int done_dev;
   const int lds1 = dkv_lds<NP>(), lds2 = fwd_lds<NP>();
-  if (!done) {
+  if (done.need(done_dev)) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
     if (e != hipSuccess) return (int)e;
-    done = true;
+    done.done(done_dev);
   }
   const int nblk = (a.S * a.H + Geo<NP>::G - 1) / Geo<NP>::G;
   {
@@ -1257,13 +1257,13 @@ int atst_attn_fwd(const AttnArgs& a, hipStream_t st) {
   if (a.o8 ? !atst_attn_fwd_q8_ok(a.NP, a.H) : !a.o) return ATST_EINVAL;
   if (a.stride < 0 || a.stride > a.NP || (a.NP == 256 && a.stride != 0 && a.stride != 256)) return ATST_EINVAL;   // packed sequences: NP < 256 kernels only
   if (a.NP == 256 && g_fwd256 == 2 && (size_t)a.NP * 3 * a.H * HD * 2 < (1u << 30)) {
-    static bool done2 = false;
-    if (!done2) {
+    static OncePerDevice done2; int done2_dev;
+    if (done2.need(done2_dev)) {
       hipError_t e = hipFuncSetAttribute((const void*)attn_fwd256v2_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * F2_BUF);
       if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_fwd256v2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * F2_BUF);
       if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_fwd256v2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * F2_BUF);
       if (e != hipSuccess) return (int)e;
-      done2 = true;
+      done2.done(done2_dev);
     }
     ProfScope ps(PK_ATTN_FWD, 4.0 * a.S * a.H * 256.0 * 256.0 * HD, st, (6.0 + (a.o ? 2.0 : 0.0) + (a.o8 ? 1.0 : 0.0)) * a.S * a.H * 256.0 * HD);
     if (a.o8 && !a.o) hipLaunchKernelGGL(attn_fwd256v2_kernel<2>, dim3(a.S), dim3(512), 2 * F2_BUF, st, a);
@@ -1272,11 +1272,11 @@ int atst_attn_fwd(const AttnArgs& a, hipStream_t st) {
     return (int)hipGetLastError();
   }
   if (a.NP == 256 && g_fwd256) {
-    static bool done = false;
-    if (!done) {
+    static OncePerDevice done; int done_dev;
+    if (done.need(done_dev)) {
       hipError_t e = hipFuncSetAttribute((const void*)attn_fwd256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * F256_BUF);
       if (e != hipSuccess) return (int)e;
-      done = true;
+      done.done(done_dev);
     }
     ProfScope ps(PK_ATTN_FWD, 4.0 * a.S * a.H * 256.0 * 256.0 * HD, st, 8.0 * a.S * a.H * 256.0 * HD);
     hipLaunchKernelGGL(attn_fwd256_kernel, dim3(a.S), dim3(512), 2 * F256_BUF, st, a);
@@ -1297,12 +1297,12 @@ int atst_attn_bwd(const AttnArgs& a, hipStream_t st) {
   if (a.dqkv8 && !(atst_attn_bwd_q8_ok(a.NP) && a.dscratch)) return ATST_EINVAL;
   if (a.stride < 0 || a.stride > a.NP || (a.NP == 256 && a.stride != 0 && a.stride != 256)) return ATST_EINVAL;
   if (a.NP == 256 && g_bwd256 && a.dscratch) {
-    static bool done = false;
-    if (!done) {
+    static OncePerDevice done; int done_dev;
+    if (done.need(done_dev)) {
       hipError_t e = hipFuncSetAttribute((const void*)attn_bwd256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, B256_LDS);
       if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, B256_LDS);
       if (e != hipSuccess) return (int)e;
-      done = true;
+      done.done(done_dev);
     }
     const long rows = (long)a.S * 256;
     {
@@ -1320,11 +1320,11 @@ int atst_attn_bwd(const AttnArgs& a, hipStream_t st) {
   }
   if (a.NP == 32 && g_bwd32) {                                     // one wave per (sequence, head): both halves from one staging pass
     constexpr int LDS32 = 4 * (4 * 32 * A_LD * 2 + 2 * 32 * 4);
-    static bool done32 = false;
-    if (!done32) {
+    static OncePerDevice done32; int done32_dev;
+    if (done32.need(done32_dev)) {
       hipError_t e = hipFuncSetAttribute((const void*)attn_bwd32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS32);
       if (e != hipSuccess) return (int)e;
-      done32 = true;
+      done32.done(done32_dev);
     }
     ProfScope ps(PK_ATTN_BWD_DKV, 18.0 * a.S * a.H * 32.0 * 32.0 * HD, st, 16.0 * a.S * a.H * 32.0 * HD);
     hipLaunchKernelGGL(attn_bwd32_kernel, dim3((a.S * a.H + 3) / 4), dim3(256), LDS32, st, a);

@@ -231,12 +231,12 @@ __global__ __launch_bounds__(256) void attn_hp_bwd_kernel(const float* __restric
   for (int d = 0; d < 64; ++d) { out[C + d] = dk[d]; out[2 * C + d] = dv[d]; }
 }
 static int hp_attn_lds_attr(int NP) {                               // dynamic LDS beyond 64 KB needs the attribute (once per kernel)
-  static bool done = false;
-  if (done) return ATST_OK;
+  static OncePerDevice done; int done_dev;
+  if (!done.need(done_dev)) return ATST_OK;
   hipError_t e = hipFuncSetAttribute((const void*)attn_hp_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 64 * 4);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_hp_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * 256 * 64 + 2 * 256) * 4);
   if (e != hipSuccess) return (int)e;
-  done = true; (void)NP;
+  done.done(done_dev); (void)NP;
   return ATST_OK;
 }
 

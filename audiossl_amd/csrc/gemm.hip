@@ -1725,21 +1725,21 @@ static bool build_wgrad_map(WgradGroup& g, int splits, int nblk) {
 int g_tn_map = 1;           // 130/131: grouped wgrad: (problem, split) groups packed onto XCDs (131, default) / round-3 order tile + ntiles * split (130)
 int g_tn_cfg = 1;           // 120 + c: wgrad schedule: 0 = every wave issues behind the hand-off ; 1 = wave rows staggered (default) ; 2 = 32-row stages, 4-deep ring
 template <class C> int launch_tn_tall(const WgradArgs& p, int nblk, hipStream_t st) {
-  static bool attr = false;
-  if (!attr) {
+  static OncePerDevice attr; int attr_dev;
+  if (attr.need(attr_dev)) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_tall_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
     if (e != hipSuccess) return (int)e;
-    attr = true;
+    attr.done(attr_dev);
   }
   hipLaunchKernelGGL(gemm_tn_tall_kernel<C>, dim3(nblk), dim3(C::THREADS), C::LDS, st, p);
   return (int)hipGetLastError();
 }
 template <class C> int launch_tn_tall_group(const WgradGroup& g, int nblk, hipStream_t st) {
-  static bool attr = false;
-  if (!attr) {
+  static OncePerDevice attr; int attr_dev;
+  if (attr.need(attr_dev)) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_tall_group_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
     if (e != hipSuccess) return (int)e;
-    attr = true;
+    attr.done(attr_dev);
   }
   hipLaunchKernelGGL(gemm_tn_tall_group_kernel<C>, dim3(nblk), dim3(C::THREADS), C::LDS, st, g);
   return (int)hipGetLastError();
@@ -1817,11 +1817,11 @@ template <int EPI> constexpr int prof_kind() { return EPI == EPI_LNBWD ? PK_GEMM
 template <int EPI, int BMT, int NSTG, int WTM, bool KS = false>
 int launch_nt_cfg(const GemmArgs& a, hipStream_t st) {
   using G = NtGeo<BMT, NSTG, WTM>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static OncePerDevice attr_done; int attr_done_dev;
+  if (attr_done.need(attr_done_dev)) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, BMT, NSTG, WTM, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
     if (e != hipSuccess) return (int)e;
-    attr_done = true;
+    attr_done.done(attr_done_dev);
   }
   const int nblk = ((a.M + BMT - 1) / BMT) * (a.N / BN) * (KS ? a.ksplit : 1);
   ProfScope ps(prof_kind<EPI>(), 2.0 * a.M * a.N * a.K, st, nt_bytes<EPI>(a));
@@ -1832,11 +1832,11 @@ template <int EPI, int MI, bool LN, bool F8 = false, bool TR = false, bool PH = 
 int launch_nt_row384_cfg(const GemmArgs& a, hipStream_t st) {
   using RG = row384::Geo<MI>;
   constexpr int LDS = TR ? RG::NSTG * RG::STAGE + row384::BNR * 4 : row384::lds_bytes<MI, EPI, LN>();
-  static bool attr_done = false;
-  if (!attr_done) {
+  static OncePerDevice attr_done; int attr_done_dev;
+  if (attr_done.need(attr_done_dev)) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_row384_kernel<EPI, MI, LN, F8, TR, PH>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return (int)e;
-    attr_done = true;
+    attr_done.done(attr_done_dev);
   }
   const int nblk = ((a.M + RG::BMR - 1) / RG::BMR) * (a.N / row384::BNR);
   hipLaunchKernelGGL((gemm_nt_row384_kernel<EPI, MI, LN, F8, TR, PH>), dim3(nblk), dim3(row384::THREADS), LDS, st, a);
@@ -1847,11 +1847,11 @@ int launch_nt_w4_cfg(const GemmArgs& a, hipStream_t st) {
   using G = w4::Geo<WM>;
   constexpr int LDS = G::template lds_bytes<EPI, LN>();
   static_assert(LDS <= 81920, "two blocks per CU");
-  static bool attr_done = false;
-  if (!attr_done) {
+  static OncePerDevice attr_done; int attr_done_dev;
+  if (attr_done.need(attr_done_dev)) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<EPI, WM, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return (int)e;
-    attr_done = true;
+    attr_done.done(attr_done_dev);
   }
   const int nblk = ((a.M + G::BM - 1) / G::BM) * (a.N / G::BNB);
   hipLaunchKernelGGL((gemm_nt_w4_kernel<EPI, WM, LN>), dim3(nblk), dim3(256), LDS, st, a);
@@ -1859,12 +1859,12 @@ int launch_nt_w4_cfg(const GemmArgs& a, hipStream_t st) {
 }
 template <int EPI, bool F8 = false>
 int launch_nt_p8(const GemmArgs& a, hipStream_t st) {
-  static bool attr_done = false;
+  static OncePerDevice attr_done; int attr_done_dev;
   constexpr int lds = p8::RING;
-  if (!attr_done) {
+  if (attr_done.need(attr_done_dev)) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_p8_kernel<EPI, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
-    attr_done = true;
+    attr_done.done(attr_done_dev);
   }
   ProfScope ps(prof_kind<EPI>(), (F8 ? 4.0 : 2.0) * a.M * a.N * a.K, st, nt_bytes<EPI>(a));      // F8: K counts byte pairs here
   GemmArgs b = a; b.skew = g_p8_skew;
@@ -1894,12 +1894,11 @@ int tt_num_cus() {
 }
 template <int EPI, bool SU>
 int launch_nt_tt_cfg(const GemmArgs& a, hipStream_t st) {
-  static bool attr_done[16] = {false};
-  int dev = 0; (void)hipGetDevice(&dev); dev = dev < 0 || dev >= 16 ? 0 : dev;
-  if (!attr_done[dev]) {
+  static OncePerDevice attr_done; int dev;
+  if (attr_done.need(dev)) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_tt_kernel<EPI, SU>, hipFuncAttributeMaxDynamicSharedMemorySize, tt::LDS_BYTES);
     if (e != hipSuccess) return (int)e;
-    attr_done[dev] = true;
+    attr_done.done(dev);
   }
   const int T = (a.M / tt::BM) * (a.N / tt::BNT);
   ProfScope ps(prof_kind<EPI>(), 2.0 * a.M * a.N * a.K, st, nt_bytes<EPI>(a));
@@ -2082,11 +2081,11 @@ int atst_gemm_tn(const WgradArgs& a, hipStream_t st) {
   const int splits = (p.M + p.m_per_split - 1) / p.m_per_split;
   const int nblk = tiles * splits;
   ProfScope ps(PK_GEMM_TN, 2.0 * p.M * p.N * p.K, st, 2.0 * p.M * ((double)p.N + p.K) + 4.0 * p.N * p.K);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static OncePerDevice attr_done; int attr_done_dev;
+  if (attr_done.need(attr_done_dev)) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WGRAD_LDS_BYTES);
     if (e != hipSuccess) return (int)e;
-    attr_done = true;
+    attr_done.done(attr_done_dev);
   }
   hipLaunchKernelGGL(gemm_tn_kernel, dim3(nblk), dim3(256), WGRAD_LDS_BYTES, st, p);
   return (int)hipGetLastError();

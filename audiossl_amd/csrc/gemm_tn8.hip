@@ -188,7 +188,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(Wgrad8Args p) {
 // The e4m3 weight gradients of ONE transformer block in one launch (the four Linears share M and the M-split): what a launch pays besides its MFMAs is
 // the fp32 atomics that combine the M-splits -- splits x 4 N K bytes per problem, and a problem launched alone needs ~512 / tiles splits to fill two rounds
 // of the chip: 132 MB of atomics for EVERY problem, 59-88 us each (tools/tn8_ablate.sh: 21 % of fc1's launch, 59 % of proj's).  Together the four
-// problems are 108 tiles: 7 splits fill three rounds, and the atomics of all four are 198 MB instead of 528.
+// problems are 108 tiles: 2 splits = 216 blocks fill ONE round (84 % of the CUs) with 57 MB of atomics for all four -- measured best of 1 / 2 / 3 / 7 / 14
+// splits (872 / 473-499 / 658 / 495-520 / 555-580 us, profiles/r05_tn8_group_splits.txt); the launcher below picks it.
 struct Wgrad8Group { Wgrad8Args it[4]; int first_tile[5]; int n; };
 __global__ __launch_bounds__(512, 2) void gemm_tn8_group_kernel(Wgrad8Group g) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -217,11 +218,11 @@ int atst_gemm_tn8(const uint8_t* dY8, const uint8_t* X8, int M, int N, int K, in
   if (mps < 4 * RM8) mps = 4 * RM8;
   a.m_per_split = mps;
   splits = (M + mps - 1) / mps;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static OncePerDevice attr_done; int attr_done_dev;
+  if (attr_done.need(attr_done_dev)) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_tn8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NSTG8 * STG);
     if (e != hipSuccess) return (int)e;
-    attr_done = true;
+    attr_done.done(attr_done_dev);
   }
   ProfScope ps(PK_GEMM_TN, 2.0 * M * N * K, st, (double)M * ((double)N + K) + 4.0 * N * K);
   hipLaunchKernelGGL(gemm_tn8_kernel, dim3(tiles * splits), dim3(512), NSTG8 * STG, st, a);
@@ -252,11 +253,11 @@ int atst_gemm_tn8_group(const Wgrad8Item* items, int n, int M, hipStream_t st) {
   if (mps < 4 * RM8) mps = 4 * RM8;
   splits = (M + mps - 1) / mps;
   for (int i = 0; i < n; ++i) g.it[i].m_per_split = mps;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static OncePerDevice attr_done; int attr_done_dev;
+  if (attr_done.need(attr_done_dev)) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_tn8_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NSTG8 * STG);
     if (e != hipSuccess) return (int)e;
-    attr_done = true;
+    attr_done.done(attr_done_dev);
   }
   ProfScope ps(PK_GEMM_TN, flops, st, bytes);
   hipLaunchKernelGGL(gemm_tn8_group_kernel, dim3(tiles * splits), dim3(512), NSTG8 * STG, st, g);

@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_FP8_TFLOPS = 5000.0       # dense e4m3 MFMA peak (same table): what a kernel on v_mfma_scale_f32_32x32x64_f8f6f4 is priced against
 PEAK_HBM_GBS = 8000.0
 
 
@@ -279,6 +280,11 @@ def main():
     roof, kernels, step_hbm = None, [], None
     ridge = PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)              # FLOP per HBM byte where the two roofs meet
 
+    def is_fp8_kernel(name):
+        """In an fp8 pass the encoder GEMMs (every nt epilogue but the fp32-output head Linears and the patch embed) and the weight gradients of a
+        block run on e4m3 operands (v_mfma_scale_f32_32x32x64_f8f6f4); a few small launches of the same class (heads, patch weight gradient) stay bf16."""
+        return (name.startswith("gemm_nt_kernel<") and not name.startswith(("gemm_nt_kernel<1", "gemm_nt_kernel<5"))) or name == "gemm_tn_kernel"
+
     def kernel_table():
         """Per-kernel-class table from the in-library HIP-event records collected since the last call (clears them)."""
         nk = lib.atst_profile_kinds()
@@ -405,15 +411,22 @@ def main():
             rec = {"workload": WORKLOAD_NAMES[wl].replace("small", arch) + (", 10s@32kHz, 128 mel, 128 x 8 patches" if hires else ", 10s@16kHz"),
                    "arch": arch, "dtype": DTYPE_NAMES[dtype], "clips_per_gpu": B, "steps": n_t, "warmup": n_w, "value": round(v2, 2), "unit": "clips/s",
                    "ms_per_step": round(dt2 / n_t * 1e3, 3), "flops_per_clip_G": round(fpc2 / 1e9, 2),
-                   "mfma_roofline_frac_step": round(v2 * fpc2 / 1e12 / PEAK_BF16_TFLOPS, 4)}
+                   "mfma_roofline_frac_step": round(v2 * fpc2 / 1e12 / PEAK_BF16_TFLOPS, 4), "mfma_roofline_frac_step_peak": "bf16 dense (2500 TFLOP/s)"}
+            if dtype == "fp8":                                      # the same step priced against the peak of the dtype its GEMMs run in
+                rec["mfma_roofline_frac_step_of_bf16_peak"] = rec["mfma_roofline_frac_step"]
+                rec["mfma_roofline_frac_step_of_dtype_peak"] = round(v2 * fpc2 / 1e12 / PEAK_FP8_TFLOPS, 4)
             if tab:
                 d2 = tab[0]
-                pk = PEAK_BF16_TFLOPS if d2["bound"] == "mfma" else PEAK_HBM_GBS
+                f8k = dtype == "fp8" and d2["bound"] == "mfma" and is_fp8_kernel(d2["kernel"])
+                pk = (PEAK_FP8_TFLOPS if f8k else PEAK_BF16_TFLOPS) if d2["bound"] == "mfma" else PEAK_HBM_GBS
                 rec["dominant_kernel"] = {"kernel": d2["kernel"], "bound": d2["bound"], "achieved": d2["achieved"], "unit": d2["unit"], "peak": pk,
                                           "frac": round(d2["achieved"] / pk, 4), "avg_launch_us": d2["avg_us"],
                                           "share_of_timed_kernel_ms": round(d2["total_ms"] / sum(r["total_ms"] for r in tab), 3), "timed_one_launch_in": 5}
+                if f8k:
+                    rec["dominant_kernel"]["peak_is"] = "e4m3 dense MFMA"
+                    rec["dominant_kernel"]["frac_of_bf16_peak"] = round(d2["achieved"] / PEAK_BF16_TFLOPS, 4)
                 if "tflops" in d2:
-                    rec["dominant_kernel"]["mfma_frac"] = round(d2["tflops"] / PEAK_BF16_TFLOPS, 4)
+                    rec["dominant_kernel"]["mfma_frac"] = round(d2["tflops"] / (PEAK_FP8_TFLOPS if f8k else PEAK_BF16_TFLOPS), 4)
             also.append(rec)
             del eng2, step2
             torch.cuda.empty_cache()

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round measurement pass on the GPU box: bench lines, rocprofv3 kernel stats of the default bench command, PMC traffic passes.
 # usage (inside gpurun): bash tools/round_measure.sh <tag>
-tag=${1:-r05}
+# The rocprofv3 passes run `bench.py --no-also`: the kernel stats are the headline workload's alone (round 5's mixed in the five `also` workloads).
+tag=${1:-r06}
 head=${2:-$(cat tools/.head 2>/dev/null || echo unknown)}      # the GPU box has no .git: pass HEAD as $2 (or write tools/.head before the call)
 out=gpurun_out/$tag
 mkdir -p $out
@@ -9,9 +10,9 @@ export TMPDIR=/tmp
 timeout 600 python bench.py > $out/bench_clip6.json 2> $out/bench_clip6.err
 timeout 300 python bench.py --workload clip2 --no-cpu-baseline > $out/bench_clip2.json 2> $out/bench_clip2.err
 timeout 300 python bench.py --workload frame --no-cpu-baseline > $out/bench_frame.json 2> $out/bench_frame.err
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o clip6 -- python3 bench.py > $out/bench_clip6_under_rocprof.json 2> $out/prof.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o clip6 -- python3 bench.py --no-also > $out/bench_clip6_under_rocprof.json 2> $out/prof.err
 # the same command with the second stream off (ATST_OVERLAP_LT=0): per-kernel durations without the time a launch shares the chip with the other chain
-ATST_OVERLAP_LT=0 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_excl -o clip6_exclusive -- python3 bench.py --no-cpu-baseline > $out/bench_clip6_exclusive_under_rocprof.json 2> $out/prof_excl.err
+ATST_OVERLAP_LT=0 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_excl -o clip6_exclusive -- python3 bench.py --no-cpu-baseline --no-also > $out/bench_clip6_exclusive_under_rocprof.json 2> $out/prof_excl.err
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o f -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile > /dev/null 2> $out/pmc_fetch.err
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o w -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile > /dev/null 2> $out/pmc_write.err
 python tools/traffic_from_pmc.py $out/pmc_fetch $out/pmc_write $out/traffic_clip6.json clip6 "$head" 3
