@@ -390,7 +390,8 @@ def main():
         del eng, step
         torch.cuda.empty_cache()
         for wl, arch, dtype, hires in (("frame", "small", "bf16", False), ("clip2", "small", "bf16", False), ("clip2", "base", "bf16", False),
-                                       ("clip2", "base", "fp8", False), ("clip2", "base", "fp8", True)):
+                                       ("clip2", "base", "fp8", False), ("clip2", "base", "fp8", True),
+                                       ("frame", "base", "bf16", False), ("frame", "base", "fp8", False)):   # ATST-Frame base: the reference's train_base.sh recipe
             if (wl, arch, dtype, hires) == headline:
                 continue
             n_w, n_t = 3, args.also_steps

@@ -483,8 +483,50 @@ def gen_base_step(name="base_2views_depth2"):
     save(name, **arrs)
 
 
+def gen_frame_base(name="frame_base_depth2"):
+    """ATST-Frame *base* (methods/atstframe/train_base.sh:4-17, audio_transformer.py:287-288: FrameAST(embed_dim 768, 12 heads)) at depth 2: the
+    reference's frame MultiCropWrapper + ByolLoss(symmetric) around it (model.py:24-76), B = 8 sequences per view with ragged lengths, one block mask per
+    sequence shared by both views -- ~2.6 k masked head rows through the 768 -> 4096 -> 256 heads.  Assembled from its parts like gen_frame."""
+    import audio_transformer as fat      # methods/atstframe/audio_transformer.py
+    import byol as fbyol                 # methods/atstframe/byol.py
+    depth, B = 2, 8
+    mk = lambda: fat.FrameAST(patch_h=64, patch_w=4, embed_dim=768, depth=depth, num_heads=12, qkv_bias=False,
+                              norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), pos_type="cut", patch_embed="Linear")
+    torch.manual_seed(5)
+    student = fbyol.MultiCropWrapper(mk(), 768, predictor=True)
+    teacher = fbyol.MultiCropWrapper(mk(), 768, predictor=False)
+    loss_fn = fbyol.ByolLoss(symmetric=True)
+    W = O.recipe_weights("base", depth=depth, frame=True, seed=71)
+    student.load_state_dict({k[len("student."):]: v for k, v in W.items() if k.startswith("student.")})
+    teacher.load_state_dict({k[len("teacher."):]: v for k, v in W.items() if k.startswith("teacher.")})
+    for p in teacher.parameters():
+        p.requires_grad = False
+    student.train(); teacher.train()
+    mels = [O.recipe_mel(B, 1001, seed=73), O.recipe_mel(B, 1001, seed=74)]
+    ln = torch.tensor([1001, 702, 1001, 941, 1001, 523, 1001, 881])
+    lens = [ln, ln.clone()]
+    rs = np.random.RandomState(77)
+    m = torch.from_numpy(np.stack([O.block_mask(250, 0.65, 5, rng=rs) for _ in range(B)]))
+    masks = [m, m]
+    rates = [x.item() for x in torch.linspace(0, 0.1, depth)]
+    torch.manual_seed(79)
+    with RandRecorder() as rr:
+        tea = teacher(mels, lens, masks, False)
+        n_t = len(rr.draws)
+        stu = student(mels, lens, masks, True)
+        loss, std_s, std_t = loss_fn(stu, tea)
+    loss.backward()
+    arrs = dict(B=B, depth=depth, lengths=np.stack([l.numpy() for l in lens]), mask=m.numpy(), M=stu.shape[0],
+                loss=loss.item(), std_s=std_s.item(), std_t=std_t.item(),
+                teacher_out=tea.detach().numpy()[::23], student_out=stu.detach().numpy()[::23],
+                keep_t0=keep_from_draws(rr.draws[:n_t], depth, rates).numpy(),
+                keep_s0=keep_from_draws(rr.draws[n_t:], depth, rates).numpy())
+    arrs.update(grad_digest(student.named_parameters()))
+    save(name, **arrs)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["blocks", "clip2", "clip2_nodrop", "clip6", "frame", "sched", "encgrad", "clip2_b16", "clip2_b64", "infer", "aug", "frame_infer", "frame_asym", "frame_cnn", "base_encgrad", "base_step"]
+    which = sys.argv[1:] or ["blocks", "clip2", "clip2_nodrop", "clip6", "frame", "sched", "encgrad", "clip2_b16", "clip2_b64", "infer", "aug", "frame_infer", "frame_asym", "frame_cnn", "base_encgrad", "base_step", "frame_base"]
     if "aug" in which:
         gen_aug()
     if "frame_infer" in which:
@@ -522,3 +564,5 @@ if __name__ == "__main__":
         gen_base_encoder_grad()
     if "base_step" in which:
         gen_base_step()
+    if "frame_base" in which:
+        gen_frame_base()

@@ -138,6 +138,26 @@ def test_frame_step(golden_dir):
     grad_check(G, [(n, p) for n, p in leaves])
 
 
+def test_frame_base_step(golden_dir):
+    """ATST-Frame *base* (FrameAST at embed_dim 768, 12 heads: atstframe/audio_transformer.py:287-288, train_base.sh) at depth 2, B = 8 ragged sequences
+    per view, one block mask per sequence: the oracle against the imported reference's MultiCropWrapper + ByolLoss (make_golden.py frame_base)."""
+    G = load(golden_dir, "frame_base_depth2")
+    B, depth = int(G["B"]), int(G["depth"])
+    W = O.recipe_weights("base", depth=depth, frame=True, seed=71)
+    leaves = student_leaves(W)
+    mels = [O.recipe_mel(B, 1001, seed=73), O.recipe_mel(B, 1001, seed=74)]
+    lens = [torch.from_numpy(l) for l in G["lengths"]]
+    rs = np.random.RandomState(77)
+    m = np.stack([O.block_mask(250, 0.65, 5, rng=rs) for _ in range(B)])
+    assert np.array_equal(m, G["mask"])
+    masks = [torch.from_numpy(m)] * 2
+    loss, std_s, std_t = O.frame_atst_forward(W, mels, lens, masks, "base", [torch.from_numpy(G["keep_t0"])], [torch.from_numpy(G["keep_s0"])], depth=depth)
+    loss.backward()
+    assert abs(loss.item() - float(G["loss"])) < 1e-5
+    assert abs(std_s.item() - float(G["std_s"])) < 1e-5 and abs(std_t.item() - float(G["std_t"])) < 1e-5
+    grad_check(G, [(n, p) for n, p in leaves])
+
+
 def test_frame_step_asymmetric(golden_dir):
     """FrameATST(symmetric=False): teacher on view 0, student on the masked view 1, one cosine pair (model.py:73-76)."""
     G = load(golden_dir, "frame_small_asym")

@@ -516,6 +516,47 @@ def test_frame_step_vs_reference_golden():
             assert abs(nerr) < 5e-2 and r < 7.5e-2, (k, r, nerr)          # measured worst 4.8e-2 (x1.5)
 
 
+# measured (MI355X): bf16 loss 3.9e-4, outputs 9.3e-3 / 5.9e-3, gradients 1.9e-2 mean / 2.5e-2 worst ; fp8 (all 12 GEMMs e4m3) 1.4e-4, 0.123 / 0.072, 0.167 / 0.214 -- x 1.5
+FRAME_BASE_TOL = {False: dict(loss=5e-3, out=1.4e-2, mean=2.9e-2, worst=3.8e-2), True: dict(loss=5e-3, out=0.19, mean=0.25, worst=0.32)}
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+def test_frame_base_step_vs_reference_golden(fp8):
+    """ATST-Frame *base* (the reference's train_base.sh recipe: FrameAST at embed_dim 768, 12 heads -- atstframe/audio_transformer.py:287-288) at depth 2,
+    B = 8 ragged sequences per view, one block mask per sequence, against the imported reference (tests/golden/frame_base_depth2.npz): exact masked-row
+    count, loss, head outputs in (b, n) row order, gradients.  fp8: the same step twice on the fp8 engine -- step 1 e4m3 forward + recording bf16
+    backward, step 2 all 12 GEMMs of a block on e4m3 operands with `fp8_lean` (no bf16 LayerNorm / GELU copies) under a RAGGED head row count
+    (~2.6 k rows, never a multiple of 256) -- against the fp32 reference: the e4m3 staircase, bounds = measured x 1.5."""
+    G = load("frame_base_depth2")
+    B, depth = int(G["B"]), int(G["depth"])
+    eng = AtstEngine("base", frame=True, depth=depth, fp8=fp8)
+    eng.load_weights(O.recipe_weights("base", depth=depth, frame=True, seed=71))
+    mels = [O.recipe_mel(B, 1001, seed=73), O.recipe_mel(B, 1001, seed=74)]
+    lens = [torch.from_numpy(l) for l in G["lengths"]]
+    masks = [torch.from_numpy(G["mask"])] * 2
+    tol = FRAME_BASE_TOL[fp8]
+    for step in range(2 if fp8 else 1):
+        if fp8:
+            assert eng.fp8_bwd_state == step + 1
+        loss, std_s, std_t = eng.forward(mels, lens, masks, [torch.from_numpy(G["keep_t0"])], [torch.from_numpy(G["keep_s0"])])
+        eng.backward()
+        s_out, t_out = eng.last_outputs
+        assert s_out.shape[0] == int(G["M"])                              # ragged masked & valid gather: exact row count
+        rs, rt = rel(s_out.cpu().numpy()[::23], G["student_out"]), rel(t_out.cpu().numpy()[::23], G["teacher_out"])
+        tab = grad_table(eng, G)
+        assert len(tab) == 14 + 11 * depth and "encoder.mask_embed" in tab          # frame model: mask_embed IS trained (146 tensors at depth 12)
+        mean = sum(r * n for k, (r, _, n) in tab.items() if k not in CANCELLING) / sum(n for k, (_, _, n) in tab.items() if k not in CANCELLING)
+        worst = max(((k, v) for k, v in tab.items() if k not in CANCELLING), key=lambda kv: kv[1][0])
+        print(f"\n[frame base {'fp8 step %d' % (step + 1) if fp8 else 'bf16'}] rows {s_out.shape[0]} loss {loss.item():.6f} (ref {float(G['loss']):.6f}) "
+              f"out rel {rs:.2e} {rt:.2e}; gradient weighted mean rel-L2 {mean:.3e}; worst {worst[0]} {worst[1][0]:.3e}")
+        assert abs(loss.item() - float(G["loss"])) < tol["loss"]
+        assert abs(std_s.item() - float(G["std_s"])) < 10 * tol["loss"] and abs(std_t.item() - float(G["std_t"])) < 10 * tol["loss"]
+        assert rs < tol["out"] and rt < tol["out"]
+        assert mean < tol["mean"] and worst[1][0] < tol["worst"], (mean, worst)
+    if fp8:
+        assert sum(eng.fp8_saturation().values()) == 0
+
+
 @pytest.mark.parametrize("width,B", [(401, 8), (501, 32)])           # 100 tokens in 128-row tiles, S = 16 ; 125 tokens, S = 64: both PACKED (row stride < tile rows)
 def test_frame_short_crop_packed_vs_oracle(width, B):
     """ATST-Frame on short crops (--anchor_len 4 / 5): the sequences are stored packed (row stride = token count), so the mask-token
