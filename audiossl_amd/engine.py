@@ -10,6 +10,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
+import warnings
 from collections import OrderedDict
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -208,6 +209,12 @@ class EncoderPass:
         e.mel, e.valid = hip.ptr(mel), hip.ptr(valid)
         e.rowflag, e.dp_scale = hip.ptr(rowflag), hip.ptr(dp_scale)
         e.fp8_lean = self._lean_mode()                      # bf16 activation copies the announced backward will not read are not written
+        if getattr(e, "fp8", 0) and self.net == "student" and self.train and self.eng.f8a_scale_used is not None:
+            # The e4m3 weight gradients of this pass de-scale with the activation scales THIS forward quantises with; the running scales move on
+            # between forward and backward.  The snapshot is taken here, per pass and in stream order in front of the forward (every student pass
+            # of a step copies the same values), so a caller that drives EncoderPass.forward() / backward() directly cannot pair a forward with a
+            # stale snapshot (it used to be refreshed only by AtstEngine._fp8_after_forward()).
+            self.eng.f8a_scale_used.copy_(self.eng.f8a_scale[0])
         if self.precise:
             hip.check(hip.load().atst_encoder_hp_fwd(C.byref(e), hip.stream()), "atst_encoder_hp_fwd")
         else:
@@ -329,7 +336,7 @@ class HeadPass:
         hip.call("atst_bn_finish_f32", hip.ptr(mean), hip.ptr(m2), 0.0 if on_dev else float(count), hip.ptr(cdev), BN_MOMENTUM, BN_EPS,
                  hip.ptr(bn["running_mean"]), hip.ptr(bn["running_var"]), hip.ptr(bn["num_batches_tracked"]), hip.ptr(rstd), HEAD_HIDDEN, st)
         out = _rows_buf(R, HEAD_OUT, torch.float32, dev)
-        if eng.precise or _HEAD_SPLIT2 == "all" or (_HEAD_SPLIT2 == "gated" and self.net == "student" and self.which == "projector"):
+        if eng.precise or eng.head_split2 == "all" or (eng.head_split2 == "gated" and self.net == "student" and self.which == "projector"):
             # second Linear in split-bf16 where its output feeds ANOTHER head's BatchNorm+ReLU gates: the student projector (the predictor follows)
             y3 = _rows_buf(R, 3 * HEAD_HIDDEN, torch.bfloat16, dev)
             hip.call("atst_bn_apply_relu_split3_bf16", hip.ptr(h), hip.ptr(mean), hip.ptr(rstd), hip.ptr(self._w("1.weight", f32=True)),
@@ -433,7 +440,8 @@ class HeadPass:
 
 
 _HEAD_PAD = os.environ.get("ATST_HEAD_PAD", "1") != "0"
-_HEAD_SPLIT2 = os.environ.get("ATST_HEAD_SPLIT2", "gated")      # second head Linear in split-bf16: "gated" (only in front of another head), "all" (rounds 1-4)
+_HEAD_SPLIT2 = os.environ.get("ATST_HEAD_SPLIT2", "gated")      # default of AtstEngine(head_split2=...): second head Linear in split-bf16: "gated" (only in front of another head), "all" (rounds 1-4), "none"
+_PAD_FALLBACK_WARNED = False
 
 
 def _gemm(A, B, M, N, K, epi, out):
@@ -441,12 +449,19 @@ def _gemm(A, B, M, N, K, epi, out):
     to 4096, so the GEMM may run over the next multiple of 256 rows -- the geometry the 256 x 256 phased kernel takes (ATST-Frame's ~83 k masked rows are
     never such a multiple).  The extra output rows are computed from whatever the operand's padding rows hold and land in the output's padding rows; every
     consumer (BatchNorm sums, the next kernels) works on [:M]."""
+    global _PAD_FALLBACK_WARNED
     Mp = -(-M // 256) * 256 if (_HEAD_PAD and M > 4096) else M
     if Mp != M:                                              # the padding rows must exist in both allocations (host-side check, no device work)
+        # rows M .. Mp - 1 of A are uninitialised memory and their products land in out's padding rows: only an epilogue whose output rows are
+        # independent of each other (plain fp32 store: no column sums, no amax, no row statistics) may run over them (ADVICE r5)
+        assert epi == hip.EPI_F32, "padded head GEMMs are fp32-store only"
         for t in (A, out):
             room = t.untyped_storage().nbytes() - t.storage_offset() * t.element_size()
             if room < Mp * t.stride(0) * t.element_size():
                 Mp = M
+                if not _PAD_FALLBACK_WARNED:
+                    _PAD_FALLBACK_WARNED = True
+                    warnings.warn("head GEMM operand is not a _rows_buf() view: running over %d rows on the 128-row kernel (slower)" % M)
     hip.call("atst_gemm_nt_bf16", hip.ptr(A), hip.ptr(B), Mp, N, K, K, K, epi, hip.ptr(out), N, None, None, None, None, 1,
              None, None, None, None, None, hip.stream())
 
@@ -484,13 +499,20 @@ class AtstEngine:
 
     def __init__(self, arch: str = "small", frame: bool = False, depth: Optional[int] = None, ncrops: int = 2,
                  device: Optional[torch.device] = None, drop_path_rate: float = 0.1, n_pos: int = 251, fp8: bool = False,
-                 symmetric: bool = True, patch_embed: str = "Linear", precise: bool = False, patch_h: int = 64, patch_w: int = 4):
+                 symmetric: bool = True, patch_embed: str = "Linear", precise: bool = False, patch_h: int = 64, patch_w: int = 4,
+                 head_split2: Optional[str] = None):
         if arch not in ARCH:
             raise RuntimeError("arch {} is not implemented".format(arch))      # ref: models/atst/atst.py:17
         hip.load()                                                               # fail loudly when the .so is missing
         if not torch.cuda.is_available():
             raise hip.HipError("AtstEngine needs a HIP device (MI355X); there is no CPU product path")
         self.arch, self.frame, self.ncrops = arch, frame, ncrops
+        # Second Linear of a head on split-bf16 operands ([hi | lo | hi] x [hi | hi | lo], ~2^-16) or plain bf16: "gated" (default, round 5) = split only
+        # where another head's BatchNorm + ReLU gates read the output (student projector); "all" = every head (rounds 1-4: parity runs); "none".
+        # Measured deviation of "gated" from "all" on the goldens: DESIGN.md section 4 "Round 6".  Environment default: ATST_HEAD_SPLIT2.
+        self.head_split2 = _HEAD_SPLIT2 if head_split2 is None else head_split2
+        if self.head_split2 not in ("gated", "all", "none"):
+            raise ValueError("head_split2 must be 'gated', 'all' or 'none'")
         if not symmetric and not frame:
             raise hip.HipError("symmetric=False is the ATST-Frame option (methods/atstframe/model.py:68-76)")
         self.symmetric = bool(symmetric)
@@ -1024,7 +1046,6 @@ class AtstEngine:
         that saw nothing keep their scale.  MAX-reduced over the ranks (replicas quantise on one grid)."""
         if not self.fp8 or self.f8a_hist is None:
             return
-        self.f8a_scale_used.copy_(self.f8a_scale[0])                 # what this step's student forward quantised with (read by its backward)
         torch.amax(self.f8a_amax_sites, dim=-1, out=self.f8a_amax)
         self.f8a_amax_sites.zero_()
         if parallel._collective():
