@@ -297,14 +297,14 @@ static int encoder_bwd_range(const atst_encoder_t* e, int lo, int hi, bool head,
 
   // C == 384: the two N = 384 dgrad GEMMs of a block own whole rows, so their epilogue runs the LayerNorm backward itself
   // (no dh round trip through HBM, no separate pass over x and the residual gradient)
-  const bool fuse_lnb = C == 384;
+  const bool fuse_lnb = C == 384 && !(e->fp8 && e->fp8_bwd >= 1);   // (an fp8 backward -- recording or on -- runs the unfused LayerNorm backward, whose kernel writes the e4m3 gradient copies and their amax: round 6, d = 384)
   // fp8 dgrad (BASELINE.json configs[4]): the fc2 / fc1 / proj dgrad GEMMs of a block on e4m3 operands; qkv dgrad and weight gradients stay bf16.  Gradient
   // operands use DELAYED scaling: site (block i, k) -- k = 0: g (into fc2), 1: du (into fc1), 2: g2 (into proj), 3: dqkv (into qkv: fp8_wgrad >= 2) -- is
   // quantised with g8_scale[4 i + k], the scale derived from the amax seen in the previous step, and records this step's amax in
   // g8_amax[4 i + k]; fp8_bwd == 1 only records (first step: bf16 dgrad), == 2 also computes in fp8.
-  const bool rec8 = e->fp8 && e->fp8_bwd >= 1 && e->g8_amax && !fuse_lnb;
+  const bool rec8 = e->fp8 && e->fp8_bwd >= 1 && e->g8_amax && !fuse_lnb;   // (!fuse_lnb: implied)
   const bool use8 = rec8 && e->fp8_bwd >= 2 && e->p8t && e->g8_scale && e->w_dq;
-  const bool use8w = use8 && e->fp8_wgrad && e->f8_act_scale_bwd && M % 64 == 0;   // e4m3 weight gradients of fc1 / fc2 / proj (C = 768: N, K multiples of 256)
+  const bool use8w = use8 && e->fp8_wgrad && e->f8_act_scale_bwd && M % 64 == 0;   // e4m3 weight gradients of fc1 / fc2 / proj (N, K multiples of 128: C = 768 and, round 6, C = 384)
   // fp8_wgrad == 2: the qkv Linear too -- the NP = 256 attention backward then writes dqkv as e4m3 ONLY (site 3) and both the qkv weight gradient
   // and the qkv dgrad read that copy.  fp8_wgrad == 3 (or 2 while the dgrad itself is still recording): bf16 qkv gradient, site 3's amax taken by
   // a pass over the bf16 dqkv -- the step that gives the site its first scale.

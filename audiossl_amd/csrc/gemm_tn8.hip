@@ -66,8 +66,12 @@ DEVFN void tn8_body(const Wgrad8Args& pa, int tile, int split, char* smem_raw) {
   p.m_per_split = __builtin_amdgcn_readfirstlane(pa.m_per_split);
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wid >> 2, wk = wid & 3;
-  const int ntk = p.K / TK8;
+  const int ntk = (p.K + TK8 - 1) / TK8;
   const int n0 = (tile / ntk) * TN8, k0 = (tile % ntk) * TK8;
+  // N, K are multiples of 128 (round 6: d = 384 -- 384, 1152, 1536): the last tile of a dimension may be HALF valid.  Its upper 128 columns are staged
+  // from the lower 128 again (in-range addresses, products never stored) -- 384 = 1.5 tiles costs 2; the four problems of an ATST-small block are 38 tiles
+  // for 27 tiles' worth of output, and still run ~3x the bf16 grouped kernel.
+  const bool half_n = n0 + TN8 > p.N, half_k = k0 + TK8 > p.K;
   const int m_begin = split * p.m_per_split;
   int m_end = m_begin + p.m_per_split; if (m_end > p.M) m_end = p.M;
   if (m_begin >= m_end) return;
@@ -79,8 +83,8 @@ DEVFN void tn8_body(const Wgrad8Args& pa, int tile, int split, char* smem_raw) {
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int row = (2 * wid + j) * 4 + (lane >> 4), ch = (lane & 15) ^ ((row & 7) << 1);
-    vo[0][j] = (unsigned)(row * p.ldy + ch * 16);
-    vo[1][j] = (unsigned)(row * p.ldx + ch * 16);
+    vo[0][j] = (unsigned)(row * p.ldy + ((half_n ? ch & 7 : ch) * 16));
+    vo[1][j] = (unsigned)(row * p.ldx + ((half_k ? ch & 7 : ch) * 16));
   }
   const char* by = sgpr_ptr8(p.dY + (size_t)m_begin * p.ldy + n0);
   const char* bx = sgpr_ptr8(p.X + (size_t)m_begin * p.ldx + k0);
@@ -174,13 +178,14 @@ DEVFN void tn8_body(const Wgrad8Args& pa, int tile, int split, char* smem_raw) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + wn * 128 + i * 32 + crow32(r, hi), k = k0 + wk * 64 + j * 32 + l31;
+        if (n >= p.N || k >= p.K) continue;                            // (uniform per wave: the invalid half of an edge tile is a whole wave row / two wave columns)
         if (!(ATST_TN8_ABL & 8)) atomicAdd(p.dW + (size_t)n * p.ldw + k, acc[i][j][r] * dq); else asm volatile("" :: "v"(acc[i][j][r] * dq));
       }
 }
 
 __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(Wgrad8Args p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int tiles = (p.N / TN8) * (p.K / TK8);
+  const int tiles = ((p.N + TN8 - 1) / TN8) * ((p.K + TK8 - 1) / TK8);
   const int id = xcd_remap(blockIdx.x, gridDim.x);                // all tiles of one M-split run on one XCD (they stream the same dY8 / X8 rows)
   tn8_body(p, id % tiles, id / tiles, smem_raw);
 }
@@ -206,12 +211,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_group_kernel(Wgrad8Group g) {
 
 static int tn8_splits(int tiles) { const int s = (192 + tiles - 1) / tiles; return s < 1 ? 1 : s; }   // one round, >= 3/4 of the 256 CUs
 
-// dW[N, K] (fp32, ldw) += (1 / (*scale_y * *scale_x)) dY8[M, N]^T X8[M, K]; N, K multiples of 256, M a multiple of 64, ldy / ldx multiples of 16.
+// dW[N, K] (fp32, ldw) += (1 / (*scale_y * *scale_x)) dY8[M, N]^T X8[M, K]; N, K multiples of 128 (256 x 256 tiles, the last one of a dimension half valid), M a multiple of 64, ldy / ldx multiples of 16.
 int atst_gemm_tn8(const uint8_t* dY8, const uint8_t* X8, int M, int N, int K, int ldy, int ldx, float* dW, int ldw, const float* scale_y,
                   const float* scale_x, hipStream_t st) {
-  if (!dY8 || !X8 || !dW || M <= 0 || M % RM8 || N % TN8 || K % TK8 || ldy % 16 || ldx % 16) return ATST_EINVAL;
+  if (!dY8 || !X8 || !dW || M <= 0 || M % RM8 || N % 128 || K % 128 || ldy % 16 || ldx % 16) return ATST_EINVAL;
   Wgrad8Args a{dY8, X8, M, N, K, ldy, ldx, dW, ldw, scale_y, scale_x, 0};
-  const int tiles = (N / TN8) * (K / TK8);
+  const int tiles = ((N + TN8 - 1) / TN8) * ((K + TK8 - 1) / TK8);
   int splits = tn8_splits(tiles);                                   // (two rounds -- 512 / tiles -- paid 132 MB of atomics per launch: tools/tn8_ablate.sh)
   int mps = (M + splits - 1) / splits;
   mps = ((mps + RM8 - 1) / RM8) * RM8;
@@ -229,16 +234,16 @@ int atst_gemm_tn8(const uint8_t* dY8, const uint8_t* X8, int M, int N, int K, in
   return (int)hipGetLastError();
 }
 
-// dW_i += dY8_i^T X8_i / (scale_y_i scale_x_i) for up to four problems that share M (one transformer block); every N_i, K_i a multiple of 256.
+// dW_i += dY8_i^T X8_i / (scale_y_i scale_x_i) for up to four problems that share M (one transformer block); every N_i, K_i a multiple of 128.
 int atst_gemm_tn8_group(const Wgrad8Item* items, int n, int M, hipStream_t st) {
   if (n < 1 || n > 4 || M <= 0 || M % RM8) return ATST_EINVAL;
   Wgrad8Group g{}; g.n = n;
   double flops = 0.0, bytes = 0.0;
   for (int i = 0; i < n; ++i) {
     const Wgrad8Item& it = items[i];
-    if (!it.dY8 || !it.X8 || !it.dW || it.N % TN8 || it.K % TK8 || it.ldy % 16 || it.ldx % 16) return ATST_EINVAL;
+    if (!it.dY8 || !it.X8 || !it.dW || it.N % 128 || it.K % 128 || it.ldy % 16 || it.ldx % 16) return ATST_EINVAL;
     g.it[i] = Wgrad8Args{it.dY8, it.X8, M, it.N, it.K, it.ldy, it.ldx, it.dW, it.ldw, it.scale_y, it.scale_x, 0};
-    g.first_tile[i + 1] = g.first_tile[i] + (it.N / TN8) * (it.K / TK8);
+    g.first_tile[i + 1] = g.first_tile[i] + ((it.N + TN8 - 1) / TN8) * ((it.K + TK8 - 1) / TK8);
     flops += 2.0 * M * it.N * it.K; bytes += (double)M * ((double)it.N + it.K) + 4.0 * it.N * it.K;
   }
   // M-splits: ONE round of blocks, the smallest count that occupies >= 3/4 of the chip.  Measured on the four problems of an ATST-base block (108 tiles,

@@ -48,7 +48,7 @@ struct WgradArgs {
   int m_per_split;                   // 0 = auto
 };
 int atst_gemm_tn(const WgradArgs& a, hipStream_t st);
-// e4m3 weight gradient (gemm_tn8.hip): dW += dY8^T X8 / (*scale_y * *scale_x); N, K % 256 == 0, M % 64 == 0
+// e4m3 weight gradient (gemm_tn8.hip): dW += dY8^T X8 / (*scale_y * *scale_x); N, K % 128 == 0 (256 x 256 tiles, the last of a dimension half valid), M % 64 == 0
 int atst_gemm_tn8(const uint8_t* dY8, const uint8_t* X8, int M, int N, int K, int ldy, int ldx, float* dW, int ldw, const float* scale_y,
                   const float* scale_x, hipStream_t st);
 struct Wgrad8Item { const uint8_t* dY8; const uint8_t* X8; int N, K, ldy, ldx; float* dW; int ldw; const float* scale_y; const float* scale_x; };

@@ -568,7 +568,7 @@ class AtstEngine:
             self.p8t = z(L.n_student, torch.uint8)
             self.g8_scale, self.g8_amax = torch.ones(4 * self.depth, device=dev), z(4 * self.depth)
             self.g8_amax_sites = z(4 * self.depth * hip.AMAX_SITE_STRIDE).view(4 * self.depth, hip.AMAX_SITE_STRIDE)
-            self.fp8_bwd_state = 1 if (self.cfg["embed_dim"] == 768 and os.environ.get("ATST_FP8_BWD", "1") != "0") else 0
+            self.fp8_bwd_state = 1 if (self.cfg["embed_dim"] in (384, 768) and os.environ.get("ATST_FP8_BWD", "1") != "0") else 0   # d = 384: round 6 (gemm_tn8 takes N, K % 128; the fp8 backward runs the unfused LayerNorm backward)
             # e4m3 weight gradients of fc1 / fc2 / proj (round 5; with the e4m3 dgrad only: they share its gradient-operand copies).  f8a_scale_used:
             # the student's forward activation scales as the forward of the current step used them (snapshot taken before they are advanced)
             self.fp8_wgrad = bool(self.fp8_bwd_state) and os.environ.get("ATST_FP8_WGRAD", "1") != "0"

@@ -391,7 +391,8 @@ def main():
         torch.cuda.empty_cache()
         for wl, arch, dtype, hires in (("frame", "small", "bf16", False), ("clip2", "small", "bf16", False), ("clip2", "base", "bf16", False),
                                        ("clip2", "base", "fp8", False), ("clip2", "base", "fp8", True),
-                                       ("frame", "base", "bf16", False), ("frame", "base", "fp8", False)):   # ATST-Frame base: the reference's train_base.sh recipe
+                                       ("frame", "base", "bf16", False), ("frame", "base", "fp8", False),    # ATST-Frame base: the reference's train_base.sh recipe
+                                       ("clip6", "small", "fp8", False)):                                    # all-e4m3 + fp8_lean at d = 384 (round 6)
             if (wl, arch, dtype, hires) == headline:
                 continue
             n_w, n_t = 3, args.also_steps

@@ -119,7 +119,7 @@ int atst_quant_weights_fp8(const float* p32, const int32_t* table, int n, uint8_
 int atst_gemm_tn_bf16(const uint16_t* dY, const uint16_t* X, int M, int N, int K, int ldy, int ldx, float* dW, int ldw,
                       int m_per_split, void* stream);
 /* The same on OCP e4m3 copies of both operands (m-major bytes, as the fp8 forward / dgrad write them), v_mfma_scale_f32_32x32x64_f8f6f4 on
- * transposed LDS reads (ds_read_b64_tr_b8): dW[N,K] += dY8[M,N]^T X8[M,K] / (*scale_y * *scale_x).  N, K multiples of 256, M a multiple of 64.       */
+ * transposed LDS reads (ds_read_b64_tr_b8): dW[N,K] += dY8[M,N]^T X8[M,K] / (*scale_y * *scale_x).  N, K multiples of 128, M a multiple of 64.       */
 int atst_gemm_tn_fp8(const uint8_t* dY8, const uint8_t* X8, int M, int N, int K, int ldy, int ldx, float* dW, int ldw, const float* scale_y,
                      const float* scale_x, void* stream);
 /* Up to 4 independent weight gradients in one launch (the four nn.Linear of a Block, modules/transformer.py:124-150):

@@ -862,15 +862,16 @@ def test_configs4_base_fp8_hires_as_one_thing():
     assert torch.isfinite(eng.p32).all() and torch.isfinite(eng.g32).all()
 
 
-def test_fp8_multi_step_loss_curve_tracks_bf16():
+@pytest.mark.parametrize("arch", ["base", "small"])
+def test_fp8_multi_step_loss_curve_tracks_bf16(arch):
     """a multi-step comparison before trusting the e4m3 dgrad by default.  16 optimizer steps (fwd + bwd + HF-AdamW + EMA) of
     ATST-base (depth 2) from the same weights on the same stream of batches, three ways: bf16 | e4m3 forward, bf16 dgrad | e4m3 forward +
     fc2 / fc1 / proj dgrad (running activation scales, delayed gradient scales, 16-step windows).  The loss curves must stay together -- measured
     (tools/debug/fp8_curve.py, 24 steps): max |loss - bf16| 0.011, mean 0.0035 for both fp8 runs, the two fp8 runs within 0.003 of each other --
-    and nothing may be clipped on the way."""
+    and nothing may be clipped on the way.  arch "small" (round 6): the same at d = 384, where the fp8 backward became available this round."""
     from audiossl_amd.engine import AtstEngine
     N, depth, B = 16, 2, 16
-    W = O.recipe_weights("base", depth=depth, seed=7)
+    W = O.recipe_weights(arch, depth=depth, seed=7)
 
     def data(step):
         g = torch.Generator().manual_seed(1000 + step)
@@ -882,7 +883,7 @@ def test_fp8_multi_step_loss_curve_tracks_bf16():
         return mels
 
     def run(kind):
-        eng = AtstEngine("base", depth=depth, drop_path_rate=0.0, fp8=kind != "bf16")
+        eng = AtstEngine(arch, depth=depth, drop_path_rate=0.0, fp8=kind != "bf16")
         eng.load_weights(W)
         if kind == "fp8_fwd":
             eng.fp8_bwd_state = 0
@@ -901,7 +902,7 @@ def test_fp8_multi_step_loss_curve_tracks_bf16():
     for kind in ("fp8_fwd", "fp8"):
         curves[kind], sat = run(kind)
         d = [abs(a - b) for a, b in zip(curves[kind], ref)]
-        print(f"\n[fp8 curve] {kind}: max |loss - bf16| {max(d):.4f} mean {sum(d) / N:.4f}; last loss {curves[kind][-1]:.4f} (bf16 {ref[-1]:.4f}); clipped {sat}")
+        print(f"\n[fp8 curve {arch}] {kind}: max |loss - bf16| {max(d):.4f} mean {sum(d) / N:.4f}; last loss {curves[kind][-1]:.4f} (bf16 {ref[-1]:.4f}); clipped {sat}")
         assert all(math.isfinite(v) for v in curves[kind]) and max(d) < 3e-2 and sum(d) / N < 1e-2
         assert sat == {"student": 0, "teacher": 0}
     assert max(abs(a - b) for a, b in zip(curves["fp8"], curves["fp8_fwd"])) < 1e-2
@@ -1051,7 +1052,8 @@ def test_gemm_fp8_phased_kernel(M, N, K):
         assert relerr(got.float(), other.float()) < 4e-3
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (1024, 768, 768), (8192 + 64, 768, 3072), (4096, 3072, 768)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (1024, 768, 768), (8192 + 64, 768, 3072), (4096, 3072, 768),
+                                   (1024, 384, 384), (2048 + 64, 1152, 384), (4096, 384, 1536), (512, 128, 128)])   # multiples of 128: half-valid edge tiles (d = 384)
 def test_gemm_tn_fp8_weight_gradient(M, N, K):
     """e4m3 weight gradient (csrc/gemm_tn8.hip: transposed LDS reads ds_read_b64_tr_b8 + MX-scaled MFMA): dW += dY8^T X8 / (sy sx) against an fp64
     matmul of the SAME e4m3 values (only the summation order differs), accumulation into a non-zero dW, asymmetric operands (a transposed or
@@ -1072,11 +1074,12 @@ def test_gemm_tn_fp8_weight_gradient(M, N, K):
     assert relerr(dW, ref16) < 8e-2
 
 
+@pytest.mark.parametrize("C", [768, 384])
 @pytest.mark.parametrize("M", [4096, 8192 + 192])
-def test_gemm_tn_group_fp8_matches_single_launches(M):
+def test_gemm_tn_group_fp8_matches_single_launches(M, C):
     """The four e4m3 weight gradients of an ATST-base block in ONE launch (atst_gemm_tn_group_fp8: shared M, shared M-splits, a fraction of the fp32
-    atomics) against the same four problems launched one by one, and against the fp64 product of the e4m3 values; 3- and 4-problem groups, own scales."""
-    C = 768
+    atomics) against the same four problems launched one by one, and against the fp64 product of the e4m3 values; 3- and 4-problem groups, own scales.
+    C = 384 (round 6): every dimension is a multiple of 128 but not of 256 -- 38 tiles with half-valid edges."""
     shapes = [(4 * C, C), (C, 4 * C), (C, C), (3 * C, C)]                          # fc1, fc2, proj, qkv: (N, K)
     g = torch.Generator().manual_seed(M)
     ops = []
