@@ -63,8 +63,13 @@ template <int EPI, bool SCALE = true>
 DEVFN void epi_fetch8(const GemmArgs& p, int row, int col, EpiAux& x) {
   const size_t idx = (size_t)row * p.ldc + col;
   if constexpr (EPI == EPI_RESID) {
+    if (p.resid_bf16) {                                            // bf16 residual stream (fp8 inference passes): one 16-B load of 8 values
+      const bf16x8 r = ld_pol<3>(reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.resid) + idx));
+      x.a0 = f32x4{bf2f(r[0]), bf2f(r[1]), bf2f(r[2]), bf2f(r[3])}; x.a1 = f32x4{bf2f(r[4]), bf2f(r[5]), bf2f(r[6]), bf2f(r[7])};
+    } else {
     x.a0 = ld_pol<3>(reinterpret_cast<const f32x4*>(p.resid + idx));
     x.a1 = ld_pol<3>(reinterpret_cast<const f32x4*>(p.resid + idx + 4));
+    }
     if constexpr (SCALE) x.s = p.row_scale ? p.row_scale[row / p.rows_per_seq] : 1.0f;   // else: the caller supplies it
   } else if constexpr (EPI == EPI_DGELU) {
 #if ATST_EPI_ABL & 4
@@ -145,7 +150,8 @@ DEVFN void epilogue8(const GemmArgs& p, int row, int col, f32x4 v0, f32x4 v1, co
       w0 = f32x4{m8, 0.f, 0.f, 0.f}; w1 = f32x4{0.f, 0.f, 0.f, 0.f};   // for the running amax of this site (row-384 kernel)
     }
   } else if constexpr (EPI == EPI_RESID) {
-    st_f32(p.C, idx, x.a0 + x.s * (v0 + b0), x.a1 + x.s * (v1 + b1));
+    if (p.out_bf16) st_bf16_b(p.C, idx, x.a0 + x.s * (v0 + b0), x.a1 + x.s * (v1 + b1), std::integral_constant<int, 4>{});   // (read back by the next LayerNorm: policy of the row-wise bf16 rows)
+    else st_f32(p.C, idx, x.a0 + x.s * (v0 + b0), x.a1 + x.s * (v1 + b1));
   } else if constexpr (EPI == EPI_DGELU) {
     const bf16x8 u = __builtin_bit_cast(bf16x8, x.a0);
 #if !(ATST_EPI_ABL & 1)
@@ -1806,7 +1812,7 @@ double nt_bytes(const GemmArgs& a) {
   if (EPI == EPI_BF16) b += 2.0 * mn;
   if (EPI == EPI_F32) b += 4.0 * mn;
   if (EPI == EPI_BIAS_GELU) b += (a.C2 ? 2.0 * mn : 0.0) + (a.C ? 2.0 * mn : 0.0) + (a.q8 ? mn : 0.0);   // a (bf16 and / or e4m3), u only when it is saved (training)
-  if (EPI == EPI_RESID) b += 8.0 * mn + (a.ln_out ? 2.0 * mn : 0.0);
+  if (EPI == EPI_RESID) b += (a.resid_bf16 ? 2.0 : 4.0) * mn + (a.out_bf16 ? 2.0 : 4.0) * mn + (a.ln_out ? 2.0 * mn : 0.0);
   if (EPI == EPI_DGELU) b += 2.0 * mn + (a.C ? 2.0 * mn : 0.0) + (a.q8 ? mn : 0.0);      // u in ; du out (bf16 and / or e4m3)
   if (EPI == EPI_PATCH) b += 4.0 * mn;
   if (EPI == EPI_LNBWD) b += 8.0 * mn + (a.resid ? 4.0 * mn : 0.0) + (a.lnb_g ? 2.0 * mn : 0.0);   // x in, dx out, dres in, g out
@@ -2001,9 +2007,11 @@ int launch_nt(const GemmArgs& a, hipStream_t st) {
 
 }  // namespace
 
+int g_f8_resid16 = 1;        // tuning hook 2100 / 2101: fp8 inference / teacher passes keep their residual stream in bf16 (read by engine.hip): off / on
 int g_tn_group_splits = 0;   // tuning hook 1500 + s: M-splits of the grouped bf16 weight gradient (0 = cost model)
 void atst_gemm_nt_set_variant(int v) {
-  if (v >= 2000 && v < 2100) g_tt = v - 2000;
+  if (v >= 2100 && v < 2102) g_f8_resid16 = v - 2100;
+  else if (v >= 2000 && v < 2100) g_tt = v - 2000;
   else if (v >= 1000 && v < 2000) g_p8_skew = v - 1000;
   else if (v >= 396 && v <= 397) g_ph = v - 396;
   else if (v >= 390) g_p8 = v - 390;

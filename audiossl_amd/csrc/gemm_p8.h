@@ -294,7 +294,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(GemmArgs p) {
         for (int k = 0; k < ITEMS; ++k) {
           const int idx = tid + THREADS * k;
 #if !(ATST_P8_ABL & 2)
-          r[k] = ld_pol<3>(reinterpret_cast<const f32x4*>(p.resid + (size_t)(m0 + tile_row_of(part, idx >> 6)) * p.ldc + n0 + (idx & 63) * 4));
+          const size_t ri = (size_t)(m0 + tile_row_of(part, idx >> 6)) * p.ldc + n0 + (idx & 63) * 4;
+          if (p.resid_bf16) {                                     // bf16 residual stream (fp8 inference passes): 8 B per lane, a wave instruction = one 512-B row segment
+            const bf16x4 rb = ld_pol<3>(reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(p.resid) + ri));
+            r[k] = f32x4{bf2f(rb[0]), bf2f(rb[1]), bf2f(rb[2]), bf2f(rb[3])};
+          } else {
+            r[k] = ld_pol<3>(reinterpret_cast<const f32x4*>(p.resid + ri));
+          }
 #endif
         }
       }
@@ -322,6 +328,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(GemmArgs p) {
 #endif
         f32x4 o = v;
         if constexpr (EPI == EPI_RESID) o = rres[part % (PFR + 1)][k] + sS4[trow] * v;
+        if (EPI == EPI_RESID && p.out_bf16) {
+          bf16x4 ob; ob[0] = f2bf(o[0]); ob[1] = f2bf(o[1]); ob[2] = f2bf(o[2]); ob[3] = f2bf(o[3]);
+          st_pol<4>(ob, reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.C) + (size_t)(m0 + trow) * p.ldc + n0 + c4));
+        } else
         st_pol<1>(o, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (size_t)(m0 + trow) * p.ldc + n0 + c4));
       }
       if (part < 7) lds_barrier();

@@ -35,6 +35,7 @@ struct GemmArgs {
   const float* dq;                   // fp8 GEMMs: device scalar multiplied into the accumulators (1 / (scale_A * scale_B)); null = 1
   int fp8;                           // operands are OCP e4m3 bytes (K, lda, ldb in elements = bytes); MX-scaled MFMA, unit block scales
   int skew;                          // only read by tools/experiments/gemm_r02_variants.hip (start-up skew experiment)
+  int resid_bf16, out_bf16;          // EPI_RESID, e4m3 operands (fp8 inference / teacher passes, round 6): the residual stream is read / written as bf16 [M, ldc] instead of fp32
   int ksplit;                        // set by the launcher (EPI_F32, tiny grids, long K): K is split over `ksplit` blocks per output tile
   float* ks_ws;                      // split-K workspace [ksplit][M][N] of partial sums (library-owned, per stream)
 };
@@ -61,6 +62,8 @@ int atst_gemm_tn_group(const WgradArgs* items, int n, hipStream_t st);   // inde
 int atst_ln_fwd(const float* x, const float* gamma, const float* beta, bf16* y, float* mean, float* rstd, int M, int C, hipStream_t st,
                 uint8_t* y8 = nullptr, float s8 = 1.0f, unsigned* sat = nullptr, const float* s8p = nullptr, float* amax8 = nullptr);
                 // y8: optional e4m3 copy of y * scale (fp8 forward), scale = *s8p (device, delayed scaling) or s8 ; sat: clipped-element counter ; amax8: max |y| (atomicMax)
+int atst_ln_fwd_b16in(const bf16* x, const float* gamma, const float* beta, bf16* y, float* mean, float* rstd, int M, int C, hipStream_t st,
+                      uint8_t* y8 = nullptr, float s8 = 1.0f, unsigned* sat = nullptr, const float* s8p = nullptr, float* amax8 = nullptr);   // bf16 residual stream in (fp8 inference passes)
 int atst_ln_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, int M, int C, hipStream_t st);   // fp32 output, no statistics (inference taps)
 struct LnBwdArgs {
   const bf16* dy;                    // [M,C] gradient wrt the LN output

@@ -28,8 +28,8 @@ template <int W> DEVFN void st_fp8(uint8_t* dst, const float* v, float s) {     
   }
 }
 
-template <int VPT, typename OUT = bf16>   // values per lane = C / 64 ; OUT = bf16 (GEMM operand) or float (inference taps)
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+template <int VPT, typename OUT = bf16, typename IN = float>   // values per lane = C / 64 ; OUT = bf16 (GEMM operand) or float (inference taps) ; IN = float, or bf16: the residual stream of an fp8 inference pass (round 6)
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const IN* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, OUT* __restrict__ y,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out, int M,
                                                      uint8_t* __restrict__ y8 = nullptr, float s8c = 1.0f, unsigned* __restrict__ sat = nullptr,
@@ -51,14 +51,20 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   }
   unsigned nclip = 0;                                             // fp8 forward: elements of the e4m3 copy clipped at +-448
   for (int row = wave; row < M; row += nwaves) {
-    const float* xr = x + (size_t)row * C;
+    const IN* xr = x + (size_t)row * C;
     float v[VPT];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
-      const fvec t = *reinterpret_cast<const fvec*>(xr + MP::col(i, lane));
+      if constexpr (sizeof(IN) == 2) {
+        const hvec t = *reinterpret_cast<const hvec*>(xr + MP::col(i, lane));
 #pragma unroll
-      for (int e = 0; e < W; ++e) { v[W * i + e] = t[e]; s += t[e]; }
+        for (int e = 0; e < W; ++e) { v[W * i + e] = bf2f(t[e]); s += v[W * i + e]; }
+      } else {
+        const fvec t = *reinterpret_cast<const fvec*>(xr + MP::col(i, lane));
+#pragma unroll
+        for (int e = 0; e < W; ++e) { v[W * i + e] = t[e]; s += t[e]; }
+      }
     }
     const float mu = wave_sum(s) * (1.0f / C);
     float q = 0.f;
@@ -186,6 +192,18 @@ int atst_ln_fwd(const float* x, const float* gamma, const float* beta, bf16* y, 
   ProfScope ps(PK_LN_FWD, (double)M * C * (4.0 + (y ? 2.0 : 0.0) + (y8 ? 1.0 : 0.0)), st);      // read fp32, write bf16 and / or e4m3
   if (C == 384) hipLaunchKernelGGL(ln_fwd_kernel<6>, dim3(ln_grid(M)), dim3(256), 0, st, x, gamma, beta, y, mean, rstd, M, y8, s8, sat, s8p, amax8);
   else if (C == 768) hipLaunchKernelGGL(ln_fwd_kernel<12>, dim3(ln_grid(M)), dim3(256), 0, st, x, gamma, beta, y, mean, rstd, M, y8, s8, sat, s8p, amax8);
+  else return ATST_EINVAL;
+  return (int)hipGetLastError();
+}
+
+// the same LayerNorm on a bf16 residual stream (fp8 inference / teacher passes, round 6): reads 2 B per element instead of 4
+int atst_ln_fwd_b16in(const bf16* x, const float* gamma, const float* beta, bf16* y, float* mean, float* rstd, int M, int C, hipStream_t st,
+                      uint8_t* y8, float s8, unsigned* sat, const float* s8p, float* amax8) {
+  if (M <= 0) return ATST_OK;
+  if (!y && !y8) return ATST_EINVAL;
+  ProfScope ps(PK_LN_FWD, (double)M * C * (2.0 + (y ? 2.0 : 0.0) + (y8 ? 1.0 : 0.0)), st);
+  if (C == 384) hipLaunchKernelGGL((ln_fwd_kernel<6, bf16, bf16>), dim3(ln_grid(M)), dim3(256), 0, st, x, gamma, beta, y, mean, rstd, M, y8, s8, sat, s8p, amax8);
+  else if (C == 768) hipLaunchKernelGGL((ln_fwd_kernel<12, bf16, bf16>), dim3(ln_grid(M)), dim3(256), 0, st, x, gamma, beta, y, mean, rstd, M, y8, s8, sat, s8p, amax8);
   else return ATST_EINVAL;
   return (int)hipGetLastError();
 }

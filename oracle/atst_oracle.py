@@ -165,6 +165,7 @@ class _HeadLinear(torch.autograd.Function):         # forward ~exact (split-bf16
 
 _FP8 = False
 _FP8_ACT = {}
+_FP8_RESID16 = False                                 # emulate_fp8(resid_bf16=True): no-grad passes keep their residual stream in bf16 (csrc/engine.hip, round 6)
 FP8_ACT_SCALE, FP8_ACT_SCALE_GELU = 8.0, 4.0        # csrc/engine.hip ACT_SCALE / ACT_SCALE_GELU
 
 
@@ -173,20 +174,22 @@ class emulate_fp8:
     operands -- activations x fixed scale, weights x 448 / amax per tensor, both saturated at +-448 -- exactly like the HIP
     fp8 path (csrc/engine.hip gemm8, csrc/optim.hip quant kernels); gradients flow as if the bf16 operands had been used."""
 
-    def __init__(self, on: bool = True, act_scales=None):
+    def __init__(self, on: bool = True, act_scales=None, resid_bf16: bool = True):
         """act_scales: optional {weight key: scale of that Linear's INPUT activation} -- the running (delayed) scales of a later step
-        (AtstEngine.f8a_scale); sites not listed use the constants FP8_ACT_SCALE / FP8_ACT_SCALE_GELU (= the first step)."""
-        self.on, self.act_scales = on, dict(act_scales or {})
+        (AtstEngine.f8a_scale); sites not listed use the constants FP8_ACT_SCALE / FP8_ACT_SCALE_GELU (= the first step).
+        resid_bf16 (round 6): passes evaluated WITHOUT gradient (teacher / inference) keep their residual stream in bf16 -- the sum of every residual
+        add is rounded -- like the HIP fp8 inference passes (csrc/engine.hip `xb16`; tuning hook 2100 switches it off there, False here)."""
+        self.on, self.act_scales, self.resid_bf16 = on, dict(act_scales or {}), resid_bf16
 
     def __enter__(self):
-        global _FP8, _FP8_ACT
-        self.prev, _FP8 = (_FP8, _FP8_ACT), self.on
-        _FP8_ACT = self.act_scales
+        global _FP8, _FP8_ACT, _FP8_RESID16
+        self.prev, _FP8 = (_FP8, _FP8_ACT, _FP8_RESID16), self.on
+        _FP8_ACT, _FP8_RESID16 = self.act_scales, self.resid_bf16
         return self
 
     def __exit__(self, *a):
-        global _FP8, _FP8_ACT
-        _FP8, _FP8_ACT = self.prev
+        global _FP8, _FP8_ACT, _FP8_RESID16
+        _FP8, _FP8_ACT, _FP8_RESID16 = self.prev
 
 
 def _q8(x: Tensor, scale) -> Tensor:
@@ -394,14 +397,15 @@ def block_forward(W: Weights, pre: str, x: Tensor, bias: Optional[Tensor], num_h
     y = _rg(_linear(y, W, pre + "attn.proj.weight", W[pre + "attn.proj.bias"]), "g_proj_out")
     if keep_attn is not None and drop_prob > 0.0:
         y = y / (1.0 - drop_prob) * keep_attn.to(y.dtype)[:, None, None]
-    x = x + y
+    r16 = _FP8 and _FP8_RESID16 and not torch.is_grad_enabled()     # fp8 inference / teacher passes: bf16 residual stream (rounded at every add)
+    x = _bf(x + y) if r16 else x + y
     h = _rb(F.layer_norm(x, (C,), W[pre + "norm2.weight"], W[pre + "norm2.bias"], LN_EPS), "ln2", "g_ln2")
     h = _rg(_linear(h, W, pre + "mlp.fc1.weight", W[pre + "mlp.fc1.bias"]), "g_fc1_out")
     h = _r(_GeluSavedBf16.apply(h), "gelu_out") if _EMU else F.gelu(h)      # exact erf GELU (nn.GELU default)
     h = _rg(_linear(h, W, pre + "mlp.fc2.weight", W[pre + "mlp.fc2.bias"], FP8_ACT_SCALE_GELU), "g_fc2_out")
     if keep_mlp is not None and drop_prob > 0.0:
         h = h / (1.0 - drop_prob) * keep_mlp.to(h.dtype)[:, None, None]
-    return x + h
+    return _bf(x + h) if r16 else x + h
 
 
 def encoder_tokens(W: Weights, pre: str, mel: Tensor, length: Optional[Tensor], use_cls: bool,
