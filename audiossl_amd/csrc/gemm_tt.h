@@ -191,6 +191,20 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_tt_kernel(GemmArgs p, int T) {
   const int rb0 = r8 * 128 + ((c8l ^ r8) << 4);                      // staging read-back: row 8 j + r8, chunk c8l
   const unsigned vst = (unsigned)((r8 * p.ldc + c8l * 8) * 2);         // byte offset of this lane's 16-B piece inside an 8-row group of the output
   int ep_m0 = 0, ep_n0 = 0;
+  // L2 prefetch of the NEXT tile's A rows (round 6, after the in-step profile): with two stages of lead the stream hides an L2 hit, not an HBM miss --
+  // stand-alone (operands resident in the 256-MB last-level cache after the first repetition) qkv ran 137 us, inside the training step 175.  In stage 1
+  // of its round every EP wave touches one dword of every 128-B line of 64 rows of the tile the stream turns to at the end of this round: K / 64 loads per
+  // wave; their common destination register is released in stage 5 behind a counted wait (the stores of stages 1 .. 4 were issued after them and may
+  // stay in flight: vmcnt retires in order), four stages = several HBM latencies later.
+  int touch_m0 = -1;
+  float touch_reg = 0.f;
+  auto touch_next = [&]() {
+#ifndef ATST_TT_NO_TOUCH
+    if (touch_m0 < 0) return;
+    const char* a = reinterpret_cast<const char*>(p.A) + (size_t)(touch_m0 + tw * 64 + lane) * p.lda * 2;
+    for (int j = 0; j < nk; ++j) { asm volatile("global_load_dword %0, %1, off" : "+v"(touch_reg) : "v"(a) : "memory"); a += 128; }
+#endif
+  };
   f32x4 bb[2][4];                                                     // bias of this lane's columns: [nb][g] = columns nb * 32 + 8 g + 4 hi .. + 3 of the wave's 64
   // Block row q of the tile as an ITEM: values -> bf16 -> staging (C) ... read back (R) ... whole-line stores (S).  PASS 0: acc + bias (plain output /
   // pre-activation u) ; PASS 1: GELU of it.  The three steps of an item sit in different places of the instruction stream (v2a: with C, R, S of one item
@@ -242,6 +256,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_tt_kernel(GemmArgs p, int T) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) bb[nb][g] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
+      if (!fin) touch_next();
+    }
+    if constexpr (S == 5) {                                          // the prefetch loads of stage 1 have landed: behind them only the 12 (u and a: 28) stores of stages 1 .. 4
+      constexpr int TOUCH_N = (ATST_TT_ABL & 1) ? 0 : ((EPI == EPI_BIAS_GELU && SU) ? 28 : 12);
+      if (!fin) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(touch_reg) : "n"(TOUCH_N) : "memory");
     }
 #if !(ATST_TT_ABL & 1)
     constexpr std::integral_constant<int, (S >= 1 && S <= 4) ? S - 1 : 0> qc{};      // the block row staged in this stage
@@ -297,6 +316,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_tt_kernel(GemmArgs p, int T) {
     } else {
       if (r >= 1) {                                                  // EP: tile r - 1
         tile_mn(r - 1, ep_m0, ep_n0);
+        { int tn0; touch_m0 = -1; if (r + 1 < nt) tile_mn(r + 1, touch_m0, tn0); }
         if (ATST_TT_PRIO == 2) __builtin_amdgcn_s_setprio(2);
         ep_round(r == nt);
         if (ATST_TT_PRIO == 2) __builtin_amdgcn_s_setprio(0);
