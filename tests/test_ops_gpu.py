@@ -977,17 +977,18 @@ def test_fp8_forward_saturation_counter_and_running_scales():
     assert eng.fp8_saturation() == {"student": 0, "teacher": 0}               # adapted: nothing clips any more
 
 
-def test_fp8_forward_only_state_is_saved_and_restored():
+def test_fp8_forward_only_state_is_saved_and_restored(monkeypatch):
     """the forward activation scales, their 16-step amax window and its cursor are live for EVERY fp8 engine, also when the e4m3
-    dgrad is off (ATST-small, or ATST_FP8_BWD=0) -- fp8_state() / load_fp8_state() must carry them, or a resumed run restarts from the
-    constants 8 / 8 / 8 / 4 with an empty window."""
+    dgrad is off (ATST_FP8_BWD=0; until round 6 also every ATST-small engine) -- fp8_state() / load_fp8_state() must carry them, or a resumed run
+    restarts from the constants 8 / 8 / 8 / 4 with an empty window."""
     from audiossl_amd.engine import AtstEngine
+    monkeypatch.setenv("ATST_FP8_BWD", "0")
     depth, B = 1, 2
     W = O.recipe_weights("small", depth=depth, seed=7)
     mels = [O.recipe_mel(B, 1001, seed=1).to(DEV), O.recipe_mel(B, 1001, seed=2).to(DEV)]
     lens = [torch.full((B,), 1001)] * 2
     eng = AtstEngine("small", depth=depth, drop_path_rate=0.0, fp8=True)
-    assert eng.fp8_bwd_state == 0                                              # d = 384: forward-only fp8
+    assert eng.fp8_bwd_state == 0                                              # forward-only fp8 (ATST_FP8_BWD=0)
     eng.load_weights(W)
     for _ in range(3):
         eng.forward(mels, lens)

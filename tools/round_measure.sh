@@ -16,6 +16,13 @@ ATST_OVERLAP_LT=0 timeout 900 rocprofv3 --kernel-trace --stats --output-format c
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o f -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile > /dev/null 2> $out/pmc_fetch.err
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o w -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile > /dev/null 2> $out/pmc_write.err
 python tools/traffic_from_pmc.py $out/pmc_fetch $out/pmc_write $out/traffic_clip6.json clip6 "$head" 3
+# round 6: the all-e4m3 step at d = 384 (bench line + whole-step PMC traffic next to the bf16 one), ATST-Frame base
+timeout 300 python bench.py --dtype fp8 --no-cpu-baseline --no-also > $out/bench_small_fp8_clip6.json 2> $out/bench_small_fp8.err
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch8 -o f -- python3 bench.py --dtype fp8 --steps 3 --warmup 2 --no-cpu-baseline --no-profile --no-also > /dev/null 2> $out/pmc_fetch8.err
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write8 -o w -- python3 bench.py --dtype fp8 --steps 3 --warmup 2 --no-cpu-baseline --no-profile --no-also > /dev/null 2> $out/pmc_write8.err
+python tools/traffic_from_pmc.py $out/pmc_fetch8 $out/pmc_write8 $out/traffic_small_fp8_clip6.json clip6-fp8 "$head" 5
+timeout 300 python bench.py --arch base --workload frame --no-cpu-baseline --no-also > $out/bench_base_frame.json 2> $out/bench_base_frame.err
+timeout 300 python bench.py --arch base --workload frame --dtype fp8 --no-cpu-baseline --no-also > $out/bench_base_fp8_frame.json 2>> $out/bench_base_frame.err
 # extra data points: ATST-base bf16 / fp8 / fp8 at the configs[4] input geometry ; the fp32 parity mode next to bf16 at the same batch
 timeout 300 python bench.py --arch base --workload clip2 --no-cpu-baseline > $out/bench_base_clip2.json 2> $out/bench_base.err
 timeout 300 python bench.py --arch base --workload clip2 --dtype fp8 --no-cpu-baseline > $out/bench_base_fp8_clip2.json 2>> $out/bench_base.err
@@ -24,5 +31,5 @@ timeout 600 python bench.py --precise --workload clip2 --batch 64 --steps 8 --wa
 timeout 300 python bench.py --workload clip2 --batch 64 --steps 40 --no-cpu-baseline --no-profile > $out/bench_bf16_clip2_b64.json 2>> $out/bench_precise.err
 find $out -name "*_kernel_stats.csv" | head; cat $out/bench_clip6.json | cut -c1-400
 # the raw per-dispatch counter CSVs are large: keep only the summary json in the merge-back
-rm -rf $out/pmc_fetch $out/pmc_write
+rm -rf $out/pmc_fetch $out/pmc_write $out/pmc_fetch8 $out/pmc_write8
 find $out/prof $out/prof_excl -type f ! -name "*_kernel_stats.csv" -delete
