@@ -635,7 +635,10 @@ DEVFN void lnb_flush(const GemmArgs& p, const LnbCols& cs, float* red, int tid) 
 // 40 registers beside the 192 accumulators); the two wave rows run one barrier apart, so that each SIMD's two waves alternate between their MFMA
 // cluster and their fragment reads / LDS-DMA; k-tile t + 2 is staged during phases 1-3 of k-tile t (inline-asm LDS-DMA, scalar base + lane offset)
 // and the only vector-memory wait is a counted `vmcnt(5)` in the last phase of a k-tile.
-template <int EPI, int MI, bool LN = false, bool F8 = false, bool TR = false, bool PH = false>
+// PH == 2 (round 6): the same phased loop on 64-DEEP k-tiles of whole 128-B rows (two 80-KB slots = all of the LDS): the two-team experiment measured the
+// same bytes streaming at 44 B/clk/CU as whole lines and at 28 as 64-B rows (DESIGN.md section 3 "Round 6").  Eight phases (ks, mh) per k-tile, k-tile t + 1 staged in
+// phases 1 .. 5 of k-tile t (10 pieces per wave), `vmcnt(0)` in the last phase.  Chunk c of row r at c ^ ((r >> 1) & 7) as in gemm_p8.h.
+template <int EPI, int MI, bool LN = false, bool F8 = false, bool TR = false, int PH = 0>
 __global__ __launch_bounds__(512, (MI == 2 ? ATST_MI2_WPS : 2)) void gemm_nt_row384_kernel(GemmArgs p) {
   static_assert(!TR || (EPI == EPI_BF16 && !LN), "transposed accumulators: store-only bf16 epilogue");
   static_assert(!PH || (MI == 4 && !F8 && !TR), "phased main loop: 256-row tile, bf16 operands");
@@ -692,6 +695,79 @@ __global__ __launch_bounds__(512, (MI == 2 ? ATST_MI2_WPS : 2)) void gemm_nt_row
     }
   }
 
+  if constexpr (PH == 2) {
+    constexpr int BKL = 64, ROWL = 128, A_BY = BMR * ROWL, STG = A_BY + BNR * ROWL;   // 32 KB + 48 KB
+    const int nk = p.K / BKL;                                      // >= 2 (launcher)
+    const int wu = __builtin_amdgcn_readfirstlane(wid);
+    // LDS-DMA: a piece = 8 rows x 128 B; wave w stages A pieces 4 w .. 4 w + 3 and B pieces 6 w .. 6 w + 5; lane (r8, c) fetches chunk c ^ key(row)
+    const int r8 = lane >> 3, c8 = lane & 7;
+    unsigned voA[4], voB[6];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = (wu * 4 + j) * 8 + r8;
+      int ra = m0 + row; ra = ra < p.M ? ra : p.M - 1;              // clamp: rows >= M are never stored
+      voA[j] = (unsigned)((ra - m0) * p.lda + (c8 ^ ((row >> 1) & 7)) * 8) * 2u;
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int row = (wu * 6 + j) * 8 + r8;
+      voB[j] = (unsigned)(row * p.ldb + (c8 ^ ((row >> 1) & 7)) * 8) * 2u;
+    }
+    const char* baseA = sgpr_ptr(p.A + (size_t)m0 * p.lda);
+    const char* baseB = sgpr_ptr(p.B + (size_t)n0 * p.ldb);
+    const unsigned ldsA = lds_addr(smem_raw) + wu * 4 * 1024, ldsB = lds_addr(smem_raw) + A_BY + wu * 6 * 1024;
+    auto stage_piece = [&](int kt, int slot, int j) {               // j: 0 .. 3 = A pieces ; 4 .. 9 = B pieces
+      const size_t kofs = (size_t)kt * (BKL * 2);
+      if (j < 4) p8_glds16(voA[j < 4 ? j : 0], baseA + kofs, ldsA + slot * STG + j * 1024);
+      else p8_glds16(voB[j >= 4 ? j - 4 : 0], baseB + kofs, ldsB + slot * STG + (j - 4) * 1024);
+    };
+    const int xk = (l31 >> 1) & 7;
+    const int fA0 = (wm * 128 + l31) * ROWL + ((hi ^ xk) << 4), fB0 = A_BY + (wn * 96 + l31) * ROWL + ((hi ^ xk) << 4);
+    bf16x8 fa[2][2], fb[2][3];                                      // A: [mh][rb] ; B: [ks & 1][ni]
+    auto read_a = [&](int slot, int ks, int mh) {
+      int b0 = fA0; asm volatile("" : "+v"(b0));
+      const char* s = lds + slot * STG + mh * 64 * ROWL;
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) fa[mh][rb] = *reinterpret_cast<const bf16x8*>(s + (b0 ^ (ks << 5)) + rb * 32 * ROWL);
+    };
+    auto read_b = [&](int slot, int ks) {
+      int b0 = fB0; asm volatile("" : "+v"(b0));
+      const char* s = lds + slot * STG;
+#pragma unroll
+      for (int ni = 0; ni < 3; ++ni) fb[ks & 1][ni] = *reinterpret_cast<const bf16x8*>(s + (b0 ^ (ks << 5)) + ni * 32 * ROWL);
+    };
+#pragma unroll
+    for (int j = 0; j < 10; ++j) stage_piece(0, 0, j);
+    p8_wait_vm<0>();
+    asm volatile("s_barrier" ::: "memory");
+    if ((wu >> 2) == 1) asm volatile("s_barrier" ::: "memory");     // the upper wave row runs one barrier behind the lower one
+    for (int t = 0; t < nk; ++t) {
+      const int slot = t & 1, slot1 = slot ^ 1;
+      const bool more = t + 1 < nk;
+      auto phase = [&](auto kstag, auto mhtag) {
+        constexpr int ks = decltype(kstag)::value, mh = decltype(mhtag)::value, ph = 2 * ks + mh;
+        if constexpr (mh == 0) read_b(slot, ks);
+        read_a(slot, ks, mh);
+        if (more) {                                                 // k-tile t + 1 into the slot k-tile t - 1 was read from (its last reads: phase 7, both wave rows past them from phase 1 on)
+          if constexpr (ph >= 1 && ph <= 5) { stage_piece(t + 1, slot1, 2 * (ph - 1)); stage_piece(t + 1, slot1, 2 * (ph - 1) + 1); }
+          if constexpr (ph == 7) p8_wait_vm<0>();                   // k-tile t + 1 has landed -- mine; the barrier makes it everyone's
+        }
+        asm volatile("s_barrier" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+          for (int ni = 0; ni < 3; ++ni) acc[2 * mh + rb][ni] = mfma32(fa[mh][rb], fb[ks & 1][ni], acc[2 * mh + rb][ni]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_barrier" ::: "memory");
+      };
+      static_for<8>([&](auto phtag) { constexpr int q = decltype(phtag)::value; phase(std::integral_constant<int, (q >> 1)>{}, std::integral_constant<int, (q & 1)>{}); });
+    }
+    if ((wu >> 2) == 0) asm volatile("s_barrier" ::: "memory");     // re-align the wave rows: every operand read is done, the ring is free
+  } else
   if constexpr (PH) {
     const int nk = p.K / BK;                                       // >= 2 (checked by the launcher)
     const int wu = __builtin_amdgcn_readfirstlane(wid);
@@ -1769,7 +1845,7 @@ int g_dgelu_row384 = 2;     // 306/307/308: dGELU GEMM on the 256x384 tile never
 int g_w4_mode = 0;          // 330 + m: 4-wave two-blocks-per-CU kernels: 0 only for small grids ; 2 = 256x192 (plain epilogues) + 128x384 (row-wise) everywhere ; 3 = 256x192 for the plain epilogues only
 int g_w4_min_m = 8192;      // 350/351: apply the tall / 4-wave kernels from M = 8192 / from any M (parity tests run small shapes)
 int g_w4_auto = 1;          // 360/361: 4-wave kernels for launches of <= 1.5 rounds of 256 x 384 tiles
-int g_ph = 1;               // 396/397: phased main loop (template parameter PH) of the 256 x 384 tile: off / on
+int g_ph = 1;               // 396/397/398: phased main loop (template parameter PH) of the 256 x 384 tile: off / on (32-deep, three 40-KB slots) / 64-deep whole-line stages (two 80-KB slots, round 6)
 int g_p8_skew = 0;          // 1000 + c: start-up skew of every other first-round block of the phased kernel, c x 1024 cycles (experiment)
 int g_p8 = 3;               // 390/391/392/393: 256 x 256 phased kernel (gemm_p8.h) for N % 256 == 0, K % 128 == 0, M % 256 == 0, M >= 8192: off / bf16 operands only / also e4m3
                             // except fc1 + GELU / every e4m3 GEMM (default since the lean outputs: fc1 + GELU 606 -> 592 us, base fp8 +0.8 ... 1.8 %)
@@ -1834,10 +1910,10 @@ int launch_nt_cfg(const GemmArgs& a, hipStream_t st) {
   hipLaunchKernelGGL((gemm_nt_kernel<EPI, BMT, NSTG, WTM, KS>), dim3(nblk), dim3(G::THREADS), G::LDS, st, a);
   return (int)hipGetLastError();
 }
-template <int EPI, int MI, bool LN, bool F8 = false, bool TR = false, bool PH = false>
+template <int EPI, int MI, bool LN, bool F8 = false, bool TR = false, int PH = 0>
 int launch_nt_row384_cfg(const GemmArgs& a, hipStream_t st) {
   using RG = row384::Geo<MI>;
-  constexpr int LDS = TR ? RG::NSTG * RG::STAGE + row384::BNR * 4 : row384::lds_bytes<MI, EPI, LN>();
+  constexpr int LDS = PH == 2 ? 163840 : TR ? RG::NSTG * RG::STAGE + row384::BNR * 4 : row384::lds_bytes<MI, EPI, LN>();   // PH == 2: two 80-KB slots
   static OncePerDevice attr_done; int attr_done_dev;
   if (attr_done.need(attr_done_dev)) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_row384_kernel<EPI, MI, LN, F8, TR, PH>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -1951,14 +2027,14 @@ int launch_nt_row384(const GemmArgs& a, hipStream_t st) {
   }
   // 256-row tiles: the operand ring of one block covers twice the output (6.7 vs 10.7 KB staged per 128x128 unit)
   const bool tall = a.M >= (g_w4_min_m < 8192 ? g_w4_min_m : 8192) && (g_row384_tall == 2 || (g_row384_tall == 1 && EPI == EPI_BF16 && (a.K >= 768 || a.N >= 768)));
-  const bool ph = g_ph && tall && a.K >= 2 * BK;                   // phased main loop of the 256-row tile
+  const int ph = (g_ph && tall && a.K >= 2 * BK) ? ((g_ph == 2 && a.K % 64 == 0 && a.K >= 128) ? 2 : 1) : 0;   // phased main loop of the 256-row tile (2: 64-deep whole-line stages, hook 398)
   if constexpr (EPI == EPI_RESID) {
-    if (a.ln_out) return tall ? (ph ? launch_nt_row384_cfg<EPI, 4, true, false, false, true>(a, st) : launch_nt_row384_cfg<EPI, 4, true>(a, st)) : launch_nt_row384_cfg<EPI, 2, true>(a, st);
+    if (a.ln_out) return tall ? (ph == 2 ? launch_nt_row384_cfg<EPI, 4, true, false, false, 2>(a, st) : ph ? launch_nt_row384_cfg<EPI, 4, true, false, false, 1>(a, st) : launch_nt_row384_cfg<EPI, 4, true>(a, st)) : launch_nt_row384_cfg<EPI, 2, true>(a, st);
   }
   if constexpr (EPI == EPI_BF16) {
     if (g_bf16_tr) return tall ? launch_nt_row384_cfg<EPI, 4, false, false, true>(a, st) : launch_nt_row384_cfg<EPI, 2, false, false, true>(a, st);
   }
-  return tall ? (ph ? launch_nt_row384_cfg<EPI, 4, false, false, false, true>(a, st) : launch_nt_row384_cfg<EPI, 4, false>(a, st)) : launch_nt_row384_cfg<EPI, 2, false>(a, st);
+  return tall ? (ph == 2 ? launch_nt_row384_cfg<EPI, 4, false, false, false, 2>(a, st) : ph ? launch_nt_row384_cfg<EPI, 4, false, false, false, 1>(a, st) : launch_nt_row384_cfg<EPI, 4, false>(a, st)) : launch_nt_row384_cfg<EPI, 2, false>(a, st);
 }
 template <int EPI>
 int launch_nt(const GemmArgs& a, hipStream_t st) {
@@ -2013,7 +2089,7 @@ void atst_gemm_nt_set_variant(int v) {
   if (v >= 2100 && v < 2102) g_f8_resid16 = v - 2100;
   else if (v >= 2000 && v < 2100) g_tt = v - 2000;
   else if (v >= 1000 && v < 2000) g_p8_skew = v - 1000;
-  else if (v >= 396 && v <= 397) g_ph = v - 396;
+  else if (v >= 396 && v <= 398) g_ph = v - 396;
   else if (v >= 390) g_p8 = v - 390;
   else if (v >= 380) g_f32_splitk = v - 380;
   else if (v >= 370) g_bf16_tr = v - 370;

@@ -67,6 +67,30 @@ def test_gemm_nt_plain(M, N, K):
     assert relerr(outb.float(), ref + bias) < 4e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(8192 + 77, 1152, 384), (8192, 384, 1536), (16384 + 256, 384, 128)])
+def test_gemm_nt_row384_whole_line_main_loop_same_bits(M, N, K):
+    """Hook 398 (round 6): the phased main loop of the 256 x 384 tile on 64-deep k-tiles of whole 128-B rows (two 80-KB slots) instead of 32-deep ones of
+    64-B rows.  Every accumulator sees its k-steps in the same ascending order, so the fp32 output is BIT-identical to hook 397; ragged last row tile,
+    K = 128 (two k-tiles: all prologue and tail), plain and fused epilogues."""
+    lib = hip.load()
+    A, B = bf(rnd(M, K, seed=1, scale=0.5)), bf(rnd(N, K, seed=2, scale=0.5))
+    bias, resid = rnd(N, seed=3), rnd(M, N, seed=4)
+    res = {}
+    try:
+        lib.atst_tune_gemm_variant(360)                                   # (keep the 8-wave tile for every shape)
+        for hook in (397, 398):
+            lib.atst_tune_gemm_variant(hook)
+            f32, _ = gemm_nt(A, B, hip.EPI_F32, torch.float32, bias=bias)
+            b16, _ = gemm_nt(A, B, hip.EPI_BF16, torch.bfloat16, bias=bias)
+            x, _ = gemm_nt(A, B, hip.EPI_RESID, torch.float32, bias=bias, resid=resid)
+            res[hook] = (f32, b16, x)
+    finally:
+        lib.atst_tune_gemm_variant(397); lib.atst_tune_gemm_variant(361)
+    assert relerr(res[398][0], A.float() @ B.float().t() + bias) < 2e-5
+    for a, b in zip(res[397], res[398]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("M,N,K", [(1536, 256, 12288), (512, 256, 12288), (1536, 384, 4096), (200, 128, 2048 + 32)])
 def test_gemm_nt_f32_split_k(M, N, K):
     """fp32-output GEMMs with a handful of output tiles and a long K (the second head Linear: 24 tiles x 384 k-tiles) split K over the idle CUs;
@@ -286,6 +310,7 @@ def test_layernorm(C):
 @pytest.mark.parametrize("M,K,hook,with_up", [(640, 128, None, True),          # 128-row tile, 8 waves
                                               (2048 + 40, 1152, None, True),  # <= 1.5 rounds: 128x384 tile on 4 waves, ragged
                                               (8192 + 64, 1536, 360, True),   # 256-row tile, 8 waves (4-wave auto-selection off)
+                                              (8192 + 64, 1152, (360, 398), True),   # ... with the 64-deep whole-line main loop (hook 398, round 6)
                                               (700, 384, None, False)])       # block 0: no upstream operand / bias gradient
 def test_gemm_lnbwd_epilogue(M, K, hook, with_up):
     """dgrad GEMM whose epilogue is the LayerNorm backward (EPI_LNBWD) vs autograd of layer_norm on the fp32 product."""
@@ -301,15 +326,15 @@ def test_gemm_lnbwd_epilogue(M, K, hook, with_up):
     dx = torch.empty(M, C, device=DEV)
     g = torch.empty(M, C, dtype=torch.bfloat16, device=DEV) if with_up else None
     dgamma, dbeta, dbu = (torch.full((C,), 0.125, device=DEV) for _ in range(3))
-    if hook is not None:
-        lib.atst_tune_gemm_variant(hook)
+    for hk in (() if hook is None else ((hook,) if isinstance(hook, int) else hook)):
+        lib.atst_tune_gemm_variant(hk)
     try:
         hip.call("atst_gemm_nt_lnbwd_bf16", hip.ptr(dY), hip.ptr(Wt), M, K, hip.ptr(x), hip.ptr(mean.contiguous()), hip.ptr(rstd.contiguous()),
                  hip.ptr(gamma), hip.ptr(dres), hip.ptr(dx), hip.ptr(g), hip.ptr(scale), rps, hip.ptr(dgamma), hip.ptr(dbeta),
                  hip.ptr(dbu) if with_up else None, hip.stream())
     finally:
         if hook is not None:
-            lib.atst_tune_gemm_variant(361)
+            lib.atst_tune_gemm_variant(361); lib.atst_tune_gemm_variant(397)
     dy = dY.float() @ Wt.float().t()
     xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
     torch.nn.functional.layer_norm(xr, (C,), gr, br, 1e-6).backward(dy)
@@ -324,7 +349,7 @@ def test_gemm_lnbwd_epilogue(M, K, hook, with_up):
         assert float((dbu - 0.125).abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("M,K,hook", [(640, 128, None), (2048 + 40, 384, None), (8192 + 64, 1536, 360)])   # 128-row tile / 4-wave 128x384 / 256-row tile
+@pytest.mark.parametrize("M,K,hook", [(640, 128, None), (2048 + 40, 384, None), (8192 + 64, 1536, 360), (8192 + 64, 384, (360, 398))])   # 128-row tile / 4-wave 128x384 / 256-row tile / the same with the 64-deep whole-line main loop
 def test_gemm_resid_layernorm_epilogue(M, K, hook):
     """residual GEMM whose epilogue also emits LayerNorm(new row) + its statistics vs the fp32 formulation."""
     C, rps = 384, 32
@@ -336,14 +361,14 @@ def test_gemm_resid_layernorm_epilogue(M, K, hook):
     x = torch.empty(M, C, device=DEV)
     h = torch.empty(M, C, dtype=torch.bfloat16, device=DEV)
     mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
-    if hook is not None:
-        lib.atst_tune_gemm_variant(hook)
+    for hk in (() if hook is None else ((hook,) if isinstance(hook, int) else hook)):
+        lib.atst_tune_gemm_variant(hk)
     try:
         hip.call("atst_gemm_nt_resid_ln_bf16", hip.ptr(A), hip.ptr(B), M, K, hip.ptr(bias), hip.ptr(resid), hip.ptr(scale), rps, hip.ptr(x),
                  hip.ptr(gamma), hip.ptr(beta), hip.ptr(h), hip.ptr(mean), hip.ptr(rstd), hip.stream())
     finally:
         if hook is not None:
-            lib.atst_tune_gemm_variant(361)
+            lib.atst_tune_gemm_variant(361); lib.atst_tune_gemm_variant(397)
     want = resid + scale.repeat_interleave(rps)[:M, None] * (A.float() @ B.float().t() + bias)
     assert relerr(x, want) < 2e-5
     assert relerr(mean, want.mean(1)) < 2e-5
