@@ -398,7 +398,7 @@ def main():
                                        ("clip6", "small", "fp8", False)):                                    # all-e4m3 + fp8_lean at d = 384 (round 6)
             if (wl, arch, dtype, hires) == headline:
                 continue
-            n_w, n_t = 3, args.also_steps
+            n_w, n_t = (8 if wl == "frame" else 3), args.also_steps       # ATST-Frame: its head batch is the masked rows of the step -- a few more steps until the row-buffer capacities have all been seen by the allocator
             eng2, step2, info2 = build_job(wl, arch, dtype, hires, B, world, rank, dev, n_w + n_t + 2)
             for k in range(n_w):
                 step2(k)
