@@ -301,6 +301,7 @@ __global__ __launch_bounds__((NtGeo<BMT, NSTG, WTM>::THREADS), (NtGeo<BMT, NSTG,
   f32x4 bias0, bias1;
   epi_bias8(p, n0 + c8, bias0, bias1);
   f32x4 csum0 = {0.f, 0.f, 0.f, 0.f}, csum1 = csum0;              // EPI_DGELU: column sums of du = fc1 bias gradient
+  float omax = 0.f;                                               // EPI_DGELU: running max |du| (fp8 backward, recording step)
 #pragma unroll
   for (int part = 0; part < BMT / 64; ++part) {
     EpiAux aux[NPASS];
@@ -337,10 +338,19 @@ __global__ __launch_bounds__((NtGeo<BMT, NSTG, WTM>::THREADS), (NtGeo<BMT, NSTG,
         }
         epilogue8<EPI>(p, row, n0 + c8, *reinterpret_cast<const f32x4*>(sC + rl * C_LD + c8),
                        *reinterpret_cast<const f32x4*>(sC + rl * C_LD + c8 + 4), bias0, bias1, aux[pass], w0, w1);
-        if constexpr (EPI == EPI_DGELU) { csum0 += w0; csum1 += w1; }
+        if constexpr (EPI == EPI_DGELU) {
+          csum0 += w0; csum1 += w1;
+          if (p.q8_amax) {                                         // recording step of the fp8 backward (delayed scaling): max |du| of this launch -- launches below 8192 rows at K = 384 land on this
+#pragma unroll                                                     // kernel, and without the post the du site kept its start-up scale (found by the 2-rank d = 384 fp8 test, round 6)
+            for (int e = 0; e < 4; ++e) omax = fmaxf(omax, fmaxf(fabsf(w0[e]), fabsf(w1[e])));
+          }
+        }
       }
     }
     if (part + 1 < BMT / 64) __syncthreads();
+  }
+  if constexpr (EPI == EPI_DGELU) {
+    if (p.q8_amax) amax_post(p.q8_amax, wave_max(omax), lane, blockIdx.x * (G::THREADS / 64) + (tid >> 6));
   }
   if constexpr (EPI == EPI_DGELU) {
     if (p.colsum) {                                               // block-reduce over the RPP row groups, one atomic per column

@@ -19,7 +19,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--mode", default="clip", choices=["clip", "frame", "frame_ragged", "base_fp8"])
+    ap.add_argument("--mode", default="clip", choices=["clip", "frame", "frame_ragged", "base_fp8", "small_fp8"])
     ap.add_argument("--out", required=True)
     ap.add_argument("--overlap", type=int, default=1)
     ap.add_argument("--batch", type=int, default=4, help="clips per rank")
@@ -36,10 +36,10 @@ def main():
     from oracle import atst_oracle as O                       # seeded input recipes only (test infrastructure)
 
     frame = args.mode in ("frame", "frame_ragged")
-    fp8 = args.mode == "base_fp8"                             # BASELINE.json configs[4] under DDP: ATST-base, every GEMM of a block on e4m3 operands
+    fp8 = args.mode in ("base_fp8", "small_fp8")                             # BASELINE.json configs[4] under DDP: ATST-base, every GEMM of a block on e4m3 operands
     depth, Bt = (2 if fp8 else 4), args.batch * args.ranks    # total clips
     if fp8:
-        eng = AtstEngine("base", depth=depth, ncrops=2, drop_path_rate=0.1, fp8=True)
+        eng = AtstEngine("base" if args.mode == "base_fp8" else "small", depth=depth, ncrops=2, drop_path_rate=0.1, fp8=True)   # small_fp8: the all-e4m3 step at d = 384 (round 6)
     else:
         eng = AtstEngine("small", frame=frame, depth=depth, ncrops=2 if frame else 3, drop_path_rate=0.1)
     eng.overlap_comm = bool(args.overlap)

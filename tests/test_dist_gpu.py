@@ -109,18 +109,19 @@ def test_eight_ranks_equal_one_rank_on_the_concatenated_batch(tmp_path, mode):
     assert _rel(eight["teacher"], one["teacher"]) < 5e-5
 
 
-def test_two_ranks_equal_one_rank_base_fp8(tmp_path):
+@pytest.mark.parametrize("mode", ["base_fp8", "small_fp8"])
+def test_two_ranks_equal_one_rank_base_fp8(tmp_path, mode):
     """BASELINE.json configs[4] is an 8-GPU DDP job: ATST-base with every GEMM of a block on e4m3 operands, two ranks (8 clips each) against one
     process on the 16-clip batch, second step (the first records the delayed scales).  The amax of every quantisation site is MAX-reduced over the
     ranks, so both runs quantise on the same grids (checked on the scales); what is left is summation order meeting the
     e4m3 staircase (a value next to a rounding boundary lands on either side), far inside the fp8 path's own distance from bf16."""
-    one = _worker(tmp_path, "one_fp8", 1, "base_fp8", batch=8)
-    two = _worker(tmp_path, "two_fp8", 2, "base_fp8", 1, batch=8)
+    one = _worker(tmp_path, "one_fp8", 1, mode, batch=8)                    # small_fp8 (round 6): the same at d = 384
+    two = _worker(tmp_path, "two_fp8", 2, mode, 1, batch=8)
     assert int(two["world"]) == 2 and float(two["same"][0]) == 1.0          # ranks hold identical parameters after the step
     import numpy as np
     g = _rel(two["grads"], one["grads"])
     sg = float(np.max(np.abs(two["g8_scale"] * 2.0 / one["g8_scale"] - 1.0))); sa = float(np.max(np.abs(two["f8a_scale"] / one["f8a_scale"] - 1.0)))
-    print(f"\n[2 ranks vs 1, base fp8] loss {float(two['loss'][0]):.6f} vs {float(one['loss'][0]):.6f}; flat gradient rel {g:.2e}; scales: gradient sites {sg:.1e}, forward sites {sa:.1e}")
+    print(f"\n[2 ranks vs 1, {mode}] loss {float(two['loss'][0]):.6f} vs {float(one['loss'][0]):.6f}; flat gradient rel {g:.2e}; scales: gradient sites {sg:.1e}, forward sites {sa:.1e}")
     # same quantisation grids: a rank's activation gradients are world x the single process's (its loss is the mean over ITS clips; DDP averages the
     # parameter gradients afterwards), so its gradient scales are 1 / world of them -- scale x value, i.e. the e4m3 code, is the same; forward scales equal
     assert sg < 1e-2 and sa < 1e-2
