@@ -362,7 +362,7 @@ def test_small_fp8_encoder_gradient_vs_reference_golden():
     assert res[0][1] < FP8S_GRAD_FWD and res[1][1] < FP8S_GRAD_ALL and res[1][2][1][0] < FP8S_GRAD_WORST
 
 
-FP8S_CLS, FP8S_GRAD_FWD, FP8S_GRAD_ALL, FP8S_GRAD_WORST = 0.13, 0.12, 0.21, 0.33   # measured 8.8e-2 ; 8.0e-2 ; 0.137 ; 0.216 (blocks.7.mlp.fc1.weight) -- x1.5 (12 layers; the d = 768 golden has 3)
+FP8S_CLS, FP8S_GRAD_FWD, FP8S_GRAD_ALL, FP8S_GRAD_WORST = 0.13, 0.12, 0.15, 0.20   # measured 8.8e-2 ; 8.0e-2 ; 9.9e-2 ; 0.132 (blocks.11.norm2.weight) -- x1.5 (12 layers; the d = 768 golden has 3).  (Before the du-amax fix of the 128 x 128 dGELU kernel: 0.137 / 0.216.)
 
 
 FP8_CLS, FP8_GRAD_FWD, FP8_GRAD_ALL, FP8_GRAD_WORST = 0.12, 0.11, 0.14, 0.26   # measured 7.9e-2 ; 7.2e-2 ; 9.1e-2 ; 0.169 (pos_embed) -- x1.5
