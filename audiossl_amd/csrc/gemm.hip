@@ -1861,7 +1861,7 @@ int g_p8 = 3;               // 390/391/392/393: 256 x 256 phased kernel (gemm_p8
                             // except fc1 + GELU / every e4m3 GEMM (default since the lean outputs: fc1 + GELU 606 -> 592 us, base fp8 +0.8 ... 1.8 %)
                             // operands (default; except fc1 + GELU, whose e4m3 epilogue -- u, a, the e4m3 copy of a, amax -- measured 640 vs 647 us on the 256 x 384 tile).
                             // Same box, same call, base fp8 step: 2405-2407 (391) -> 2453-2476 clips/s (392), profiles/r05_p8_fp8_step_ab.txt
-int g_tt = 0;               // 2000 + v: two-team persistent kernel (gemm_tt.h): 0 off / 1 plain bf16 + fc1-GELU launches it takes
+int g_tt = 0;               // 2000 + v: persistent overlap kernels (gemm_tt.h): 0 off / 1 two teams of four waves / 2 one stream, 4 waves x 512 registers -- for the plain bf16 + fc1-GELU launches they take
 int g_f32_splitk = 1;       // 380/381: split-K for fp32-output GEMMs with <= 64 output tiles and K >= 2048
 // Split-K workspace: per (device, stream) -- kernels of one stream run in order, so one buffer per stream is race-free; the null stream is the same
 // handle on every device, hence the device in the key (round-4 ADVICE).  Sized on first use for the largest head shape of the path
@@ -1997,8 +1997,25 @@ int launch_nt_tt_cfg(const GemmArgs& a, hipStream_t st) {
   hipLaunchKernelGGL((gemm_nt_tt_kernel<EPI, SU>), dim3(tt_num_cus()), dim3(tt::THREADS), tt::LDS_BYTES, st, a, T);
   return (int)hipGetLastError();
 }
+template <int EPI, bool SU>
+int launch_nt_t1_cfg(const GemmArgs& a, hipStream_t st) {         // the same overlap as ONE instruction stream: 4 waves, one per SIMD, 512 registers (hook 2002)
+  static OncePerDevice attr_done; int dev;
+  if (attr_done.need(dev)) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_t1_kernel<EPI, SU>, hipFuncAttributeMaxDynamicSharedMemorySize, tt::LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr_done.done(dev);
+  }
+  const int T = (a.M / tt::BM) * (a.N / tt::BNT);
+  ProfScope ps(prof_kind<EPI>(), 2.0 * a.M * a.N * a.K, st, nt_bytes<EPI>(a));
+  hipLaunchKernelGGL((gemm_nt_t1_kernel<EPI, SU>), dim3(tt_num_cus()), dim3(256), tt::LDS_BYTES, st, a, T);
+  return (int)hipGetLastError();
+}
 template <int EPI>
 int launch_nt_tt(const GemmArgs& a, hipStream_t st) {
+  if (g_tt == 2) {
+    if constexpr (EPI == EPI_BIAS_GELU) { if (!a.C) return launch_nt_t1_cfg<EPI, false>(a, st); }
+    if constexpr (EPI == EPI_BF16 || EPI == EPI_BIAS_GELU) return launch_nt_t1_cfg<EPI, true>(a, st);
+  }
   if constexpr (EPI == EPI_BIAS_GELU) { if (!a.C) return launch_nt_tt_cfg<EPI, false>(a, st); }
   if constexpr (EPI == EPI_BF16 || EPI == EPI_BIAS_GELU) return launch_nt_tt_cfg<EPI, true>(a, st);
   return ATST_EINVAL;

@@ -332,3 +332,249 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_tt_kernel(GemmArgs p, int T) {
 #undef TT_FENCE
 #undef TT_NEXT_STAGE
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------------
+// The SAME overlap as one instruction stream: the 4-wave, one-wave-per-SIMD, 512-register form VERDICT r5 item 1 sketched (tuning hook 2002).  A wave keeps
+// TWO accumulator sets (2 x 128 registers): in round r it multiplies tile r into set r & 1 and, between the MFMA pairs of that main loop, runs the epilogue
+// items of tile r - 1 out of the other set -- staged, read back and stored by the same micro-ops as the two-team kernel above, placed by hand: a stage is 16
+// MFMA pairs = 16 slots; slots 0 .. 11 carry the wave's 12 LDS-DMA pieces of stage s + 2, slot 0 the read-back of the item staged a stage earlier, slots
+// 1 .. 8 (u and a: 1 .. 4 and 6 .. 9) the conversion of this stage's item, slots 12 .. 15 the stores -- BEHIND the stage's pieces, so that the operand wait
+// of the next stage (`vmcnt(N)`, N = the stores just issued) does not sit behind them.  Same tile (256 x 128), same ring, same staging, same stream.
+template <int EPI, bool SU>
+__global__ __launch_bounds__(256, 1) void gemm_nt_t1_kernel(GemmArgs p, int T) {
+  using namespace tt;
+  static_assert(EPI == EPI_BF16 || EPI == EPI_BIAS_GELU, "epilogues carried so far");
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int tid = threadIdx.x, lane = tid & 63, tw = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = tw >> 1, wc = tw & 1, hi = lane >> 5, l31 = lane & 31;
+  const int G = gridDim.x, rb = xcd_remap(blockIdx.x, G);
+  const int ntn = p.N / BNT;
+  const int nt = rb < T ? (T - rb + G - 1) / G : 0;
+  if (nt == 0) return;
+  const int nk = p.K / BKT;
+  const int r8 = lane >> 3, c8l = lane & 7;
+  unsigned voA[2], voB[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par) {
+    const int ch = c8l ^ (4 * par + (r8 >> 1));
+    voA[par] = (unsigned)((r8 * p.lda + ch * 8) * 2); voB[par] = (unsigned)((r8 * p.ldb + ch * 8) * 2);
+  }
+  const size_t pa = (size_t)8 * p.lda * 2, pb = (size_t)8 * p.ldb * 2;
+  const unsigned lds0 = lds_addr(smem_raw);
+  int cur_j = 0, cur_s = 0;
+  const char* curA; const char* curB;
+  auto tile_mn = [&](int j, int& m0, int& n0) { const int id = j * G + rb, mi = id / ntn; m0 = mi * BM; n0 = (id - mi * ntn) * BNT; };
+  auto set_tile = [&](int j) {
+    int m0, n0; tile_mn(j, m0, n0);
+    curA = sgpr_ptr(reinterpret_cast<const char*>(p.A) + (size_t)m0 * p.lda * 2);
+    curB = sgpr_ptr(reinterpret_cast<const char*>(p.B) + (size_t)n0 * p.ldb * 2);
+  };
+  auto dma_piece = [&](int i, int slot) {
+    const bool is_b = i >= 8;
+    const int idx = is_b ? 4 * tw + (i - 8) : 8 * tw + i;
+    const unsigned dst = lds0 + slot * STAGE + (is_b ? A_BYTES : 0) + idx * 1024;
+    if (is_b) p8_glds16(voB[i & 1], curB + idx * pb, dst); else p8_glds16(voA[i & 1], curA + idx * pa, dst);
+  };
+  auto dma_advance = [&]() {
+    curA += ROWB; curB += ROWB;
+    if (++cur_s == nk) { cur_s = 0; if (cur_j + 1 < nt) ++cur_j; set_tile(cur_j); }
+  };
+  int slot_c = 0;
+  auto slot_next = [&]() { return slot_c == NS - 1 ? 0 : slot_c + 1; };
+  auto slot_issue = [&]() { return slot_c == 0 ? NS - 1 : slot_c - 1; };
+  const int keyf = (l31 >> 1) & 7;
+  const int fA0 = (wr * 128 + l31) * ROWB + ((hi ^ keyf) << 4), fB0 = A_BYTES + (wc * 64 + l31) * ROWB + ((hi ^ keyf) << 4);
+  f32x16 acc[2][4][2];
+  bf16x8 xa[4], xb[2], ya[4], yb[2];
+  // (every lane-dependent address below starts from a LAUNDERED copy of its base: derived from the base directly, hipcc hoists all the variants out of the
+  // round loop -- dozens of registers beside 256 accumulators -- and spills them; a reload is a vector-memory operation inside the counted waits)
+  auto rd = [&](int slot, int ks, bf16x8 (&fa)[4], bf16x8 (&fb)[2]) {
+    const char* s = smem_raw + slot * STAGE;
+    int a0 = fA0, b0 = fB0;
+    asm volatile("" : "+v"(a0), "+v"(b0));
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) fb[nb] = *reinterpret_cast<const bf16x8*>(s + ((b0 ^ (ks << 5)) + nb * 32 * ROWB));
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) fa[mb] = *reinterpret_cast<const bf16x8*>(s + ((a0 ^ (ks << 5)) + mb * 32 * ROWB));
+  };
+  // ---- epilogue micro-ops (tile r - 1, accumulator set Q)
+  char* stg = smem_raw + RING + tw * STG_WAVE;
+  const int wb0 = l31 * 128 + hi * 8 + ((l31 & 7) << 4);
+  const int rb0 = r8 * 128 + ((c8l ^ r8) << 4);
+  const unsigned vst = (unsigned)((r8 * p.ldc + c8l * 8) * 2);
+  int ep_m0 = 0, ep_n0 = 0;
+  f32x4 bb[2][4];
+  tt_u32x4 wq[4], wu[4];
+  auto ep_c1 = [&](auto qtag, auto passtag, auto qstag, int k) __attribute__((always_inline)) {      // one (nb, g) group of item (block row q, PASS) out of set QS
+    constexpr int q = decltype(qtag)::value, PASS = decltype(passtag)::value, QS = decltype(qstag)::value;
+    const int nb = k >> 2, g = k & 3;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      // BOTH accumulator sets have to live in the accumulator half of the register file (2 x 128 of the 256 AGPRs): read through an "a"-constrained
+      // v_accvgpr_read, or hipcc keeps the set the epilogue reads in arch VGPRs -- 128 of the 256 that fragments, bias, staging data and addresses share --
+      // and spills it in 30-register clumps inside the round (each reload a vector-memory operation inside the counted waits).  The set was written a round
+      // ago: no MFMA -> accvgpr_read hazard to pad.
+      float av;
+      asm("v_accvgpr_read_b32 %0, %1" : "=v"(av) : "a"(acc[QS][q][nb][4 * g + e]));
+      v[e] = av + bb[nb][g][e];
+    }
+    if constexpr (PASS == 1) {
+      const f32x2 a0 = gelu_bf16dst2(f32x2{v[0], v[1]}), a1 = gelu_bf16dst2(f32x2{v[2], v[3]});
+      v[0] = a0[0]; v[1] = a0[1]; v[2] = a1[0]; v[3] = a1[1];
+    }
+    int w0 = wb0; asm volatile("" : "+v"(w0));
+    *reinterpret_cast<tt_u32x2*>(stg + (w0 ^ ((nb * 4 + g) << 4))) = __builtin_bit_cast(tt_u32x2, pack_bf16x4(v));
+  };
+  auto ep_R = [&](tt_u32x4 (&w)[4]) __attribute__((always_inline)) {
+    int r0 = rb0; asm volatile("" : "+v"(r0));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = *reinterpret_cast<const tt_u32x4*>(stg + r0 + j * 1024);
+  };
+  auto ep_S1 = [&](int q, int j, const tt_u32x4 (&w)[4], void* out) __attribute__((always_inline)) {
+    char* obase = reinterpret_cast<char*>(out) + ((size_t)(ep_m0 + wr * 128 + q * 32) * p.ldc + ep_n0 + wc * 64) * 2;
+    unsigned v0 = vst; asm volatile("" : "+v"(v0));
+    __builtin_nontemporal_store(w[j], reinterpret_cast<tt_u32x4*>(obase + (size_t)j * 8 * p.ldc * 2 + v0));
+  };
+  constexpr std::integral_constant<int, 0> P0{}; constexpr std::integral_constant<int, 1> P1{};
+  // the epilogue work of slot I of stage S (see the header): static indices everywhere
+  auto ep_slot = [&](auto stag, auto itag, auto qstag) __attribute__((always_inline)) {
+    constexpr int S = decltype(stag)::value, I = decltype(itag)::value;
+    constexpr std::integral_constant<int, (S >= 1 && S <= 4) ? S - 1 : 0> qc{};
+    constexpr bool stage_c = S >= 1 && S <= 4, stage_s = S >= 2 && S <= 5;
+    if constexpr (EPI == EPI_BIAS_GELU && SU) {
+      if constexpr (I == 0 && stage_s) ep_R(wq);                                          // a(q - 1)
+      if constexpr (I >= 1 && I <= 4 && stage_c) { ep_c1(qc, P0, qstag, 2 * (I - 1)); ep_c1(qc, P0, qstag, 2 * (I - 1) + 1); }
+      if constexpr (I == 5 && stage_c) ep_R(wu);                                          // u(q)
+      if constexpr (I >= 6 && I <= 9 && stage_c) { ep_c1(qc, P1, qstag, 2 * (I - 6)); ep_c1(qc, P1, qstag, 2 * (I - 6) + 1); }
+      if constexpr (I >= 12 && stage_s) ep_S1(S - 2, I - 12, wq, p.C2);
+      if constexpr (I >= 12 && stage_c) ep_S1(S - 1, I - 12, wu, p.C);
+    } else {
+      constexpr bool gelu = EPI == EPI_BIAS_GELU;
+      if constexpr (I == 0 && stage_s) ep_R(wq);
+      if constexpr (I >= 1 && I <= 8 && stage_c) { if constexpr (gelu) ep_c1(qc, P1, qstag, I - 1); else ep_c1(qc, P0, qstag, I - 1); }
+      if constexpr (I >= 12 && stage_s) ep_S1(S - 2, I - 12, wq, gelu ? p.C2 : p.C);
+    }
+  };
+  // stores a stage issues behind its pieces = what may stay in flight at the head of the next stage
+  auto stores_of = [](int s) constexpr { return (EPI == EPI_BIAS_GELU && SU) ? ((s >= 2 && s <= 4) ? 8 : (s == 1 || s == 5) ? 4 : 0) : ((s >= 2 && s <= 5) ? 4 : 0); };
+#define TT_FENCE() __builtin_amdgcn_sched_barrier(0)
+  // one stage: S < 0 = a stage without epilogue work (rolled loop) ; P = accumulator set of the main loop
+  auto stage = [&](auto stag, auto ptag, auto first, auto mltag, auto eptag, bool more, int nwait) __attribute__((always_inline)) {
+    constexpr int S = decltype(stag)::value, P = decltype(ptag)::value;
+    constexpr bool do_ml = decltype(mltag)::value, do_ep = decltype(eptag)::value;
+    constexpr bool FIRST = decltype(first)::value;
+    if constexpr (do_ml) {
+      if (nwait == 0) p8_wait_vm<0>(); else if (nwait == 4) p8_wait_vm<4>(); else p8_wait_vm<8>();
+      asm volatile("s_barrier" ::: "memory");
+    }
+    if constexpr (S == 0) {
+      if constexpr (do_ep) {                                        // bias of this lane's columns: the oldest vector-memory operations of the stage -- landed by the next head
+        const float* src = p.bias ? p.bias + ep_n0 + wc * 64 + 4 * hi : reinterpret_cast<const float*>(p.B) + 4 * hi;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) tt_gload16(src + nb * 32 + 8 * g, bb[nb][g]);
+      }
+    }
+    if constexpr (S == 1) {
+      if constexpr (do_ep) {
+        if constexpr (!do_ml) tt_wait_all(bb); else asm volatile("" : "+v"(bb[0][0]), "+v"(bb[0][1]), "+v"(bb[0][2]), "+v"(bb[0][3]), "+v"(bb[1][0]), "+v"(bb[1][1]), "+v"(bb[1][2]), "+v"(bb[1][3]));   // (with a main loop: this stage's head waited vmcnt(0))
+        if (!p.bias) {
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bb[nb][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
+    const int si = slot_issue();
+    auto mm2 = [&](auto f, int mb, bf16x8 (&fa)[4], bf16x8 (&fb)[2]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        if constexpr (decltype(f)::value) {
+          const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          acc[P][mb][nb] = mfma32(fb[nb], fa[mb], z);
+        } else {
+          acc[P][mb][nb] = mfma32(fb[nb], fa[mb], acc[P][mb][nb]);
+        }
+      }
+    };
+    auto slot = [&](auto itag) __attribute__((always_inline)) {     // what follows MFMA pair I
+      constexpr int I = decltype(itag)::value;
+      TT_FENCE();
+      if constexpr (I < 12 && do_ml) dma_piece(I, si);
+      if constexpr (S >= 0 && do_ep) ep_slot(stag, itag, std::integral_constant<int, P ^ 1>{});
+      TT_FENCE();
+    };
+    constexpr std::integral_constant<bool, false> NF{};
+    if constexpr (do_ml) rd(slot_c, 1, ya, yb);
+    TT_FENCE();
+    if constexpr (do_ml) mm2(first, 0, xa, xb); slot(std::integral_constant<int, 0>{});
+    if constexpr (do_ml) mm2(first, 1, xa, xb); slot(std::integral_constant<int, 1>{});
+    if constexpr (do_ml) mm2(first, 2, xa, xb); slot(std::integral_constant<int, 2>{});
+    if constexpr (do_ml) mm2(first, 3, xa, xb); slot(std::integral_constant<int, 3>{});
+    if constexpr (do_ml) rd(slot_c, 2, xa, xb);
+    TT_FENCE();
+    if constexpr (do_ml) mm2(NF, 0, ya, yb); slot(std::integral_constant<int, 4>{});
+    if constexpr (do_ml) mm2(NF, 1, ya, yb); slot(std::integral_constant<int, 5>{});
+    if constexpr (do_ml) mm2(NF, 2, ya, yb); slot(std::integral_constant<int, 6>{});
+    if constexpr (do_ml) mm2(NF, 3, ya, yb); slot(std::integral_constant<int, 7>{});
+    if constexpr (do_ml) rd(slot_c, 3, ya, yb);
+    TT_FENCE();
+    if constexpr (do_ml) mm2(NF, 0, xa, xb); slot(std::integral_constant<int, 8>{});
+    if constexpr (do_ml) mm2(NF, 1, xa, xb); slot(std::integral_constant<int, 9>{});
+    if constexpr (do_ml) mm2(NF, 2, xa, xb); slot(std::integral_constant<int, 10>{});
+    if constexpr (do_ml) mm2(NF, 3, xa, xb); slot(std::integral_constant<int, 11>{});
+    if constexpr (do_ml) { if (more) rd(slot_next(), 0, xa, xb); }
+    TT_FENCE();
+    if constexpr (do_ml) mm2(NF, 0, ya, yb); slot(std::integral_constant<int, 12>{});
+    if constexpr (do_ml) mm2(NF, 1, ya, yb); slot(std::integral_constant<int, 13>{});
+    if constexpr (do_ml) mm2(NF, 2, ya, yb); slot(std::integral_constant<int, 14>{});
+    if constexpr (do_ml) mm2(NF, 3, ya, yb); slot(std::integral_constant<int, 15>{});
+    TT_FENCE();
+    if constexpr (do_ml) { dma_advance(); slot_c = slot_next(); }
+    (void)FIRST;
+  };
+  auto round = [&](auto ptag, auto mltag, auto eptag, int nwait0) __attribute__((always_inline)) {
+    constexpr std::integral_constant<bool, true> TF{}; constexpr std::integral_constant<bool, false> NF{};
+    constexpr bool do_ml = decltype(mltag)::value, do_ep = decltype(eptag)::value;
+    if constexpr (do_ml) rd(slot_c, 0, xa, xb);
+    stage(std::integral_constant<int, 0>{}, ptag, TF, mltag, eptag, true, nwait0);
+    stage(std::integral_constant<int, 1>{}, ptag, NF, mltag, eptag, true, do_ep ? stores_of(0) : 0);
+    stage(std::integral_constant<int, 2>{}, ptag, NF, mltag, eptag, true, do_ep ? stores_of(1) : 0);
+    stage(std::integral_constant<int, 3>{}, ptag, NF, mltag, eptag, true, do_ep ? stores_of(2) : 0);
+    stage(std::integral_constant<int, 4>{}, ptag, NF, mltag, eptag, true, do_ep ? stores_of(3) : 0);
+    stage(std::integral_constant<int, 5>{}, ptag, NF, mltag, eptag, nk > 6, do_ep ? stores_of(4) : 0);
+    if constexpr (do_ml) {
+      for (int s = 6; s < nk; ++s) stage(std::integral_constant<int, -1>{}, ptag, NF, TF, NF, s + 1 < nk, (do_ep && s == 6) ? stores_of(5) : 0);
+    }
+  };
+  // ---- prologue: stages 0 and 1 of the stream
+  set_tile(0);
+#pragma unroll
+  for (int st = 0; st < NS - 1; ++st) {
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) dma_piece(i, st);
+    dma_advance();
+  }
+  p8_wait_vm<NPW>();
+  asm volatile("s_barrier" ::: "memory");
+  constexpr std::integral_constant<bool, true> YES{}; constexpr std::integral_constant<bool, false> NO{};
+  constexpr std::integral_constant<int, 0> E0{}; constexpr std::integral_constant<int, 1> E1{};
+  round(E0, YES, NO, 0);                                             // round 0: nothing to store yet
+  // rounds 1 .. nt - 1: main loop + the epilogue of the previous tile, in one instruction stream.  Two rounds per loop iteration, so that both accumulator-set
+  // assignments are straight-line code (an if / else on the round's parity made hipcc reconcile 256 accumulator registers at the join: ~60 spills per round).
+  // nw: what the head of stage 0 may leave in flight = the stores of the previous round's last stage (only when that round had six stages and an epilogue)
+  int r = 1;
+  for (; r + 1 < nt; r += 2) {
+    tile_mn(r - 1, ep_m0, ep_n0);
+    round(E1, YES, YES, (r >= 2 && nk == 6) ? stores_of(5) : 0);
+    tile_mn(r, ep_m0, ep_n0);
+    round(E0, YES, YES, nk == 6 ? stores_of(5) : 0);
+  }
+  if (r < nt) { tile_mn(r - 1, ep_m0, ep_n0); round(E1, YES, YES, (r >= 2 && nk == 6) ? stores_of(5) : 0); }
+  tile_mn(nt - 1, ep_m0, ep_n0);                                     // the last tile's epilogue alone
+  if (nt & 1) round(E1, NO, YES, 0); else round(E0, NO, YES, 0);
+#undef TT_FENCE
+}

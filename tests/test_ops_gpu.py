@@ -227,7 +227,7 @@ def test_gemm_nt_two_team_kernel(M, N, K):
     res = {}
     try:
         lib.atst_tune_gemm_variant(351)
-        for hook in (2000, 2001):
+        for hook in (2000, 2001, 2002):                                  # 2002: the same overlap as ONE instruction stream (4 waves x 512 registers, two accumulator sets)
             lib.atst_tune_gemm_variant(hook)
             b16, _ = gemm_nt(A, B, hip.EPI_BF16, torch.bfloat16, bias=bias)
             b16nb, _ = gemm_nt(A, B, hip.EPI_BF16, torch.bfloat16)
@@ -236,13 +236,14 @@ def test_gemm_nt_two_team_kernel(M, N, K):
             res[hook] = (b16, b16nb, u, a, a2)
     finally:
         lib.atst_tune_gemm_variant(2000); lib.atst_tune_gemm_variant(350)
-    b16, b16nb, u, a, a2 = res[2001]
-    assert relerr(b16.float(), ref + bias) < 4e-3 and relerr(b16nb.float(), ref) < 4e-3
-    assert relerr(u.float(), ref + bias) < 4e-3 and relerr(a.float(), torch.nn.functional.gelu(ref + bias)) < 5e-3
-    assert torch.equal(a, a2)
-    for got, other in zip(res[2001], res[2000]):                          # the kernels it replaces: same sums up to the fp32 accumulation order
-        assert relerr(got.float(), other.float()) < 4e-3
-    assert float((b16.float() - res[2000][0].float()).abs().max()) <= 0.07 * float(ref.abs().max())      # no misplaced row / column anywhere
+    for hook in (2001, 2002):
+        b16, b16nb, u, a, a2 = res[hook]
+        assert relerr(b16.float(), ref + bias) < 4e-3 and relerr(b16nb.float(), ref) < 4e-3, hook
+        assert relerr(u.float(), ref + bias) < 4e-3 and relerr(a.float(), torch.nn.functional.gelu(ref + bias)) < 5e-3, hook
+        assert torch.equal(a, a2), hook
+        for got, other in zip(res[hook], res[2000]):                      # the kernels it replaces: same sums up to the fp32 accumulation order
+            assert relerr(got.float(), other.float()) < 4e-3, hook
+        assert float((b16.float() - res[2000][0].float()).abs().max()) <= 0.07 * float(ref.abs().max()), hook      # no misplaced row / column anywhere
 
 
 @pytest.mark.parametrize("M,N,K,split", [(1000, 256, 384, 0), (64, 128, 128, 0), (4099, 384, 256, 512), (777, 1152, 384, 0),
