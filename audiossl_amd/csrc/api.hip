@@ -68,6 +68,33 @@ int atst_gemm_nt_fp8(const uint8_t* A8, const uint8_t* B8, int M, int N, int K, 
   if ((epi == EPI_BIAS_GELU && (!bias || !C2)) || (epi == EPI_RESID && (!bias || !resid)) || epi == EPI_DGELU || epi == EPI_PATCH) return ATST_EINVAL;
   return atst_gemm_nt(a, ST(stream));
 }
+// round 6 (d = 384, all-e4m3 step): the two row-wise epilogues on e4m3 operands, with the e4m3 copy of the bf16 row they produce
+int atst_gemm_nt_resid_ln_fp8(const uint8_t* A8, const uint8_t* B8, int M, int K, const float* dq, const float* a_scale, const float* bias, const float* resid,
+                              const float* row_scale, int rows_per_seq, float* x_out, const float* ln_gamma, const float* ln_beta, uint16_t* ln_out,
+                              uint8_t* ln_out8, const float* out8_scale, float* out8_amax, uint32_t* out8_sat, float* ln_mean, float* ln_rstd, void* stream) {
+  if (!A8 || !B8 || !bias || !resid || !x_out || !ln_gamma || !ln_beta || (!ln_out && !ln_out8) || !ln_mean || !ln_rstd || (ln_out8 && !out8_scale)) return ATST_EINVAL;
+  GemmArgs a{};
+  a.A = CBF(A8); a.B = CBF(B8); a.M = M; a.N = 384; a.K = K; a.lda = K; a.ldb = K; a.epi = EPI_RESID; a.C = x_out; a.ldc = 384;
+  a.bias = bias; a.resid = resid; a.row_scale = row_scale; a.rows_per_seq = rows_per_seq > 0 ? rows_per_seq : 1;
+  a.fp8 = 1; a.dq = dq; a.dq_mul = 1.0f; a.dq_div = a_scale;
+  a.ln_gamma = ln_gamma; a.ln_beta = ln_beta; a.ln_out = BF(ln_out); a.ln_mean = ln_mean; a.ln_rstd = ln_rstd;
+  a.q8 = ln_out8; a.q8_scale_ptr = out8_scale; a.q8_amax = ln_out8 ? out8_amax : nullptr; a.q8_sat = out8_sat;
+  return atst_gemm_nt(a, ST(stream));
+}
+int atst_gemm_nt_lnbwd_q8(const void* dY, const void* Wt, int operands_fp8, int M, int K, const float* dq, const float* dy_scale, const float* x, const float* mean,
+                          const float* rstd, const float* gamma, const float* dres, float* dx, uint16_t* g, uint8_t* g8, const float* g8_scale, float* g8_amax,
+                          const float* row_scale, int rows_per_seq, float* dgamma, float* dbeta, float* dbias_up, void* stream) {
+  if (!dY || !Wt || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || (g8 && !g8_scale) || (operands_fp8 && !dq)) return ATST_EINVAL;
+  GemmArgs a{};
+  a.A = reinterpret_cast<const bf16*>(dY); a.B = reinterpret_cast<const bf16*>(Wt); a.M = M; a.N = 384; a.K = K; a.lda = K; a.ldb = K; a.epi = EPI_LNBWD;
+  a.C = dx; a.ldc = 384;
+  if (operands_fp8) { a.fp8 = 1; a.dq = dq; a.dq_mul = 1.0f; a.dq_div = dy_scale; }
+  a.resid = dres; a.row_scale = row_scale; a.rows_per_seq = rows_per_seq > 0 ? rows_per_seq : 1; a.ln_gamma = gamma;
+  a.ln_mean = const_cast<float*>(mean); a.ln_rstd = const_cast<float*>(rstd); a.lnb_x = x; a.lnb_g = BF(g);
+  a.lnb_dgamma = dgamma; a.lnb_dbeta = dbeta; a.lnb_dbias_up = dbias_up;
+  a.q8 = g8; a.q8_scale_ptr = g8_scale; a.q8_amax = g8_amax;
+  return atst_gemm_nt(a, ST(stream));
+}
 int atst_quant_fp8_bf16(const uint16_t* x, size_t n, float scale, uint8_t* y, void* stream) { return atst_quant_fp8(CBF(x), n, scale, y, ST(stream)); }
 int atst_quant_fp8_dyn_bf16(const uint16_t* x, size_t n, const float* scale, uint8_t* y, float* amax, void* stream) {
   return atst_quant_fp8_dyn(CBF(x), n, scale, y, amax, ST(stream));

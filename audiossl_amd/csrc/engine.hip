@@ -7,6 +7,7 @@
 #include "../../include/atst_hip.h"
 
 extern int g_f8_resid16;          // gemm.hip: tuning hook 2100 / 2101
+extern int g_f8_fuse_ln;          // gemm.hip: tuning hook 2110 / 2111
 namespace {
 
 struct LayerWs {
@@ -92,9 +93,11 @@ constexpr float ACT_SCALE = 8.0f, ACT_SCALE_GELU = 4.0f;   // activation scales 
 int gemm8(const uint8_t* A8, const uint8_t* B8, int M, int N, int K, int epi, void* C, hipStream_t st, const float* w_dq, float act_scale,
           const float* bias = nullptr, const float* resid = nullptr, const float* row_scale = nullptr, int rps = 1, void* C2 = nullptr,
           uint8_t* q8 = nullptr, float q8_scale = 1.0f, unsigned* q8_sat = nullptr, const float* act_scale_dev = nullptr,
-          const float* q8_scale_dev = nullptr, float* q8_amax = nullptr, int resid_bf16 = 0, int out_bf16 = 0) {
+          const float* q8_scale_dev = nullptr, float* q8_amax = nullptr, int resid_bf16 = 0, int out_bf16 = 0,
+          const float* ln_g = nullptr, const float* ln_b = nullptr, bf16* ln_out = nullptr, float* ln_mean = nullptr, float* ln_rstd = nullptr) {
   GemmArgs a{};
   a.resid_bf16 = resid_bf16; a.out_bf16 = out_bf16;
+  a.ln_gamma = ln_g; a.ln_beta = ln_b; a.ln_out = ln_out; a.ln_mean = ln_mean; a.ln_rstd = ln_rstd;   // EPI_RESID, N == 384: + LayerNorm of the new row (q8: its e4m3 copy)
   a.A = reinterpret_cast<const bf16*>(A8); a.B = reinterpret_cast<const bf16*>(B8); a.M = M; a.N = N; a.K = K; a.lda = K; a.ldb = K;
   a.epi = epi; a.C = C; a.ldc = N; a.C2 = C2; a.bias = bias; a.resid = resid; a.row_scale = row_scale; a.rows_per_seq = rps;
   a.fp8 = 1; a.dq = w_dq; a.dq_mul = 1.0f / act_scale; a.q8 = q8; a.q8_scale = q8_scale; a.q8_sat = q8_sat;
@@ -111,6 +114,19 @@ int gemm_lnbwd(const bf16* dY, const bf16* Wt, int M, int K, const float* x, con
   a.A = dY; a.B = Wt; a.M = M; a.N = 384; a.K = K; a.lda = K; a.ldb = K; a.epi = EPI_LNBWD; a.C = dx; a.ldc = 384;
   a.resid = dres; a.row_scale = row_scale; a.rows_per_seq = rps; a.ln_gamma = gamma; a.ln_mean = const_cast<float*>(mean);
   a.ln_rstd = const_cast<float*>(rstd); a.lnb_x = x; a.lnb_g = g; a.lnb_dgamma = dgamma; a.lnb_dbeta = dbeta; a.lnb_dbias_up = dbias_up;
+  return atst_gemm_nt(a, st);
+}
+// the same with e4m3 bookkeeping (round 6, d = 384): dY / Wt are e4m3 bytes when `w_dq` is given (per-tensor factor *w_dq, gradient scale *a_scale),
+// and the epilogue also writes g8 = e4m3(bf16(row_scale dx) * *g8_scale) and posts max |row_scale dx| to g8_amax -- what ln_bwd_kernel does in the unfused step
+int gemm_lnbwd8(const void* dY, const void* Wt, int M, int K, const float* w_dq, const float* a_scale, const float* x, const float* mean, const float* rstd,
+                const float* gamma, const float* dres, float* dx, bf16* g, uint8_t* g8, const float* g8_scale, float* g8_amax, const float* row_scale, int rps,
+                float* dgamma, float* dbeta, float* dbias_up, hipStream_t st) {
+  GemmArgs a{};
+  a.A = reinterpret_cast<const bf16*>(dY); a.B = reinterpret_cast<const bf16*>(Wt); a.M = M; a.N = 384; a.K = K; a.lda = K; a.ldb = K; a.epi = EPI_LNBWD; a.C = dx; a.ldc = 384;
+  if (w_dq) { a.fp8 = 1; a.dq = w_dq; a.dq_mul = 1.0f; a.dq_div = a_scale; }
+  a.resid = dres; a.row_scale = row_scale; a.rows_per_seq = rps; a.ln_gamma = gamma; a.ln_mean = const_cast<float*>(mean);
+  a.ln_rstd = const_cast<float*>(rstd); a.lnb_x = x; a.lnb_g = g; a.lnb_dgamma = dgamma; a.lnb_dbeta = dbeta; a.lnb_dbias_up = dbias_up;
+  a.q8 = g8; a.q8_scale_ptr = g8_scale; a.q8_amax = g8_amax;
   return atst_gemm_nt(a, st);
 }
 // e4m3 dgrad GEMM: dY8 [M,K] (gradient operand, quantised with the device scale *a_scale), Wt8 [N,K] (transposed weight shadow, per-tensor
@@ -214,7 +230,13 @@ extern "C" int atst_encoder_fwd(const atst_encoder_t* e, void* stream) {
       // the residual GEMM epilogues and the LayerNorm kernels move.  The stream lives in the pass's (unused: lean) bf16 LayerNorm-1 buffer; the patch stage
       // and the taps of the inference API stay fp32 (block 0 reads the fp32 tokens).  Hook 2100 switches it off.
       const bool xb16 = !e->train && !e->tap && g_f8_resid16;
+      // d = 384 (round 6): the proj / fc2 GEMM blocks own whole rows, so -- as in the bf16 step -- their epilogue is also the LayerNorm of the new residual
+      // row: the e4m3 operand of the next GEMM (and its amax / clip count), the row statistics and, unless lean, the bf16 copy come out of the GEMM
+      // and the two ln_fwd passes of a block go away.  fp32 residual stream only (training passes; an inference pass keeps bf16 stream + LayerNorm pass).
+      const bool fl8 = C == 384 && g_f8_fuse_ln && !xb16;
       bf16* const xb = w.L[0].h1;
+      if (fl8 && i > 0) {}                          // LN1 of this block came out of the previous block's fc2 epilogue
+      else
       if (xb16 && i > 0) RUN(atst_ln_fwd_b16in(xb, p + lo.ln1_w, p + lo.ln1_b, h1o, l.mean1, l.rstd1, M, C, st, l.h18, ACT_SCALE, sat, scp(0), amp(0)));
       else
       RUN(atst_ln_fwd(w.x[2 * i], p + lo.ln1_w, p + lo.ln1_b, h1o, l.mean1, l.rstd1, M, C, st, l.h18, ACT_SCALE, sat, scp(0), amp(0)));
@@ -237,6 +259,9 @@ extern "C" int atst_encoder_fwd(const atst_encoder_t* e, void* stream) {
         RUN(gemm8(l.o8, q8 + lo.proj_w, M, C, C, EPI_RESID, xb, st, dq + 1, ACT_SCALE, p + lo.proj_b, i > 0 ? reinterpret_cast<const float*>(xb) : w.x[0], s1, RS, nullptr, nullptr,
                   1.0f, nullptr, scp(1), nullptr, nullptr, i > 0 ? 1 : 0, 1));
         RUN(atst_ln_fwd_b16in(xb, p + lo.ln2_w, p + lo.ln2_b, h2o, l.mean2, l.rstd2, M, C, st, l.h28, ACT_SCALE, sat, scp(2), amp(2)));
+      } else if (fl8) {
+        RUN(gemm8(l.o8, q8 + lo.proj_w, M, C, C, EPI_RESID, w.x[2 * i + 1], st, dq + 1, ACT_SCALE, p + lo.proj_b, w.x[2 * i], s1, RS, nullptr, l.h28, ACT_SCALE, sat, scp(1),
+                  scp(2), amp(2), 0, 0, p + lo.ln2_w, p + lo.ln2_b, h2o, l.mean2, l.rstd2));
       } else {
       RUN(gemm8(l.o8, q8 + lo.proj_w, M, C, C, EPI_RESID, w.x[2 * i + 1], st, dq + 1, ACT_SCALE, p + lo.proj_b, w.x[2 * i], s1, RS, nullptr, nullptr, 1.0f, nullptr, scp(1)));
       RUN(atst_ln_fwd(w.x[2 * i + 1], p + lo.ln2_w, p + lo.ln2_b, h2o, l.mean2, l.rstd2, M, C, st, l.h28, ACT_SCALE, sat, scp(2), amp(2)));
@@ -245,7 +270,16 @@ extern "C" int atst_encoder_fwd(const atst_encoder_t* e, void* stream) {
                 l.a8, ACT_SCALE_GELU, sat, scp(2), scp(3), amp(3)));
       if (xb16) RUN(gemm8(l.a8, q8 + lo.fc2_w, M, C, 4 * C, EPI_RESID, xb, st, dq + 3, ACT_SCALE_GELU, p + lo.fc2_b, reinterpret_cast<const float*>(xb), s2, RS, nullptr, nullptr,
                           1.0f, nullptr, scp(3), nullptr, nullptr, 1, 1));
-      else
+      else if (fl8) {                                 // fc2 + residual + (LN1 of the next block -> its e4m3 qkv operand | final norm -> bf16)
+        const bool last = i + 1 == e->depth;
+        const LayerWs& nl = w.L[last ? i : i + 1];
+        const atst_layer_off_t& no = o.layer[last ? i : i + 1];
+        const float* nsc = (!last && e->f8_act_scale) ? e->f8_act_scale + 4 * (i + 1) : nullptr;
+        float* nam = (!last && e->f8_act_amax) ? e->f8_act_amax + (size_t)(4 * (i + 1)) * AMAX_SITE_STRIDE : nullptr;
+        RUN(gemm8(l.a8, q8 + lo.fc2_w, M, C, 4 * C, EPI_RESID, w.x[2 * i + 2], st, dq + 3, ACT_SCALE_GELU, p + lo.fc2_b, w.x[2 * i + 1], s2, RS, nullptr,
+                  last ? nullptr : nl.h18, ACT_SCALE, last ? nullptr : sat, scp(3), nsc, nam, 0, 0,
+                  p + (last ? o.norm_w : no.ln1_w), p + (last ? o.norm_b : no.ln1_b), last ? w.hN : (lean >= 2 ? nullptr : nl.h1), last ? w.meanN : nl.mean1, last ? w.rstdN : nl.rstd1));
+      } else
       RUN(gemm8(l.a8, q8 + lo.fc2_w, M, C, 4 * C, EPI_RESID, w.x[2 * i + 2], st, dq + 3, ACT_SCALE_GELU, p + lo.fc2_b, w.x[2 * i + 1], s2, RS, nullptr, nullptr, 1.0f, nullptr, scp(3)));
     } else {
       if (i == 0 || !fuse_ln) RUN(atst_ln_fwd(w.x[2 * i], p + lo.ln1_w, p + lo.ln1_b, l.h1, l.mean1, l.rstd1, M, C, st));
@@ -278,6 +312,8 @@ extern "C" int atst_encoder_fwd(const atst_encoder_t* e, void* stream) {
     }
   }
   if (f8 && !e->train && !e->tap && g_f8_resid16 && e->depth > 0) RUN(atst_ln_fwd_b16in(w.L[0].h1, p + o.norm_w, p + o.norm_b, w.hN, w.meanN, w.rstdN, M, C, st));
+  else
+  if (f8 && C == 384 && g_f8_fuse_ln) {}            // the final norm came out of the last fc2 epilogue
   else
   if (!fuse_ln) RUN(atst_ln_fwd(w.x[2 * e->depth], p + o.norm_w, p + o.norm_b, w.hN, w.meanN, w.rstdN, M, C, st));
   return ATST_OK;
@@ -325,6 +361,9 @@ static int encoder_bwd_range(const atst_encoder_t* e, int lo, int hi, bool head,
   // g8_amax[4 i + k]; fp8_bwd == 1 only records (first step: bf16 dgrad), == 2 also computes in fp8.
   const bool rec8 = e->fp8 && e->fp8_bwd >= 1 && e->g8_amax && !fuse_lnb;   // (!fuse_lnb: implied)
   const bool use8 = rec8 && e->fp8_bwd >= 2 && e->p8t && e->g8_scale && e->w_dq;
+  // d = 384 with the e4m3 dgrads ON (round 6): the LayerNorm backward is back inside the fc1 / qkv dgrad epilogues, which now also write the e4m3 gradient
+  // copies and post their amax (the recording step, fp8_bwd == 1, keeps the separate pass)
+  const bool fuse_lnb8 = C == 384 && use8 && g_f8_fuse_ln;
   const bool use8w = use8 && e->fp8_wgrad && e->f8_act_scale_bwd && M % 64 == 0;   // e4m3 weight gradients of fc1 / fc2 / proj (N, K multiples of 128: C = 768 and, round 6, C = 384)
   // fp8_wgrad == 2: the qkv Linear too -- the NP = 256 attention backward then writes dqkv as e4m3 ONLY (site 3) and both the qkv weight gradient
   // and the qkv dgrad read that copy.  fp8_wgrad == 3 (or 2 while the dgrad itself is still recording): bf16 qkv gradient, site 3's amax taken by
@@ -365,6 +404,10 @@ static int encoder_bwd_range(const atst_encoder_t* e, int lo, int hi, bool head,
     if (fuse_lnb) {
       RUN(gemm_lnbwd(w.du, qt + lo_.fc1_w, M, 4 * C, w.x[2 * i + 1], l.mean2, l.rstd2, p + lo_.ln2_w, cur, oth, w.g2, dps(i, 0), RS,
                      G + lo_.ln2_w, G + lo_.ln2_b, G + lo_.proj_b, st));
+      float* t = cur; cur = oth; oth = t;
+    } else if (fuse_lnb8) {
+      RUN(gemm_lnbwd8(w.du8, e->p8t + lo_.fc1_w, M, 4 * C, e->w_dq + 4 * i + 2, gs8(i, 1), w.x[2 * i + 1], l.mean2, l.rstd2, p + lo_.ln2_w, cur, oth,
+                      skip16 ? nullptr : w.g2, w.g28, gs8(i, 2), ga8(i, 2), dps(i, 0), RS, G + lo_.ln2_w, G + lo_.ln2_b, G + lo_.proj_b, st));
       float* t = cur; cur = oth; oth = t;
     } else {
       if (use8) RUN(gemm8_bwd(w.du8, e->p8t + lo_.fc1_w, M, C, 4 * C, EPI_BF16, w.dh, st, e->w_dq + 4 * i + 2, gs8(i, 1)));
@@ -413,6 +456,12 @@ static int encoder_bwd_range(const atst_encoder_t* e, int lo, int hi, bool head,
     if (fuse_lnb) {
       RUN(gemm_lnbwd(w.dqkv, qt + lo_.qkv_w, M, 3 * C, w.x[2 * i], l.mean1, l.rstd1, p + lo_.ln1_w, cur, oth, i > 0 ? w.g : nullptr,
                      i > 0 ? dps(i - 1, 1) : nullptr, RS, G + lo_.ln1_w, G + lo_.ln1_b, i > 0 ? G + o.layer[i - 1].fc2_b : nullptr, st));
+      float* t = cur; cur = oth; oth = t;
+    } else if (fuse_lnb8) {                           // e4m3 operands when the attention backward wrote dqkv8, bf16 otherwise (local views) -- the e4m3 copy of g either way
+      RUN(gemm_lnbwd8(use8q ? (const void*)w.dqkv8 : (const void*)w.dqkv, use8q ? (const void*)(e->p8t + lo_.qkv_w) : (const void*)(qt + lo_.qkv_w), M, 3 * C,
+                      use8q ? e->w_dq + 4 * i + 0 : nullptr, use8q ? gs8(i, 3) : nullptr, w.x[2 * i], l.mean1, l.rstd1, p + lo_.ln1_w, cur, oth,
+                      (i > 0 && !skip16) ? w.g : nullptr, i > 0 ? w.g8 : nullptr, i > 0 ? gs8(i - 1, 0) : nullptr, i > 0 ? ga8(i - 1, 0) : nullptr,
+                      i > 0 ? dps(i - 1, 1) : nullptr, RS, G + lo_.ln1_w, G + lo_.ln1_b, i > 0 ? G + o.layer[i - 1].fc2_b : nullptr, st));
       float* t = cur; cur = oth; oth = t;
     } else {
       // the qkv dgrad: e4m3 when the attention backward wrote the e4m3 dqkv itself (a quantisation PASS over a bf16 dqkv -- 906 MB, 255 us at

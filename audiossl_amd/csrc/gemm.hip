@@ -507,10 +507,29 @@ DEVFN void st_bf16_row(bf16* rowp, const float* v /* [12]: columns 128 j + 4 li 
   st_pol<4>(wide, reinterpret_cast<u32x4*>(rowp + (odd ? 128 + 4 * (li - 1) : 4 * li)));
   st_pol<4>(c2, reinterpret_cast<u32x2*>(rowp + 256 + 4 * li));
 }
+// e4m3 copy of a row-wise epilogue's bf16 row (round 6: the all-e4m3 step at d = 384 keeps its LayerNorms inside the GEMM epilogues).  384 B per
+// row = 12 B per lane: a pair of lanes swaps one dword, so that even lanes hold 8 consecutive columns of the first 128 and odd lanes 8 of the second
+// -- one 8-B store for both -- and the last 128 columns follow as one 4-B store (two instructions, like the bf16 row).
+struct RowQ8 { float s, amax; unsigned nclip; };                  // scale of the copy ; running max |value| (the site's next scale) ; elements clipped at +-448
+DEVFN unsigned pack_e4m3x4(const float* v, float s) {
+  int q = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(v[0] * s, -448.f, 448.f), __builtin_amdgcn_fmed3f(v[1] * s, -448.f, 448.f), 0, false);
+  q = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(v[2] * s, -448.f, 448.f), __builtin_amdgcn_fmed3f(v[3] * s, -448.f, 448.f), q, true);
+  return (unsigned)q;
+}
+DEVFN void st_e4m3_row(uint8_t* rowp, const float* v /* [12]: bf16-rounded values of columns 128 j + 4 li + e */, float s, int li, bool live) {
+  const unsigned c0 = pack_e4m3x4(v, s), c1 = pack_e4m3x4(v + 4, s), c2 = pack_e4m3x4(v + 8, s);
+  const bool odd = li & 1;
+  const unsigned recv = __builtin_amdgcn_update_dpp(0u, odd ? c0 : c1, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]: every lane takes part
+  if (!live) return;
+  const u32x2 wide = odd ? u32x2{recv, c1} : u32x2{c0, recv};
+  st_pol<4>(wide, reinterpret_cast<u32x2*>(rowp + (odd ? 128 + 4 * (li - 1) : 4 * li)));
+  st_pol<4>(c2, reinterpret_cast<unsigned*>(rowp + 256 + 4 * li));
+}
 // residual + LayerNorm forward of the new row: x_new = resid + s (acc + bias) -> fp32 stream ; h = LN(x_new) -> bf16 operand
 // of the next GEMM ; row statistics saved for the LayerNorm backward.  ref: Block.forward, audiossl/modules/transformer.py:136-150.
+template <bool Q8>
 DEVFN void lnf_row(const GemmArgs& p, int row, const float* sRow, const float* sBias, const float* sGamma, const float* sBeta,
-                   float sc, const f32x4* rv, int li, float* sStatRow /* LDS: {mean, rstd} of this row, written out once per tile */) {
+                   float sc, const f32x4* rv, int li, float* sStatRow /* LDS: {mean, rstd} of this row, written out once per tile */, RowQ8& q8) {
   float v[12];
   float sum = 0.f;
 #pragma unroll
@@ -534,7 +553,23 @@ DEVFN void lnf_row(const GemmArgs& p, int row, const float* sRow, const float* s
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[4 * j + e] = (v[4 * j + e] - mu) * rs * g4[e] + e4[e];
   }
-  st_bf16_row(p.ln_out + (size_t)row * 384, v, li);
+  if constexpr (Q8) {
+    if (p.q8) {                                                    // e4m3 copy of the SAME bf16 values (A operand of the next e4m3 GEMM), as ln_fwd_kernel writes it
+      float cm = 0.f;
+#pragma unroll
+      for (int k = 0; k < 12; ++k) { v[k] = bf2f(f2bf(v[k])); cm = fmaxf(cm, fabsf(v[k])); }
+      st_e4m3_row(p.q8 + (size_t)row * 384, v, q8.s, li, true);
+      q8.amax = fmaxf(q8.amax, cm);
+      asm volatile("" : "+v"(q8.amax));                            // pinned: see lnb_fold4
+      if (cm * q8.s > 448.f) {                                     // rare: count exactly
+#pragma unroll
+        for (int k = 0; k < 12; ++k) q8.nclip += fabsf(v[k] * q8.s) > 448.f ? 1u : 0u;
+      }
+    }
+    if (p.ln_out) st_bf16_row(p.ln_out + (size_t)row * 384, v, li);   // (not written when every reader takes the e4m3 copy: fp8_lean)
+  } else {
+    st_bf16_row(p.ln_out + (size_t)row * 384, v, li);
+  }
   if (li == 0) { sStatRow[0] = mu; sStatRow[1] = rs; }
 }
 // LayerNorm backward of one row, fused into the N == 384 dgrad epilogues (EPI_LNBWD).  dy comes from the staged fp32
@@ -564,8 +599,9 @@ DEVFN void lnb_fold4(float* acc2, const float* d4) {               // acc2[e] +=
 // reduction -- with 168+ accumulator registers still live in the first parts, every value kept in a register there is a
 // spill (measured with x and dres copied to registers so that the slot could be refilled before the arithmetic: 116 B of
 // scratch per lane and 375 / 306 us instead of 307 / 237 us for the fc1 / qkv dgrad GEMMs at M = 131072).
+template <bool Q8>
 DEVFN void lnb_row(const GemmArgs& p, int row, bool live, const float* sRow, const float* sGamma, float sc, float mu, float rs,
-                   const char* slot, bool has_res, int hh, int li, LnbCols& cs) {
+                   const char* slot, bool has_res, int hh, int li, LnbCols& cs, RowQ8& q8) {
   float s1 = 0.f, s2 = 0.f;                                        // live == false (row beyond M): every contribution is zero
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
@@ -601,8 +637,24 @@ DEVFN void lnb_row(const GemmArgs& p, int row, bool live, const float* sRow, con
     if (live) st_pol<2>(o, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (size_t)row * 384 + col));
     lnb_fold4(cs.du + 2 * j, gs + 4 * j);
   }
+  if constexpr (Q8) {
+    if (p.q8_amax) {                                               // max |g| of the site (dead rows: zeros) -- the next step's scale
+      float cm = 0.f;
+#pragma unroll
+      for (int k = 0; k < 12; ++k) cm = fmaxf(cm, fabsf(gs[k]));
+      q8.amax = fmaxf(q8.amax, cm);
+      asm volatile("" : "+v"(q8.amax));                            // pinned: see lnb_fold4
+    }
+  }
   if (p.lnb_g) {                                                   // every lane takes part in the DPP exchange; dead rows do not store
     if (live) st_bf16_row(p.lnb_g + (size_t)row * 384, gs, li);
+  }
+  if constexpr (Q8) {
+    if (p.q8) {                                                    // e4m3 copy of the bf16 values (A operand of the e4m3 proj / fc2 dgrad and weight-gradient GEMMs)
+#pragma unroll
+      for (int k = 0; k < 12; ++k) gs[k] = bf2f(f2bf(gs[k]));
+      st_e4m3_row(p.q8 + (size_t)row * 384, gs, q8.s, li, live);
+    }
   }
 }
 // Block reduction of the column sums of lnb_row over the NW waves of a block (red: >= 3 * NW * 384 floats of LDS that no
@@ -648,7 +700,9 @@ DEVFN void lnb_flush(const GemmArgs& p, const LnbCols& cs, float* red, int tid) 
 // PH == 2 (round 6): the same phased loop on 64-DEEP k-tiles of whole 128-B rows (two 80-KB slots = all of the LDS): the two-team experiment measured the
 // same bytes streaming at 44 B/clk/CU as whole lines and at 28 as 64-B rows (DESIGN.md section 3 "Round 6").  Eight phases (ks, mh) per k-tile, k-tile t + 1 staged in
 // phases 1 .. 5 of k-tile t (10 pieces per wave), `vmcnt(0)` in the last phase.  Chunk c of row r at c ^ ((r >> 1) & 7) as in gemm_p8.h.
-template <int EPI, int MI, bool LN = false, bool F8 = false, bool TR = false, int PH = 0>
+// Q8: the row-wise epilogues also write the e4m3 copy of their bf16 row (and its amax); a compile-time switch so that the bf16 step's instantiations keep
+// their register allocation (with the copy as a run-time branch the LayerNorm-backward epilogue spilled 19-25 registers where it had spilled none).
+template <int EPI, int MI, bool LN = false, bool F8 = false, bool TR = false, int PH = 0, bool Q8 = false>
 __global__ __launch_bounds__(512, (MI == 2 ? ATST_MI2_WPS : 2)) void gemm_nt_row384_kernel(GemmArgs p) {
   static_assert(!TR || (EPI == EPI_BF16 && !LN), "transposed accumulators: store-only bf16 epilogue");
   static_assert(!PH || (MI == 4 && !F8 && !TR), "phased main loop: 256-row tile, bf16 operands");
@@ -994,7 +1048,7 @@ __global__ __launch_bounds__(512, (MI == 2 ? ATST_MI2_WPS : 2)) void gemm_nt_row
   // VMEM operations of one pair: 5 stores (3 x 16 B fp32 row + 2 bf16 row) + 6 / 3 LDS-DMA refill pieces (LayerNorm backward /
   // residual + LayerNorm).  Outstanding behind a refill when it is needed: see rowin_wait.
   constexpr int NVM = (lnbwd ? 5 + 6 : 5 + 3 + 5) - 2;
-  const bool exact_vm = m0 + BMR <= p.M && (!lnbwd || (p.lnb_g && p.resid));
+  const bool exact_vm = m0 + BMR <= p.M && (!lnbwd || ((p.lnb_g || p.q8) && p.resid));   // (a bf16 row AND its e4m3 copy: more stores than NVM counts -- a stricter wait, never a shorter one)
   using EL = row384::EpiLds<MI, rowwise, NT>;
   float* sC = reinterpret_cast<float*>(smem_raw);
   float* sBias = sC + EL::SC;                                     // bias of this block's 384 columns (zeros when absent)
@@ -1064,6 +1118,8 @@ __global__ __launch_bounds__(512, (MI == 2 ? ATST_MI2_WPS : 2)) void gemm_nt_row
 #pragma unroll
     for (int i = 0; i < 6; ++i) lcs.dg[i] = lcs.db[i] = lcs.du[i] = 0.f;
   }
+  RowQ8 rq8{1.0f, 0.f, 0u};                                       // row-wise epilogues: optional e4m3 copy of the bf16 row they write (LayerNorm output / row_scale dx)
+  if constexpr (rowwise && Q8) { if (p.q8) rq8.s = p.q8_scale_ptr ? *p.q8_scale_ptr : (p.q8_scale != 0.f ? p.q8_scale : 1.0f); }
 #pragma unroll
   for (int part = 0; part < NPART; ++part) {
     const int mi = part >> 1, h = part & 1;
@@ -1106,7 +1162,7 @@ __global__ __launch_bounds__(512, (MI == 2 ? ATST_MI2_WPS : 2)) void gemm_nt_row
         if (q > 0 && part > 0) rowin_wait<NVM>(exact_vm && part + 1 < NPART);
         if constexpr (lnbwd) {
           const float mu = sStat[trow], rs = sStat[BMR + trow];
-          lnb_row(p, row, row < p.M, sC + rl * CLD, sGamma, sScale[trow], mu, rs, slot, p.resid != nullptr, hh, li, lcs);
+          lnb_row<Q8>(p, row, row < p.M, sC + rl * CLD, sGamma, sScale[trow], mu, rs, slot, p.resid != nullptr, hh, li, lcs, rq8);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the slot has been read: refill it with the next part's rows
           if (part + 1 < NPART) rowin_part(part + 1, q);
         } else {
@@ -1115,7 +1171,7 @@ __global__ __launch_bounds__(512, (MI == 2 ? ATST_MI2_WPS : 2)) void gemm_nt_row
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the slot has been copied out: refill it with the next part's rows
           if (part + 1 < NPART) rowin_part(part + 1, q);
           // Fused residual + LayerNorm of the NEXT sub-layer: replaces a separate HBM pass (ln_fwd_kernel) over x.
-          if (row < p.M) lnf_row(p, row, sC + rl * CLD, sBias, sGamma, sBeta, sScale[trow], rres, li, sStat + 2 * trow);
+          if (row < p.M) lnf_row<Q8>(p, row, sC + rl * CLD, sBias, sGamma, sBeta, sScale[trow], rres, li, sStat + 2 * trow, rq8);
         }
       }
     } else {
@@ -1164,6 +1220,10 @@ __global__ __launch_bounds__(512, (MI == 2 ? ATST_MI2_WPS : 2)) void gemm_nt_row
   if constexpr (EPI == EPI_BIAS_GELU) {
     if (p.q8 && p.q8_amax) amax_post(p.q8_amax, wave_max(omax), lane, blockIdx.x * WAVES + wid);
   }
+  if constexpr (rowwise && Q8) {
+    if (p.q8_amax) amax_post(p.q8_amax, wave_max(rq8.amax), lane, blockIdx.x * WAVES + wid);
+    if constexpr (fused_ln) { if (p.q8) f8_sat_add(p.q8_sat, rq8.nclip); }
+  }
   if constexpr (lnbwd) lnb_flush<WAVES>(p, lcs, sC, tid);        // 9,216 floats of the staging area, behind a barrier
   if constexpr (fused_ln) {                                       // row statistics of the whole tile: two store instructions per wave instead of two per row
     lds_barrier();
@@ -1206,7 +1266,7 @@ template <int WM> struct Geo {
 };
 }
 
-template <int EPI, int WM, bool LN = false>
+template <int EPI, int WM, bool LN = false, bool Q8 = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_w4_kernel(GemmArgs p) {
   using G = w4::Geo<WM>;
   constexpr int WN = G::WN, BM = G::BM, BNB = G::BNB, CLD = G::CLD, NA = G::NA, NB = G::NB, MI = 4;
@@ -1317,7 +1377,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_w4_kernel(GemmArgs p) {
   constexpr bool rowwise = fused_ln || lnbwd;                     // (WM == 1) half a wave per row, inputs through per-wave LDS slots: see rowin_issue
   constexpr int NT = lnbwd ? 2 : 1;
   constexpr int NVM = (lnbwd ? 5 + 6 : 5 + 3 + 5) - 2;            // see the 8-wave kernel
-  const bool exact_vm = m0 + BM <= p.M && (!lnbwd || (p.lnb_g && p.resid));
+  const bool exact_vm = m0 + BM <= p.M && (!lnbwd || ((p.lnb_g || p.q8) && p.resid));
   static_assert(!lnbwd || WM == 1, "the LayerNorm backward needs whole rows");
   float* sC = reinterpret_cast<float*>(smem_raw);
   float* sBias = sC + G::RP * (rowwise ? CLD : G::CLD2);
@@ -1355,6 +1415,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_w4_kernel(GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) lcs.dg[i] = lcs.db[i] = lcs.du[i] = 0.f;
   }
+  RowQ8 rq8{1.0f, 0.f, 0u};                                       // see the 8-wave kernel
+  if constexpr (rowwise && Q8) { if (p.q8) rq8.s = p.q8_scale_ptr ? *p.q8_scale_ptr : (p.q8_scale != 0.f ? p.q8_scale : 1.0f); }
   if constexpr (rowwise) {
     if (wid < BM / 64) {
       const int t = wid * 64 + lane, r = m0 + t < p.M ? m0 + t : p.M - 1;
@@ -1400,7 +1462,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_w4_kernel(GemmArgs p) {
         if (q > 0 && part > 0) rowin_wait<NVM>(exact_vm && part + 1 < NPART);
         if constexpr (lnbwd) {
           const float mu = sStat[trow], rs = sStat[BM + trow];
-          lnb_row(p, row, row < p.M, sC + rl * CLD, sGamma, sScale[trow], mu, rs, slot, p.resid != nullptr, hh, li, lcs);
+          lnb_row<Q8>(p, row, row < p.M, sC + rl * CLD, sGamma, sScale[trow], mu, rs, slot, p.resid != nullptr, hh, li, lcs, rq8);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the slot has been read: refill it with the next part's rows
           if (part + 1 < NPART) rowin_part(part + 1, q);
         } else {
@@ -1408,7 +1470,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_w4_kernel(GemmArgs p) {
           rowin_read(slot, 0, hh, li, rres);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the slot has been copied out: refill it with the next part's rows
           if (part + 1 < NPART) rowin_part(part + 1, q);
-          if (row < p.M) lnf_row(p, row, sC + rl * CLD, sBias, sGamma, sBeta, sScale[trow], rres, li, sStat + 2 * trow);
+          if (row < p.M) lnf_row<Q8>(p, row, sC + rl * CLD, sBias, sGamma, sBeta, sScale[trow], rres, li, sStat + 2 * trow, rq8);
         }
       }
     } else {
@@ -1437,6 +1499,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_w4_kernel(GemmArgs p) {
       lds_barrier();
       for (int c = tid; c < BNB; c += 256) atomicAdd(p.colsum + n0 + c, sCol[c]);
     }
+  }
+  if constexpr (rowwise && Q8) {
+    if (p.q8_amax) amax_post(p.q8_amax, wave_max(rq8.amax), lane, blockIdx.x * 4 + wid);
+    if constexpr (fused_ln) { if (p.q8) f8_sat_add(p.q8_sat, rq8.nclip); }
   }
   if constexpr (lnbwd) lnb_flush<4>(p, lcs, sC, tid);
   if constexpr (fused_ln) {
@@ -1898,12 +1964,14 @@ double nt_bytes(const GemmArgs& a) {
   if (EPI == EPI_BF16) b += 2.0 * mn;
   if (EPI == EPI_F32) b += 4.0 * mn;
   if (EPI == EPI_BIAS_GELU) b += (a.C2 ? 2.0 * mn : 0.0) + (a.C ? 2.0 * mn : 0.0) + (a.q8 ? mn : 0.0);   // a (bf16 and / or e4m3), u only when it is saved (training)
-  if (EPI == EPI_RESID) b += (a.resid_bf16 ? 2.0 : 4.0) * mn + (a.out_bf16 ? 2.0 : 4.0) * mn + (a.ln_out ? 2.0 * mn : 0.0);
+  if (EPI == EPI_RESID) b += (a.resid_bf16 ? 2.0 : 4.0) * mn + (a.out_bf16 ? 2.0 : 4.0) * mn + (a.ln_out ? 2.0 * mn : 0.0) + (a.q8 ? mn : 0.0);
   if (EPI == EPI_DGELU) b += 2.0 * mn + (a.C ? 2.0 * mn : 0.0) + (a.q8 ? mn : 0.0);      // u in ; du out (bf16 and / or e4m3)
   if (EPI == EPI_PATCH) b += 4.0 * mn;
-  if (EPI == EPI_LNBWD) b += 8.0 * mn + (a.resid ? 4.0 * mn : 0.0) + (a.lnb_g ? 2.0 * mn : 0.0);   // x in, dx out, dres in, g out
+  if (EPI == EPI_LNBWD) b += 8.0 * mn + (a.resid ? 4.0 * mn : 0.0) + (a.lnb_g ? 2.0 * mn : 0.0) + (a.q8 ? mn : 0.0);   // x in, dx out, dres in, g out (bf16 and / or e4m3)
   return b;
 }
+// EPI_RESID whose epilogue is also the LayerNorm of the new row: a bf16 LayerNorm output, or (e4m3 step at d = 384, lean) only its e4m3 copy
+inline bool ln_fused(const GemmArgs& a) { return a.ln_out || (a.fp8 && a.q8 && a.ln_gamma && a.epi == EPI_RESID); }
 template <int EPI> constexpr int prof_kind() { return EPI == EPI_LNBWD ? PK_GEMM_NT6 : PK_GEMM_NT0 + EPI; }
 
 template <int EPI, int BMT, int NSTG, int WTM, bool KS = false>
@@ -1920,33 +1988,33 @@ int launch_nt_cfg(const GemmArgs& a, hipStream_t st) {
   hipLaunchKernelGGL((gemm_nt_kernel<EPI, BMT, NSTG, WTM, KS>), dim3(nblk), dim3(G::THREADS), G::LDS, st, a);
   return (int)hipGetLastError();
 }
-template <int EPI, int MI, bool LN, bool F8 = false, bool TR = false, int PH = 0>
+template <int EPI, int MI, bool LN, bool F8 = false, bool TR = false, int PH = 0, bool Q8 = false>
 int launch_nt_row384_cfg(const GemmArgs& a, hipStream_t st) {
   using RG = row384::Geo<MI>;
   constexpr int LDS = PH == 2 ? 163840 : TR ? RG::NSTG * RG::STAGE + row384::BNR * 4 : row384::lds_bytes<MI, EPI, LN>();   // PH == 2: two 80-KB slots
   static OncePerDevice attr_done; int attr_done_dev;
   if (attr_done.need(attr_done_dev)) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_row384_kernel<EPI, MI, LN, F8, TR, PH>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_row384_kernel<EPI, MI, LN, F8, TR, PH, Q8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return (int)e;
     attr_done.done(attr_done_dev);
   }
   const int nblk = ((a.M + RG::BMR - 1) / RG::BMR) * (a.N / row384::BNR);
-  hipLaunchKernelGGL((gemm_nt_row384_kernel<EPI, MI, LN, F8, TR, PH>), dim3(nblk), dim3(row384::THREADS), LDS, st, a);
+  hipLaunchKernelGGL((gemm_nt_row384_kernel<EPI, MI, LN, F8, TR, PH, Q8>), dim3(nblk), dim3(row384::THREADS), LDS, st, a);
   return (int)hipGetLastError();
 }
-template <int EPI, int WM, bool LN>
+template <int EPI, int WM, bool LN, bool Q8 = false>
 int launch_nt_w4_cfg(const GemmArgs& a, hipStream_t st) {
   using G = w4::Geo<WM>;
   constexpr int LDS = G::template lds_bytes<EPI, LN>();
   static_assert(LDS <= 81920, "two blocks per CU");
   static OncePerDevice attr_done; int attr_done_dev;
   if (attr_done.need(attr_done_dev)) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<EPI, WM, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<EPI, WM, LN, Q8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return (int)e;
     attr_done.done(attr_done_dev);
   }
   const int nblk = ((a.M + G::BM - 1) / G::BM) * (a.N / G::BNB);
-  hipLaunchKernelGGL((gemm_nt_w4_kernel<EPI, WM, LN>), dim3(nblk), dim3(256), LDS, st, a);
+  hipLaunchKernelGGL((gemm_nt_w4_kernel<EPI, WM, LN, Q8>), dim3(nblk), dim3(256), LDS, st, a);
   return (int)hipGetLastError();
 }
 template <int EPI, bool F8 = false>
@@ -1967,7 +2035,7 @@ int launch_nt_p8(const GemmArgs& a, hipStream_t st) {
 template <int EPI>
 bool p8_ok(const GemmArgs& a) {
   constexpr bool epi_ok = EPI == EPI_BF16 || EPI == EPI_F32 || EPI == EPI_BIAS_GELU || EPI == EPI_RESID || EPI == EPI_DGELU;
-  return epi_ok && g_p8 && !a.ln_out && (a.fp8 || !a.q8) && a.N % p8::BNP == 0 && a.K % (2 * p8::BKP) == 0 && a.M % p8::BM == 0 &&
+  return epi_ok && g_p8 && !ln_fused(a) && (a.fp8 || !a.q8) && a.N % p8::BNP == 0 && a.K % (2 * p8::BKP) == 0 && a.M % p8::BM == 0 &&
          a.M >= (g_w4_min_m < 8192 ? 256 : 8192) && a.lda % 8 == 0 && a.ldb % 8 == 0;
 }
 // two-team persistent kernel (gemm_tt.h): one block per CU, the epilogue of a tile under the main loop of the next
@@ -2023,7 +2091,17 @@ int launch_nt_tt(const GemmArgs& a, hipStream_t st) {
 template <int EPI>
 int launch_nt_row384(const GemmArgs& a, hipStream_t st) {
   if (a.fp8) {                                                    // e4m3 operands seen as byte pairs: K, lda, ldb are already halved
+    if constexpr (EPI == EPI_LNBWD) {                             // round 6: the LayerNorm backward in the epilogue of an e4m3 dgrad GEMM (d = 384)
+      ProfScope ps(prof_kind<EPI>(), 4.0 * a.M * a.N * a.K, st, nt_bytes<EPI>(a));
+      return launch_nt_row384_cfg<EPI, 4, false, true, false, 0, true>(a, st);
+    } else
     if constexpr (EPI == EPI_BF16 || EPI == EPI_BIAS_GELU || EPI == EPI_RESID || EPI == EPI_F32 || EPI == EPI_DGELU) {
+      if constexpr (EPI == EPI_RESID) {
+        if (ln_fused(a)) {                                        // ... and the LayerNorm forward of the new residual row
+          ProfScope ps(prof_kind<EPI>(), 4.0 * a.M * a.N * a.K, st, nt_bytes<EPI>(a));
+          return launch_nt_row384_cfg<EPI, 4, true, true, false, 0, true>(a, st);
+        }
+      }
       if (g_nt_variant < 0 && g_p8 >= 2 && (EPI != EPI_BIAS_GELU || g_p8 >= 3) && p8_ok<EPI>(a)) return launch_nt_p8<EPI, true>(a, st);
       ProfScope ps(prof_kind<EPI>(), 4.0 * a.M * a.N * a.K, st, nt_bytes<EPI>(a));
       if constexpr (EPI == EPI_BF16) { if (g_bf16_tr) return launch_nt_row384_cfg<EPI, 4, false, true, true>(a, st); }
@@ -2034,6 +2112,15 @@ int launch_nt_row384(const GemmArgs& a, hipStream_t st) {
   }
   ProfScope ps(prof_kind<EPI>(), 2.0 * a.M * a.N * a.K, st, nt_bytes<EPI>(a));
   constexpr bool rowwise_only = EPI == EPI_LNBWD;                 // epilogues that exist only on whole-row tiles
+  if constexpr (EPI == EPI_LNBWD) {
+    // bf16 operands, but the epilogue also writes the e4m3 copy of g / posts its amax (e4m3 step at d = 384, groups whose attention backward writes a bf16 dqkv:
+    // the 1 s local views): the Q8 instantiations -- 4-wave blocks for the small grids, like the plain ones below
+    if (a.q8 || a.q8_amax) {
+      const long tiles8q = (long)((a.M + 255) / 256);
+      if (g_w4_auto && a.M >= 2048 && tiles8q <= 384) return launch_nt_w4_cfg<EPI, 1, false, true>(a, st);
+      return launch_nt_row384_cfg<EPI, 4, false, false, false, 0, true>(a, st);
+    }
+  }
 
   // Fewer than 1.5 rounds of 256 x 384 tiles (the 1 s local views: M = 32768, N = 384 -> 128 blocks on 256 CUs): the 4-wave
   // kernels launch twice as many, half as large blocks, two per CU.  Measured at M = 32768 (profiles/r02_gemm_bench.txt):
@@ -2044,19 +2131,19 @@ int launch_nt_row384(const GemmArgs& a, hipStream_t st) {
   if ((g_w4_mode && a.M >= g_w4_min_m) || small_grid) {
     const int w4m = g_w4_mode ? g_w4_mode : 2;
     if constexpr (EPI == EPI_RESID) {
-      if (a.ln_out) { if (w4m != 3) return launch_nt_w4_cfg<EPI, 1, true>(a, st); }
+      if (ln_fused(a)) { if (w4m != 3) return launch_nt_w4_cfg<EPI, 1, true>(a, st); }
     }
     if constexpr (rowwise_only) {
       if (w4m != 3) return launch_nt_w4_cfg<EPI, 1, false>(a, st);
     } else {
-      if (!a.ln_out) return launch_nt_w4_cfg<EPI, 2, false>(a, st);
+      if (!ln_fused(a)) return launch_nt_w4_cfg<EPI, 2, false>(a, st);
     }
   }
   // 256-row tiles: the operand ring of one block covers twice the output (6.7 vs 10.7 KB staged per 128x128 unit)
   const bool tall = a.M >= (g_w4_min_m < 8192 ? g_w4_min_m : 8192) && (g_row384_tall == 2 || (g_row384_tall == 1 && EPI == EPI_BF16 && (a.K >= 768 || a.N >= 768)));
   const int ph = (g_ph && tall && a.K >= 2 * BK) ? ((g_ph == 2 && a.K % 64 == 0 && a.K >= 128) ? 2 : 1) : 0;   // phased main loop of the 256-row tile (2: 64-deep whole-line stages, hook 398)
   if constexpr (EPI == EPI_RESID) {
-    if (a.ln_out) return tall ? (ph == 2 ? launch_nt_row384_cfg<EPI, 4, true, false, false, 2>(a, st) : ph ? launch_nt_row384_cfg<EPI, 4, true, false, false, 1>(a, st) : launch_nt_row384_cfg<EPI, 4, true>(a, st)) : launch_nt_row384_cfg<EPI, 2, true>(a, st);
+    if (ln_fused(a)) return tall ? (ph == 2 ? launch_nt_row384_cfg<EPI, 4, true, false, false, 2>(a, st) : ph ? launch_nt_row384_cfg<EPI, 4, true, false, false, 1>(a, st) : launch_nt_row384_cfg<EPI, 4, true>(a, st)) : launch_nt_row384_cfg<EPI, 2, true>(a, st);
   }
   if constexpr (EPI == EPI_BF16) {
     if (g_bf16_tr) return tall ? launch_nt_row384_cfg<EPI, 4, false, false, true>(a, st) : launch_nt_row384_cfg<EPI, 2, false, false, true>(a, st);
@@ -2069,8 +2156,8 @@ int launch_nt(const GemmArgs& a, hipStream_t st) {
     if (a.N != 384 || a.ldc != 384 || !a.ln_gamma || !a.ln_mean || !a.ln_rstd || !a.lnb_x || !a.lnb_dgamma || !a.lnb_dbeta || !a.C) return ATST_EINVAL;
     return launch_nt_row384<EPI>(a, st);
   } else {
-    if (a.ln_out) {                                               // fused LayerNorm needs the block to own whole rows
-      if (EPI != EPI_RESID || a.N != 384 || !a.ln_gamma || !a.ln_beta || !a.ln_mean || !a.ln_rstd) return ATST_EINVAL;
+    if (ln_fused(a)) {                                            // fused LayerNorm needs the block to own whole rows
+      if (EPI != EPI_RESID || a.N != 384 || a.ldc != 384 || !a.ln_gamma || !a.ln_beta || !a.ln_mean || !a.ln_rstd) return ATST_EINVAL;
       if constexpr (EPI == EPI_RESID) return launch_nt_row384<EPI>(a, st);
     }
     int v = g_nt_variant;
@@ -2111,9 +2198,11 @@ int launch_nt(const GemmArgs& a, hipStream_t st) {
 }  // namespace
 
 int g_f8_resid16 = 1;        // tuning hook 2100 / 2101: fp8 inference / teacher passes keep their residual stream in bf16 (read by engine.hip): off / on
+int g_f8_fuse_ln = 1;        // tuning hook 2110 / 2111: the e4m3 step at d = 384 runs its LayerNorms (forward and backward) inside the GEMM epilogues (read by engine.hip): off / on
 int g_tn_group_splits = 0;   // tuning hook 1500 + s: M-splits of the grouped bf16 weight gradient (0 = cost model)
 void atst_gemm_nt_set_variant(int v) {
-  if (v >= 2100 && v < 2102) g_f8_resid16 = v - 2100;
+  if (v >= 2110 && v < 2112) g_f8_fuse_ln = v - 2110;
+  else if (v >= 2100 && v < 2102) g_f8_resid16 = v - 2100;
   else if (v >= 2000 && v < 2100) g_tt = v - 2000;
   else if (v >= 1000 && v < 2000) g_p8_skew = v - 1000;
   else if (v >= 396 && v <= 398) g_ph = v - 396;
@@ -2137,10 +2226,14 @@ int atst_gemm_nt(const GemmArgs& a0, hipStream_t st) {
   GemmArgs a = a0;
   // outputs that may be left out: the bf16 activation of fc1 + GELU and the bf16 du of the dGELU dgrad, when an e4m3 copy is written instead
   if ((a.epi == EPI_BIAS_GELU && !a.C2 && !a.q8) || (a.epi == EPI_DGELU && !a.C && !a.q8) || (a.epi != EPI_BIAS_GELU && a.epi != EPI_DGELU && !a.C)) return ATST_EINVAL;
-  if (a.fp8) {                                                    // e4m3: K a multiple of 64 bytes, row-384 tile only, no fused LayerNorm
-    if (a.M <= 0 || a.N % 384 || a.K % 64 || a.lda % 16 || a.ldb % 16 || a.ln_out) return ATST_EINVAL;
+  if (a.fp8) {                                                    // e4m3: K a multiple of 64 bytes, row-384 tile only; row-wise epilogues (round 6): N == 384, fp32 residual stream
+    if (a.M <= 0 || a.N % 384 || a.K % 64 || a.lda % 16 || a.ldb % 16) return ATST_EINVAL;
+    if (a.ln_out && a.epi != EPI_RESID) return ATST_EINVAL;
+    if (ln_fused(a) && (a.N != 384 || a.ldc != 384 || !a.ln_gamma || !a.ln_beta || !a.ln_mean || !a.ln_rstd || a.resid_bf16 || a.out_bf16 || !a.resid)) return ATST_EINVAL;
+    if (a.epi == EPI_LNBWD && (a.N != 384 || a.ldc != 384 || !a.ln_gamma || !a.ln_mean || !a.ln_rstd || !a.lnb_x || !a.lnb_dgamma || !a.lnb_dbeta)) return ATST_EINVAL;
     a.K /= 2; a.lda /= 2; a.ldb /= 2;
     switch (a.epi) {
+      case EPI_LNBWD: return launch_nt_row384<EPI_LNBWD>(a, st);
       case EPI_BF16: return launch_nt_row384<EPI_BF16>(a, st);
       case EPI_F32: return launch_nt_row384<EPI_F32>(a, st);
       case EPI_BIAS_GELU: return launch_nt_row384<EPI_BIAS_GELU>(a, st);
@@ -2150,7 +2243,7 @@ int atst_gemm_nt(const GemmArgs& a0, hipStream_t st) {
     return ATST_EINVAL;
   }
   if (a.M <= 0 || a.N % BN || a.K % BK || a.lda % 8 || a.ldb % 8) return ATST_EINVAL;
-  if (a.q8) return ATST_EINVAL;                                   // e4m3 copies of an output are written by the e4m3 GEMMs only (row-384 epilogues own the scale plumbing)
+  if (a.q8 && a.epi != EPI_LNBWD) return ATST_EINVAL;             // e4m3 copies of an output: the e4m3 GEMMs, and the LayerNorm-backward epilogue of a bf16 dgrad GEMM
   switch (a.epi) {
     case EPI_BF16: return launch_nt<EPI_BF16>(a, st);
     case EPI_F32: return launch_nt<EPI_F32>(a, st);

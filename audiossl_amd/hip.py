@@ -69,6 +69,8 @@ _SIGS = {
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "atst_gemm_nt_resid_ln_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 7),
     "atst_gemm_nt_lnbwd_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 8 + [C.c_int] + [C.c_void_p] * 4),
+    "atst_gemm_nt_resid_ln_fp8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 11),
+    "atst_gemm_nt_lnbwd_q8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 13 + [C.c_int] + [C.c_void_p] * 4),
     "atst_gemm_nt_fp8": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_void_p,
                                    C.c_float, C.c_void_p]),
     "atst_quant_fp8_bf16": (C.c_int, [C.c_void_p, C.c_size_t, C.c_float, C.c_void_p, C.c_void_p]),

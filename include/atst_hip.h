@@ -99,6 +99,21 @@ int atst_gemm_nt_resid_ln_bf16(const uint16_t* A, const uint16_t* B, int M, int 
 int atst_gemm_nt_lnbwd_bf16(const uint16_t* dY, const uint16_t* Wt, int M, int K, const float* x, const float* mean, const float* rstd,
                             const float* gamma, const float* dres, float* dx, uint16_t* g, const float* row_scale, int rows_per_seq,
                             float* dgamma, float* dbeta, float* dbias_up, void* stream);
+/* Round 6 -- the two row-wise epilogues above for the all-e4m3 step at d = 384 (what atst_encoder_fwd / _bwd launch for proj, fc2 and for the fc1 / qkv
+ * dgrads when C = 384 and fp8 is on; Block.forward and its autograd, audiossl/modules/transformer.py:136-150):
+ *   atst_gemm_nt_resid_ln_fp8: A8 [M,K], B8 [384,K] e4m3 bytes (K % 64 == 0), acc * *dq / *a_scale (a_scale: device scale of A8, or null = 1) ;
+ *     x_out / ln_mean / ln_rstd as atst_gemm_nt_resid_ln_bf16 ; ln_out (bf16) and / or ln_out8 = e4m3(bf16(LayerNorm(x_out)) * *out8_scale) -- the operand of
+ *     the next e4m3 GEMM ; out8_amax (an ATST_AMAX_SITE_STRIDE-float site, or null) receives max |bf16 LayerNorm output| ; out8_sat (or null) counts
+ *     the elements clipped at +-448.
+ *   atst_gemm_nt_lnbwd_q8: the LayerNorm-backward dgrad epilogue with dY / Wt either e4m3 bytes (operands_fp8 = 1: acc * *dq / *dy_scale) or bf16
+ *     (operands_fp8 = 0: dq, dy_scale unused), which also writes g8 = e4m3(bf16(row_scale dx) * *g8_scale) (or null) and posts max |row_scale dx| to the
+ *     site g8_amax (or null) -- what atst_layernorm_bwd's fp8 form does in the unfused step.  g (bf16) may be null.                                     */
+int atst_gemm_nt_resid_ln_fp8(const uint8_t* A8, const uint8_t* B8, int M, int K, const float* dq, const float* a_scale, const float* bias, const float* resid,
+                              const float* row_scale, int rows_per_seq, float* x_out, const float* ln_gamma, const float* ln_beta, uint16_t* ln_out,
+                              uint8_t* ln_out8, const float* out8_scale, float* out8_amax, uint32_t* out8_sat, float* ln_mean, float* ln_rstd, void* stream);
+int atst_gemm_nt_lnbwd_q8(const void* dY, const void* Wt, int operands_fp8, int M, int K, const float* dq, const float* dy_scale, const float* x, const float* mean,
+                          const float* rstd, const float* gamma, const float* dres, float* dx, uint16_t* g, uint8_t* g8, const float* g8_scale, float* g8_amax,
+                          const float* row_scale, int rows_per_seq, float* dgamma, float* dbeta, float* dbias_up, void* stream);
 /* The same GEMM on OCP e4m3 operands (A8 [M,K], B8 [N,K] bytes; N % 384 == 0, K % 64 == 0) with v_mfma_scale_f32_32x32x64_f8f6f4:
  * C = epilogue(dq_mul * (*dq) * A8 B8^T); epilogues BF16 / F32 / BIAS_GELU / RESID.  north_star "fp8 MFMA QKV/MLP GEMMs".      */
 int atst_gemm_nt_fp8(const uint8_t* A8, const uint8_t* B8, int M, int N, int K, int lda, int ldb, int epi, void* C, int ldc,

@@ -377,6 +377,110 @@ def test_gemm_resid_layernorm_epilogue(M, K, hook):
     assert relerr(h.float(), torch.nn.functional.layer_norm(want, (C,), gamma, beta, 1e-6)) < 4e-3
 
 
+def _e4m3(x, scale):
+    return (x.float() * scale).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+
+
+def _codes_close(got_u8, want_f8, frac=2e-3):
+    """e4m3 bytes of a value that went through a different (but equivalent) fp32 summation order: equal, except that a value sitting on a rounding
+    boundary may land on the neighbouring code -- at most `frac` of the elements, and never further than one code apart."""
+    g, w = got_u8.view(torch.float8_e4m3fn).float(), want_f8.float()
+    diff = g != w
+    if float(diff.float().mean()) > frac:
+        return False
+    gi, wi = got_u8.view(torch.uint8).int(), want_f8.view(torch.uint8).int()
+    mag = lambda c: torch.where(c >= 128, -(c - 128), c)                       # sign-magnitude byte -> ordered integer
+    return int((mag(gi) - mag(wi)).abs().max()) <= 1
+
+
+@pytest.mark.parametrize("M,K,both", [(700, 384, True), (8192 + 64, 1536, False), (2048 + 40, 384, False)])
+def test_gemm_resid_layernorm_epilogue_fp8(M, K, both):
+    """Round 6: the residual GEMM on e4m3 operands whose epilogue is also the LayerNorm of the new row, written as the e4m3 operand of the next GEMM
+    (+ its amax and clip count) and, optionally, as bf16 -- against the fp32 formulation on the dequantised operands."""
+    C, rps = 384, 32
+    A, B = rnd(M, K, seed=1, scale=0.5), rnd(C, K, seed=2, scale=0.5)
+    sa, sb = 8.0, 64.0
+    A8, B8 = _e4m3(A, sa).view(torch.uint8).contiguous(), _e4m3(B, sb).view(torch.uint8).contiguous()
+    dq, asc = torch.tensor([1.0 / sb], device=DEV), torch.tensor([sa], device=DEV)
+    bias, resid = rnd(C, seed=3), rnd(M, C, seed=4) * 2 + 0.2
+    gamma, beta = 1 + 0.1 * rnd(C, seed=5), 0.1 * rnd(C, seed=6)
+    scale = ((torch.arange((M + rps - 1) // rps, device=DEV) % 3).float() * 0.625).contiguous()
+    x = torch.empty(M, C, device=DEV)
+    h = torch.empty(M, C, dtype=torch.bfloat16, device=DEV) if both else None
+    h8 = torch.empty(M, C, dtype=torch.uint8, device=DEV)
+    s8 = torch.tensor([96.0], device=DEV)                                       # large enough that a few elements clip at +-448
+    site, sat = torch.zeros(hip.AMAX_SITE_STRIDE, device=DEV), torch.zeros(1, dtype=torch.int32, device=DEV)
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    hip.call("atst_gemm_nt_resid_ln_fp8", hip.ptr(A8), hip.ptr(B8), M, K, hip.ptr(dq), hip.ptr(asc), hip.ptr(bias), hip.ptr(resid), hip.ptr(scale), rps, hip.ptr(x),
+             hip.ptr(gamma), hip.ptr(beta), hip.ptr(h), hip.ptr(h8), hip.ptr(s8), hip.ptr(site), hip.ptr(sat), hip.ptr(mean), hip.ptr(rstd), hip.stream())
+    acc = (A8.view(torch.float8_e4m3fn).double() @ B8.view(torch.float8_e4m3fn).double().t()).float() / (sa * sb)
+    want = resid + scale.repeat_interleave(rps)[:M, None] * (acc + bias)
+    assert relerr(x, want) < 2e-5
+    assert relerr(mean, want.mean(1)) < 2e-5
+    assert relerr(rstd, torch.rsqrt(want.var(1, unbiased=False) + 1e-6)) < 2e-5
+    ln = torch.nn.functional.layer_norm(x, (C,), gamma, beta, 1e-6)             # of the kernel's own x: isolates the LayerNorm + quantisation
+    lnb = ln.bfloat16()
+    if both:
+        assert relerr(h.float(), ln) < 4e-3
+        lnb = h                                                                # the e4m3 copy is the copy of THESE bf16 values
+        assert torch.equal(h8.view(torch.float8_e4m3fn).float(), _e4m3(h, 96.0).float())
+    else:
+        assert _codes_close(h8, _e4m3(lnb, 96.0), frac=2e-2)                   # bf16 rounding boundaries of LN(x) move a code now and then
+    assert abs(float(site.max()) - float(lnb.float().abs().max())) <= 0.02 * float(lnb.float().abs().max())
+    nclip = int(((lnb.float() * 96.0).abs() > 448.0).sum())
+    assert nclip > 0 and abs(int(sat) - nclip) <= max(2, nclip // 50)
+
+
+@pytest.mark.parametrize("M,K,f8,g16,hook", [(700, 384, True, True, None), (8192 + 64, 1536, True, False, None), (2048 + 40, 1152, False, False, None),
+                                             (8192 + 64, 1152, False, True, 360),      # bf16 operands on the 8-wave 256-row tile (4-wave auto-selection off)
+                                             (640, 1152, True, False, None)])
+def test_gemm_lnbwd_epilogue_q8(M, K, f8, g16, hook):
+    """Round 6: the LayerNorm-backward dgrad epilogue that also writes the e4m3 copy of g and its amax, on e4m3 or bf16 operands."""
+    C, rps = 384, 32
+    dYf, Wtf = rnd(M, K, seed=1, scale=0.5), rnd(C, K, seed=2, scale=0.5)
+    sy, sw = 16.0, 64.0
+    if f8:
+        dY, Wt = _e4m3(dYf, sy).view(torch.uint8).contiguous(), _e4m3(Wtf, sw).view(torch.uint8).contiguous()
+        dy = (dY.view(torch.float8_e4m3fn).double() @ Wt.view(torch.float8_e4m3fn).double().t()).float() / (sy * sw)
+    else:
+        dY, Wt = bf(dYf), bf(Wtf)
+        dy = dY.float() @ Wt.float().t()
+    dq, dsc = torch.tensor([1.0 / sw], device=DEV), torch.tensor([sy], device=DEV)
+    x = rnd(M, C, seed=3) * 2 + 0.3
+    gamma, beta = 1 + 0.1 * rnd(C, seed=4), 0.1 * rnd(C, seed=5)
+    mean, var = x.mean(1), x.var(1, unbiased=False)
+    rstd = torch.rsqrt(var + 1e-6)
+    dres = rnd(M, C, seed=6)
+    scale = ((torch.arange((M + rps - 1) // rps, device=DEV) % 3).float() * 0.625).contiguous()
+    dx = torch.empty(M, C, device=DEV)
+    g = torch.empty(M, C, dtype=torch.bfloat16, device=DEV) if g16 else None
+    g8 = torch.empty(M, C, dtype=torch.uint8, device=DEV)
+    s8 = torch.tensor([24.0], device=DEV)
+    site = torch.zeros(hip.AMAX_SITE_STRIDE, device=DEV)
+    dgamma, dbeta, dbu = (torch.full((C,), 0.125, device=DEV) for _ in range(3))
+    lib = hip.load()
+    if hook is not None:
+        lib.atst_tune_gemm_variant(hook)
+    try:
+        hip.call("atst_gemm_nt_lnbwd_q8", hip.ptr(dY), hip.ptr(Wt), 1 if f8 else 0, M, K, hip.ptr(dq), hip.ptr(dsc), hip.ptr(x), hip.ptr(mean.contiguous()),
+                 hip.ptr(rstd.contiguous()), hip.ptr(gamma), hip.ptr(dres), hip.ptr(dx), hip.ptr(g), hip.ptr(g8), hip.ptr(s8), hip.ptr(site), hip.ptr(scale), rps,
+                 hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(dbu), hip.stream())
+    finally:
+        if hook is not None:
+            lib.atst_tune_gemm_variant(361)
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    torch.nn.functional.layer_norm(xr, (C,), gr, br, 1e-6).backward(dy)
+    want_dx = dres + xr.grad
+    assert relerr(dx, want_dx) < 3e-5
+    assert relerr(dgamma, gr.grad + 0.125) < 3e-5 and relerr(dbeta, br.grad + 0.125) < 3e-5
+    gs = dx * scale.repeat_interleave(rps)[:M, None]                            # of the kernel's own dx
+    assert relerr(dbu, gs.sum(0) + 0.125) < 3e-5
+    if g16:
+        assert torch.equal(g.float(), gs.bfloat16().float())
+    assert torch.equal(g8.view(torch.float8_e4m3fn).float(), _e4m3(gs.bfloat16(), 24.0).float())
+    assert float(site.max()) == float(gs.abs().max())
+
+
 def attn_ref(qkv, valid, S, H, NP):
     C = H * 64
     q, k, v = qkv.float().reshape(S, NP, 3, H, 64).permute(2, 0, 3, 1, 4)
