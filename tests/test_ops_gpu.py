@@ -1054,13 +1054,17 @@ def test_fp8_inference_pass_bf16_residual_stream(arch):
     length = torch.tensor([1001, 1001, 702, 1001, 523, 941])
     feats = {}
     try:
+        lib.atst_tune_gemm_variant(2110)                                # d = 384: the fused LayerNorm epilogues (fp32 stream) would take precedence over the bf16 stream
         for hook in (2101, 2100):
             lib.atst_tune_gemm_variant(hook)
             ep = eng._pass("teacher", S, 1001, False, 0)
             out = ep.forward(mel.cuda(), eng._valid(length, 1), None, None)
             feats[hook] = out.float().view(S, 256, d)[:, 0].cpu()
+        lib.atst_tune_gemm_variant(2111); lib.atst_tune_gemm_variant(2101)   # the shipped configuration
+        out = eng._pass("teacher", S, 1001, False, 0).forward(mel.cuda(), eng._valid(length, 1), None, None)
+        feats["shipped"] = out.float().view(S, 256, d)[:, 0].cpu()
     finally:
-        lib.atst_tune_gemm_variant(2101)
+        lib.atst_tune_gemm_variant(2101); lib.atst_tune_gemm_variant(2111)
     errs = {}
     for hook, r16 in ((2101, True), (2100, False)):
         with torch.no_grad(), O.emulate_bf16(), O.emulate_fp8(resid_bf16=r16):
@@ -1074,6 +1078,14 @@ def test_fp8_inference_pass_bf16_residual_stream(arch):
     assert errs[2101] < 5.5e-2 and errs[2100] < 5.5e-2                  # the bound of test_fp8_encoder_forward_and_step_base
     assert d_modes < 6e-2                                               # measured 4.1e-2 (small) : a 2^-9 perturbation of the stream moves a few per cent of the e4m3 codes behind it
     assert relerr(feats[2101], cls32) < 1.2 * relerr(feats[2100], cls32) + 1e-2
+    # the shipped inference pass: base = the bf16 stream (bit for bit the 2101 run); small = fp32 stream with the LayerNorms in the GEMM epilogues
+    if arch == "base":
+        assert torch.equal(feats["shipped"], feats[2101])
+    else:
+        with torch.no_grad(), O.emulate_bf16(), O.emulate_fp8(resid_bf16=False):
+            cls_f = O.encoder_forward(W, "teacher.encoder.", mel, length, arch, depth=depth, drop_path_rate=0.0)
+        print(f"[fp8 inference, small, fused LayerNorm epilogues] CLS vs emulation {relerr(feats['shipped'], cls_f):.3e}; vs the separate-pass fp32-stream run {relerr(feats['shipped'], feats[2100]):.3e}")
+        assert relerr(feats["shipped"], cls_f) < 5.5e-2 and relerr(feats["shipped"], feats[2100]) < 6e-2
 
 
 def test_fp8_forward_saturation_counter_and_running_scales():
