@@ -525,6 +525,26 @@ DEVFN void st_e4m3_row(uint8_t* rowp, const float* v /* [12]: bf16-rounded value
   st_pol<4>(wide, reinterpret_cast<u32x2*>(rowp + (odd ? 128 + 4 * (li - 1) : 4 * li)));
   st_pol<4>(c2, reinterpret_cast<unsigned*>(rowp + 256 + 4 * li));
 }
+// the two row stores from already-packed groups (lnb_row<Q8>: a group is packed as soon as its four values exist, so that 9 dwords instead of 12 floats live across the loop)
+DEVFN void st_bf16_row_packed(bf16* rowp, u32x2 c0, u32x2 c1, u32x2 c2, int li, bool live) {
+  const bool odd = li & 1;
+  const u32x2 send = odd ? c0 : c1;
+  u32x2 recv;
+  recv[0] = __builtin_amdgcn_update_dpp(0u, send[0], 0xB1, 0xF, 0xF, true);
+  recv[1] = __builtin_amdgcn_update_dpp(0u, send[1], 0xB1, 0xF, 0xF, true);
+  if (!live) return;
+  const u32x4 wide = odd ? u32x4{recv[0], recv[1], c1[0], c1[1]} : u32x4{c0[0], c0[1], recv[0], recv[1]};
+  st_pol<4>(wide, reinterpret_cast<u32x4*>(rowp + (odd ? 128 + 4 * (li - 1) : 4 * li)));
+  st_pol<4>(c2, reinterpret_cast<u32x2*>(rowp + 256 + 4 * li));
+}
+DEVFN void st_e4m3_row_packed(uint8_t* rowp, unsigned c0, unsigned c1, unsigned c2, int li, bool live) {
+  const bool odd = li & 1;
+  const unsigned recv = __builtin_amdgcn_update_dpp(0u, odd ? c0 : c1, 0xB1, 0xF, 0xF, true);
+  if (!live) return;
+  const u32x2 wide = odd ? u32x2{recv, c1} : u32x2{c0, recv};
+  st_pol<4>(wide, reinterpret_cast<u32x2*>(rowp + (odd ? 128 + 4 * (li - 1) : 4 * li)));
+  st_pol<4>(c2, reinterpret_cast<unsigned*>(rowp + 256 + 4 * li));
+}
 // residual + LayerNorm forward of the new row: x_new = resid + s (acc + bias) -> fp32 stream ; h = LN(x_new) -> bf16 operand
 // of the next GEMM ; row statistics saved for the LayerNorm backward.  ref: Block.forward, audiossl/modules/transformer.py:136-150.
 template <bool Q8>
@@ -619,6 +639,38 @@ DEVFN void lnb_row(const GemmArgs& p, int row, bool live, const float* sRow, con
     lnb_fold4(cs.dg + 2 * j, ddg); lnb_fold4(cs.db + 2 * j, ddb);  // both half-waves get here: no early exit for dead rows
   }
   const float c1 = half_sum(s1) * (1.0f / 384.0f), c2 = half_sum(s2) * (1.0f / 384.0f);
+  if constexpr (Q8) {                                              // the same arithmetic; every 4-column group is packed (bf16 and e4m3) as soon as it exists
+    u32x2 pb[3]; unsigned p8[3]; float cm = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int col = j * 128 + li * 4;
+      const f32x4 d4 = *reinterpret_cast<const f32x4*>(sRow + col), g4 = *reinterpret_cast<const f32x4*>(sGamma + col);
+      const f32x4 x4 = *reinterpret_cast<const f32x4*>(slot + ROWIN_PAIR_BYTES + hh * 1536 + j * 512 + li * 16);
+      f32x4 r4 = {0.f, 0.f, 0.f, 0.f};
+      if (has_res) r4 = *reinterpret_cast<const f32x4*>(slot + hh * 1536 + j * 512 + li * 16);
+      f32x4 o; float g4s[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xh = (x4[e] - mu) * rs;
+        o[e] = live ? r4[e] + rs * (d4[e] * g4[e] - c1 - xh * c2) : 0.f;
+        g4s[e] = o[e] * sc;
+        cm = fmaxf(cm, fabsf(g4s[e]));
+      }
+      if (live) st_pol<2>(o, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (size_t)row * 384 + col));
+      lnb_fold4(cs.du + 2 * j, g4s);
+      pb[j] = pack_bf16x4(g4s);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g4s[e] = bf2f(f2bf(g4s[e]));
+      p8[j] = pack_e4m3x4(g4s, q8.s);                             // e4m3 copy of the bf16 values (A operand of the e4m3 proj / fc2 dgrad and weight-gradient GEMMs)
+    }
+    if (p.q8_amax) {                                               // max |g| of the site (dead rows: zeros) -- the next step's scale
+      q8.amax = fmaxf(q8.amax, cm);
+      asm volatile("" : "+v"(q8.amax));                            // pinned: see lnb_fold4
+    }
+    if (p.lnb_g) st_bf16_row_packed(p.lnb_g + (size_t)row * 384, pb[0], pb[1], pb[2], li, live);   // every lane takes part in the DPP exchange; dead rows do not store
+    if (p.q8) st_e4m3_row_packed(p.q8 + (size_t)row * 384, p8[0], p8[1], p8[2], li, live);
+    return;
+  }
   float gs[12];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
@@ -637,24 +689,8 @@ DEVFN void lnb_row(const GemmArgs& p, int row, bool live, const float* sRow, con
     if (live) st_pol<2>(o, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (size_t)row * 384 + col));
     lnb_fold4(cs.du + 2 * j, gs + 4 * j);
   }
-  if constexpr (Q8) {
-    if (p.q8_amax) {                                               // max |g| of the site (dead rows: zeros) -- the next step's scale
-      float cm = 0.f;
-#pragma unroll
-      for (int k = 0; k < 12; ++k) cm = fmaxf(cm, fabsf(gs[k]));
-      q8.amax = fmaxf(q8.amax, cm);
-      asm volatile("" : "+v"(q8.amax));                            // pinned: see lnb_fold4
-    }
-  }
   if (p.lnb_g) {                                                   // every lane takes part in the DPP exchange; dead rows do not store
     if (live) st_bf16_row(p.lnb_g + (size_t)row * 384, gs, li);
-  }
-  if constexpr (Q8) {
-    if (p.q8) {                                                    // e4m3 copy of the bf16 values (A operand of the e4m3 proj / fc2 dgrad and weight-gradient GEMMs)
-#pragma unroll
-      for (int k = 0; k < 12; ++k) gs[k] = bf2f(f2bf(gs[k]));
-      st_e4m3_row(p.q8 + (size_t)row * 384, gs, q8.s, li, live);
-    }
   }
 }
 // Block reduction of the column sums of lnb_row over the NW waves of a block (red: >= 3 * NW * 384 floats of LDS that no
