@@ -64,6 +64,12 @@ int atst_version(void);   /* = ATST_ABI_VERSION of the header the library was bu
  *   1400+s M-splits of the grouped e4m3 weight gradient (0 = automatic: one round of blocks on >= 3/4 of the CUs)
  *   408/409 NP=32 attention backward: dK,dV kernel + dQ kernel / one fused kernel, one wave per (sequence, head) (default)
  *   410/411 fp8 forward, e4m3 copy of the attention output: a quantisation pass over the bf16 output / written by the NP=256 forward kernel (default)
+ *   396/397/398 phased main loop of the 256 x 384 tile: off / 32-deep k-tiles (default) / 64-deep k-tiles of whole 128-B rows
+ *   1500+s M-splits of the grouped bf16 weight gradient (0 = cost model)
+ *   2000/2001/2002 persistent GEMM kernels with a tile's epilogue under the next tile's main loop (csrc/gemm_tt.h): off (default) / two teams of 4 waves /
+ *               one stream of 4 waves x 512 registers -- built, measured, rejected (DESIGN.md section 3 "Round 6")
+ *   2100/2101 fp8 inference / teacher passes keep their residual stream in bf16: off / on (default; d = 384 takes 2111's fused epilogues on the fp32 stream instead)
+ *   2110/2111 e4m3 step at d = 384: LayerNorm forward / backward as separate passes / inside the GEMM epilogues (default)
  * The measured-and-rejected GEMM variants of round 2 (64-deep ring stages, ping-pong main loop, register epilogue, start-up
  * skew, phase tracers) are not part of this library: tools/experiments/gemm_r02_variants.hip (ATST_GEMM_VARIANTS=1 build).          */
 int atst_tune_gemm_variant(int v);
