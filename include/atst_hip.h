@@ -70,6 +70,7 @@ int atst_version(void);   /* = ATST_ABI_VERSION of the header the library was bu
  *               one stream of 4 waves x 512 registers -- built, measured, rejected (DESIGN.md section 3 "Round 6")
  *   2100/2101 fp8 inference / teacher passes keep their residual stream in bf16: off / on (default; d = 384 takes 2111's fused epilogues on the fp32 stream instead)
  *   2110/2111 e4m3 step at d = 384: LayerNorm forward / backward as separate passes / inside the GEMM epilogues (default)
+ *   2120/2121 e4m3 GEMMs of at most 1.5 rounds of 256 x 384 tiles: 8-wave kernel (default) / 4-wave kernels, two blocks per CU (measured -0.5 % in the step)
  * The measured-and-rejected GEMM variants of round 2 (64-deep ring stages, ping-pong main loop, register epilogue, start-up
  * skew, phase tracers) are not part of this library: tools/experiments/gemm_r02_variants.hip (ATST_GEMM_VARIANTS=1 build).          */
 int atst_tune_gemm_variant(int v);

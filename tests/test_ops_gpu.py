@@ -1237,6 +1237,33 @@ def test_gemm_fp8_phased_kernel(M, N, K):
         assert relerr(got.float(), other.float()) < 4e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(2048 + 40, 1152, 384), (4096, 384, 384), (26624, 384, 1536)])
+def test_gemm_fp8_small_grid_four_wave_kernel(M, N, K):
+    """Round 6: e4m3 GEMMs whose grid is at most 1.5 rounds of 256 x 384 tiles (the 1 s local views of the e4m3 step at d = 384) run on the 4-wave
+    kernels, two blocks per CU (hook 2121; 2120 = the 8-wave 256-row tile, the default: the 4-wave form measured -0.5 % in the step).  Every accumulator sees the same k-tiles in the same order:
+    the plain-bf16 epilogue is bit-identical between the two, and both match the fp64 product of the same e4m3 values."""
+    lib = hip.load()
+    g = torch.Generator().manual_seed(M + N)
+    A = (torch.randn(M, K, generator=g) * 1.5).to(DEV).bfloat16()
+    W = (torch.randn(N, K, generator=g) * 0.05).to(DEV).bfloat16()
+    A8 = torch.empty(M, K, dtype=torch.uint8, device=DEV); W8 = torch.empty(N, K, dtype=torch.uint8, device=DEV)
+    hip.call("atst_quant_fp8_bf16", hip.ptr(A), M * K, 8.0, hip.ptr(A8), hip.stream())
+    hip.call("atst_quant_fp8_bf16", hip.ptr(W), N * K, 64.0, hip.ptr(W8), hip.stream())
+    dq = torch.tensor([1.0 / 64.0], device=DEV)
+    ref = (A8.view(torch.float8_e4m3fn).double() @ W8.view(torch.float8_e4m3fn).double().t()).float() / (8.0 * 64.0)
+    outs = {}
+    try:
+        for hook in (2120, 2121):
+            lib.atst_tune_gemm_variant(hook)
+            out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+            hip.call("atst_gemm_nt_fp8", hip.ptr(A8), hip.ptr(W8), M, N, K, K, K, hip.EPI_BF16, hip.ptr(out), N, None, None, None, None, 1, hip.ptr(dq), 1.0 / 8.0, hip.stream())
+            outs[hook] = out
+    finally:
+        lib.atst_tune_gemm_variant(2120)
+    assert relerr(outs[2121].float(), ref) < 4e-3
+    assert torch.equal(outs[2120], outs[2121])
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 256, 256), (1024, 768, 768), (8192 + 64, 768, 3072), (4096, 3072, 768),
                                    (1024, 384, 384), (2048 + 64, 1152, 384), (4096, 384, 1536), (512, 128, 128)])   # multiples of 128: half-valid edge tiles (d = 384)
 def test_gemm_tn_fp8_weight_gradient(M, N, K):
