@@ -158,6 +158,7 @@ int atst_layernorm_bwd(const uint16_t* dy, const float* x, const float* mean, co
   return atst_ln_bwd(a, ST(stream));
 }
 
+int atst_attention_fp8_ok(int NP, int H, int backward) { return backward ? (atst_attn_bwd_q8_ok(NP) ? 1 : 0) : (atst_attn_fwd_q8_ok(NP, H) ? 1 : 0); }
 int atst_attention_fwd(const uint16_t* qkv, const int* valid, uint16_t* o, float* lse, int S, int H, int NP, void* stream) {
   AttnArgs a{};
   a.qkv = CBF(qkv); a.valid = valid; a.o = BF(o); a.lse = lse; a.S = S; a.H = H; a.NP = NP;

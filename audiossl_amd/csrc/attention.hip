@@ -153,6 +153,23 @@ DEVFN void store_row64_e4m3(uint8_t* row, const f32x16& t0, const f32x16& t1, fl
     *reinterpret_cast<u32x4*>(row + t * 32 + 16 * hi) = o;
   }
 }
+// the same for kernels whose tile may hold rows that are not theirs to write (packed sequences, NP < 256): every lane takes part in the swaps, only live rows store
+DEVFN void store_row64_e4m3_if(bool live, uint8_t* row, const f32x16& t0, const f32x16& t1, float mul, float s8, int hi) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const f32x16& v = t == 0 ? t0 : t1;
+    unsigned X[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) X[g] = pack4_e4m3(v[4 * g] * mul, v[4 * g + 1] * mul, v[4 * g + 2] * mul, v[4 * g + 3] * mul, s8);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      auto r = __builtin_amdgcn_permlane32_swap(X[k], X[k + 2], false, false);
+      X[k] = r[0]; X[k + 2] = r[1];
+    }
+    const u32x4 o = {X[0], X[2], X[1], X[3]};
+    if (live) *reinterpret_cast<u32x4*>(row + t * 32 + 16 * hi) = o;
+  }
+}
 // the e4m3 twin of store_tile64_staged: 32 rows x 64 B through 2 KB of the wave's LDS region (16-B chunks XOR-permuted by the row pair), then
 // 2 store instructions of 16 complete 64-B rows each
 DEVFN void store_tile64_staged_e4m3(uint8_t* g00, size_t ld /* bytes between rows */, const f32x16& t0, const f32x16& t1, float mul, float s8,
@@ -186,9 +203,13 @@ DEVFN void zero16(f32x16& a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NP>
+// MODE (round 6, NP = 32: the 1 s local views of the e4m3 step): as in attn_fwd256v2_kernel -- 0 = bf16 output ; 1 = bf16 + the e4m3 copy p.o8 (amax -> p.o8_amax, clipped
+// elements -> p.o8_sat) ; 2 = e4m3 only
+template <int NP, int MODE = 0>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
   using GE = Geo<NP>;
+  float s8 = 1.0f, rmax = 0.f;
+  if constexpr (MODE != 0) s8 = p.o8_scale ? *p.o8_scale : p.o8_scale_k;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hi = lane >> 5, l31 = lane & 31;
   const int C = p.H * HD;
@@ -253,6 +274,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
       }
     }
     const float inv = 1.0f / l_run;
+    if constexpr (MODE != 2) {
     bf16* orow = p.o + ((size_t)s * RS + q0 + l31) * C + h * HD;
     if (qlive) {
 #pragma unroll
@@ -264,7 +286,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
         *reinterpret_cast<bf16x4*>(orow + 32 + 8 * g + 4 * hi) = b;
       }
     }
+    }
+    if constexpr (MODE != 0) {                                     // what atst_quant_fp8_dyn did over the stored bf16 values
+      store_row64_e4m3_if(qlive, p.o8 + ((size_t)s * RS + q0 + l31) * C + h * HD, o0, o1, inv, s8, hi);
+      const float cm = qlive ? bf2f(f2bf(amax16(o0, amax16(o1, 0.f)) * inv)) : 0.f;
+      rmax = fmaxf(rmax, cm);
+      if (cm * s8 > 448.f && p.o8_sat) {
+        unsigned n = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) n += (fabsf(bf2f(f2bf(o0[r] * inv)) * s8) > 448.f ? 1u : 0u) + (fabsf(bf2f(f2bf(o1[r] * inv)) * s8) > 448.f ? 1u : 0u);
+        if (n) atomicAdd(p.o8_sat, n);
+      }
+    }
     if (hi == 0) p.lse[((size_t)s * p.H + h) * NP + q0 + l31] = m_run + __logf(l_run);   // lse is [S, H, NP] whatever the row stride
+  }
+  if constexpr (MODE != 0) {
+    if (p.o8_amax) amax_post(p.o8_amax, wave_max(rmax), lane, blockIdx.x * 4 + wid);
   }
 }
 
@@ -736,14 +773,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
 // here Q, K, V, dO are staged once (18 KB per pair, wave-private), O is read once for D = rowsum(dO * O), and the 32 x 32 score tile is simply
 // computed in both orientations (S for dK / dV: lane = key ; S^T for dQ: lane = query) -- 16 extra MFMAs cost nothing next to a second pass
 // over memory and a second launch.
+// MODE (round 6): 0 = bf16 dqkv ; 2 = ONLY the e4m3 copy p.dqkv8 + max |bf16(dqkv)| over the live rows posted to p.q8_amax, as attn_bwd256_kernel<2>: the qkv dgrad
+// and weight gradient of the local views then read e4m3 like those of the 10 s views.
+template <int MODE = 0>
 __global__ __launch_bounds__(256) void attn_bwd32_kernel(AttnArgs p) {
   constexpr int NP = 32, MAT = NP * A_LD;
+  float s8 = 1.0f, gmax = 0.f;
+  if constexpr (MODE == 2) s8 = *p.q8_scale;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hi = lane >> 5, l31 = lane & 31;
   const int C = p.H * HD;
   const size_t ld = 3 * (size_t)C;
   const int pair = blockIdx.x * 4 + wid;
-  if (pair >= p.S * p.H) return;                                  // wave-private LDS, no block barrier below
+  if (pair >= p.S * p.H) return;                                  // wave-private LDS, no block barrier below (MODE 2: nothing to post either)
   const int s = pair / p.H, h = pair % p.H;
   constexpr int PAIR_BYTES = 4 * MAT * 2 + 2 * NP * 4;
   char* pb = smem_raw + wid * PAIR_BYTES;
@@ -811,6 +853,12 @@ __global__ __launch_bounds__(256) void attn_bwd32_kernel(AttnArgs p) {
         dk1 = mfma32(ld_frag_tr(sQ, A_LD, 16 * t, 32, lane), dsf, dk1);
       }
     }
+    if constexpr (MODE == 2) {
+      uint8_t* dk8 = p.dqkv8 + ((size_t)s * RS + l31) * ld + C + h * HD;
+      store_row64_e4m3_if(live, dk8, dk0, dk1, 1.0f, s8, hi);
+      store_row64_e4m3_if(live, dk8 + C, dv0, dv1, 1.0f, s8, hi);
+      if (live) gmax = amax16(dk0, amax16(dk1, amax16(dv0, amax16(dv1, gmax))));
+    } else
     if (live) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -852,6 +900,10 @@ __global__ __launch_bounds__(256) void attn_bwd32_kernel(AttnArgs p) {
         dq1 = mfma32(ld_frag_tr(sK, A_LD, 16 * t, 32, lane), dsf, dq1);
       }
     }
+    if constexpr (MODE == 2) {
+      store_row64_e4m3_if(live, p.dqkv8 + ((size_t)s * RS + l31) * ld + h * HD, dq0, dq1, 1.0f, s8, hi);
+      if (live) gmax = amax16(dq0, amax16(dq1, gmax));
+    } else {
     bf16* dqrow = p.dqkv + ((size_t)s * RS + l31) * ld + h * HD;
     if (live) {
 #pragma unroll
@@ -863,7 +915,9 @@ __global__ __launch_bounds__(256) void attn_bwd32_kernel(AttnArgs p) {
         *reinterpret_cast<bf16x4*>(dqrow + 32 + 8 * g + 4 * hi) = b;
       }
     }
+    }
   }
+  if constexpr (MODE == 2) amax_post(p.q8_amax, bf2f(f2bf(wave_max(gmax))), lane, blockIdx.x * 4 + wid);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1211,11 +1265,19 @@ int launch_fwd(const AttnArgs& a, hipStream_t st) {
   const int lds = fwd_lds<NP>();
   if (done.need(done_dev)) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if constexpr (NP == 32) {
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_fwd_kernel<NP, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_fwd_kernel<NP, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    }
     if (e != hipSuccess) return (int)e;
     done.done(done_dev);
   }
   const int nblk = (a.S * a.H + Geo<NP>::G - 1) / Geo<NP>::G;
-  ProfScope ps(PK_ATTN_FWD, 4.0 * a.S * a.H * (double)NP * NP * HD, st, 8.0 * a.S * a.H * (double)NP * HD);     // QK^T + PV on the padded geometry
+  ProfScope ps(PK_ATTN_FWD, 4.0 * a.S * a.H * (double)NP * NP * HD, st, (6.0 + (a.o ? 2.0 : 0.0) + (a.o8 ? 1.0 : 0.0)) * a.S * a.H * (double)NP * HD);     // QK^T + PV on the padded geometry
+  if constexpr (NP == 32) {
+    if (a.o8 && !a.o) { hipLaunchKernelGGL((attn_fwd_kernel<NP, 2>), dim3(nblk), dim3(256), lds, st, a); return (int)hipGetLastError(); }
+    if (a.o8) { hipLaunchKernelGGL((attn_fwd_kernel<NP, 1>), dim3(nblk), dim3(256), lds, st, a); return (int)hipGetLastError(); }
+  }
   hipLaunchKernelGGL(attn_fwd_kernel<NP>, dim3(nblk), dim3(256), lds, st, a);
   return (int)hipGetLastError();
 }
@@ -1247,11 +1309,12 @@ int g_bwd256 = 1;          // merged per-sequence backward kernel for NP = 256 (
 int g_fwd256 = 2;          // NP = 256 forward: 2 = two-pass softmax + LDS-DMA head loop, 1 = online-softmax head loop, 0 = per-(sequence, head) kernel (tuning hooks 404 / 401 / 400)
 int g_bwd32 = 1;           // 408 / 409: NP = 32 backward as two kernels (A/B) / one fused kernel (default)
 int g_bwd_row_stores = 0;  // 406 / 407: NP = 256 backward dK / dV stores row-per-lane (A/B) / LDS-transposed full lines (default)
+int g_q8_np32 = 1;         // 412 / 413: the NP = 32 kernels (forward: e4m3 copy of the output ; fused backward: e4m3-only dqkv) take part in the e4m3 step: off / on (round 6)
 int g_fwd_q8 = 1;          // 410 / 411: fp8 forward, e4m3 copy of the attention output by a separate pass (A/B) / by the NP = 256 forward kernel itself (default)
-void atst_attn_set_variant(int v) { if (v == 10 || v == 11) g_fwd_q8 = v == 11; else if (v == 8 || v == 9) g_bwd32 = v == 9; else if (v == 6 || v == 7) g_bwd_row_stores = v == 6; else if (v == 4) g_fwd256 = 2; else if (v >= 2) g_bwd256 = v - 2; else g_fwd256 = v; }
+void atst_attn_set_variant(int v) { if (v == 12 || v == 13) g_q8_np32 = v == 13; else if (v == 10 || v == 11) g_fwd_q8 = v == 11; else if (v == 8 || v == 9) g_bwd32 = v == 9; else if (v == 6 || v == 7) g_bwd_row_stores = v == 6; else if (v == 4) g_fwd256 = 2; else if (v >= 2) g_bwd256 = v - 2; else g_fwd256 = v; }
 
 // the e4m3 output of the forward exists in the two-pass NP = 256 kernel only (engine.hip asks; otherwise it quantises the bf16 output in a pass)
-bool atst_attn_fwd_q8_ok(int NP, int H) { return NP == 256 && g_fwd_q8 && g_fwd256 == 2 && (size_t)NP * 3 * H * HD * 2 < (1u << 30); }
+bool atst_attn_fwd_q8_ok(int NP, int H) { return (NP == 256 && g_fwd_q8 && g_fwd256 == 2 && (size_t)NP * 3 * H * HD * 2 < (1u << 30)) || (NP == 32 && g_q8_np32 && g_fwd_q8); }
 int atst_attn_fwd(const AttnArgs& a, hipStream_t st) {
   if (a.S <= 0) return ATST_OK;
   if (a.o8 ? !atst_attn_fwd_q8_ok(a.NP, a.H) : !a.o) return ATST_EINVAL;
@@ -1291,10 +1354,10 @@ int atst_attn_fwd(const AttnArgs& a, hipStream_t st) {
   return ATST_EINVAL;
 }
 // the e4m3 output of the backward exists in the merged NP = 256 kernel only (engine.hip asks before it plans a block's qkv gradient GEMMs)
-bool atst_attn_bwd_q8_ok(int NP) { return NP == 256 && g_bwd256; }
+bool atst_attn_bwd_q8_ok(int NP) { return (NP == 256 && g_bwd256) || (NP == 32 && g_bwd32 && g_q8_np32); }
 int atst_attn_bwd(const AttnArgs& a, hipStream_t st) {
   if (a.S <= 0) return ATST_OK;
-  if (a.dqkv8 && !(atst_attn_bwd_q8_ok(a.NP) && a.dscratch)) return ATST_EINVAL;
+  if (a.dqkv8 && !(atst_attn_bwd_q8_ok(a.NP) && (a.dscratch || a.NP == 32) && a.q8_scale && a.q8_amax)) return ATST_EINVAL;
   if (a.stride < 0 || a.stride > a.NP || (a.NP == 256 && a.stride != 0 && a.stride != 256)) return ATST_EINVAL;
   if (a.NP == 256 && g_bwd256 && a.dscratch) {
     static OncePerDevice done; int done_dev;
@@ -1322,12 +1385,14 @@ int atst_attn_bwd(const AttnArgs& a, hipStream_t st) {
     constexpr int LDS32 = 4 * (4 * 32 * A_LD * 2 + 2 * 32 * 4);
     static OncePerDevice done32; int done32_dev;
     if (done32.need(done32_dev)) {
-      hipError_t e = hipFuncSetAttribute((const void*)attn_bwd32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS32);
+      hipError_t e = hipFuncSetAttribute((const void*)attn_bwd32_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS32);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd32_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS32);
       if (e != hipSuccess) return (int)e;
       done32.done(done32_dev);
     }
-    ProfScope ps(PK_ATTN_BWD_DKV, 18.0 * a.S * a.H * 32.0 * 32.0 * HD, st, 16.0 * a.S * a.H * 32.0 * HD);
-    hipLaunchKernelGGL(attn_bwd32_kernel, dim3((a.S * a.H + 3) / 4), dim3(256), LDS32, st, a);
+    ProfScope ps(PK_ATTN_BWD_DKV, 18.0 * a.S * a.H * 32.0 * 32.0 * HD, st, (a.dqkv8 ? 13.0 : 16.0) * a.S * a.H * 32.0 * HD);
+    if (a.dqkv8) hipLaunchKernelGGL(attn_bwd32_kernel<2>, dim3((a.S * a.H + 3) / 4), dim3(256), LDS32, st, a);
+    else hipLaunchKernelGGL(attn_bwd32_kernel<0>, dim3((a.S * a.H + 3) / 4), dim3(256), LDS32, st, a);
     return (int)hipGetLastError();
   }
   switch (a.NP) {

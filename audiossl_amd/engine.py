@@ -227,7 +227,7 @@ class EncoderPass:
         if not (eng.fp8 and e.train and getattr(eng, "fp8_lean", False)) or getattr(eng, "fp8_bwd_state", 0) != 2 or self.M % 64:
             return 0
         mode = eng.fp8_wgrad_mode()
-        return 0 if mode == 0 else (2 if (mode == 2 and e.NP == 256) else 1)
+        return 0 if mode == 0 else (2 if (mode == 2 and hip.load().atst_attention_fp8_ok(int(e.NP), int(e.H), 1)) else 1)   # NP = 256 and (round 6) 32: the attention backward writes dqkv as e4m3
 
     def _check_lean(self):
         if self.e.fp8_lean and self.e.fp8_lean > self._lean_mode():

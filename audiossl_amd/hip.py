@@ -88,6 +88,7 @@ _SIGS = {
     "atst_layernorm_bwd": (C.c_int, [C.c_void_p] * 9 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_void_p]),
     "atst_attention_fwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]),
     "atst_attention_bwd": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 3 + [C.c_void_p]),
+    "atst_attention_fp8_ok": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "atst_attention_fwd_fp8": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 3 + [C.c_void_p]),
     "atst_attention_bwd_fp8": (C.c_int, [C.c_void_p] * 9 + [C.c_int] * 3 + [C.c_void_p]),
     "atst_patchify_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

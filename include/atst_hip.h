@@ -163,6 +163,9 @@ int atst_layernorm_bwd(const uint16_t* dy, const float* x, const float* mean, co
                        float* dgamma, float* dbeta, float* dbias_up, int M, int C, void* stream);
 /* Attention.forward + get_attention_mask: audiossl/modules/transformer.py:107-121,152-159                            */
 int atst_attention_fwd(const uint16_t* qkv, const int* valid, uint16_t* o, float* lse, int S, int H, int NP, void* stream);
+/* 1 when the attention kernels of tile size NP write the e4m3 copy themselves (forward: atst_attention_fwd_fp8's o8 ; backward: atst_attention_bwd_fp8's dqkv8):
+ * NP = 256 and, since round 6, NP = 32 (the 1 s local views).  A caller that plans `fp8_lean` = 2 for a pass asks this first (audiossl_amd/engine.py).        */
+int atst_attention_fp8_ok(int NP, int H, int backward);
 /* the same forward (NP == 256 only) that also writes the OCP e4m3 copy o8 [S*NP, C] = e4m3(bf16(o) * *scale), clamped to +-448 -- the operand of the
  * e4m3 proj GEMM -- next to o, or INSTEAD of it (o == NULL: inference passes).  amax_site (or NULL): max |bf16(o)| (ATST_AMAX_SITE_STRIDE floats,
  * atomicMax) ; sat (or NULL): number of clipped elements added.  ATST_EINVAL for any other NP.                                                */

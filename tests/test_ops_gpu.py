@@ -516,7 +516,7 @@ def test_attention(NP, valid):
         # keys beyond `valid` receive exactly zero gradient
         inval = (rowvalid == 0).reshape(-1)
         assert float(got[inval][:, 1:].abs().max()) == 0.0 if inval.any() else True
-    if NP == 256:
+    if NP in (256, 32):                                                 # (NP = 32, round 6: the 1 s local views take part in the e4m3 step)
         # fp8 forward: the e4m3 copy of the output written by the kernel itself, next to the bf16 output (training) or instead of it (inference):
         # the codes of the SAME bf16 values, their max |.| in the amax site, the clipped elements counted
         o_amax = float(o.float().abs().max())
