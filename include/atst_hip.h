@@ -64,6 +64,7 @@ int atst_version(void);   /* = ATST_ABI_VERSION of the header the library was bu
  *   1400+s M-splits of the grouped e4m3 weight gradient (0 = automatic: one round of blocks on >= 3/4 of the CUs)
  *   408/409 NP=32 attention backward: dK,dV kernel + dQ kernel / one fused kernel, one wave per (sequence, head) (default)
  *   410/411 fp8 forward, e4m3 copy of the attention output: a quantisation pass over the bf16 output / written by the NP=256 forward kernel (default)
+ *   412/413 NP = 32 attention kernels in the e4m3 step (forward: e4m3 copy of the output ; fused backward: e4m3-only dqkv): off / on (default)
  *   396/397/398 phased main loop of the 256 x 384 tile: off / 32-deep k-tiles (default) / 64-deep k-tiles of whole 128-B rows
  *   1500+s M-splits of the grouped bf16 weight gradient (0 = cost model)
  *   2000/2001/2002 persistent GEMM kernels with a tile's epilogue under the next tile's main loop (csrc/gemm_tt.h): off (default) / two teams of 4 waves /
