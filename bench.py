@@ -189,7 +189,7 @@ def main():
     ap.add_argument("--arch", default="small", choices=["small", "base"],
                     help="small = the headline model (BASELINE configs[1..3]); base (d = 768, 12 heads) is an extra data point")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"],
-                    help="fp8: the four Linear layers of every block run their forward AND (d = 768) their dgrad and weight-gradient GEMMs on OCP e4m3 operands "
+                    help="fp8: the four Linear layers of every block run their forward AND their dgrad and weight-gradient GEMMs on OCP e4m3 operands "
                          "(MX-scaled MFMA, delayed scaling; the attention backward writes dqkv as e4m3); saved activations the attention needs stay bf16 "
                          "(BASELINE.json configs[4]: use with --arch base)")
     ap.add_argument("--precise", action="store_true",
@@ -391,11 +391,13 @@ def main():
     if args.also and world == 1 and not args.precise:
         headline = (args.workload, args.arch, args.dtype, args.hires)
         del eng, step
+        import gc
+        gc.collect()                                                # engine <-> pass reference cycles: without the collection every pass's workspace stayed allocated (258 GiB after eight passes)
         torch.cuda.empty_cache()
         for wl, arch, dtype, hires in (("frame", "small", "bf16", False), ("clip2", "small", "bf16", False), ("clip2", "base", "bf16", False),
                                        ("clip2", "base", "fp8", False), ("clip2", "base", "fp8", True),
                                        ("frame", "base", "bf16", False), ("frame", "base", "fp8", False),    # ATST-Frame base: the reference's train_base.sh recipe
-                                       ("clip6", "small", "fp8", False)):                                    # all-e4m3 + fp8_lean at d = 384 (round 6)
+                                       ("clip6", "small", "fp8", False), ("frame", "small", "fp8", False)):   # all-e4m3 + fp8_lean at d = 384 (round 6)
             if (wl, arch, dtype, hires) == headline:
                 continue
             n_w, n_t = (8 if wl == "frame" else 3), args.also_steps       # ATST-Frame: its head batch is the masked rows of the step -- a few more steps until the row-buffer capacities have all been seen by the allocator
@@ -434,7 +436,10 @@ def main():
                     rec["dominant_kernel"]["mfma_frac"] = round(d2["tflops"] / (PEAK_FP8_TFLOPS if f8k else PEAK_BF16_TFLOPS), 4)
             also.append(rec)
             del eng2, step2
+            gc.collect()
             torch.cuda.empty_cache()
+            if os.environ.get("ATST_BENCH_MEM"):
+                print(f"[bench] after `also` {wl} {arch} {dtype}: allocated {torch.cuda.memory_allocated() / 2**30:.2f} GiB, reserved {torch.cuda.memory_reserved() / 2**30:.2f} GiB", file=sys.stderr)
 
     # N ranks on N distinct devices, as RCCL sees them: every rank reports its device index and PCI bus id
     rccl = None
