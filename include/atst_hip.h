@@ -40,7 +40,9 @@ enum { ATST_EPI_BF16 = 0, ATST_EPI_F32 = 1, ATST_EPI_BIAS_GELU = 2, ATST_EPI_RES
  *   110  round 4: atst_encoder_t grew f8_sat / f8_act_scale / f8_act_amax ; every amax argument (atst_quant_fp8_dyn_bf16, g8_amax, f8_act_amax) is an
  *        ATST_AMAX_SITE_STRIDE-float SITE, not one float ; fb_weights of atst_mel_frontend_f32 is tap-major [fb_maxlen][n_mels]
  *   120  round 5: atst_encoder_t grew fp8_wgrad / f8_act_scale_bwd ; an fp8 training workspace also holds per-layer e4m3 activation copies
- *        and an e4m3 dqkv ; fp8_lean ; atst_gemm_tn_fp8, atst_gemm_tn_group_fp8, atst_attention_fwd_fp8, atst_attention_bwd_fp8 */
+ *        and an e4m3 dqkv ; fp8_lean ; atst_gemm_tn_fp8, atst_gemm_tn_group_fp8, atst_attention_fwd_fp8, atst_attention_bwd_fp8
+ *        (round 6 ADDED entry points without changing an existing one -- atst_gemm_nt_resid_ln_fp8, atst_gemm_nt_lnbwd_q8, atst_attention_fp8_ok -- and widened two
+ *        preconditions: atst_gemm_tn_fp8 takes N, K multiples of 128, the fp8 attention entries take NP = 32: the version stays 120)                        */
 #define ATST_ABI_VERSION 120
 int atst_version(void);   /* = ATST_ABI_VERSION of the header the library was built from */
 /* Tuning hooks for A/B measurements (tools/gemm_bench.py, env ATST_TUNE=a,b,... read by audiossl_amd/hip.py); defaults are the
@@ -167,9 +169,9 @@ int atst_attention_fwd(const uint16_t* qkv, const int* valid, uint16_t* o, float
 /* 1 when the attention kernels of tile size NP write the e4m3 copy themselves (forward: atst_attention_fwd_fp8's o8 ; backward: atst_attention_bwd_fp8's dqkv8):
  * NP = 256 and, since round 6, NP = 32 (the 1 s local views).  A caller that plans `fp8_lean` = 2 for a pass asks this first (audiossl_amd/engine.py).        */
 int atst_attention_fp8_ok(int NP, int H, int backward);
-/* the same forward (NP == 256 only) that also writes the OCP e4m3 copy o8 [S*NP, C] = e4m3(bf16(o) * *scale), clamped to +-448 -- the operand of the
+/* the same forward (NP == 256 and, since round 6, NP == 32 -- ask atst_attention_fp8_ok) that also writes the OCP e4m3 copy o8 [S*NP, C] = e4m3(bf16(o) * *scale), clamped to +-448 -- the operand of the
  * e4m3 proj GEMM -- next to o, or INSTEAD of it (o == NULL: inference passes).  amax_site (or NULL): max |bf16(o)| (ATST_AMAX_SITE_STRIDE floats,
- * atomicMax) ; sat (or NULL): number of clipped elements added.  ATST_EINVAL for any other NP.                                                */
+ * atomicMax) ; sat (or NULL): number of clipped elements added.  ATST_EINVAL for NP = 64 / 128.                                                 */
 int atst_attention_fwd_fp8(const uint16_t* qkv, const int* valid, uint16_t* o, uint8_t* o8, const float* scale, float* amax_site, uint32_t* sat,
                            float* lse, int S, int H, int NP, void* stream);
 /* dscratch: optional fp32 [S,H,NP] scratch (rowsum(dO*O)); when given and NP == 256 the merged per-sequence kernel runs */
