@@ -177,9 +177,9 @@ int atst_attention_fwd_fp8(const uint16_t* qkv, const int* valid, uint16_t* o, u
 /* dscratch: optional fp32 [S,H,NP] scratch (rowsum(dO*O)); when given and NP == 256 the merged per-sequence kernel runs */
 int atst_attention_bwd(const uint16_t* qkv, const int* valid, const uint16_t* o, const float* lse, const uint16_t* d_o,
                        uint16_t* dqkv, float* dscratch, int S, int H, int NP, void* stream);
-/* the same backward (NP == 256 only, dscratch required) writing dqkv as OCP e4m3 ONLY: dqkv8 [S*NP, 3*C] = e4m3(bf16(dqkv) * *scale), clamped to +-448;
+/* the same backward (NP == 256 with dscratch, or -- round 6 -- NP == 32, the fused one-wave-per-pair kernel; dscratch unused there) writing dqkv as OCP e4m3 ONLY: dqkv8 [S*NP, 3*C] = e4m3(bf16(dqkv) * *scale), clamped to +-448;
  * max |bf16(dqkv)| is posted into the amax SITE (ATST_AMAX_SITE_STRIDE floats, atomicMax).  The operand of the e4m3 qkv dgrad / weight gradient of
- * the fp8 training step (atst_encoder_t.fp8_wgrad == 2); ATST_EINVAL for any other NP.                                                       */
+ * the fp8 training step (atst_encoder_t.fp8_wgrad == 2); ATST_EINVAL for NP = 64 / 128.                                                        */
 int atst_attention_bwd_fp8(const uint16_t* qkv, const int* valid, const uint16_t* o, const float* lse, const uint16_t* d_o,
                            uint8_t* dqkv8, const float* scale, float* amax_site, float* dscratch, int S, int H, int NP, void* stream);
 /* PatchEmbed_v2 gather: audiossl/models/atst/audio_transformer.py:56-75 (bit-exact index map, bf16 values)          */
