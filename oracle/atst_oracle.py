@@ -272,7 +272,7 @@ def _rg(x, site=None):
 
 
 def _rb(x, site=None, gsite=None):
-    return _rg(_r(x, site), gsite)
+    return _r(x, site) if gsite == "-" else _rg(_r(x, site), gsite)      # "-": this gradient is not rounded on the HIP side
 
 
 def _w(W: Weights, k: str) -> Tensor:
@@ -385,7 +385,11 @@ def block_forward(W: Weights, pre: str, x: Tensor, bias: Optional[Tensor], num_h
     streams differ); output scaled by 1/(1-drop_prob).  ref: transformer.py:95-150."""
     S, N, C = x.shape
     hd = C // num_heads
-    h = _rb(F.layer_norm(x, (C,), W[pre + "norm1.weight"], W[pre + "norm1.bias"], LN_EPS), "ln1", "g_ln1")
+    # d = 384: the HIP dgrad GEMM in front of a LayerNorm runs that LayerNorm's backward in its epilogue, on the fp32 accumulators -- the gradient of the
+    # LayerNorm output is never rounded to bf16 there (csrc/gemm.hip EPI_LNBWD); at d = 768 it passes through HBM as bf16 (sites g_ln1 / g_ln2).  The e4m3 recording
+    # step at d = 384 (first backward) runs the separate pass and does round: one step, not modelled.
+    g_ln1, g_ln2 = ("-", "-") if C == 384 else ("g_ln1", "g_ln2")
+    h = _rb(F.layer_norm(x, (C,), W[pre + "norm1.weight"], W[pre + "norm1.bias"], LN_EPS), "ln1", g_ln1)
     qkv = _rb(_linear(h, W, pre + "attn.qkv.weight", W.get(pre + "attn.qkv.bias")), "qkv", "g_qkv")
     qkv = qkv.reshape(S, N, 3, num_heads, hd).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0], qkv[1], qkv[2]
@@ -399,7 +403,7 @@ def block_forward(W: Weights, pre: str, x: Tensor, bias: Optional[Tensor], num_h
         y = y / (1.0 - drop_prob) * keep_attn.to(y.dtype)[:, None, None]
     r16 = _FP8 and _FP8_RESID16 and not torch.is_grad_enabled()     # fp8 inference / teacher passes: bf16 residual stream (rounded at every add)
     x = _bf(x + y) if r16 else x + y
-    h = _rb(F.layer_norm(x, (C,), W[pre + "norm2.weight"], W[pre + "norm2.bias"], LN_EPS), "ln2", "g_ln2")
+    h = _rb(F.layer_norm(x, (C,), W[pre + "norm2.weight"], W[pre + "norm2.bias"], LN_EPS), "ln2", g_ln2)
     h = _rg(_linear(h, W, pre + "mlp.fc1.weight", W[pre + "mlp.fc1.bias"]), "g_fc1_out")
     h = _r(_GeluSavedBf16.apply(h), "gelu_out") if _EMU else F.gelu(h)      # exact erf GELU (nn.GELU default)
     h = _rg(_linear(h, W, pre + "mlp.fc2.weight", W[pre + "mlp.fc2.bias"], FP8_ACT_SCALE_GELU), "g_fc2_out")
