@@ -2,6 +2,7 @@
 // Reference: audiossl/models/atst/byol.py:6-22 (Linear -> BatchNorm1d(train) -> ReLU -> Linear), :24-78 (loss, monitors).
 // Statistics are fp32; the cross-rank (SyncBatchNorm) combination of [mean, M2, count] and of [sum_dy, sum_dy_xhat] is
 // done by the host between these kernels (tiny vectors), see audiossl_amd/engine.py.
+#include <cstdlib>
 #include "common.h"
 #include "kernels.h"
 
@@ -72,6 +73,100 @@ __global__ void bn_apply_relu_kernel(const float* __restrict__ h, const float* _
     y[i] = f2bf(v > 0.f ? v : 0.f);
   }
 }
+
+// Round 6: the three element-wise BatchNorm kernels of the heads as COLUMN-FIXED row streams.  The flat-index forms above / below fetch the four (six)
+// per-column parameter vectors again for every 16 B of data -- five to seven vector-memory instructions per useful one -- and ran at 2.5-2.8 TB/s on the
+// ATST-Frame heads (41 k-83 k rows x 4096 columns: 7 % of the Frame step); here a thread owns four columns, keeps their parameters in registers and walks down
+// the rows, two rows in flight.  Block = 64 column threads x 4 row lanes (1-KiB row segments per wave), grid (N / 256, row groups).  Same arithmetic per element.
+#ifndef BN_CT
+#define BN_CT 64
+#endif
+struct BnCols { f32x4 mu, rs, gm, bt; };
+DEVFN BnCols bn_cols(const float* mean, const float* rstd, const float* gamma, const float* beta, int col) {
+  return BnCols{*reinterpret_cast<const f32x4*>(mean + col), *reinterpret_cast<const f32x4*>(rstd + col), *reinterpret_cast<const f32x4*>(gamma + col),
+                *reinterpret_cast<const f32x4*>(beta + col)};
+}
+template <bool SPLIT3>
+__global__ __launch_bounds__(256) void bn_apply_relu_cols_kernel(const float* __restrict__ h, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta, int R, int N,
+                                                                 bf16* __restrict__ y) {
+  constexpr int CT = BN_CT, RL = 256 / CT;                         // column threads per block, row lanes
+  const int c = threadIdx.x % CT, rg = threadIdx.x / CT;
+  const int col = (blockIdx.x * CT + c) * 4;
+  if (col >= N) return;
+  const BnCols q = bn_cols(mean, rstd, gamma, beta, col);
+  const int step = gridDim.y * RL;
+  auto one = [&](int r, const f32x4& x) {
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = (x[e] - q.mu[e]) * q.rs[e] * q.gm[e] + q.bt[e];
+      v = v > 0.f ? v : 0.f;
+      hi[e] = f2bf(v);
+      if constexpr (SPLIT3) lo[e] = f2bf(v - bf2f(hi[e]));
+    }
+    if constexpr (SPLIT3) {
+      bf16* o = y + (size_t)r * 3 * (size_t)N + col;
+      *reinterpret_cast<bf16x4*>(o) = hi; *reinterpret_cast<bf16x4*>(o + N) = lo; *reinterpret_cast<bf16x4*>(o + 2 * (size_t)N) = hi;
+    } else {
+      *reinterpret_cast<bf16x4*>(y + (size_t)r * N + col) = hi;
+    }
+  };
+  int r = blockIdx.y * RL + rg;
+  for (; r + 3 * step < R; r += 4 * step) {                        // four rows in flight
+    f32x4 x[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(h + (size_t)(r + k * step) * N + col));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) one(r + k * step, x[k]);
+  }
+  for (; r < R; r += step) one(r, *reinterpret_cast<const f32x4*>(h + (size_t)r * N + col));
+}
+template <typename OUT>
+__global__ __launch_bounds__(256) void bn_bwd_dx_cols_kernel(const float* __restrict__ dy, const float* __restrict__ h, const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ sum_dy, const float* __restrict__ sum_dy_xhat, float inv_count,
+                                                             int R, int N, OUT* __restrict__ dh) {
+  typedef OUT out4 __attribute__((ext_vector_type(4)));
+  constexpr int CT = BN_CT, RL = 256 / CT;
+  const int c = threadIdx.x % CT, rg = threadIdx.x / CT;
+  const int col = (blockIdx.x * CT + c) * 4;
+  if (col >= N) return;
+  const BnCols q = bn_cols(mean, rstd, gamma, beta, col);
+  const f32x4 s1 = *reinterpret_cast<const f32x4*>(sum_dy + col), s2 = *reinterpret_cast<const f32x4*>(sum_dy_xhat + col);
+  const int step = gridDim.y * RL;
+  auto one = [&](int r, const f32x4& hv, const f32x4& dv) {
+    out4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float xh = (hv[e] - q.mu[e]) * q.rs[e];
+      const float d = (xh * q.gm[e] + q.bt[e] > 0.f) ? dv[e] : 0.f;
+      o[e] = (OUT)(q.gm[e] * q.rs[e] * (d - s1[e] * inv_count - xh * s2[e] * inv_count));
+    }
+    *reinterpret_cast<out4*>(dh + (size_t)r * N + col) = o;
+  };
+  int r = blockIdx.y * RL + rg;
+  for (; r + 3 * step < R; r += 4 * step) {                        // four rows = eight loads in flight
+    f32x4 hv[4], dv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      hv[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(h + (size_t)(r + k * step) * N + col));
+      dv[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dy + (size_t)(r + k * step) * N + col));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) one(r + k * step, hv[k], dv[k]);
+  }
+  for (; r < R; r += step) one(r, *reinterpret_cast<const f32x4*>(h + (size_t)r * N + col), *reinterpret_cast<const f32x4*>(dy + (size_t)r * N + col));
+}
+// grid of the column-fixed kernels: N / 256 column blocks x enough row groups for ~4096 blocks (at least 8 rows per thread when there are that many)
+inline dim3 bn_cols_grid(int R, int N) {
+  constexpr int CT = BN_CT, RL = 256 / CT;
+  const int gx = (N + 4 * CT - 1) / (4 * CT);
+  int gy = (R + 8 * RL - 1) / (8 * RL); const int cap = (4096 + gx - 1) / gx;
+  if (gy > cap) gy = cap; if (gy < 1) gy = 1;
+  return dim3(gx, gy);
+}
+inline bool bn_cols_on() { static const bool on = !(getenv("ATST_BN_COLS") && getenv("ATST_BN_COLS")[0] == '0'); return on; }   // ATST_BN_COLS=0: the flat-index kernels (A/B)
 
 // same, but emits the split-bf16 operand [hi | lo | hi] (row stride 3N) for the following Linear (see split3_kernel)
 __global__ void bn_apply_relu_split3_kernel(const float* __restrict__ h, const float* __restrict__ mean,
@@ -260,6 +355,10 @@ int atst_bn_finish(const float* mean, const float* m2, float count, const float*
 int atst_bn_apply_relu(const float* h, const float* mean, const float* rstd, const float* gamma, const float* beta,
                        int R, int N, bf16* y, hipStream_t st) {
   const size_t total = (size_t)R * N;
+  if (N % 4 == 0 && bn_cols_on()) {
+    hipLaunchKernelGGL(bn_apply_relu_cols_kernel<false>, bn_cols_grid(R, N), dim3(256), 0, st, h, mean, rstd, gamma, beta, R, N, y);
+    return (int)hipGetLastError();
+  }
   int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(bn_apply_relu_kernel, dim3(grid), dim3(256), 0, st, h, mean, rstd, gamma, beta, total, N, y);
   return (int)hipGetLastError();
@@ -268,6 +367,10 @@ int atst_bn_apply_relu_split3(const float* h, const float* mean, const float* rs
                               int R, int N, bf16* y, hipStream_t st) {
   const size_t total = (size_t)R * N;
   if (N % 4) return ATST_EINVAL;
+  if (bn_cols_on()) {
+    hipLaunchKernelGGL(bn_apply_relu_cols_kernel<true>, bn_cols_grid(R, N), dim3(256), 0, st, h, mean, rstd, gamma, beta, R, N, y);
+    return (int)hipGetLastError();
+  }
   int grid = (int)((total / 4 + 255) / 256); if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(bn_apply_relu_split3_kernel, dim3(grid), dim3(256), 0, st, h, mean, rstd, gamma, beta, total, N, y);
   return (int)hipGetLastError();
@@ -286,6 +389,10 @@ int atst_bn_bwd_dx(const float* dy, const float* h, const float* mean, const flo
                    bf16* dh, hipStream_t st) {
   const size_t total = (size_t)R * N;
   if (N % 4) return ATST_EINVAL;
+  if (bn_cols_on()) {
+    hipLaunchKernelGGL(bn_bwd_dx_cols_kernel<bf16>, bn_cols_grid(R, N), dim3(256), 0, st, dy, h, mean, rstd, gamma, beta, sum_dy, sum_dy_xhat, inv_count, R, N, dh);
+    return (int)hipGetLastError();
+  }
   int grid = (int)((total / 4 + 255) / 256); if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(bn_bwd_dx_kernel<bf16>, dim3(grid), dim3(256), 0, st, dy, h, mean, rstd, gamma, beta, sum_dy, sum_dy_xhat,
                      inv_count, total, N, dh);
@@ -296,6 +403,10 @@ int atst_bn_bwd_dx_fp32(const float* dy, const float* h, const float* mean, cons
                         float* dh, hipStream_t st) {
   const size_t total = (size_t)R * N;
   if (N % 4) return ATST_EINVAL;
+  if (bn_cols_on()) {
+    hipLaunchKernelGGL(bn_bwd_dx_cols_kernel<float>, bn_cols_grid(R, N), dim3(256), 0, st, dy, h, mean, rstd, gamma, beta, sum_dy, sum_dy_xhat, inv_count, R, N, dh);
+    return (int)hipGetLastError();
+  }
   int grid = (int)((total / 4 + 255) / 256); if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(bn_bwd_dx_kernel<float>, dim3(grid), dim3(256), 0, st, dy, h, mean, rstd, gamma, beta, sum_dy, sum_dy_xhat,
                      inv_count, total, N, dh);
