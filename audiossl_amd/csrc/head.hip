@@ -214,10 +214,15 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const float* __restric
       }
     };
     int r = blockIdx.y * 4 + rg;
-    for (; r + step < R; r += 2 * step) {                           // two rows in flight (four 16-B loads), accumulated in row order
-      const f32x4 h0 = *reinterpret_cast<const f32x4*>(h + (size_t)r * N + col), d0 = *reinterpret_cast<const f32x4*>(dy + (size_t)r * N + col);
-      const f32x4 h1 = *reinterpret_cast<const f32x4*>(h + (size_t)(r + step) * N + col), d1 = *reinterpret_cast<const f32x4*>(dy + (size_t)(r + step) * N + col);
-      acc(h0, d0); acc(h1, d1);
+    for (; r + 3 * step < R; r += 4 * step) {                       // four rows in flight (eight 16-B loads), accumulated in row order
+      f32x4 hv[4], dv[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        hv[k] = *reinterpret_cast<const f32x4*>(h + (size_t)(r + k * step) * N + col);
+        dv[k] = *reinterpret_cast<const f32x4*>(dy + (size_t)(r + k * step) * N + col);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc(hv[k], dv[k]);
     }
     for (; r < R; r += step) acc(*reinterpret_cast<const f32x4*>(h + (size_t)r * N + col), *reinterpret_cast<const f32x4*>(dy + (size_t)r * N + col));
   }
