@@ -247,3 +247,32 @@ def test_hf_adamw_restatement_against_torch_adamw():
         moved = float((p - p0).abs().max())
         diff = float((p - q.detach()).abs().max())
         assert moved > 5e-3 and diff < tol, (lr, wd, eps, moved, diff)
+
+
+def test_frame_row_bookkeeping_on_the_host():
+    """ATST-Frame's per-step host bookkeeping (AtstEngine._valid / _frame_rows / _host_cat; numpy since round 6: CPU torch ops there stalled in the intra-op
+    thread pool on busy hosts) against a plain-Python restatement of the reference's selection: the masked frames that are real frames, in (b, n) order, as flat
+    row indices s * stride + n; rowflag = the mask image on the padded / packed row grid.  ref: methods/atstframe/audio_transformer.py:183-207 (mask_index
+    applied to the valid frames), models/atst/audio_transformer.py:70-71 (patch_length)."""
+    import types
+    rng = np.random.default_rng(5)
+    fake = types.SimpleNamespace(patch_w=4, device=torch.device("cpu"), upload=lambda t: t)
+    for S, n_tok, stride in ((7, 250, 256), (64, 25, 25), (3, 100, 128)):
+        width = n_tok * 4 + 1
+        lengths = torch.from_numpy(rng.integers(5, width + 1, size=S)); lengths[0] = width
+        valid = E.AtstEngine._valid(fake, lengths, 0, n_tok)
+        want_valid = [min((int(l) - int(l) % 4) // 4, n_tok) for l in lengths]
+        assert valid.dtype == torch.int32 and valid.tolist() == want_valid
+        assert E.AtstEngine._valid(fake, lengths, 1, n_tok + 1).tolist() == [v + 1 for v in want_valid]          # clip encoders: + CLS
+        mk = torch.from_numpy(rng.random((S, n_tok)) < 0.6)
+        rows, rowflag = E.AtstEngine._frame_rows(fake, mk, valid, stride, True)
+        want_rows = [s * stride + n for s in range(S) for n in range(n_tok) if bool(mk[s, n]) and n < want_valid[s]]
+        assert rows.dtype == torch.int32 and rows.tolist() == want_rows
+        rf = rowflag.reshape(S, stride)
+        assert rf.dtype == torch.uint8 and torch.equal(rf[:, :n_tok].bool(), mk) and int(rf[:, n_tok:].sum()) == 0
+        rows2, none = E.AtstEngine._frame_rows(fake, mk, valid, stride, False)
+        assert none is None and torch.equal(rows2, rows)
+    a, b = torch.arange(5), torch.arange(5, 9)
+    assert torch.equal(E._host_cat([a, b]), torch.cat([a, b])) and E._host_cat([a]) is a
+    m = [torch.from_numpy(rng.random((4, 10)) < 0.5) for _ in range(3)]
+    assert torch.equal(E._host_cat(m), torch.cat(m)) and E._host_cat(m).dtype == torch.bool
