@@ -9,7 +9,8 @@ sys.path.insert(0, ROOT)
 from audiossl_amd.engine import AtstEngine
 from oracle import atst_oracle as O
 N, depth, B = int(os.environ.get("N", 24)), int(os.environ.get("DEPTH", 2)), int(os.environ.get("B", 16))
-W = O.recipe_weights("base", depth=depth, seed=7)
+ARCH, CROPS = os.environ.get("ARCH", "base"), int(os.environ.get("CROPS", 2))     # round 6: ARCH=small CROPS=6 = the clip6 recipe (2 views of 10 s + 4 of 1 s) at d = 384
+W = O.recipe_weights(ARCH, depth=depth, seed=7)
 
 
 def data(step):
@@ -21,18 +22,21 @@ def data(step):
         f = torch.rand(B, 1, 64, 1, generator=g); tt = torch.linspace(0, 1, 1001).view(1, 1, 1, -1)
         m = m * 0.3 + 0.7 * torch.sin(6.28 * (3 * f + 2 * tt * torch.rand(B, 1, 1, 1, generator=g)))
         mels.append(m.contiguous())
+    for v in range(CROPS - 2):                                   # 1 s local views: a window of the first global view
+        o = int(torch.randint(0, 900, (1,), generator=g))
+        mels.append(mels[0][..., o:o + 101].contiguous())
     return mels
 
 
 def run(kind):
-    eng = AtstEngine("base", depth=depth, drop_path_rate=0.0, fp8=kind != "bf16")
+    eng = AtstEngine(ARCH, depth=depth, ncrops=CROPS, drop_path_rate=0.0, fp8=kind != "bf16")
     eng.load_weights(W)
     if kind == "fp8_fwd":
         eng.fp8_bwd_state = 0
     losses = []
     for step in range(N):
         mels = [m.cuda() for m in data(step)]
-        lens = [torch.full((B,), 1001)] * 2
+        lens = [torch.full((B,), 1001)] * 2 + [torch.full((B,), 101)] * (CROPS - 2)
         loss = eng.forward(mels, lens)[0]
         eng.backward()
         eng.optimizer_step(5e-4, 0.04, 0.99)
@@ -41,7 +45,7 @@ def run(kind):
     return losses, eng.p32.clone(), sat
 
 
-_e0 = AtstEngine("base", depth=depth, drop_path_rate=0.0); _e0.load_weights(W); P0 = _e0.p32.clone(); del _e0
+_e0 = AtstEngine(ARCH, depth=depth, ncrops=CROPS, drop_path_rate=0.0); _e0.load_weights(W); P0 = _e0.p32.clone(); del _e0
 ref, p_ref, _ = run("bf16")
 print("step  " + " ".join(f"{i:7d}" for i in range(N)))
 print("bf16  " + " ".join(f"{v:7.4f}" for v in ref))
